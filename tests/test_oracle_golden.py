@@ -1,0 +1,153 @@
+"""Pins the oracle (oracle/vb2_oracle.c + oracle/refio.py) to the reference:
+
+* the known-answer LLK values of the reference's ComputeMixLLKs,
+  bit for bit;
+* the reference's own CTest fixtures: six expected .Ancestry files and two
+  .selfSM files (CMakeLists.txt:86-147), byte for byte / field for field;
+* the reference's own AmoebaMinimizer (oracle/_ref, compiled in place from
+  /root/reference/MathGenMin.cpp): identical trajectories.
+
+CPU only.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding, refio
+
+HAPMAP = "hapmap/hapmap_3.3.b37.dat"
+
+
+def cxx_default(x):
+    """std::ostream default formatting of a double (precision 6, %g)."""
+    return "%g" % x
+
+
+def ancestry_text(pc, pc2):
+    # ContaminationEstimator.cpp:176-180
+    out = "PC\tContaminatingSample\tIntendedSample\n"
+    for i, (a, b) in enumerate(zip(pc, pc2)):
+        out += "%d\t%s\t%s\n" % (i + 1, cxx_default(a), cxx_default(b))
+    return out
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    with open(os.path.join(golden_dir, "kat.json")) as fh:
+        return json.load(fh)
+
+
+def _data(golden_dir, pileup):
+    flat, panel, viewer = refio.load_flat(os.path.join(golden_dir, HAPMAP),
+                                          os.path.join(golden_dir, pileup), 2, sanity_disabled=True)
+    return binding.OracleData(flat), flat, viewer
+
+
+@pytest.mark.parametrize("name", ["result.Pileup", "test.LongRead.pileup"])
+def test_known_answer_llk_bit_exact(golden_dir, kat, name):
+    spec = kat["inputs"][name]
+    od, flat, viewer = _data(golden_dir, spec["pileup"])
+    assert flat.num_marker == 9787
+    assert len(viewer.base_info) == spec["sites"]
+    assert viewer.num_bases == spec["bases"]
+    assert viewer.avg_depth == spec["avg_depth"]
+    for pt, hx in zip(kat["points"], spec["llk_hex"]):
+        got = od.llk(pt["pc1"], pt["pc2"], pt["alpha"])
+        assert got == float.fromhex(hx), (pt, got.hex(), hx)
+
+
+@pytest.mark.parametrize("model", ["result", "longread", "within", "within_fixpc", "fixalpha",
+                                   "heter_fixpc"])
+def test_golden_ancestry_and_selfsm(golden_dir, kat, model):
+    spec = kat["models"][model]
+    od, flat, viewer = _data(golden_dir, spec["pileup"])
+    res = od.optimize(**spec["args"])
+    with open(os.path.join(golden_dir, spec["ancestry"])) as fh:
+        assert ancestry_text(res["pc"], res["pc2"]) == fh.read()
+    assert res["alpha"] == spec["alpha"]
+    assert -res["llk1"] == spec["llk1"]
+    assert -res["llk0"] == spec["llk0"]
+    if "num_eval" in spec:
+        assert res["num_eval"] == spec["num_eval"]
+    if "selfsm" in spec:
+        with open(os.path.join(golden_dir, spec["selfsm"])) as fh:
+            row = fh.read().splitlines()[1].split("\t")
+        # main.cpp:396-404: SEQ_SM NA NA #SNPS #READS AVG_DP FREEMIX FREELK1 FREELK0 ...
+        freemix = res["alpha"] if res["alpha"] < 0.5 else 1.0 - res["alpha"]
+        assert row[3] == str(flat.num_marker)
+        assert row[5] == cxx_default(viewer.avg_depth)
+        assert row[6] == cxx_default(freemix)
+        assert row[7] == cxx_default(-res["llk1"])
+        assert row[8] == cxx_default(-res["llk0"])
+
+
+def _need_ref():
+    if binding.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference and no prebuilt library)")
+
+
+@pytest.mark.parametrize("args", [{}, {"within_ancestry": True}, {"fix_alpha": 0.1},
+                                  {"fix_pc": [0.034756, 0.0193]}])
+def test_search_matches_reference_amoeba(golden_dir, args):
+    """Same objective, reference's AmoebaMinimizer vs the restatement: every
+    evaluation point and value identical, bit for bit."""
+    _need_ref()
+    od, _, _ = _data(golden_dir, "test.LongRead.pileup")
+    a = od.optimize(minimizer="oracle", trace_capacity=4096, **args)
+    b = od.optimize(minimizer="reference", trace_capacity=4096, **args)
+    assert a["num_eval"] == b["num_eval"] and a["trace_count"] == b["trace_count"]
+    for key in ("alpha", "pc1", "pc2", "llk"):
+        assert np.array_equal(a["trace"][key], b["trace"][key]), key
+    assert a["alpha"] == b["alpha"] and a["llk1"] == b["llk1"] and a["llk0"] == b["llk0"]
+
+
+def test_amoeba_generic_functions_match_reference():
+    """Nelder-Mead restatement vs reference on plain test functions, including
+    one that exhausts cycleMax (returns DBL_MAX and leaves the point alone)."""
+    _need_ref()
+
+    def rosen(v):
+        return float(100.0 * (v[1] - v[0] ** 2) ** 2 + (1 - v[0]) ** 2)
+
+    def quad5(v):
+        return float(np.sum((np.arange(1, 6) * (v - 0.3)) ** 2) + 1.0)
+
+    def plateau(v):   # exercises the tie rules (<= / >) and the shrink step
+        return float(np.floor(abs(v[0]) * 4) + np.floor(abs(v[1]) * 4))
+
+    for fn, start, tol in [(rosen, [-1.2, 1.0], 1e-10), (quad5, [0.0] * 5, 1e-12),
+                           (plateau, [2.3, -1.7], 1e-8), (lambda v: float(v[0] ** 2), [3.0], 1e-14)]:
+        ev_a, ev_b = [], []
+        ra, pa = binding.amoeba(lambda v: (ev_a.append(v.copy()), fn(v))[1], start, tol, "oracle")
+        rb, pb = binding.amoeba(lambda v: (ev_b.append(v.copy()), fn(v))[1], start, tol, "reference")
+        assert ra == rb
+        assert np.array_equal(pa, pb)
+        assert len(ev_a) == len(ev_b)
+        assert all(np.array_equal(x, y) for x, y in zip(ev_a, ev_b))
+
+
+def test_sanity_filter_and_threads(golden_dir):
+    """The depth filter of h:246-249 changes which markers count; OpenMP thread
+    count changes the sum only at rounding level."""
+    flat, panel, viewer = refio.load_flat(os.path.join(golden_dir, HAPMAP),
+                                          os.path.join(golden_dir, "test.LongRead.pileup"), 2,
+                                          sanity_disabled=False)
+    assert flat.sd_depth > 0
+    od_f = binding.OracleData(flat)
+    flat2, _, _ = refio.load_flat(os.path.join(golden_dir, HAPMAP),
+                                  os.path.join(golden_dir, "test.LongRead.pileup"), 2,
+                                  sanity_disabled=True)
+    od_u = binding.OracleData(flat2)
+    a = od_f.llk([0.01, 0.01], [0.02, 0.0], 0.1)
+    b = od_u.llk([0.01, 0.01], [0.02, 0.0], 0.1)
+    depths = np.diff(flat.site_off)
+    lo, hi = flat.avg_depth - 3 * flat.sd_depth, flat.avg_depth + 3 * flat.sd_depth
+    if ((depths < lo) | (depths > hi)).any():
+        assert a != b
+    else:
+        assert a == b
+    t1 = od_u.llk([0.01, 0.01], [0.02, 0.0], 0.1, num_thread=1)
+    t4 = od_u.llk([0.01, 0.01], [0.02, 0.0], 0.1, num_thread=4)
+    assert abs(t1 - t4) <= 1e-12 * abs(t1)
