@@ -1,0 +1,229 @@
+/*
+ * vb2_abi.h -- C-ABI of the MI355X-native contamination-likelihood core.
+ *
+ * This is the drop-in boundary for the one hot path of VerifyBamID2
+ * (Griffan/VerifyBamID): the genotype-mixture log-likelihood
+ * FullLLKFunc::ComputeMixLLKs and the Nelder-Mead search that drives it.
+ * The reference has no FFI layer; its seam for this path is the libStatGen
+ * functor  VectorFunc::Evaluate(Vector&)  (statgen/MathVector.h:281-308),
+ * installed with  myMinimizer.func = &fn  (ContaminationEstimator.cpp:212,246,
+ * 279,304,325), and one level below it the pure-compute member
+ *   double ComputeMixLLKs(const std::vector<double>& pc1,
+ *                         const std::vector<double>& pc2, double alpha)
+ * (ContaminationEstimator.h:194-195).  Each entry point below names the
+ * reference interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types; every function
+ * returns 0 on success and a negative vb2_status otherwise and never throws;
+ * vb2_last_error() gives the message for the calling thread.  A context is
+ * thread-compatible (one thread at a time), like the reference's estimator.
+ * All arithmetic on the path is IEEE-754 binary64.
+ *
+ * There is NO CPU fallback: every compute entry point fails with
+ * VB2_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef VB2_ABI_H_
+#define VB2_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VB2_ABI_VERSION 1
+
+typedef enum vb2_status {
+    VB2_OK = 0,
+    VB2_ERR_INVALID = -1,    /* bad argument                                     */
+    VB2_ERR_NO_DEVICE = -2,  /* no usable HIP device / kernel image not loadable */
+    VB2_ERR_HIP = -3,        /* a HIP runtime call failed                        */
+    VB2_ERR_IO = -4,         /* file could not be read / written                 */
+    VB2_ERR_NOMEM = -5,
+    VB2_ERR_SANITY = -6      /* marker sanity check failed (main.cpp:371-379)    */
+} vb2_status;
+
+typedef struct vb2_ctx vb2_ctx;
+
+/* ------------------------------------------------------------------------- *
+ * 1. Likelihood context: the data ComputeMixLLKs reaches through `ptr`
+ *    (ContaminationEstimator.h:82, 236-276), handed over ONCE.
+ *
+ *    Markers are in panel order (= row order of .UD/.mu/.bed).  read_off has
+ *    num_marker+1 entries; marker i owns bases/quals[read_off[i]..read_off[i+1]).
+ *    An empty range means "marker absent from the pileup" (baseInfoIndex < 0,
+ *    h:239) or depth 0 (h:244).  bases are the pileup characters
+ *    ". , A C G T N a c g t n" and quals are ASCII Phred+33, exactly as
+ *    SimplePileupViewer stores them (SimplePileupViewer.h:60-61,94-95).
+ *    All arrays are caller-owned host memory and may be freed after
+ *    vb2_ctx_create returns.
+ * ------------------------------------------------------------------------- */
+typedef struct vb2_input {
+    int32_t num_marker;        /* NumMarker                         (h:446)        */
+    int32_t num_pc;            /* numPC                             (h:49)         */
+    const double *ud;          /* UD[i][k], row-major M x num_pc    (h:452)        */
+    const double *means;       /* means[i]                          (h:454)        */
+    const int64_t *read_off;   /* [M+1]                                            */
+    const char *bases;         /* viewer.baseInfo, concatenated in panel order     */
+    const char *quals;         /* viewer.qualInfo                                  */
+    const char *alt_base;      /* resolvedMarkers[i].altBase        (h:472)        */
+    const double *known_af;    /* resolvedMarkers[i].knownAFValue or NULL (h:473)  */
+    double avg_depth;          /* viewer.avgDepth                                  */
+    double sd_depth;           /* viewer.sdDepth                                   */
+    int32_t sanity_disabled;   /* isSanityCheckDisabled: skips the +-3sd filter of h:246-249 */
+    int32_t reserved;
+} vb2_input;
+
+typedef struct vb2_options {
+    int32_t device;            /* HIP device ordinal, -1 = current device          */
+    int32_t flags;             /* VB2_OPT_* bits                                   */
+    void *stream;              /* hipStream_t to run on; NULL = context-owned      */
+} vb2_options;
+
+typedef struct vb2_info {
+    int32_t abi_version;
+    int32_t device;
+    int32_t num_marker;        /* panel markers                                    */
+    int32_t num_pc;
+    int64_t num_active_marker; /* markers that survive h:239-249                   */
+    int64_t num_read;          /* bases of the active markers                      */
+    int64_t num_read_other;    /* of those, class "other" (folded into a constant) */
+    int32_t num_code;          /* distinct (class, quality) pairs in the data      */
+    int32_t num_tile;          /* 64-marker wave tiles                             */
+    int64_t device_bytes;      /* HBM held by the context                          */
+    /* SURVEY 8(d) algorithmic bytes of ONE evaluation: 2*R + M_active*(8k+12) */
+    int64_t algorithmic_bytes_per_eval;
+    char device_name[64];
+    char arch[32];
+} vb2_info;
+
+/* Builds the device-resident SoA form of the input (classification, quality
+ * clamping, marker filtering and the alpha-independent partial sums happen
+ * here, once).  Replaces BuildResolvedMarkers + the per-call prologue of
+ * ComputeMixLLKs (ContaminationEstimator.cpp:67-86; h:236-249, 285-299). */
+int vb2_ctx_create(const vb2_input *in, const vb2_options *opt, vb2_ctx **out);
+void vb2_ctx_destroy(vb2_ctx *ctx);
+int vb2_ctx_info(const vb2_ctx *ctx, vb2_info *info);
+
+/* Replaces  ComputeMixLLKs(pc1, pc2, alpha)  (ContaminationEstimator.h:194-314)
+ * for B parameter points at once.  pc1/pc2 are B x num_pc row-major, alpha has
+ * B entries, llk_out receives B values of +LLK (not negated, like the
+ * reference's return value).  Synchronous; host pointers. */
+int vb2_llk_eval_batch(vb2_ctx *ctx, int32_t num_point, const double *pc1,
+                       const double *pc2, const double *alpha, double *llk_out);
+
+/* Same evaluation with DEVICE pointers, enqueued on `stream` (NULL = the
+ * context's stream) without any host synchronisation:
+ *   d_points : num_point x (2*num_pc+1) doubles, each row = pc1[0..k) pc2[0..k) alpha
+ *   d_llk_out: num_point doubles
+ * Used by the multi-GPU path (the caller all-reduces d_llk_out over RCCL) and by
+ * the bench. */
+int vb2_llk_eval_batch_device(vb2_ctx *ctx, int32_t num_point, const double *d_points,
+                              double *d_llk_out, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * 2. Estimator: FullLLKFunc::Initialize/Evaluate/CalculateLLK0 and
+ *    ContaminationEstimator::OptimizeLLK with its six Optimize* wrappers
+ *    (ContaminationEstimator.h:316-442, ContaminationEstimator.cpp:88-332),
+ *    driving AmoebaMinimizer (MathGenMin.cpp:313-443).
+ * ------------------------------------------------------------------------- */
+typedef struct vb2_model {
+    int32_t is_heter;          /* !--WithinAncestry            (main.cpp:287)      */
+    int32_t is_pc_fixed;       /* --FixPC                      (main.cpp:291-308)  */
+    int32_t is_alpha_fixed;    /* --FixAlpha                   (main.cpp:309-313)  */
+    int32_t is_af_known;       /* --KnownAF                    (main.cpp:314-319)  */
+    double fix_alpha;          /* --FixAlpha value                                 */
+    const double *fix_pc;      /* --FixPC values (num_pc) or NULL                  */
+    double epsilon;            /* --Epsilon, 1e-8 by default   (main.cpp:76)       */
+    int32_t verbose;           /* --Verbose: per-evaluation notice (h:435-440)     */
+    int32_t reserved;
+} vb2_model;
+
+#define VB2_MAX_PC 64
+
+typedef struct vb2_estimate {
+    double alpha;              /* fn.globalAlpha                                   */
+    double llk1;               /* fn.llk1 (= -LLK at the best evaluated point)     */
+    double llk0;               /* fn.llk0                                          */
+    double pc[VB2_MAX_PC];     /* fn.globalPC   (contaminating sample)             */
+    double pc2[VB2_MAX_PC];    /* fn.globalPC2  (intended sample)                  */
+    int64_t num_eval;          /* likelihood evaluations the reference would make  */
+    int64_t num_launch_point;  /* points actually evaluated (speculation included) */
+    int32_t converged;         /* 0 if a Minimize() ran out of cycles              */
+    int32_t reserved;
+} vb2_estimate;
+
+/* The objective seam, batched: the analogue of VectorFunc::Evaluate
+ * (statgen/MathVector.h:281-308).  Must write +LLK for each point. */
+typedef int (*vb2_eval_fn)(void *user, int32_t num_point, const double *pc1,
+                           const double *pc2, const double *alpha, double *llk_out);
+
+/* Optional per-evaluation trace: one record per evaluation the REFERENCE would
+ * have made, in its order. */
+typedef struct vb2_trace {
+    int64_t capacity;
+    int64_t count;
+    double *alpha;             /* [capacity]            */
+    double *pc1;               /* [capacity * num_pc]   */
+    double *pc2;               /* [capacity * num_pc]   */
+    double *llk;               /* [capacity]            */
+} vb2_trace;
+
+/* OptimizeLLK over an arbitrary evaluator (e.g. marker shards + all-reduce). */
+int vb2_optimize_llk(vb2_eval_fn eval, void *user, int32_t num_pc, const vb2_model *model,
+                     vb2_estimate *out, vb2_trace *trace);
+/* OptimizeLLK on a context (evaluator = vb2_llk_eval_batch on ctx). */
+int vb2_ctx_optimize_llk(vb2_ctx *ctx, const vb2_model *model, vb2_estimate *out,
+                         vb2_trace *trace);
+
+/* ------------------------------------------------------------------------- *
+ * 3. File level: the --SVDPrefix/--PileupFile flow of execute()
+ *    (main.cpp:283-411): panel + pileup readers, sanity check, OptimizeLLK,
+ *    <out>.Ancestry and <out>.selfSM writers.
+ * ------------------------------------------------------------------------- */
+typedef struct vb2_run_args {
+    const char *ud_path;       /* <SVDPrefix>.UD   (main.cpp:229)                  */
+    const char *mean_path;     /* <SVDPrefix>.mu                                   */
+    const char *bed_path;      /* <SVDPrefix>.bed                                  */
+    const char *pileup_path;   /* --PileupFile                                     */
+    const char *known_af_path; /* --KnownAF or NULL                                */
+    const char *output_prefix; /* --Output (default "result"); NULL = write nothing*/
+    int32_t num_pc;            /* --NumPC (default 2)                              */
+    int32_t disable_sanity;    /* --DisableSanityCheck                             */
+    int32_t output_pileup;     /* --OutputPileup                                   */
+    int32_t device;            /* HIP device ordinal, -1 = current                 */
+    vb2_model model;
+} vb2_run_args;
+
+typedef struct vb2_run_result {
+    vb2_estimate est;
+    int32_t num_marker;        /* #SNPS                                            */
+    int32_t num_site;          /* sites shared with the pileup                     */
+    int64_t num_bases;         /* viewer.numBases                                  */
+    double avg_depth;          /* AVG_DP                                           */
+    double sd_depth;
+    double seconds_load;       /* wall-clock: readers                              */
+    double seconds_optimize;   /* wall-clock: OptimizeLLK (the "converged alpha" time) */
+} vb2_run_result;
+
+int vb2_run(const vb2_run_args *args, vb2_run_result *out);
+
+/* Host-side flattening only (no device): reads panel + pileup, resolves markers
+ * and returns the arrays of vb2_input in library-owned memory; free with
+ * vb2_flat_free.  Lets callers (tests, shard planners) inspect or slice them. */
+typedef struct vb2_flat vb2_flat;
+int vb2_flat_load(const vb2_run_args *args, vb2_flat **out);
+const vb2_input *vb2_flat_input(const vb2_flat *f);
+int vb2_flat_stats(const vb2_flat *f, vb2_run_result *out);
+void vb2_flat_free(vb2_flat *f);
+
+const char *vb2_last_error(void);
+int vb2_abi_version(void);
+/* Number of usable gfx950 devices (0 = none; compute calls will fail loudly). */
+int vb2_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VB2_ABI_H_ */

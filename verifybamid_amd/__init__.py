@@ -1,0 +1,10 @@
+"""verifybamid_amd -- MI355X-native contamination-likelihood core for VerifyBamID2.
+
+The product is libvb2.so (HIP kernels + C++ host, C-ABI in include/vb2_abi.h) and the
+`bin/VerifyBamID` command line; this package is the ctypes marshalling used by the
+tests, the bench and multi-GPU (torch.distributed) drivers.
+"""
+from .api import (LikelihoodContext, PileupData, optimize_with_evaluator, run_files)  # noqa: F401
+from . import synth  # noqa: F401
+
+__all__ = ["LikelihoodContext", "PileupData", "optimize_with_evaluator", "run_files", "synth"]

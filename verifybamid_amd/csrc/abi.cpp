@@ -1,0 +1,234 @@
+// abi.cpp -- the extern "C" surface declared in include/vb2_abi.h.
+#include <chrono>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <new>
+
+#include "context.h"
+#include "estimator.h"
+#include "hostio.h"
+
+using vb2::set_error;
+
+namespace {
+
+int guard_ctx(const vb2_ctx* ctx)
+{
+    if (!ctx || !ctx->impl) {
+        set_error("null vb2_ctx");
+        return VB2_ERR_INVALID;
+    }
+    return VB2_OK;
+}
+
+int ctx_eval_cb(void* user, int32_t n, const double* pc1, const double* pc2, const double* alpha,
+                double* out)
+{
+    return static_cast<vb2::Context*>(user)->eval_host(n, pc1, pc2, alpha, out);
+}
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+int vb2_abi_version(void) { return VB2_ABI_VERSION; }
+
+const char* vb2_last_error(void) { return vb2::g_last_error.c_str(); }
+
+int vb2_device_count(void) { return vb2::usable_device_count(); }
+
+int vb2_ctx_create(const vb2_input* in, const vb2_options* opt, vb2_ctx** out)
+{
+    if (!out) {
+        set_error("vb2_ctx_create: out is NULL");
+        return VB2_ERR_INVALID;
+    }
+    *out = nullptr;
+    try {
+        vb2::Context* c = nullptr;
+        const int rc = vb2::Context::create(in, opt, &c);
+        if (rc) return rc;
+        vb2_ctx* h = new vb2_ctx{c};
+        *out = h;
+        return VB2_OK;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return VB2_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
+}
+
+void vb2_ctx_destroy(vb2_ctx* ctx)
+{
+    if (!ctx) return;
+    delete ctx->impl;
+    delete ctx;
+}
+
+int vb2_ctx_info(const vb2_ctx* ctx, vb2_info* info)
+{
+    if (int rc = guard_ctx(ctx)) return rc;
+    if (!info) return VB2_ERR_INVALID;
+    ctx->impl->fill_info(info);
+    return VB2_OK;
+}
+
+int vb2_llk_eval_batch(vb2_ctx* ctx, int32_t num_point, const double* pc1, const double* pc2,
+                       const double* alpha, double* llk_out)
+{
+    if (int rc = guard_ctx(ctx)) return rc;
+    return ctx->impl->eval_host(num_point, pc1, pc2, alpha, llk_out);
+}
+
+int vb2_llk_eval_batch_device(vb2_ctx* ctx, int32_t num_point, const double* d_points,
+                              double* d_llk_out, void* stream)
+{
+    if (int rc = guard_ctx(ctx)) return rc;
+    if (num_point < 0 || (num_point > 0 && (!d_points || !d_llk_out))) {
+        set_error("vb2_llk_eval_batch_device: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    return ctx->impl->eval_device(num_point, d_points, d_llk_out, (hipStream_t)stream);
+}
+
+int vb2_optimize_llk(vb2_eval_fn eval, void* user, int32_t num_pc, const vb2_model* model,
+                     vb2_estimate* out, vb2_trace* trace)
+{
+    if (!eval || !model || !out || num_pc < 1 || num_pc > VB2_MAX_PC) {
+        set_error("vb2_optimize_llk: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    try {
+        vb2::Estimator est(num_pc, eval, user);
+        vb2::apply_model(est, *model);
+        est.trace = trace;
+        if (trace) trace->count = 0;
+        const int rc = est.OptimizeLLK();
+        if (rc) return rc;
+        vb2::fill_estimate(est, out);
+        return VB2_OK;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
+}
+
+int vb2_ctx_optimize_llk(vb2_ctx* ctx, const vb2_model* model, vb2_estimate* out, vb2_trace* trace)
+{
+    if (int rc = guard_ctx(ctx)) return rc;
+    return vb2_optimize_llk(ctx_eval_cb, ctx->impl, ctx->impl->num_pc, model, out, trace);
+}
+
+int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
+{
+    if (!a || !out || !a->ud_path || !a->mean_path || !a->bed_path || !a->pileup_path ||
+        a->num_pc < 1 || a->num_pc > VB2_MAX_PC) {
+        set_error("vb2_flat_load: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    *out = nullptr;
+    try {
+        std::unique_ptr<vb2_flat> f(new vb2_flat());
+        f->panel.numPC = a->num_pc;
+        int rc;
+        // constructor reads the .bed (ContaminationEstimator.cpp:47), then ReadSVDMatrix
+        if ((rc = vb2::read_bed(a->bed_path, &f->panel))) return rc;
+        if (a->known_af_path && (rc = vb2::read_known_af(a->known_af_path, &f->panel))) return rc;
+        if ((rc = vb2::read_ud(a->ud_path, &f->panel))) return rc;
+        if ((rc = vb2::read_mean(a->mean_path, &f->panel))) return rc;
+        if (f->panel.means.size() < f->panel.NumMarker || f->panel.PosVec.size() < f->panel.NumMarker) {
+            set_error(".UD has more rows than .mu/.bed");
+            return VB2_ERR_INVALID;
+        }
+        if ((rc = vb2::read_pileup(a->pileup_path, f->panel.ChooseBed, &f->viewer))) return rc;
+        f->sanity_disabled = a->disable_sanity != 0;
+        if (!f->sanity_disabled && !vb2::sanity_check(f->panel, &f->viewer)) {
+            set_error("Insufficient Available markers, check input bam depth distribution in "
+                      "output pileup file after specifying --OutputPileup");
+            f->resolve();
+            *out = f.release();
+            return VB2_ERR_SANITY;
+        }
+        f->resolve();
+        *out = f.release();
+        return VB2_OK;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return VB2_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
+}
+
+const vb2_input* vb2_flat_input(const vb2_flat* f) { return f ? &f->input : nullptr; }
+
+int vb2_flat_stats(const vb2_flat* f, vb2_run_result* out)
+{
+    if (!f || !out) return VB2_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    out->num_marker = (int32_t)f->panel.NumMarker;
+    out->num_site = f->num_site;
+    out->num_bases = f->viewer.numBases;
+    out->avg_depth = f->viewer.avgDepth;
+    out->sd_depth = f->viewer.sdDepth;
+    return VB2_OK;
+}
+
+void vb2_flat_free(vb2_flat* f) { delete f; }
+
+int vb2_run(const vb2_run_args* a, vb2_run_result* out)
+{
+    if (!a || !out) {
+        set_error("vb2_run: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    const double t0 = now_s();
+    vb2_flat* flat = nullptr;
+    int rc = vb2_flat_load(a, &flat);
+    std::unique_ptr<vb2_flat> holder(flat);
+    if (rc == VB2_ERR_SANITY && flat && a->output_pileup && a->output_prefix)
+        vb2::write_pileup(a->output_prefix, *flat);
+    if (rc) return rc;
+    vb2_flat_stats(flat, out);
+    if (a->output_pileup && a->output_prefix && (rc = vb2::write_pileup(a->output_prefix, *flat)))
+        return rc;
+
+    vb2_options opt{};
+    opt.device = a->device;
+    vb2_ctx* ctx = nullptr;
+    if ((rc = vb2_ctx_create(&flat->input, &opt, &ctx))) return rc;
+    out->seconds_load = now_s() - t0;
+
+    vb2_model model = a->model;
+    if (flat->panel.isAFknown) model.is_af_known = 1;
+    const double t1 = now_s();
+    rc = vb2_ctx_optimize_llk(ctx, &model, &out->est, nullptr);
+    out->seconds_optimize = now_s() - t1;
+    vb2_ctx_destroy(ctx);
+    if (rc) return rc;
+
+    // stdout block: which "Estimation from ..." header the reference prints
+    const bool heter = model.is_heter && !model.is_af_known;
+    const bool pcfix = (model.is_pc_fixed && model.fix_pc) || model.is_af_known;
+    const bool afix = !pcfix && model.is_alpha_fixed;
+    const char* title = nullptr;
+    if (!heter) title = pcfix ? "Estimation from OptimizeHomoFixedPC:" : afix ? nullptr : "Estimation from OptimizeHomo:";
+    else title = pcfix ? "Estimation from OptimizeHeterFixedPC:" : afix ? "Estimation from OptimizeHeterFixedAlpha:" : "Estimation from OptimizeHeter:";
+    vb2::print_summary(title, a->num_pc, out->est);
+    if (a->output_prefix) {
+        if ((rc = vb2::write_ancestry(a->output_prefix, a->num_pc, out->est.pc, out->est.pc2))) return rc;
+        if ((rc = vb2::write_selfsm(a->output_prefix, *flat, out->est, true))) return rc;
+    }
+    return VB2_OK;
+}
+
+}  // extern "C"

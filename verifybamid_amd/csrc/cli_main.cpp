@@ -1,0 +1,176 @@
+// cli_main.cpp -- command line with the reference's flag names, defaults and
+// output files for the contamination path (main.cpp:56-414), on top of the C-ABI.
+//
+//   VerifyBamID --SVDPrefix P --PileupFile F --Reference R [--NumPC k] [--Output o]
+//               [--WithinAncestry] [--FixPC a:b:..] [--FixAlpha x] [--KnownAF f]
+//               [--Epsilon e] [--DisableSanityCheck] [--OutputPileup] [--Verbose]
+//               [--NumThread n] [--Seed s]      (+ deprecated --UDPath/--MeanPath/--BedPath)
+//
+// --BamFile needs htslib (absent from this build: SURVEY.md section 8f rank 3); use
+// the reference's own --OutputPileup file with --PileupFile instead.
+// Extension: --Device n selects the GPU.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/vb2_abi.h"
+
+namespace {
+
+struct Flag {
+    enum Kind { kBool, kInt, kDouble, kString } kind;
+    void* dst;
+    bool seen;
+};
+
+void fatal(const char* msg)
+{
+    std::fprintf(stderr, "\nFATAL ERROR - \n%s\n\n", msg);
+    std::exit(EXIT_FAILURE);
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    std::fprintf(stderr,
+                 "VerifyBamID2 (MI355X-native likelihood core): DNA contamination estimation from "
+                 "sequence reads using ancestry-agnostic method.\n\n");
+
+    // defaults: main.cpp:58-79
+    std::string UDPath("Empty"), MeanPath("Empty"), BedPath("Empty"), BamFile("Empty"),
+        RefPath("Empty"), outputPrefix("result"), PileupFile("Empty"), SVDPrefix("Empty"),
+        knownAF("Empty"), fixPC("Empty");
+    double fixAlpha = -1., epsilon = 1e-8;
+    bool withinAncestry = false, outputPileup = false, verbose = false, disableSanityCheck = false;
+    int seed = 12345, nPC = 2, nthread = 4, device = -1;
+
+    std::map<std::string, Flag> flags = {
+        {"BamFile", {Flag::kString, &BamFile, false}},
+        {"PileupFile", {Flag::kString, &PileupFile, false}},
+        {"Reference", {Flag::kString, &RefPath, false}},
+        {"SVDPrefix", {Flag::kString, &SVDPrefix, false}},
+        {"Output", {Flag::kString, &outputPrefix, false}},
+        {"WithinAncestry", {Flag::kBool, &withinAncestry, false}},
+        {"DisableSanityCheck", {Flag::kBool, &disableSanityCheck, false}},
+        {"NumPC", {Flag::kInt, &nPC, false}},
+        {"FixPC", {Flag::kString, &fixPC, false}},
+        {"FixAlpha", {Flag::kDouble, &fixAlpha, false}},
+        {"KnownAF", {Flag::kString, &knownAF, false}},
+        {"NumThread", {Flag::kInt, &nthread, false}},
+        {"Seed", {Flag::kInt, &seed, false}},
+        {"Epsilon", {Flag::kDouble, &epsilon, false}},
+        {"OutputPileup", {Flag::kBool, &outputPileup, false}},
+        {"Verbose", {Flag::kBool, &verbose, false}},
+        {"UDPath", {Flag::kString, &UDPath, false}},
+        {"MeanPath", {Flag::kString, &MeanPath, false}},
+        {"BedPath", {Flag::kString, &BedPath, false}},
+        {"Device", {Flag::kInt, &device, false}},
+    };
+    for (int i = 1; i < argc; ++i) {
+        const char* a = argv[i];
+        if (std::strncmp(a, "--", 2) != 0) {
+            std::fprintf(stderr, "WARNING - ignoring stray argument %s\n", a);
+            continue;
+        }
+        auto it = flags.find(a + 2);
+        if (it == flags.end()) {
+            std::fprintf(stderr, "WARNING - unknown option %s ignored\n", a);
+            continue;
+        }
+        Flag& f = it->second;
+        if (f.seen) {   // params.cpp:114-185: an option may be given once
+            std::string m = std::string("Option ") + a + " specified more than once";
+            fatal(m.c_str());
+        }
+        f.seen = true;
+        if (f.kind == Flag::kBool) {
+            *static_cast<bool*>(f.dst) = true;
+            continue;
+        }
+        if (i + 1 >= argc) {
+            std::string m = std::string("Option ") + a + " needs a value";
+            fatal(m.c_str());
+        }
+        const char* v = argv[++i];
+        if (f.kind == Flag::kInt) *static_cast<int*>(f.dst) = std::atoi(v);
+        else if (f.kind == Flag::kDouble) *static_cast<double*>(f.dst) = std::atof(v);
+        else *static_cast<std::string*>(f.dst) = v;
+    }
+    (void)seed;     // parsed and never used by the reference either (main.cpp:137,286)
+    (void)nthread;  // the likelihood runs on the GPU; kept for command-line compatibility
+
+    // main.cpp:214-232
+    if (SVDPrefix == "Empty") {
+        if (UDPath == "Empty") fatal("--UDPath is required when --RefVCF is absent");
+        if (MeanPath == "Empty") fatal("--MeanPath is required when --RefVCF is absent");
+        if (BedPath == "Empty") fatal("--BedPath is required when --RefVCF is absent");
+    } else {
+        UDPath = SVDPrefix + ".UD";
+        MeanPath = SVDPrefix + ".mu";
+        BedPath = SVDPrefix + ".bed";
+    }
+    if (RefPath == "Empty") fatal("--Reference is required");          // main.cpp:263-266
+    if (BamFile != "Empty")
+        fatal("--BamFile needs htslib, which this build does not have; run the reference once with "
+              "--OutputPileup and pass the result with --PileupFile");
+    if (PileupFile == "Empty") fatal("--BamFile or --PileupFile is required");   // main.cpp:278-281
+
+    vb2_run_args args;
+    std::memset(&args, 0, sizeof(args));
+    args.ud_path = UDPath.c_str();
+    args.mean_path = MeanPath.c_str();
+    args.bed_path = BedPath.c_str();
+    args.pileup_path = PileupFile.c_str();
+    args.known_af_path = knownAF == "Empty" ? nullptr : knownAF.c_str();
+    args.output_prefix = outputPrefix.c_str();
+    args.num_pc = nPC;
+    args.disable_sanity = disableSanityCheck;
+    args.output_pileup = outputPileup;
+    args.device = device;
+    args.model.is_heter = !withinAncestry;
+    args.model.epsilon = epsilon;
+    args.model.verbose = verbose;
+
+    std::vector<double> tmpPC;
+    if (fixPC != "Empty") {                                            // main.cpp:291-308
+        std::fprintf(stderr, "NOTICE - you specified --fixPC, this will overide dynamic estimation of PCs\n");
+        std::stringstream ss(fixPC);
+        std::string token;
+        while (std::getline(ss, token, ':')) tmpPC.push_back(std::atof(token.c_str()));
+        if ((int)tmpPC.size() > nPC)
+            std::fprintf(stderr, "WARNING - parameter --fixPC provided larger dimension than parameter "
+                                 "--numPC(default value 2) and hence will be truncated\n");
+        if ((int)tmpPC.size() < nPC)
+            fatal("parameter --fixPC provided smaller dimension than parameter --numPC(default value 2)");
+        args.model.is_pc_fixed = 1;
+        args.model.fix_pc = tmpPC.data();
+    } else if (std::fabs(fixAlpha + 1.) > std::numeric_limits<double>::epsilon()) {   // main.cpp:309-313
+        std::fprintf(stderr, "NOTICE - you specified --fixAlpha, this will overide dynamic estimation of alpha\n");
+        args.model.is_alpha_fixed = 1;
+        args.model.fix_alpha = fixAlpha;
+    }
+    if (args.known_af_path) args.model.is_af_known = 1;               // main.cpp:314-319
+
+    vb2_run_result res;
+    const int rc = vb2_run(&args, &res);
+    if (rc != VB2_OK) {
+        if (rc == VB2_ERR_SANITY) std::fprintf(stderr, "WARNING - %s\n", vb2_last_error());
+        else std::fprintf(stderr, "\nFATAL ERROR - \n%s\n\n", vb2_last_error());
+        return EXIT_FAILURE;
+    }
+    std::fprintf(stderr, "NOTICE -   Finished phase: Load + flatten  [%.3f seconds]\n", res.seconds_load);
+    std::fprintf(stderr, "NOTICE -   Finished phase: Optimize likelihood  [%.3f seconds] "
+                         "(%lld likelihood evaluations, %lld points launched)\n",
+                 res.seconds_optimize, (long long)res.est.num_eval, (long long)res.est.num_launch_point);
+    if (!res.est.converged)
+        std::fprintf(stderr, "WARNING - Amoeba.Minimize - Couldn't converge in 50000 cycles\n");
+    std::fprintf(stderr, "NOTICE - Success!\n");
+    return 0;
+}

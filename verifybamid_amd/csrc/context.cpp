@@ -1,0 +1,374 @@
+// context.cpp -- vb2_ctx: one-time flattening of the pileup + panel into the
+// device SoA layout, and the batched likelihood evaluation entry points.
+//
+// Reference behaviour restated here (file:line relative to the reference root):
+//   marker skipping          ContaminationEstimator.h:236-249
+//   classifyBase / q clamp   ContaminationEstimator.h:180-184, 296-298
+//   Phred table              ContaminationEstimator.h:65-74
+//   COND_LK                  ContaminationEstimator.h:164-177
+// Everything that does not depend on (alpha, PC) is hoisted out of the
+// per-evaluation path: see DESIGN.md "What is computed once".
+#include "context.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace vb2 {
+
+thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+#define VB2_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_error(std::string(#call) + " failed: " + hipGetErrorString(e_));       \
+            return VB2_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+int usable_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0)
+            ++ok;
+    }
+    return ok;
+}
+
+namespace {
+
+// P(class | genotype, error?)  [err][geno][class], class 0 ref, 1 alt, 2 other
+const double kCond[2][3][3] = {
+    {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.0}, {0.0, 1.0, 0.0}},
+    {{0.0, 1.0 / 3.0, 2.0 / 3.0}, {1.0 / 6.0, 1.0 / 6.0, 2.0 / 3.0}, {1.0 / 3.0, 0.0, 2.0 / 3.0}},
+};
+
+inline int classify_base(char base, char alt)
+{
+    if (base == '.' || base == ',') return 0;
+    if (std::toupper((unsigned char)base) == std::toupper((unsigned char)alt)) return 1;
+    return 2;
+}
+
+inline int clamp_qual(char qc)
+{
+    int q = (int)(unsigned char)qc - 33;
+    if (q < 0) q = 0;
+    else if (q > 93) q = 93;
+    return q;
+}
+
+template <typename T>
+int upload(const std::vector<T>& h, T** d, int64_t* bytes)
+{
+    *d = nullptr;
+    if (h.empty()) return VB2_OK;
+    VB2_HIP(hipMalloc((void**)d, h.size() * sizeof(T)));
+    VB2_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *bytes += (int64_t)(h.size() * sizeof(T));
+    return VB2_OK;
+}
+
+}  // namespace
+
+Context::~Context()
+{
+    if (device >= 0) (void)hipSetDevice(device);
+    auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
+    fr(L.codes); fr(L.tile_row_off); fr(L.tile_rows); fr(L.ud); fr(L.mu); fr(L.ediag);
+    fr(L.known_af); fr(L.dict_perr);
+    fr(d_partials);
+    if (h_points) (void)hipHostFree(h_points);
+    if (h_out) (void)hipHostFree(h_out);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
+{
+    *out = nullptr;
+    if (!in || in->num_marker < 0 || in->num_pc < 1 || in->num_pc > VB2_MAX_PC || !in->read_off ||
+        (!in->known_af && (!in->ud || !in->means))) {
+        set_error("vb2_ctx_create: invalid input");
+        return VB2_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        set_error("vb2_ctx_create: no HIP device visible (this library has no CPU fallback)");
+        return VB2_ERR_NO_DEVICE;
+    }
+    int dev = opt ? opt->device : -1;
+    if (dev < 0) VB2_HIP(hipGetDevice(&dev));
+    if (dev >= ndev) {
+        set_error("vb2_ctx_create: device ordinal out of range");
+        return VB2_ERR_INVALID;
+    }
+    hipDeviceProp_t prop;
+    VB2_HIP(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("vb2_ctx_create: device is ") + prop.gcnArchName +
+                  ", kernels are built for gfx950 only");
+        return VB2_ERR_NO_DEVICE;
+    }
+    VB2_HIP(hipSetDevice(dev));
+
+    std::unique_ptr<Context> c(new Context());
+    c->device = dev;
+    c->num_marker = in->num_marker;
+    c->num_pc = in->num_pc;
+    std::snprintf(c->device_name, sizeof(c->device_name), "%s", prop.name);
+    std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
+
+    const int M = in->num_marker, k = in->num_pc;
+
+    // ---- Phred table, exactly the reference's pow() (h:65-74) ----
+    double phred[kNumQual];
+    for (int i = 0; i < kNumQual; ++i) phred[i] = std::pow(10.0, i / -10.0);
+
+    // log c[class][q][g], c = E[g][class]*pErr + N[g][class]*pOk: the alpha-free
+    // value of the table entry for g1 == g2 (and for class "other", any g1,g2).
+    std::vector<double> logc(3 * kNumQual * 3);
+    for (int bc = 0; bc < 3; ++bc)
+        for (int q = 0; q < kNumQual; ++q)
+            for (int g = 0; g < 3; ++g)
+                logc[(bc * kNumQual + q) * 3 + g] =
+                    std::log(kCond[1][g][bc] * phred[q] + kCond[0][g][bc] * (1.0 - phred[q]));
+
+    // ---- pass 1: which markers count (h:239-249), code histogram ----
+    std::vector<int32_t> active;
+    active.reserve(M);
+    std::vector<int64_t> code_hist(kMaxCode, 0);
+    const double lo = in->avg_depth - 3 * in->sd_depth, hi = in->avg_depth + 3 * in->sd_depth;
+    int64_t num_read = 0, num_other = 0;
+    std::vector<int32_t> eff_depth;
+    eff_depth.reserve(M);
+    for (int i = 0; i < M; ++i) {
+        const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
+        if (depth < 0) {
+            set_error("vb2_ctx_create: read_off not monotone");
+            return VB2_ERR_INVALID;
+        }
+        if (depth == 0) continue;
+        if (!in->sanity_disabled && ((double)depth < lo || (double)depth > hi)) continue;
+        int32_t eff = 0;
+        const char alt = in->alt_base[i];
+        for (int64_t j = 0; j < depth; ++j) {
+            const int bc = classify_base(in->bases[beg + j], alt);
+            if (bc == 2) { ++num_other; continue; }
+            ++code_hist[bc * kNumQual + clamp_qual(in->quals[beg + j])];
+            ++eff;
+        }
+        num_read += depth;
+        active.push_back(i);
+        eff_depth.push_back(eff);
+    }
+    const int64_t m_active = (int64_t)active.size();
+
+    // ---- dictionary: observed (class, q) pairs, most frequent first ----
+    std::vector<int> order;
+    for (int c2 = 0; c2 < kMaxCode; ++c2)
+        if (code_hist[c2] > 0) order.push_back(c2);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return code_hist[a] > code_hist[b]; });
+    const int num_code = (int)order.size();
+    std::vector<uint8_t> dict_of(kMaxCode, (uint8_t)kPadCode);
+    std::vector<double> dict_perr(num_code);
+    for (int d = 0; d < num_code; ++d) {
+        dict_of[order[d]] = (uint8_t)d;
+        const double pe = phred[order[d] % kNumQual];
+        dict_perr[d] = (order[d] / kNumQual) ? -pe : pe;      // sign carries the class
+    }
+
+    // ---- sort markers by effective depth (descending, stable) and tile ----
+    std::vector<int64_t> perm(m_active);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(),
+                     [&](int64_t a, int64_t b) { return eff_depth[a] > eff_depth[b]; });
+    const int num_tile = (int)((m_active + 63) / 64);
+    const int64_t m_pad = (int64_t)num_tile * 64;
+
+    std::vector<uint32_t> tile_row_off(num_tile), tile_rows(num_tile);
+    uint64_t total_rows = 0;
+    for (int t = 0; t < num_tile; ++t) {
+        const int32_t dmax = eff_depth[perm[(int64_t)t * 64]];   // sorted: first lane is deepest
+        tile_row_off[t] = (uint32_t)total_rows;
+        tile_rows[t] = (uint32_t)((dmax + 3) / 4);
+        total_rows += tile_rows[t];
+    }
+    if (total_rows >= (1ull << 32)) {
+        set_error("vb2_ctx_create: input too large for 32-bit row offsets");
+        return VB2_ERR_INVALID;
+    }
+
+    // unused step slots hold the padding code = num_code, a zero row of the LDS table
+    const uint32_t pad4 = 0x01010101u * (uint32_t)num_code;
+    std::vector<uint32_t> codes((size_t)total_rows * 64, pad4);
+    std::vector<double> ud_s((size_t)k * m_pad, 0.0), mu_s(m_pad, 0.0), cdiag((size_t)4 * m_pad, 0.0);
+    std::vector<double> kaf_s;
+    if (in->known_af) kaf_s.assign(m_pad, 0.0);
+    std::vector<uint8_t> tmp;
+    for (int64_t m = 0; m < m_active; ++m) {
+        const int i = active[perm[m]];
+        const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
+        const char alt = in->alt_base[i];
+        double c_other = 0.0, dg[3] = {0.0, 0.0, 0.0};
+        tmp.clear();
+        for (int64_t j = 0; j < depth; ++j) {
+            const int bc = classify_base(in->bases[beg + j], alt);
+            const int q = clamp_qual(in->quals[beg + j]);
+            const double* lc = &logc[(bc * kNumQual + q) * 3];
+            if (bc == 2) {
+                c_other += lc[0];           // same for every genotype pair
+            } else {
+                dg[0] += lc[0]; dg[1] += lc[1]; dg[2] += lc[2];
+                tmp.push_back(dict_of[bc * kNumQual + q]);
+            }
+        }
+        // reads of a marker in dictionary order: lanes of a wave then tend to hit
+        // the same or neighbouring LDS table rows at the same step (bank-friendly)
+        std::sort(tmp.begin(), tmp.end());
+        const int t = (int)(m / 64), lane = (int)(m % 64);
+        uint8_t* row0 = reinterpret_cast<uint8_t*>(&codes[(size_t)tile_row_off[t] * 64]);
+        for (size_t j = 0; j < tmp.size(); ++j)
+            row0[((j >> 2) * 64 + lane) * 4 + (j & 3)] = tmp[j];
+        if (in->known_af) {
+            kaf_s[m] = in->known_af[i];
+        } else {
+            for (int kk = 0; kk < k; ++kk) ud_s[(size_t)kk * m_pad + m] = in->ud[(size_t)i * k + kk];
+            mu_s[m] = in->means[i];
+        }
+        // the g1 == g2 terms of h:307-311 are constants of the marker
+        cdiag[m] = c_other;
+        cdiag[m_pad + m] = std::exp(dg[0] + c_other);
+        cdiag[2 * m_pad + m] = std::exp(dg[1] + c_other);
+        cdiag[3 * m_pad + m] = std::exp(dg[2] + c_other);
+    }
+
+    // ---- upload ----
+    int rc;
+    DeviceLayout& L = c->L;
+    std::memset(&L, 0, sizeof(L));
+    uint32_t* d_codes; uint32_t* d_tro; uint32_t* d_tr; double* d_ud; double* d_mu; double* d_cd;
+    double* d_kaf; double* d_dpe;
+    if ((rc = upload(codes, &d_codes, &c->device_bytes))) return rc;
+    L.codes = d_codes;
+    if ((rc = upload(tile_row_off, &d_tro, &c->device_bytes))) return rc;
+    L.tile_row_off = d_tro;
+    if ((rc = upload(tile_rows, &d_tr, &c->device_bytes))) return rc;
+    L.tile_rows = d_tr;
+    if (!in->known_af) {
+        if ((rc = upload(ud_s, &d_ud, &c->device_bytes))) return rc;
+        L.ud = d_ud;
+        if ((rc = upload(mu_s, &d_mu, &c->device_bytes))) return rc;
+        L.mu = d_mu;
+    } else {
+        if ((rc = upload(kaf_s, &d_kaf, &c->device_bytes))) return rc;
+        L.known_af = d_kaf;
+    }
+    if ((rc = upload(cdiag, &d_cd, &c->device_bytes))) return rc;
+    L.ediag = d_cd;
+    if ((rc = upload(dict_perr, &d_dpe, &c->device_bytes))) return rc;
+    L.dict_perr = d_dpe;
+    L.num_code = num_code;
+    L.num_tile = num_tile;
+    L.num_pc = k;
+    L.num_active = m_active;
+    L.m_pad = m_pad;
+
+    c->num_read = num_read;
+    c->num_read_other = num_other;
+    c->algorithmic_bytes = 2 * num_read + m_active * (8 * (int64_t)k + 12);
+
+    const int nb = std::max(1, num_blocks_for(L));
+    VB2_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * (size_t)max_points_per_launch() * nb));
+    // Host <-> device hand-off of the (tiny) parameter and result vectors goes through
+    // pinned, device-mapped host memory that the kernels access directly: no copy
+    // commands on the evaluation path.
+    const size_t pt_bytes = sizeof(double) * (size_t)kStagePoints * (2 * k + 1);
+    VB2_HIP(hipHostMalloc((void**)&c->h_points, pt_bytes, hipHostMallocMapped));
+    VB2_HIP(hipHostMalloc((void**)&c->h_out, sizeof(double) * kStagePoints, hipHostMallocMapped));
+    VB2_HIP(hipHostGetDevicePointer((void**)&c->d_points, c->h_points, 0));
+    VB2_HIP(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
+    c->device_bytes += (int64_t)(sizeof(double) * (size_t)max_points_per_launch() * nb);
+    if (opt && opt->stream) {
+        c->stream = (hipStream_t)opt->stream;
+        c->own_stream = false;
+    } else {
+        VB2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    VB2_HIP(hipDeviceSynchronize());
+    *out = c.release();
+    return VB2_OK;
+}
+
+int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipStream_t s)
+{
+    if (num_point <= 0) return VB2_OK;
+    VB2_HIP(hipSetDevice(device));
+    if (!s) s = stream;
+    if (L.num_tile == 0) {
+        VB2_HIP(launch_fill_zero(d_llk, num_point, s));
+        return VB2_OK;
+    }
+    VB2_HIP(launch_llk_eval(L, num_point, d_pts, d_partials, d_llk, s));
+    return VB2_OK;
+}
+
+int Context::eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,
+                       double* llk_out)
+{
+    if (num_point < 0 || (num_point > 0 && (!pc1 || !pc2 || !alpha || !llk_out))) {
+        set_error("vb2_llk_eval_batch: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    VB2_HIP(hipSetDevice(device));
+    const int k = num_pc, stride = 2 * k + 1;
+    for (int done = 0; done < num_point; done += kStagePoints) {
+        const int n = std::min(kStagePoints, num_point - done);
+        for (int b = 0; b < n; ++b) {
+            double* row = h_points + (size_t)b * stride;
+            std::memcpy(row, pc1 + (size_t)(done + b) * k, sizeof(double) * k);
+            std::memcpy(row + k, pc2 + (size_t)(done + b) * k, sizeof(double) * k);
+            row[2 * k] = alpha[done + b];
+        }
+        int rc = eval_device(n, d_points, d_out, stream);
+        if (rc) return rc;
+        VB2_HIP(hipStreamSynchronize(stream));
+        std::memcpy(llk_out + done, h_out, sizeof(double) * n);
+    }
+    return VB2_OK;
+}
+
+void Context::fill_info(vb2_info* info) const
+{
+    std::memset(info, 0, sizeof(*info));
+    info->abi_version = VB2_ABI_VERSION;
+    info->device = device;
+    info->num_marker = num_marker;
+    info->num_pc = num_pc;
+    info->num_active_marker = L.num_active;
+    info->num_read = num_read;
+    info->num_read_other = num_read_other;
+    info->num_code = L.num_code;
+    info->num_tile = L.num_tile;
+    info->device_bytes = device_bytes;
+    info->algorithmic_bytes_per_eval = algorithmic_bytes;
+    std::snprintf(info->device_name, sizeof(info->device_name), "%s", device_name);
+    std::snprintf(info->arch, sizeof(info->arch), "%s", arch);
+}
+
+}  // namespace vb2

@@ -1,0 +1,55 @@
+// context.h -- vb2_ctx internals.
+#ifndef VB2_CONTEXT_H_
+#define VB2_CONTEXT_H_
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <memory>
+#include <string>
+
+#include "../../include/vb2_abi.h"
+#include "llk_kernels.h"
+
+namespace vb2 {
+
+void set_error(const std::string& msg);
+extern thread_local std::string g_last_error;
+int usable_device_count();
+
+constexpr int kStagePoints = 256;   // points per host<->device staging round
+
+class Context {
+public:
+    ~Context();
+    static int create(const vb2_input* in, const vb2_options* opt, Context** out);
+    // device pointers, asynchronous on s (nullptr = own stream)
+    int eval_device(int num_point, const double* d_points, double* d_llk, hipStream_t s);
+    // host pointers, synchronous
+    int eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,
+                  double* llk_out);
+    void fill_info(vb2_info* info) const;
+
+    int device = -1;
+    int num_marker = 0;
+    int num_pc = 0;
+    DeviceLayout L{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double* d_partials = nullptr;
+    double* h_points = nullptr;   // pinned + device-mapped staging (host view)
+    double* h_out = nullptr;
+    double* d_points = nullptr;   // device view of the same memory
+    double* d_out = nullptr;
+    int64_t num_read = 0, num_read_other = 0, device_bytes = 0, algorithmic_bytes = 0;
+    char device_name[64] = {0};
+    char arch[32] = {0};
+};
+
+}  // namespace vb2
+
+struct vb2_ctx {
+    vb2::Context* impl;
+};
+
+#endif

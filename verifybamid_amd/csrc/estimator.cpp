@@ -1,0 +1,315 @@
+// estimator.cpp -- see estimator.h.
+#include "estimator.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+namespace vb2 {
+
+double FullLLKFunc::InvLogit(double x)
+{
+    const double e = std::exp(x);
+    return e / (1. + e);
+}
+
+double FullLLKFunc::Logit(double x) { return std::log(x / (1. - x)); }
+
+int FullLLKFunc::LLK(const double* pc1, const double* pc2, double alpha, double* out)
+{
+    ptr->num_launch_point += 1;
+    return ptr->eval_(ptr->user_, 1, pc1, pc2, &alpha, out);
+}
+
+static void record(Estimator* e, const double* pc1, const double* pc2, double alpha, double llk)
+{
+    e->num_eval++;
+    vb2_trace* t = e->trace;
+    if (!t) return;
+    if (t->count < t->capacity) {
+        const int64_t r = t->count;
+        const int k = e->numPC;
+        t->alpha[r] = alpha;
+        t->llk[r] = llk;
+        std::memcpy(t->pc1 + r * k, pc1, sizeof(double) * k);
+        std::memcpy(t->pc2 + r * k, pc2, sizeof(double) * k);
+    }
+    t->count++;
+}
+
+int FullLLKFunc::Initialize()
+{
+    globalPC = fixPC = globalPC2 = fixPC2 = ptr->PC[1];   // h:317
+    globalAlpha = fixAlpha = ptr->alpha;                   // h:318
+    double v = 0;
+    int rc = LLK(fixPC.data(), fixPC2.data(), fixAlpha, &v);
+    if (rc) return rc;
+    record(ptr, fixPC.data(), fixPC2.data(), fixAlpha, v);
+    llk1 = (0 - v);                                        // h:319
+    for (int k = 0; k < ptr->numPC; ++k) ptr->PC[0][k] = 0.01;
+    for (int k = 0; k < ptr->numPC; ++k) ptr->PC[1][k] = 0.01;
+    ptr->alpha = 0.03;
+    return 0;
+}
+
+int FullLLKFunc::CalculateLLK0()
+{
+    double v = 0;
+    int rc = LLK(globalPC.data(), globalPC.data(), 0, &v);
+    if (rc) return rc;
+    record(ptr, globalPC.data(), globalPC.data(), 0, v);
+    llk0 = (0 - v);
+    return 0;
+}
+
+// The six packings of h:339-433 (table in SURVEY.md 3.2).
+void FullLLKFunc::Unpack(const double* v, int dim, double* pc1, double* pc2, double* a) const
+{
+    const int k = ptr->numPC;
+    if (!ptr->isHeter) {
+        if (ptr->isPCFixed) {                               // h:342-348
+            std::memcpy(pc1, fixPC.data(), sizeof(double) * k);
+            std::memcpy(pc2, fixPC2.data(), sizeof(double) * k);
+            *a = InvLogit(v[0]);
+        } else if (ptr->isAlphaFixed) {                     // h:349-360
+            std::memcpy(pc1, v, sizeof(double) * k);
+            std::memcpy(pc2, v, sizeof(double) * k);
+            *a = fixAlpha;
+        } else {                                            // h:361-374
+            std::memcpy(pc1, v, sizeof(double) * k);
+            std::memcpy(pc2, v, sizeof(double) * k);
+            *a = InvLogit(v[k]);
+        }
+    } else {
+        if (ptr->isPCFixed) {                               // h:377-389
+            std::memcpy(pc1, v, sizeof(double) * k);
+            std::memcpy(pc2, fixPC2.data(), sizeof(double) * k);
+            *a = InvLogit(v[k]);
+        } else if (ptr->isAlphaFixed) {                     // h:390-409
+            for (int i = 0; i < k; ++i) pc1[i] = pc2[i] = 0.;
+            for (int i = 0; i < dim; ++i) {
+                if (i < k) pc1[i] = v[i];
+                else if (i < 2 * k) pc2[i - k] = v[i];
+            }
+            *a = fixAlpha;
+        } else {                                            // h:410-433
+            for (int i = 0; i < k; ++i) pc1[i] = pc2[i] = 0.;
+            *a = 0.;
+            for (int i = 0; i < dim; ++i) {
+                if (i < k) pc1[i] = v[i];
+                else if (i < 2 * k) pc2[i - k] = v[i];
+                else if (i == 2 * k) *a = InvLogit(v[i]);
+            }
+        }
+    }
+}
+
+int FullLLKFunc::EvaluateBatch(int n, const double* pts, int dim, double* y)
+{
+    const int k = ptr->numPC;
+    std::vector<double> p1((size_t)n * k), p2((size_t)n * k), a(n), llk(n);
+    for (int b = 0; b < n; ++b)
+        Unpack(pts + (size_t)b * dim, dim, &p1[(size_t)b * k], &p2[(size_t)b * k], &a[b]);
+    ptr->num_launch_point += n;
+    const int rc = ptr->eval_(ptr->user_, n, p1.data(), p2.data(), a.data(), llk.data());
+    if (rc) return rc;
+    for (int b = 0; b < n; ++b) y[b] = 0 - llk[b];
+    return 0;
+}
+
+void FullLLKFunc::Commit(const double* v, int dim, double smLLK)
+{
+    const int k = ptr->numPC;
+    double p1[VB2_MAX_PC], p2[VB2_MAX_PC], a;
+    Unpack(v, dim, p1, p2, &a);
+    record(ptr, p1, p2, a, 0 - smLLK);
+    if (smLLK < llk1) {
+        llk1 = smLLK;
+        // which of (globalPC, globalPC2, globalAlpha) move depends on the model
+        // variant exactly as in h:345-432
+        if (!ptr->isHeter) {
+            if (ptr->isPCFixed) {
+                globalAlpha = a;
+            } else if (ptr->isAlphaFixed) {
+                globalPC.assign(p1, p1 + k);
+                globalPC2.assign(p1, p1 + k);
+            } else {
+                globalPC.assign(p1, p1 + k);
+                globalPC2.assign(p1, p1 + k);
+                globalAlpha = a;
+            }
+        } else {
+            if (ptr->isPCFixed) {
+                globalPC.assign(p1, p1 + k);
+                globalAlpha = a;
+            } else if (ptr->isAlphaFixed) {
+                globalPC.assign(p1, p1 + k);
+                globalPC2.assign(p2, p2 + k);
+            } else {
+                globalPC.assign(p1, p1 + k);
+                globalPC2.assign(p2, p2 + k);
+                globalAlpha = a;
+            }
+        }
+    }
+    if (ptr->verbose)   // h:435-440 (the reference hard-codes PC indices 0 and 1)
+        std::fprintf(stderr,
+                     "NOTICE - ContaminatingSamplePC1:%f\tContaminatingSamplePC2:%f\t"
+                     "IntendedSamplePC1:%f\tIntendedSamplePC2:%f\tFREEMIX(Alpha):%f\tllk:%f\n",
+                     globalPC[0], k > 1 ? globalPC[1] : 0.0, globalPC2[0],
+                     k > 1 ? globalPC2[1] : 0.0, globalAlpha, llk1);
+}
+
+Estimator::Estimator(int nPC, vb2_eval_fn eval, void* user)
+    : numPC(nPC), PC(2, std::vector<double>(nPC, 0.)), eval_(eval), user_(user)
+{
+    fn.ptr = this;
+    fn.fixPC.assign(nPC, 0.);
+    fn.fixPC2 = fn.globalPC = fn.globalPC2 = fn.fixPC;
+}
+
+static bool run_minimizer(Estimator* e, AmoebaMinimizer& m, int dim,
+                          const std::vector<double>& start, double* ret)
+{
+    m.func = &e->fn;
+    m.speculate = e->speculate;
+    m.Reset(dim);
+    m.point = start;
+    *ret = m.Minimize(e->epsilon);
+    if (m.error && !e->error) e->error = m.error;
+    return *ret != std::numeric_limits<double>::max();
+}
+
+bool Estimator::OptimizeHeter(AmoebaMinimizer& m)
+{
+    std::vector<double> start(numPC * 2 + 1);
+    for (int i = 0; i < numPC * 2; ++i) start[i] = i < numPC ? PC[0][i] : PC[1][i - numPC];
+    start[numPC * 2] = FullLLKFunc::Logit(alpha);
+    double ret;
+    const bool ok = run_minimizer(this, m, numPC * 2 + 1, start, &ret);
+    alpha = FullLLKFunc::InvLogit(m.point[numPC * 2]);
+    for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
+    for (int i = numPC; i < numPC * 2; ++i) PC[1][i - numPC] = m.point[i];
+    return ok;
+}
+
+bool Estimator::OptimizeHeterFixedAlpha(AmoebaMinimizer& m)
+{
+    std::vector<double> start(numPC * 2);
+    for (int i = 0; i < numPC * 2; ++i) start[i] = i < numPC ? PC[0][i] : PC[1][i - numPC];
+    double ret;
+    const bool ok = run_minimizer(this, m, numPC * 2, start, &ret);
+    for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
+    for (int i = numPC; i < numPC * 2; ++i) PC[1][i - numPC] = m.point[i];
+    return ok;
+}
+
+bool Estimator::OptimizeHeterFixedPC(AmoebaMinimizer& m) { return OptimizeHomo(m); }
+
+bool Estimator::OptimizeHomo(AmoebaMinimizer& m)
+{
+    std::vector<double> start(numPC + 1);
+    for (int i = 0; i < numPC; ++i) start[i] = PC[0][i];
+    start[numPC] = FullLLKFunc::Logit(alpha);
+    double ret;
+    const bool ok = run_minimizer(this, m, numPC + 1, start, &ret);
+    alpha = FullLLKFunc::InvLogit(m.point[numPC]);
+    for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
+    return ok;
+}
+
+bool Estimator::OptimizeHomoFixedAlpha(AmoebaMinimizer& m)
+{
+    std::vector<double> start(numPC);
+    for (int i = 0; i < numPC; ++i) start[i] = PC[0][i];
+    double ret;
+    const bool ok = run_minimizer(this, m, numPC, start, &ret);
+    for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
+    return ok;
+}
+
+bool Estimator::OptimizeHomoFixedPC(AmoebaMinimizer& m)
+{
+    std::vector<double> start(1);
+    start[0] = FullLLKFunc::Logit(alpha);
+    double ret;
+    const bool ok = run_minimizer(this, m, 1, start, &ret);
+    alpha = FullLLKFunc::InvLogit(m.point[0]);
+    return ok;
+}
+
+int Estimator::OptimizeLLK()
+{
+    AmoebaMinimizer mini;
+    int rc = fn.Initialize();
+    if (rc) return rc;
+    bool ok = true;
+    if (!isHeter) {                                       // cpp:98-110
+        if (isPCFixed) ok &= OptimizeHomoFixedPC(mini);
+        else if (isAlphaFixed) ok &= OptimizeHomoFixedAlpha(mini);
+        else ok &= OptimizeHomo(mini);
+    } else {                                              // cpp:111-150
+        if (isPCFixed) {
+            ok &= OptimizeHeterFixedPC(mini);
+        } else if (isAlphaFixed) {
+            isHeter = false;
+            ok &= OptimizeHomoFixedAlpha(mini);
+            PC[1] = PC[0];
+            fn.globalPC2 = fn.globalPC;
+            isHeter = true;
+            ok &= OptimizeHeterFixedAlpha(mini);
+        } else {
+            isHeter = false;
+            ok &= OptimizeHomo(mini);
+            PC[1] = PC[0];
+            fn.globalPC2 = fn.globalPC;
+            isHeter = true;
+            ok &= OptimizeHeter(mini);
+        }
+        if (fn.globalAlpha >= 0.5) {                      // cpp:146-149 (indices 0,1 hard-coded)
+            std::swap(fn.globalPC[0], fn.globalPC2[0]);
+            if (numPC >= 2) std::swap(fn.globalPC[1], fn.globalPC2[1]);
+        }
+    }
+    if (error) return error;
+    converged = ok;
+    return fn.CalculateLLK0();                            // cpp:152-155
+}
+
+void apply_model(Estimator& est, const vb2_model& model)
+{
+    // main.cpp:285-319
+    est.verbose = model.verbose != 0;
+    est.isHeter = model.is_heter != 0;
+    if (model.epsilon > 0) est.epsilon = model.epsilon;
+    if (model.is_pc_fixed && model.fix_pc) {
+        for (int i = 0; i < est.numPC; ++i) est.PC[1][i] = model.fix_pc[i];
+        est.isPCFixed = true;
+    } else if (model.is_alpha_fixed) {
+        est.alpha = model.fix_alpha;
+        est.isAlphaFixed = true;
+    }
+    if (model.is_af_known) {
+        est.isAFknown = true;
+        est.isPCFixed = true;
+        est.isHeter = false;
+    }
+}
+
+void fill_estimate(const Estimator& est, vb2_estimate* out)
+{
+    std::memset(out, 0, sizeof(*out));
+    out->alpha = est.fn.globalAlpha;
+    out->llk1 = est.fn.llk1;
+    out->llk0 = est.fn.llk0;
+    for (int i = 0; i < est.numPC; ++i) {
+        out->pc[i] = est.fn.globalPC[i];
+        out->pc2[i] = est.fn.globalPC2[i];
+    }
+    out->num_eval = est.num_eval;
+    out->num_launch_point = est.num_launch_point;
+    out->converged = est.converged ? 1 : 0;
+}
+
+}  // namespace vb2

@@ -1,0 +1,79 @@
+// estimator.h -- host-side mirror of the reference's optimisation layer:
+//   FullLLKFunc   (ContaminationEstimator.h:76-443)   -> vb2::FullLLKFunc
+//   OptimizeLLK + Optimize{Homo,Heter}{,FixedPC,FixedAlpha}
+//                 (ContaminationEstimator.cpp:88-332) -> vb2::Estimator
+// The likelihood itself is NOT computed here: every value comes from the
+// evaluator callback (vb2_eval_fn), i.e. the HIP kernels behind the C-ABI.
+#ifndef VB2_ESTIMATOR_H_
+#define VB2_ESTIMATOR_H_
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/vb2_abi.h"
+#include "amoeba.h"
+
+namespace vb2 {
+
+class Estimator;
+
+class FullLLKFunc : public BatchObjective {
+public:
+    Estimator* ptr = nullptr;
+    double llk1 = 0., llk0 = 0.;
+    std::vector<double> fixPC, fixPC2, globalPC, globalPC2;
+    double fixAlpha = 0., globalAlpha = 0.;
+
+    static double InvLogit(double x);      // h:119-122
+    static double Logit(double x);         // h:124-127
+
+    int Initialize();                      // h:316-332
+    int CalculateLLK0();                   // h:334-337
+    int EvaluateBatch(int n, const double* pts, int dim, double* y) override;   // h:339-442 (values)
+    void Commit(const double* pt, int dim, double y) override;                  // h:339-442 (bookkeeping)
+
+private:
+    // simplex vector -> (pc1, pc2, alpha) for the active model variant
+    void Unpack(const double* v, int dim, double* pc1, double* pc2, double* alpha) const;
+    int LLK(const double* pc1, const double* pc2, double alpha, double* out);
+};
+
+class Estimator {
+public:
+    Estimator(int nPC, vb2_eval_fn eval, void* user);
+
+    // model flags, same names as the reference members (h:42-52)
+    bool isPCFixed = false, isAlphaFixed = false, isAFknown = false, isHeter = true;
+    bool verbose = false;
+    int numPC;
+    double epsilon = 1e-8;
+    double alpha = 0.5;                    // cpp:48
+    std::vector<std::vector<double>> PC;   // PC[0] contaminating, PC[1] intended (h:453)
+    FullLLKFunc fn;
+    bool speculate = true;
+
+    int OptimizeLLK();                     // cpp:88-155 (without the writers)
+
+    // bookkeeping
+    int64_t num_eval = 0, num_launch_point = 0;
+    bool converged = true;
+    int error = 0;
+    vb2_trace* trace = nullptr;
+
+    vb2_eval_fn eval_;
+    void* user_;
+
+private:
+    bool OptimizeHomoFixedPC(AmoebaMinimizer& m);      // cpp:315-332
+    bool OptimizeHomoFixedAlpha(AmoebaMinimizer& m);   // cpp:291-313
+    bool OptimizeHomo(AmoebaMinimizer& m);             // cpp:265-289
+    bool OptimizeHeterFixedPC(AmoebaMinimizer& m);     // cpp:261-263
+    bool OptimizeHeterFixedAlpha(AmoebaMinimizer& m);  // cpp:228-259
+    bool OptimizeHeter(AmoebaMinimizer& m);            // cpp:192-226
+};
+
+void apply_model(Estimator& est, const vb2_model& model);
+void fill_estimate(const Estimator& est, vb2_estimate* out);
+
+}  // namespace vb2
+#endif

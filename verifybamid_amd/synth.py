@@ -1,0 +1,101 @@
+"""Seeded synthetic pileups of the shapes BASELINE.json names (recipe: SURVEY.md 8d).
+
+Panel: UD ~ N(0, sigma_k) with column s.d. (7, 5, 3, 1.5, ...), mu ~ 2*Beta(0.8, 0.8)
+clipped to [0.02, 1.98].  Per marker: AF = clamp(mu/2); intended genotype
+g2 ~ Binom(2, AF), contaminant g1 ~ Binom(2, AF); depth ~ Poisson(mean_depth);
+each read comes from the contaminant with probability alpha_true, carries the alt
+allele with probability g/2, has Phred q ~ UniformInt[q_lo, q_hi], and is replaced by
+one of the three other bases with probability 10^(-q/10); strand 50/50 ('.'/',' for
+ref, upper/lower-case letter otherwise); quality character = q + 33.
+
+Pure numpy, deterministic for a given seed; the same arrays feed the HIP path and
+the oracle.  `write_files` emits a samtools-style pileup + .UD/.mu/.bed so the CLI and
+file readers can be exercised on the same data.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .api import PileupData
+
+_SD = (7.0, 5.0, 3.0, 1.5, 1.0, 0.8, 0.6, 0.5, 0.4, 0.3)
+_BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+_LOWER = np.frombuffer(b"acgt", dtype=np.uint8)
+
+
+def make_pileup(num_marker, mean_depth=30.0, num_pc=4, alpha_true=0.05, seed=1, q_lo=20, q_hi=40,
+                missing_frac=0.0):
+    rng = np.random.default_rng(seed)
+    M, k = int(num_marker), int(num_pc)
+    sd = np.array([_SD[i] if i < len(_SD) else 0.3 for i in range(k)])
+    ud = rng.normal(0.0, 1.0, size=(M, k)) * sd
+    mu = np.clip(2.0 * rng.beta(0.8, 0.8, size=M), 0.02, 1.98)
+    af = np.clip(mu / 2.0, 0.00005, 0.99995)
+    g2 = rng.binomial(2, af)
+    g1 = rng.binomial(2, af)
+    depth = rng.poisson(mean_depth, size=M).astype(np.int64)
+    if missing_frac > 0:
+        depth[rng.random(M) < missing_frac] = 0
+    ref_i = rng.integers(0, 4, size=M)
+    alt_i = (ref_i + rng.integers(1, 4, size=M)) % 4
+    read_off = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(depth, out=read_off[1:])
+    R = int(read_off[-1])
+    mk = np.repeat(np.arange(M), depth)
+    from_contam = rng.random(R) < alpha_true
+    g = np.where(from_contam, g1[mk], g2[mk])
+    is_alt = rng.random(R) < (g / 2.0)
+    q = rng.integers(q_lo, q_hi + 1, size=R)
+    err = rng.random(R) < np.power(10.0, -q / 10.0)
+    true_base = np.where(is_alt, alt_i[mk], ref_i[mk])
+    obs_base = np.where(err, (true_base + rng.integers(1, 4, size=R)) % 4, true_base)
+    fwd = rng.random(R) < 0.5
+    is_ref = obs_base == ref_i[mk]
+    ch = np.where(fwd, _BASES[obs_base], _LOWER[obs_base])
+    ch = np.where(is_ref, np.where(fwd, ord("."), ord(",")), ch).astype(np.uint8)
+    quals = (q + 33).astype(np.uint8)
+    alt_base = _BASES[alt_i]
+    nsite = int((depth > 0).sum())
+    avg = float(R) / nsite if nsite else float("nan")
+    d = PileupData(k, ud, mu, read_off, ch, quals, alt_base, None, avg, 0.0, True,
+                   dict(seed=seed, alpha_true=alpha_true, mean_depth=mean_depth,
+                        ref_base=_BASES[ref_i]))
+    return d
+
+
+def with_sanity_stats(d: PileupData):
+    """avgDepth/sdDepth as IsSanityCheckOK computes them (ContaminationEstimator.cpp:543-587),
+    enabling the +-3sd depth filter."""
+    depth = np.diff(d.read_off).astype(np.float64)
+    present = depth > 0
+    n = int(present.sum())
+    avg = depth.sum() / n
+    sd = float(np.sqrt((depth[present] ** 2).sum() / n - avg * avg))
+    return PileupData(d.num_pc, d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base, d.known_af,
+                      float(avg), sd, False, dict(d.meta))
+
+
+def write_files(d: PileupData, prefix):
+    """Write <prefix>.UD/.mu/.bed and <prefix>.pileup (6-column samtools pileup)."""
+    M = d.num_marker
+    ref = d.meta["ref_base"]
+    with open(prefix + ".UD", "w") as f:
+        for i in range(M):
+            f.write("\t".join(repr(float(x)) for x in d.ud[i]) + "\n")
+    with open(prefix + ".mu", "w") as f:
+        for i in range(M):
+            f.write("1:%d_%s/%s_rs%d\t%r\n" % (1000 + 10 * i, chr(ref[i]), chr(d.alt_base[i]), i,
+                                                float(d.means[i])))
+    with open(prefix + ".bed", "w") as f:
+        for i in range(M):
+            p = 1000 + 10 * i
+            f.write("1\t%d\t%d\t%s\t%s\n" % (p - 1, p, chr(ref[i]), chr(d.alt_base[i])))
+    bases = d.bases.tobytes().decode("latin-1")
+    quals = d.quals.tobytes().decode("latin-1")
+    with open(prefix + ".pileup", "w") as f:
+        for i in range(M):
+            b, e = int(d.read_off[i]), int(d.read_off[i + 1])
+            if e == b:
+                continue
+            f.write("1\t%d\t%s\t%d\t%s\t%s\n" % (1000 + 10 * i, chr(ref[i]), e - b, bases[b:e], quals[b:e]))
+    return prefix
