@@ -90,7 +90,7 @@ typedef struct vb2_info {
     int64_t num_read;          /* bases of the active markers                      */
     int64_t num_read_other;    /* of those, class "other" (folded into a constant) */
     int32_t num_code;          /* distinct (class, quality) pairs in the data      */
-    int32_t num_tile;          /* 64-marker wave tiles                             */
+    int32_t num_tile;          /* 16-marker micro-tiles                            */
     int64_t device_bytes;      /* HBM held by the context                          */
     /* SURVEY 8(d) algorithmic bytes of ONE evaluation: 2*R + M_active*(8k+12) */
     int64_t algorithmic_bytes_per_eval;

@@ -1,0 +1,173 @@
+"""CPU tests of the product's host side (no GPU needed):
+
+* libvb2.so loads and exports every symbol include/vb2_abi.h declares;
+* without a device, compute entry points fail LOUDLY (no CPU fallback);
+* the C++ optimiser (amoeba.cpp + estimator.cpp, speculative batching included)
+  reproduces the oracle's evaluation trace bit for bit when fed the same objective
+  (the oracle's LLK as the vb2_eval_fn callback -- the checker drives, the product's
+  optimiser is what is under test);
+* the C++ readers/flattening (hostio.cpp) agree with the Python restatement of the
+  reference's readers (oracle/refio.py) on the golden files and on quirky inputs.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import verifybamid_amd as vb
+from verifybamid_amd import _abi
+from oracle import binding, refio
+from oracle.bridge import flat_from_input, oracle_data
+
+HAPMAP = "hapmap/hapmap_3.3.b37.dat"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    lib = _abi.lib()
+    with open(os.path.join(ROOT, "include", "vb2_abi.h")) as fh:
+        header = fh.read()
+    declared = set(re.findall(r"\b(vb2_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vb2_eval_fn"}
+    assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vb2_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    lib = _abi.lib()
+    if lib.vb2_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    d = vb.synth.make_pileup(64, 10, 2, seed=3)
+    with pytest.raises(_abi.Vb2Error) as ei:
+        vb.LikelihoodContext(d)
+    assert ei.value.code == _abi.VB2_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.vb2_last_error() or b"gfx950" in lib.vb2_last_error()
+
+
+def _oracle_evaluator(od):
+    return lambda p1, p2, a: [od.llk(p1[i], p2[i], a[i]) for i in range(len(a))]
+
+
+@pytest.mark.parametrize("pileup", ["expected/result.Pileup", "test.LongRead.pileup"])
+@pytest.mark.parametrize("kw", [{}, {"within_ancestry": True}, {"fix_alpha": 0.1},
+                                {"fix_pc": [0.034756, 0.0193]},
+                                {"within_ancestry": True, "fix_pc": [0.034756, 0.0193]},
+                                {"within_ancestry": True, "fix_alpha": 0.25}])
+def test_cpp_optimiser_trace_equals_oracle(golden_dir, pileup, kw):
+    flat, _, _ = refio.load_flat(os.path.join(golden_dir, HAPMAP), os.path.join(golden_dir, pileup), 2)
+    od = binding.OracleData(flat)
+    got = vb.optimize_with_evaluator(_oracle_evaluator(od), 2, trace_capacity=4096, **kw)
+    want = od.optimize(trace_capacity=4096, **kw)
+    assert got["num_eval"] == want["num_eval"] == got["trace_count"]
+    assert got["num_launch_point"] >= got["num_eval"]          # speculation evaluates extra points
+    for key in ("alpha", "pc1", "pc2", "llk"):
+        assert np.array_equal(got["trace"][key], want["trace"][key]), key
+    for key in ("alpha", "llk1", "llk0"):
+        assert got[key] == want[key], key
+    assert np.array_equal(got["pc"], want["pc"]) and np.array_equal(got["pc2"], want["pc2"])
+
+
+def test_cpp_optimiser_other_dimensions():
+    """k = 1 (the reference's hard-coded index-1 swap must not run) and k = 4."""
+    for k, seed in ((1, 11), (4, 12)):
+        d = vb.synth.make_pileup(300, 12, k, alpha_true=0.6 if k == 1 else 0.1, seed=seed)
+        od = oracle_data(d)
+        got = vb.optimize_with_evaluator(_oracle_evaluator(od), k, trace_capacity=20000)
+        want = od.optimize(trace_capacity=20000)
+        assert got["num_eval"] == want["num_eval"]
+        assert np.array_equal(got["trace"]["llk"], want["trace"]["llk"])
+        assert got["alpha"] == want["alpha"] and np.array_equal(got["pc"], want["pc"])
+
+
+def test_evaluator_error_propagates():
+    def bad(p1, p2, a):
+        raise ValueError("boom")
+    with pytest.raises(ValueError):
+        vb.optimize_with_evaluator(bad, 2)
+
+
+@pytest.mark.parametrize("pileup", ["expected/result.Pileup", "test.LongRead.pileup"])
+def test_readers_match_reference_restatement(golden_dir, pileup):
+    prefix = os.path.join(golden_dir, HAPMAP)
+    d = vb.PileupData.from_files(prefix, os.path.join(golden_dir, pileup), 2, disable_sanity=True)
+    flat, panel, viewer = refio.load_flat(prefix, os.path.join(golden_dir, pileup), 2)
+    mine = flat_from_input(d)
+    assert d.num_marker == flat.num_marker == 9787
+    assert d.avg_depth == flat.avg_depth
+    assert d.meta["num_bases"] == viewer.num_bases
+    assert np.array_equal(mine.base_info_index >= 0, flat.base_info_index >= 0)
+    assert np.array_equal(d.ud, flat.ud) and np.array_equal(d.means, flat.means)
+    present = flat.base_info_index >= 0
+    assert np.array_equal(d.alt_base[present], flat.alt_base[present])
+    # same reads per marker, in the same order
+    for i in np.nonzero(present)[0]:
+        s = flat.base_info_index[i]
+        a = flat.bases[flat.site_off[s]:flat.site_off[s + 1]]
+        b = d.bases[d.read_off[i]:d.read_off[i + 1]]
+        assert np.array_equal(a, b)
+        a = flat.quals[flat.site_off[s]:flat.site_off[s + 1]]
+        b = d.quals[d.read_off[i]:d.read_off[i + 1]]
+        assert np.array_equal(a, b)
+
+
+def test_reader_quirks(tmp_path):
+    """First-char alleles, dropped unterminated last panel line, duplicate pileup line,
+    indels / ^ / * / $ handling, sites outside the panel, sanity statistics."""
+    pre = str(tmp_path / "p")
+    with open(pre + ".bed", "w") as f:
+        f.write("1\t99\t100\tA\tC,G\n1\t199\t200\tG\tT\n2\t9\t10\tC\tA\n2\t19\t20\tT\tG")   # no final \n
+    with open(pre + ".UD", "w") as f:
+        f.write("0.5 -0.25 9\n-1.5\t2.0\t9\n0.125 0.0 9\n")
+    with open(pre + ".mu", "w") as f:
+        f.write("1:100_A/C_rs1 0.4\n1:200_G/T_rs2 1.2\n2:10_C/A_rs3 0.9\n")
+    with open(pre + ".pileup", "w") as f:
+        f.write("1\t100\tA\t6\t.,c^].+2AGC$*\tIJK!LM\n"      # ^] skipped, +2AG skipped, * eats a qual
+                "1\t150\tT\t2\t..\tII\n"                      # not in the panel
+                "2\t10\tC\t3\taA-1gN\tABC\n"
+                "1\t100\tA\t2\tcc\tII\n")                     # duplicate line: counted, not stored
+    d = vb.PileupData.from_files(pre, pre + ".pileup", 2, disable_sanity=True)
+    flat, panel, viewer = refio.load_flat(pre, pre + ".pileup", 2)
+    assert d.num_marker == 3                                  # 4th bed line has no newline
+    assert chr(d.alt_base[0]) == "C"                          # "C,G" -> 'C'
+    got = [bytes(d.bases[d.read_off[i]:d.read_off[i + 1]]).decode() for i in range(3)]
+    assert got == [".,c.C", "", "aAN"]
+    quals = [bytes(d.quals[d.read_off[i]:d.read_off[i + 1]]).decode() for i in range(3)]
+    assert quals == ["IJK!L", "", "ABC"]
+    assert viewer.num_bases == d.meta["num_bases"] == 5 + 3 + 2
+    assert d.avg_depth == flat.avg_depth == 10 / 3            # 3 counted lines (duplicate included)
+    mine = flat_from_input(d)
+    od_a, od_b = binding.OracleData(mine), binding.OracleData(flat)
+    assert od_a.llk([0.1, 0.2], [0.0, 0.1], 0.07) == od_b.llk([0.1, 0.2], [0.0, 0.1], 0.07)
+
+    # sanity statistics (IsSanityCheckOK) -- too few markers, so the check itself fails
+    d2 = vb.PileupData.from_files(pre, pre + ".pileup", 2, disable_sanity=False)
+    flat2, _, v2 = refio.load_flat(pre, pre + ".pileup", 2, sanity_disabled=False)
+    assert d2.meta["sanity_ok"] is False
+    assert d2.sd_depth == flat2.sd_depth and not d2.sanity_disabled
+
+
+def test_ud_with_too_few_columns(tmp_path):
+    pre = str(tmp_path / "q")
+    open(pre + ".bed", "w").write("1\t0\t1\tA\tC\n")
+    open(pre + ".UD", "w").write("0.5\n")
+    open(pre + ".mu", "w").write("1:1_A/C 0.5\n")
+    open(pre + ".pileup", "w").write("1\t1\tA\t1\t.\tI\n")
+    with pytest.raises(_abi.Vb2Error) as ei:
+        vb.PileupData.from_files(pre, pre + ".pileup", 2)
+    assert "NumPC" in str(ei.value)
+
+
+def test_shard_partition_covers_all_reads():
+    d = vb.synth.make_pileup(1000, 20, 3, seed=5, missing_frac=0.1)
+    for world in (2, 3, 8):
+        shards = [d.shard(r, world) for r in range(world)]
+        assert sum(s.num_marker for s in shards) == d.num_marker
+        assert sum(s.num_read for s in shards) == d.num_read
+        reads = [s.num_read for s in shards]
+        assert max(reads) - min(reads) <= 2 * 60              # balanced on reads
+        cat = np.concatenate([s.bases for s in shards])
+        assert np.array_equal(cat, d.bases)

@@ -12,8 +12,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -88,7 +90,7 @@ Context::~Context()
 {
     if (device >= 0) (void)hipSetDevice(device);
     auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
-    fr(L.codes); fr(L.tile_row_off); fr(L.tile_rows); fr(L.ud); fr(L.mu); fr(L.ediag);
+    fr(L.codes); fr(L.mt_rec); fr(L.ud); fr(L.mu); fr(L.ediag);
     fr(L.known_af); fr(L.dict_perr);
     fr(d_partials);
     if (h_points) (void)hipHostFree(h_points);
@@ -192,30 +194,34 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         dict_perr[d] = (order[d] / kNumQual) ? -pe : pe;      // sign carries the class
     }
 
-    // ---- sort markers by effective depth (descending, stable) and tile ----
+    // ---- sort markers by effective depth (descending, stable); 16-marker micro-tiles ----
     std::vector<int64_t> perm(m_active);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(),
                      [&](int64_t a, int64_t b) { return eff_depth[a] > eff_depth[b]; });
-    const int num_tile = (int)((m_active + 63) / 64);
-    const int64_t m_pad = (int64_t)num_tile * 64;
+    const int num_mt = (int)((m_active + kMtMarkers - 1) / kMtMarkers);
+    const int64_t m_pad = (int64_t)num_mt * kMtMarkers;
 
-    std::vector<uint32_t> tile_row_off(num_tile), tile_rows(num_tile);
+    std::vector<uint32_t> mt_row_off(num_mt), mt_rows(num_mt);
     uint64_t total_rows = 0;
-    for (int t = 0; t < num_tile; ++t) {
-        const int32_t dmax = eff_depth[perm[(int64_t)t * 64]];   // sorted: first lane is deepest
-        tile_row_off[t] = (uint32_t)total_rows;
-        tile_rows[t] = (uint32_t)((dmax + 3) / 4);
-        total_rows += tile_rows[t];
+    for (int t = 0; t < num_mt; ++t) {
+        const int32_t dmax = eff_depth[perm[(int64_t)t * kMtMarkers]];   // first lane is deepest
+        mt_row_off[t] = (uint32_t)total_rows;
+        mt_rows[t] = (uint32_t)((dmax + 3) / 4);
+        total_rows += mt_rows[t];
     }
     if (total_rows >= (1ull << 32)) {
         set_error("vb2_ctx_create: input too large for 32-bit row offsets");
         return VB2_ERR_INVALID;
     }
 
+    const int num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    std::vector<uint2> mt_rec(num_mt);
+    for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rows[t]);
+
     // unused step slots hold the padding code = num_code, a zero row of the LDS table
     const uint32_t pad4 = 0x01010101u * (uint32_t)num_code;
-    std::vector<uint32_t> codes((size_t)total_rows * 64, pad4);
+    std::vector<uint32_t> codes((size_t)total_rows * kMtMarkers, pad4);
     std::vector<double> ud_s((size_t)k * m_pad, 0.0), mu_s(m_pad, 0.0), cdiag((size_t)4 * m_pad, 0.0);
     std::vector<double> kaf_s;
     if (in->known_af) kaf_s.assign(m_pad, 0.0);
@@ -240,10 +246,10 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         // reads of a marker in dictionary order: lanes of a wave then tend to hit
         // the same or neighbouring LDS table rows at the same step (bank-friendly)
         std::sort(tmp.begin(), tmp.end());
-        const int t = (int)(m / 64), lane = (int)(m % 64);
-        uint8_t* row0 = reinterpret_cast<uint8_t*>(&codes[(size_t)tile_row_off[t] * 64]);
+        const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
+        uint8_t* row0 = reinterpret_cast<uint8_t*>(&codes[(size_t)mt_row_off[t] * kMtMarkers]);
         for (size_t j = 0; j < tmp.size(); ++j)
-            row0[((j >> 2) * 64 + lane) * 4 + (j & 3)] = tmp[j];
+            row0[((j >> 2) * kMtMarkers + lane) * 4 + (j & 3)] = tmp[j];
         if (in->known_af) {
             kaf_s[m] = in->known_af[i];
         } else {
@@ -261,14 +267,13 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     int rc;
     DeviceLayout& L = c->L;
     std::memset(&L, 0, sizeof(L));
-    uint32_t* d_codes; uint32_t* d_tro; uint32_t* d_tr; double* d_ud; double* d_mu; double* d_cd;
+    uint32_t* d_codes; uint2* d_rec;
+    double* d_ud; double* d_mu; double* d_cd;
     double* d_kaf; double* d_dpe;
     if ((rc = upload(codes, &d_codes, &c->device_bytes))) return rc;
     L.codes = d_codes;
-    if ((rc = upload(tile_row_off, &d_tro, &c->device_bytes))) return rc;
-    L.tile_row_off = d_tro;
-    if ((rc = upload(tile_rows, &d_tr, &c->device_bytes))) return rc;
-    L.tile_rows = d_tr;
+    if ((rc = upload(mt_rec, &d_rec, &c->device_bytes))) return rc;
+    L.mt_rec = d_rec;
     if (!in->known_af) {
         if ((rc = upload(ud_s, &d_ud, &c->device_bytes))) return rc;
         L.ud = d_ud;
@@ -283,7 +288,9 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     if ((rc = upload(dict_perr, &d_dpe, &c->device_bytes))) return rc;
     L.dict_perr = d_dpe;
     L.num_code = num_code;
-    L.num_tile = num_tile;
+    L.num_mt = num_mt;
+    L.num_cu = num_cu;
+    L.ablate = std::getenv("VB2_ABLATE") ? std::atoi(std::getenv("VB2_ABLATE")) : 0;
     L.num_pc = k;
     L.num_active = m_active;
     L.m_pad = m_pad;
@@ -292,8 +299,8 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     c->num_read_other = num_other;
     c->algorithmic_bytes = 2 * num_read + m_active * (8 * (int64_t)k + 12);
 
-    const int nb = std::max(1, num_blocks_for(L));
-    VB2_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * (size_t)max_points_per_launch() * nb));
+    const int nb = kMaxGridPerCU * num_cu;
+    VB2_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * (size_t)kMaxPointsPerLaunch * nb));
     // Host <-> device hand-off of the (tiny) parameter and result vectors goes through
     // pinned, device-mapped host memory that the kernels access directly: no copy
     // commands on the evaluation path.
@@ -302,7 +309,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     VB2_HIP(hipHostMalloc((void**)&c->h_out, sizeof(double) * kStagePoints, hipHostMallocMapped));
     VB2_HIP(hipHostGetDevicePointer((void**)&c->d_points, c->h_points, 0));
     VB2_HIP(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
-    c->device_bytes += (int64_t)(sizeof(double) * (size_t)max_points_per_launch() * nb);
+    c->device_bytes += (int64_t)(sizeof(double) * (size_t)kMaxPointsPerLaunch * nb);
     if (opt && opt->stream) {
         c->stream = (hipStream_t)opt->stream;
         c->own_stream = false;
@@ -310,6 +317,13 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         VB2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
+    for (int btl = 1; btl <= 2; ++btl) {
+        const char* gv = std::getenv(btl == 1 ? "VB2_GEOM1" : "VB2_GEOM2");
+        int mw = 0, bpc = 0;
+        if (gv && std::sscanf(gv, "%d,%d", &mw, &bpc) == 2 && mw > 0 && bpc > 0 && bpc <= kMaxGridPerCU)
+            set_geom_override(btl, mw, bpc);
+    }
+    if (const char* lm = std::getenv("VB2_LANE_MAP")) set_lane_mapping(std::strcmp(lm, "plain") != 0);
     VB2_HIP(hipDeviceSynchronize());
     *out = c.release();
     return VB2_OK;
@@ -320,7 +334,7 @@ int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipS
     if (num_point <= 0) return VB2_OK;
     VB2_HIP(hipSetDevice(device));
     if (!s) s = stream;
-    if (L.num_tile == 0) {
+    if (L.num_mt == 0) {
         VB2_HIP(launch_fill_zero(d_llk, num_point, s));
         return VB2_OK;
     }
@@ -364,7 +378,7 @@ void Context::fill_info(vb2_info* info) const
     info->num_read = num_read;
     info->num_read_other = num_read_other;
     info->num_code = L.num_code;
-    info->num_tile = L.num_tile;
+    info->num_tile = L.num_mt;
     info->device_bytes = device_bytes;
     info->algorithmic_bytes_per_eval = algorithmic_bytes;
     std::snprintf(info->device_name, sizeof(info->device_name), "%s", device_name);

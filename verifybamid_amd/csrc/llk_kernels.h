@@ -3,45 +3,50 @@
 #define VB2_LLK_KERNELS_H_
 
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
 #include <stdint.h>
 
 namespace vb2 {
 
-constexpr int kNumQual = 94;         // Phred 0..93 (ContaminationEstimator.h:65-74)
-constexpr int kBlockThreads = 256;
-constexpr int kWavesPerBlock = kBlockThreads / 64;
+constexpr int kNumQual = 94;             // Phred 0..93 (ContaminationEstimator.h:65-74)
 constexpr int kMaxCode = 2 * kNumQual;   // classes ref/alt x qualities
-constexpr int kPadCode = 255;            // never a real code; maps to a zero table row
+constexpr int kPadCode = 255;            // never a real dictionary index
+constexpr int kMtMarkers = 16;           // markers per micro-tile (one 16-lane group)
+constexpr int kMaxBlockWaves = 16;       // 1024-thread blocks at most
+constexpr int kMaxPointsPerLaunch = 8;
 
-// Everything the kernel reads, in HBM.  "Sorted order" = active markers sorted by
-// (non-"other") depth, descending; position m = tile*64 + lane.
+// Everything the kernels read, in HBM.  "Sorted order" = active markers sorted by
+// (non-"other") depth, descending; position = micro_tile*16 + m.
 struct DeviceLayout {
-    const uint32_t* codes;         // [sum_t tile_rows[t]][64] dwords; byte j of row s = step 4s+j
-    const uint32_t* tile_row_off;  // [num_tile] first row of the tile
-    const uint32_t* tile_rows;     // [num_tile] rows (= ceil(max depth in tile / 4))
-    const double* ud;              // [num_pc][m_pad]  (SoA)
-    const double* mu;              // [m_pad]
-    const double* ediag;           // [4][m_pad]: c_other, exp(c_other+D[g]) for g = 0,1,2
-    const double* known_af;        // [m_pad] or nullptr
-    const double* dict_perr;       // [num_code] +10^(-q/10) for class ref, -10^(-q/10) for class alt
+    const uint32_t* codes;        // [sum_t mt_rows[t]][16] dwords; byte j of row s = read 4s+j
+    const uint2* mt_rec;          // [num_mt] {first row, rows = ceil(deepest marker / 4)}
+    const double* ud;             // [num_pc][m_pad]  (SoA)
+    const double* mu;             // [m_pad]
+    const double* ediag;          // [4][m_pad]: c_other, exp(c_other+D[g]) for g = 0,1,2
+    const double* known_af;       // [m_pad] or nullptr
+    const double* dict_perr;      // [num_code] +10^(-q/10) class ref, -10^(-q/10) class alt
     int32_t num_code;
-    int32_t num_tile;
+    int32_t num_mt;
     int32_t num_pc;
+    int32_t num_cu;               // compute units of the device
+    int32_t ablate;               // profiling aid (VB2_ABLATE): 1 no table math, 2 no read loop, 4 no epilogue math
     int64_t num_active;
-    int64_t m_pad;                 // num_tile * 64
+    int64_t m_pad;                // num_mt * 16
 };
 
-int max_points_per_launch();
+struct LaunchGeom { int grid, block_waves; };
+// Workgroups / waves per workgroup used for a launch of 4*btl points.
+LaunchGeom launch_geom(const DeviceLayout& L, int btl);
+constexpr int kMaxGridPerCU = 2;
+
 // Enqueue evaluation of num_point candidate rows (pc1 | pc2 | alpha) on stream.
-// d_partials: >= max_points_per_launch() * num_blocks doubles of scratch.
+// d_partials: >= kMaxPointsPerLaunch * kMaxGridPerCU * L.num_cu doubles of scratch.
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
                            double* d_partials, double* d_out, hipStream_t stream);
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
-
-inline int num_blocks_for(const DeviceLayout& L)
-{
-    return (L.num_tile + kWavesPerBlock - 1) / kWavesPerBlock;
-}
+// A/B switch: lanes of one ds_read_b128 service group share a candidate slot (default) or plain
+void set_lane_mapping(bool hardware_groups);
+void set_geom_override(int btl, int max_waves, int blocks_per_cu);
 
 }  // namespace vb2
 #endif

@@ -2,10 +2,13 @@
 // (reference: FullLLKFunc::ComputeMixLLKs, ContaminationEstimator.h:194-314).
 //
 // Work decomposition:
-//   * one LANE per marker, 64 markers per wave tile; markers are sorted by depth
-//     at context creation so a tile's lanes run the same number of steps;
+//   * a wave = 16 markers x 4 candidate slots: lane (m, g) walks marker m's reads for
+//     the BTL candidate points of slot g (BTL = 1 or 2 -> 4 or 8 points per launch);
+//     markers are sorted by depth at context creation and grouped in 16-marker
+//     micro-tiles so all lanes of a wave run the same number of steps;
 //   * reads are dictionary codes (class x quality), 4 per dword, stored
-//     [tile][step/4][lane] so every wave load is one contiguous 256-byte row;
+//     [micro-tile][step/4][marker]: a wave load is one contiguous 64-byte row,
+//     rows are prefetched two deep;
 //   * the per-alpha log-likelihood table (h:213-229) is rebuilt per launch in LDS,
 //     restricted to the codes that occur in the data and to the six OFF-diagonal
 //     genotype pairs: the diagonal (g1==g2) and the "other base" class do not
@@ -14,8 +17,11 @@
 //     gathers its table row from LDS with ds_read_b128 (row = 6 values per point);
 //   * epilogue per lane: UD*PC projection (h:251-267), HWE priors (h:186-192),
 //     9-term exp-sum and log with the reference's `> 0` test (h:307-311);
-//   * deterministic reduction: wave butterfly -> block -> per-block partial; a
-//     one-block finalize kernel sums the partials in a fixed order.
+//   * persistent launch: <= two workgroups per CU (table built once per workgroup);
+//     depth-sorted micro-tiles are dealt to the wave slots round-robin across
+//     workgroups, so every CU sees the same depth mix;
+//   * deterministic reduction: 16-lane butterfly -> waves of the block -> per-block
+//     partial; a one-block finalize kernel sums the partials in a fixed order.
 #include "llk_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -37,6 +43,73 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// exp(x) for x <= 0 (arguments here are sums of log-probabilities), FP64, <= 1 ulp:
+// x = k*ln2 + r, |r| <= ln2/2; degree-13 Taylor polynomial in r (truncation 4e-18);
+// 2^k applied with ldexp so results degrade gracefully into subnormals and reach 0
+// exactly where the reference's exp() underflows (the `markerLK > 0` test, h:310).
+__device__ __forceinline__ double exp_nonpos(double x)
+{
+    const double kLog2e = 1.4426950408889634074;
+    const double kLn2Hi = 6.93147180369123816490e-01;   // ln2 split (fdlibm constants)
+    const double kLn2Lo = 1.90821492927058770002e-10;
+    const double kd = rint(x * kLog2e);
+    double r = fma(-kd, kLn2Hi, x);
+    r = fma(-kd, kLn2Lo, r);
+    double p = 1.0 / 6227020800.0;                      // 1/13!
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double y = ldexp(p, (int)kd);
+    return x < -746.0 ? 0.0 : y;                        // also covers x = -inf
+}
+
+// log(x) for x >= 0, FP64 (fdlibm's e_log algorithm with explicit FMAs, ~1 ulp):
+// x = 2^e * m, m in [sqrt(1/2), sqrt(2)); f = m-1; s = f/(2+f);
+// log(m) = f - hfsq + s*(hfsq + R(s^2)).
+// log(0) = -inf (table entries whose probability is exactly 0, e.g. q = 0 / hom-ref).
+// The library log() is not used: built without FMA contraction (this file's
+// -ffp-contract=off, needed for reference-order rounding elsewhere) it expands to
+// ~115 instructions, four times this.
+__device__ __forceinline__ double log_nonneg(double x)
+{
+    const double kLn2Hi = 6.93147180369123816490e-01, kLn2Lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1), subnormals included
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);                  // 1/d, refined twice (Newton)
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    double sq = f * r;
+    sq = fma(fma(-d, sq, f), r, sq);                     // s = f/d to ~0.5 ulp
+    const double z = sq * sq;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    const double res = fma(dk, kLn2Hi, -((hfsq - fma(sq, hfsq + R, dk * kLn2Lo)) - f));
+    return x == 0.0 ? -__builtin_huge_val() : res;
+}
+
 // One table entry, with the reference's expression order (h:223-225).
 // perr_signed = +pErr(q) for class ref, -pErr(q) for class alt (one load per code;
 // the alt class is the ref class with genotypes mirrored, g -> 2-g: h:164-177).
@@ -54,7 +127,7 @@ __device__ __forceinline__ double table_entry(double alpha, double perr_signed, 
     const double one_minus_alpha = 1.0 - alpha;
     const double val = (alpha * e1 + one_minus_alpha * e2) * p_err +
                        (alpha * n1 + one_minus_alpha * n2) * p_ok;
-    return log(val);
+    return log_nonneg(val);
 }
 
 __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
@@ -67,74 +140,140 @@ __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
 }
 
 // Row stride (in doubles) of the LDS table: 6 values per candidate point, padded so
-// that stride/2 (in 16-byte slots) is odd -> 16 consecutive codes land in 16
-// distinct 4-dword bank slots for ds_read_b128 (bank = (addr/4) % 64).
-__host__ __device__ constexpr int row_stride(int bt) { return 6 * bt + ((bt % 2 == 0) ? 2 : 0); }
+// that the stride in 16-byte slots is odd -> 16 consecutive codes land in 16 distinct
+// 4-dword bank slots for ds_read_b128 (bank = (addr/4) % 64).
+__host__ __device__ constexpr int row_stride(int npoint)
+{
+    return 6 * npoint + (((3 * npoint) % 2 == 0) ? 2 : 0);
+}
 
-// BT = candidate points evaluated per launch (register-tiled).
-// LDS: table[(num_code+1)][row_stride(BT)] doubles (row num_code = zeros = padding code),
-//      then BT*kWavesPerBlock doubles of reduction scratch.
-template <int BT>
-__global__ void __launch_bounds__(kBlockThreads)
-llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points,
+// Lane -> (marker m in the micro-tile, candidate slot g).
+// HWMAP: the 16 lanes that ds_read_b128 services in one LDS pass (lanes {0-3,12-15,
+// 20-27}, {4-11,16-19,28-31} and the same +32; MI355X_MICROARCH.md, LDS) share one
+// candidate slot, so within a pass the addresses differ only by the code.
+template <bool HWMAP>
+__device__ __forceinline__ void lane_map(int lane, int& m, int& g)
+{
+    if (HWMAP) {
+        const int q = (lane >> 2) & 7;                       // quad within the 32-lane half
+        const int nib = (0x76452310u >> (4 * q)) & 7;        // (rank<<1 | group) of quad q
+        g = (nib & 1) + 2 * (lane >> 5);
+        m = ((nib >> 1) << 2) + (lane & 3);
+    } else {
+        m = lane & 15;
+        g = lane >> 4;
+    }
+}
+
+template <bool HWMAP>
+__device__ __forceinline__ int lane_of(int m, int g)
+{
+    if (HWMAP) {
+        const int idx = ((g & 1) << 2) + (m >> 2);           // group*4 + quad-rank
+        const int q = (0x74216530u >> (4 * idx)) & 7;
+        return ((g >> 1) << 5) + (q << 2) + (m & 3);
+    }
+    return (g << 4) + m;
+}
+
+// Occupancy targets: BTL=1 fits 80 VGPRs -> 6 waves/SIMD = two 768-thread workgroups
+// per CU; BTL=2 needs ~128 VGPRs -> 4 waves/SIMD = one 1024-thread workgroup per CU.
+template <int BTL> struct Geom;
+template <> struct Geom<1> { static constexpr int kMaxWaves = 12, kBlocksPerCU = 2, kWavesPerSimd = 6; };
+template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
+
+// BTL = candidate points per lane; a launch evaluates NP = 4*BTL points
+// (num_valid <= NP of them real; the rest replicate the last real point).
+template <int BTL, bool HWMAP>
+__global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPerSimd)
+llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid,
                 double* __restrict__ partials)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int RS = row_stride(BT);
+    constexpr int NP = 4 * BTL;
+    constexpr int RS = row_stride(NP);
     const int nrow = L.num_code + 1;
-    double* tab = lds;                       // [nrow][RS]
-    double* red = lds + nrow * RS;           // [BT][kWavesPerBlock]
-    double* pts = red + BT * kWavesPerBlock; // [BT][2k+1] this launch's parameter rows
+    const int nthread = blockDim.x;
+    const int nwave = nthread >> 6;
+    const int k = L.num_pc;
+    const int stride = 2 * k + 1;
+    double* tab = lds;                          // [nrow][RS]
+    double* red = lds + nrow * RS;              // [nwave][NP]
+    double* pts = red + kMaxBlockWaves * NP;    // [NP][2k+1] this launch's parameter rows
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int k = L.num_pc;
-    const int stride = 2 * k + 1;
+    int m, g;
+    lane_map<HWMAP>(lane, m, g);
 
     // parameter rows -> LDS with one coalesced load (they may live in mapped host memory)
-    for (int e = tid; e < BT * stride; e += kBlockThreads) pts[e] = points[e];
+    for (int e = tid; e < NP * stride; e += nthread) {
+        const int b = e / stride;
+        const int src = b < num_valid ? b : num_valid - 1;
+        pts[e] = points[src * stride + (e - b * stride)];
+    }
     __syncthreads();
 
     // ---- per-alpha table, off-diagonal pairs only (h:213-229) ----
-    for (int e = tid; e < nrow * 6 * BT; e += kBlockThreads) {
-        const int d = e / (6 * BT);
-        const int bp = e - d * (6 * BT);
+    for (int e = tid; e < nrow * 6 * NP; e += nthread) {
+        const int d = e / (6 * NP);
+        const int bp = e - d * (6 * NP);
         const int b = bp / 6, p = bp - b * 6;
         double v = 0.0;
         if (d < L.num_code) {
             int g1, g2;
             pair_of(p, g1, g2);
-            v = table_entry(pts[b * stride + 2 * k], L.dict_perr[d], g1, g2);
+            v = (L.ablate & 1) ? -0.01 * (d + p)
+                               : table_entry(pts[b * stride + 2 * k], L.dict_perr[d], g1, g2);
         }
         tab[d * RS + bp] = v;
     }
     __syncthreads();
 
-    double llk_lane[BT];
+    double llk_lane[BTL];
 #pragma unroll
-    for (int b = 0; b < BT; ++b) llk_lane[b] = 0.0;
+    for (int t = 0; t < BTL; ++t) llk_lane[t] = 0.0;
 
-    const int tile = blockIdx.x * kWavesPerBlock + wave;
-    if (tile < L.num_tile) {
-        double acc[BT * 6];
+    // Micro-tiles are dealt to (workgroup, wave) slots arithmetically -- consecutive
+    // (depth-sorted) tiles go to consecutive workgroups, alternate rounds run backwards
+    // -- so no work list has to be fetched before the first load of a tile can issue.
+    const uint32_t nslot = gridDim.x * (uint32_t)nwave;
+    const uint32_t u = (uint32_t)wave * gridDim.x + blockIdx.x;
+    const uint32_t padw = 0x01010101u * (uint32_t)L.num_code;
+    const double* my_tab = tab + g * (6 * BTL);
+    const double* my_pts = pts + (g * BTL) * stride;
+    const size_t mp = L.m_pad;
+    const uint32_t nround = ((uint32_t)L.num_mt + nslot - 1) / nslot;
+    for (uint32_t round = 0; round < nround; ++round) {
+        const uint64_t t64 = (uint64_t)round * nslot + ((round & 1) ? nslot - 1 - u : u);
+        if (t64 >= (uint64_t)L.num_mt) continue;             // wave-uniform
+        const uint32_t mt = (uint32_t)t64;
+        const uint2 rec = L.mt_rec[mt];                      // {first row, rows}
+        // per-marker constants: issued now, consumed after the read loop
+        const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
+        const bool live = pos < (size_t)L.num_active;
+        const size_t posc = live ? pos : 0;
+        const double cst = L.ediag[posc];
+        const double e0 = L.ediag[mp + posc], e1 = L.ediag[2 * mp + posc], e2 = L.ediag[3 * mp + posc];
+
+        double acc[BTL * 6];
 #pragma unroll
-        for (int i = 0; i < BT * 6; ++i) acc[i] = 0.0;
+        for (int i = 0; i < BTL * 6; ++i) acc[i] = 0.0;
 
         // ---- per-read accumulate (h:288-303); code rows prefetched two deep ----
-        const uint32_t* cp = L.codes + (size_t)L.tile_row_off[tile] * 64 + lane;
-        const int rows = L.tile_rows[tile];
-        const uint32_t padw = 0x01010101u * (uint32_t)L.num_code;
+        const uint32_t* cp = L.codes + (size_t)rec.x * kMtMarkers + m;
+        const int rows = (L.ablate & 2) ? 0 : (int)rec.y;
         uint32_t w_cur = rows > 0 ? cp[0] : padw;
-        uint32_t w_nxt = rows > 1 ? cp[64] : padw;
+        uint32_t w_nxt = rows > 1 ? cp[kMtMarkers] : padw;
         for (int s = 0; s < rows; ++s) {
-            const uint32_t w_n2 = (s + 2 < rows) ? cp[(size_t)(s + 2) * 64] : padw;
+            const uint32_t w_n2 = (s + 2 < rows) ? cp[(size_t)(s + 2) * kMtMarkers] : padw;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t c = (w_cur >> (8 * j)) & 0xffu;
-                const double2* row = reinterpret_cast<const double2*>(tab + c * RS);
+                const double2* row = reinterpret_cast<const double2*>(my_tab + c * RS);
 #pragma unroll
-                for (int i = 0; i < 3 * BT; ++i) {
+                for (int i = 0; i < 3 * BTL; ++i) {
                     const double2 t = row[i];
                     acc[2 * i] += t.x;
                     acc[2 * i + 1] += t.y;
@@ -145,68 +284,75 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points,
         }
 
         // ---- per-marker epilogue ----
-        const size_t m = (size_t)tile * 64 + lane;       // position in sorted order
-        if (m < (size_t)L.num_active) {
-            const size_t mp = L.m_pad;
-            const double cst = L.ediag[m];
-            const double e0 = L.ediag[mp + m], e1 = L.ediag[2 * mp + m], e2 = L.ediag[3 * mp + m];
-            double af1[BT], af2[BT];
-            if (L.known_af) {
-                const double a = L.known_af[m];
+        if (live && (L.ablate & 4)) {
 #pragma unroll
-                for (int b = 0; b < BT; ++b) af1[b] = af2[b] = a;
+            for (int t = 0; t < BTL; ++t)
+                llk_lane[t] += acc[t * 6] + acc[t * 6 + 1] + acc[t * 6 + 2] + acc[t * 6 + 3] +
+                               acc[t * 6 + 4] + acc[t * 6 + 5] + cst + e0 + e1 + e2;
+        } else if (live) {
+            double af1[BTL], af2[BTL];
+            if (L.known_af) {
+                const double a = L.known_af[pos];
+#pragma unroll
+                for (int t = 0; t < BTL; ++t) af1[t] = af2[t] = a;
             } else {
                 // h:251-267: AF = (sum_k UD[i][k]*pc[k] + mean) / 2, same op order
 #pragma unroll
-                for (int b = 0; b < BT; ++b) af1[b] = af2[b] = 0.;
+                for (int t = 0; t < BTL; ++t) af1[t] = af2[t] = 0.;
                 for (int kk = 0; kk < k; ++kk) {
-                    const double u = L.ud[(size_t)kk * mp + m];
+                    const double uu = L.ud[(size_t)kk * mp + pos];
 #pragma unroll
-                    for (int b = 0; b < BT; ++b) {
-                        af1[b] += u * pts[b * stride + kk];
-                        af2[b] += u * pts[b * stride + k + kk];
+                    for (int t = 0; t < BTL; ++t) {
+                        af1[t] += uu * my_pts[t * stride + kk];
+                        af2[t] += uu * my_pts[t * stride + k + kk];
                     }
                 }
-                const double mu = L.mu[m];
+                const double mu = L.mu[pos];
 #pragma unroll
-                for (int b = 0; b < BT; ++b) {
-                    af1[b] += mu; af1[b] /= 2.0;
-                    af2[b] += mu; af2[b] /= 2.0;
+                for (int t = 0; t < BTL; ++t) {
+                    af1[t] += mu; af1[t] /= 2.0;
+                    af2[t] += mu; af2[t] /= 2.0;
                 }
             }
 #pragma unroll
-            for (int b = 0; b < BT; ++b) {
+            for (int t = 0; t < BTL; ++t) {
                 double gf[3], gf2[3];
-                initial_gf(af1[b], gf);
-                initial_gf(af2[b], gf2);
-                const double* a = acc + b * 6;
+                initial_gf(af1[t], gf);
+                initial_gf(af2[t], gf2);
+                const double* a = acc + t * 6;
                 // h:307-311, (g1 outer, g2 inner) order; the three g1==g2 exponentials
                 // do not depend on (alpha, PC) and were taken at context creation
                 double lk = 0;
                 lk += e0 * gf[0] * gf2[0];
-                lk += exp(a[0] + cst) * gf[0] * gf2[1];
-                lk += exp(a[1] + cst) * gf[0] * gf2[2];
-                lk += exp(a[2] + cst) * gf[1] * gf2[0];
+                lk += exp_nonpos(a[0] + cst) * gf[0] * gf2[1];
+                lk += exp_nonpos(a[1] + cst) * gf[0] * gf2[2];
+                lk += exp_nonpos(a[2] + cst) * gf[1] * gf2[0];
                 lk += e1 * gf[1] * gf2[1];
-                lk += exp(a[3] + cst) * gf[1] * gf2[2];
-                lk += exp(a[4] + cst) * gf[2] * gf2[0];
-                lk += exp(a[5] + cst) * gf[2] * gf2[1];
+                lk += exp_nonpos(a[3] + cst) * gf[1] * gf2[2];
+                lk += exp_nonpos(a[4] + cst) * gf[2] * gf2[0];
+                lk += exp_nonpos(a[5] + cst) * gf[2] * gf2[1];
                 lk += e2 * gf[2] * gf2[2];
-                if (lk > 0) llk_lane[b] = log(lk);
+                if (lk > 0) llk_lane[t] += log_nonneg(lk);
             }
         }
     }
 
     // ---- deterministic block reduction -> one partial per (point, block) ----
+    // butterfly over the 16 lanes that share candidate slot g
 #pragma unroll
-    for (int b = 0; b < BT; ++b) {
-        const double s = wave_sum(llk_lane[b]);
-        if (lane == 0) red[b * kWavesPerBlock + wave] = s;
+    for (int off = 8; off >= 1; off >>= 1) {
+        const int partner = lane_of<HWMAP>(m ^ off, g);
+#pragma unroll
+        for (int t = 0; t < BTL; ++t) llk_lane[t] += __shfl(llk_lane[t], partner, 64);
+    }
+    if (m == 0) {
+#pragma unroll
+        for (int t = 0; t < BTL; ++t) red[wave * NP + g * BTL + t] = llk_lane[t];
     }
     __syncthreads();
-    if (tid < BT) {
+    if (tid < NP) {
         double s = 0;
-        for (int w = 0; w < kWavesPerBlock; ++w) s += red[tid * kWavesPerBlock + w];
+        for (int w = 0; w < nwave; ++w) s += red[w * NP + tid];
         partials[(size_t)tid * gridDim.x + blockIdx.x] = s;
     }
 }
@@ -214,12 +360,12 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points,
 // Sums the per-block partials in a fixed order -> bitwise reproducible: wave w takes
 // points w, w+4, ...; lane l adds blocks l, l+64, ... (8 independent loads in flight),
 // then a butterfly over the wave.
-__global__ void __launch_bounds__(kBlockThreads)
+__global__ void __launch_bounds__(256)
 llk_finalize_kernel(const double* __restrict__ partials, int nb, int num_point,
                     double* __restrict__ llk_out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b = wave; b < num_point; b += kWavesPerBlock) {
+    for (int b = wave; b < num_point; b += 4) {
         const double* p = partials + (size_t)b * nb;
         double s = 0;
         for (int base = 0; base < nb; base += 8 * 64) {
@@ -240,39 +386,64 @@ llk_finalize_kernel(const double* __restrict__ partials, int nb, int num_point,
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-template <int BT>
-static hipError_t launch_bt(const DeviceLayout& L, const double* d_points, double* d_partials,
-                            hipStream_t stream)
+static int g_geom_override[2][2] = {{0, 0}, {0, 0}};
+void set_geom_override(int btl, int max_waves, int blocks_per_cu)
 {
-    const int nb = num_blocks_for(L);
-    const size_t shmem =
-        sizeof(double) * (size_t)((L.num_code + 1) * row_stride(BT) + BT * kWavesPerBlock +
-                                  BT * (2 * L.num_pc + 1));
-    hipLaunchKernelGGL((llk_eval_kernel<BT>), dim3(nb), dim3(kBlockThreads), shmem, stream, L,
-                       d_points, d_partials);
-    return hipGetLastError();
+    g_geom_override[btl - 1][0] = max_waves;
+    g_geom_override[btl - 1][1] = blocks_per_cu;
 }
 
-int max_points_per_launch() { return 8; }
+LaunchGeom launch_geom(const DeviceLayout& L, int btl)
+{
+    int max_waves = btl == 1 ? Geom<1>::kMaxWaves : Geom<2>::kMaxWaves;
+    int per_cu = btl == 1 ? Geom<1>::kBlocksPerCU : Geom<2>::kBlocksPerCU;
+    if (g_geom_override[btl - 1][0] > 0) {          // experiment knob: VB2_GEOM1 / VB2_GEOM2
+        max_waves = g_geom_override[btl - 1][0] < max_waves ? g_geom_override[btl - 1][0] : max_waves;
+        per_cu = g_geom_override[btl - 1][1];
+    }
+    const int grid_target = per_cu * L.num_cu;
+    int bw = (L.num_mt + grid_target - 1) / grid_target;
+    bw = bw < 4 ? 4 : (bw > max_waves ? max_waves : bw);
+    int grid = (L.num_mt + bw - 1) / bw;
+    grid = grid < 1 ? 1 : (grid > grid_target ? grid_target : grid);
+    return LaunchGeom{grid, bw};
+}
+
+static bool g_hwmap = true;
+void set_lane_mapping(bool hw) { g_hwmap = hw; }
+
+template <int BTL, bool HWMAP>
+static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int num_valid,
+                             double* d_partials, hipStream_t stream)
+{
+    constexpr int NP = 4 * BTL;
+    const size_t shmem = sizeof(double) * (size_t)((L.num_code + 1) * row_stride(NP) +
+                                                   kMaxBlockWaves * NP + NP * (2 * L.num_pc + 1));
+    const LaunchGeom gm = launch_geom(L, BTL);
+    hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
+                       stream, L, d_points, num_valid, d_partials);
+    return hipGetLastError();
+}
 
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
                            double* d_partials, double* d_out, hipStream_t stream)
 {
     const int stride = 2 * L.num_pc + 1;
-    const int nb = num_blocks_for(L);
     int done = 0;
     while (done < num_point) {
         const int left = num_point - done;
-        hipError_t e;
         const double* p = d_points + (size_t)done * stride;
-        int step;
-        if (left >= 8)      { e = launch_bt<8>(L, p, d_partials, stream); step = 8; }
-        else if (left >= 4) { e = launch_bt<4>(L, p, d_partials, stream); step = 4; }
-        else if (left >= 2) { e = launch_bt<2>(L, p, d_partials, stream); step = 2; }
-        else                { e = launch_bt<1>(L, p, d_partials, stream); step = 1; }
+        const int step = left > 4 ? (left < 8 ? left : 8) : left;
+        hipError_t e;
+        if (step > 4)
+            e = g_hwmap ? launch_btl<2, true>(L, p, step, d_partials, stream)
+                        : launch_btl<2, false>(L, p, step, d_partials, stream);
+        else
+            e = g_hwmap ? launch_btl<1, true>(L, p, step, d_partials, stream)
+                        : launch_btl<1, false>(L, p, step, d_partials, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(kBlockThreads), 0, stream, d_partials,
-                           nb, step, d_out + done);
+        hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(256), 0, stream, d_partials,
+                           launch_geom(L, step > 4 ? 2 : 1).grid, step, d_out + done);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         done += step;
     }
