@@ -107,6 +107,16 @@ def lib():
         raise ImportError(
             "verifybamid_amd: %s is missing; build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C verifybamid_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes
+    # in one process cannot both own the device, so when torch is installed it must be
+    # loaded FIRST: libvb2.so's NEEDED libamdhip64.so.7 then binds to the copy that is
+    # already mapped, and torch streams/events/tensors interoperate with our launches.
+    # (The C++ command line never loads torch and uses /opt/rocm's runtime.)
+    if os.environ.get("VB2_NO_TORCH", "") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     L.vb2_last_error.restype = C.c_char_p
     L.vb2_abi_version.restype = C.c_int
