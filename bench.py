@@ -142,9 +142,20 @@ def main():
         bytes_per_launch = info["algorithmic_bytes_per_eval"] * B
         step_us = 1e3 * dev_ms / args.steps
         achieved = bytes_per_launch / (step_us * 1e-6) / 1e9
+        # HBM-side bytes per launch cannot be read live (PMC needs rocprofv3): take the value
+        # measured by the committed PMC passes of this same command when the shape matches
+        traffic, traffic_src = None, None
+        for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) \
+                if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            f = os.path.join(ROOT, "profiles", rnd, "traffic_b%d.json" % B)
+            if os.path.exists(f):
+                tj = json.load(open(f))
+                if tj.get("markers") == args.markers and tj.get("num_pc") == k:
+                    traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    break
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "llk_eval_kernel<%d>" % min(B, 8),
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "device_us_per_launch": step_us,

@@ -354,6 +354,24 @@ def test_insufficient_markers_fails_sanity(golden_dir, tmp_path):
     assert ei.value.code == _abi.VB2_ERR_SANITY
 
 
+def test_marker_sharded_single_process(c2):
+    """The marker-sharded evaluator (sum of per-shard partial LLKs) driving the library's
+    optimiser gives the same estimate as the single-context search."""
+    d, _ = c2
+    ctxs = [vb.LikelihoodContext(d.shard(r, 4)) for r in range(4)]
+    try:
+        def evaluate(pc1, pc2, alpha):
+            return sum(c.llk(pc1, pc2, alpha) for c in ctxs)
+        est = vb.optimize_with_evaluator(evaluate, 2)
+    finally:
+        for c in ctxs:
+            c.close()
+    with vb.LikelihoodContext(d) as ctx:
+        one = ctx.optimize()
+    assert abs(est["alpha"] - one["alpha"]) <= 1e-6
+    assert abs(est["llk1"] - one["llk1"]) <= 1e-9 * abs(one["llk1"])
+
+
 def test_device_pointer_api_on_torch_stream(c2):
     import torch
     d, _ = c2
