@@ -155,8 +155,9 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     std::vector<int64_t> code_hist(kMaxCode, 0);
     const double lo = in->avg_depth - 3 * in->sd_depth, hi = in->avg_depth + 3 * in->sd_depth;
     int64_t num_read = 0, num_other = 0;
-    std::vector<int32_t> eff_depth;
+    std::vector<int32_t> eff_depth;     // runs per marker (see below)
     eff_depth.reserve(M);
+    std::vector<int64_t> local_hist(kMaxCode, 0);
     for (int i = 0; i < M; ++i) {
         const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
         if (depth < 0) {
@@ -165,14 +166,19 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         }
         if (depth == 0) continue;
         if (!in->sanity_disabled && ((double)depth < lo || (double)depth > hi)) continue;
-        int32_t eff = 0;
+        // steps of this marker in the kernel = runs of equal (class, quality): one
+        // (code, count) pair per distinct code, counts above 255 split
         const char alt = in->alt_base[i];
+        std::fill(local_hist.begin(), local_hist.end(), 0);
         for (int64_t j = 0; j < depth; ++j) {
             const int bc = classify_base(in->bases[beg + j], alt);
             if (bc == 2) { ++num_other; continue; }
-            ++code_hist[bc * kNumQual + clamp_qual(in->quals[beg + j])];
-            ++eff;
+            const int c2 = bc * kNumQual + clamp_qual(in->quals[beg + j]);
+            ++code_hist[c2];
+            ++local_hist[c2];
         }
+        int32_t eff = 0;
+        for (int c2 = 0; c2 < kMaxCode; ++c2) eff += (int32_t)((local_hist[c2] + 254) / 255);
         num_read += depth;
         active.push_back(i);
         eff_depth.push_back(eff);
@@ -207,7 +213,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     for (int t = 0; t < num_mt; ++t) {
         const int32_t dmax = eff_depth[perm[(int64_t)t * kMtMarkers]];   // first lane is deepest
         mt_row_off[t] = (uint32_t)total_rows;
-        mt_rows[t] = (uint32_t)((dmax + 3) / 4);
+        mt_rows[t] = (uint32_t)((dmax + 1) / 2);             // two runs per dword
         total_rows += mt_rows[t];
     }
     if (total_rows >= (1ull << 32)) {
@@ -219,19 +225,20 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     std::vector<uint2> mt_rec(num_mt);
     for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rows[t]);
 
-    // unused step slots hold the padding code = num_code, a zero row of the LDS table
-    const uint32_t pad4 = 0x01010101u * (uint32_t)num_code;
+    // a dword holds two runs: code0 | count0<<8 | code1<<16 | count1<<24; unused slots hold
+    // the padding code = num_code (a zero row of the LDS table) with count 0
+    const uint32_t pad4 = 0x00010001u * (uint32_t)num_code;
     std::vector<uint32_t> codes((size_t)total_rows * kMtMarkers, pad4);
     std::vector<double> ud_s((size_t)k * m_pad, 0.0), mu_s(m_pad, 0.0), cdiag((size_t)4 * m_pad, 0.0);
     std::vector<double> kaf_s;
     if (in->known_af) kaf_s.assign(m_pad, 0.0);
-    std::vector<uint8_t> tmp;
+    std::vector<uint32_t> run_of(num_code + 1, 0);
     for (int64_t m = 0; m < m_active; ++m) {
         const int i = active[perm[m]];
         const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
         const char alt = in->alt_base[i];
         double c_other = 0.0, dg[3] = {0.0, 0.0, 0.0};
-        tmp.clear();
+        std::fill(run_of.begin(), run_of.end(), 0);
         for (int64_t j = 0; j < depth; ++j) {
             const int bc = classify_base(in->bases[beg + j], alt);
             const int q = clamp_qual(in->quals[beg + j]);
@@ -240,16 +247,24 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
                 c_other += lc[0];           // same for every genotype pair
             } else {
                 dg[0] += lc[0]; dg[1] += lc[1]; dg[2] += lc[2];
-                tmp.push_back(dict_of[bc * kNumQual + q]);
+                ++run_of[dict_of[bc * kNumQual + q]];
             }
         }
-        // reads of a marker in dictionary order: lanes of a wave then tend to hit
-        // the same or neighbouring LDS table rows at the same step (bank-friendly)
-        std::sort(tmp.begin(), tmp.end());
+        // runs in dictionary order: lanes of a wave then tend to hit the same or
+        // neighbouring LDS table rows at the same step (bank-friendly)
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
         uint8_t* row0 = reinterpret_cast<uint8_t*>(&codes[(size_t)mt_row_off[t] * kMtMarkers]);
-        for (size_t j = 0; j < tmp.size(); ++j)
-            row0[((j >> 2) * kMtMarkers + lane) * 4 + (j & 3)] = tmp[j];
+        size_t j = 0;
+        for (int d = 0; d < num_code; ++d) {
+            for (uint32_t left = run_of[d]; left > 0;) {
+                const uint32_t n = left > 255 ? 255 : left;
+                uint8_t* slot = row0 + ((j >> 1) * kMtMarkers + lane) * 4 + (j & 1) * 2;
+                slot[0] = (uint8_t)d;
+                slot[1] = (uint8_t)n;
+                left -= n;
+                ++j;
+            }
+        }
         if (in->known_af) {
             kaf_s[m] = in->known_af[i];
         } else {

@@ -18,8 +18,8 @@ constexpr int kMaxPointsPerLaunch = 8;
 // Everything the kernels read, in HBM.  "Sorted order" = active markers sorted by
 // (non-"other") depth, descending; position = micro_tile*16 + m.
 struct DeviceLayout {
-    const uint32_t* codes;        // [sum_t mt_rows[t]][16] dwords; byte j of row s = read 4s+j
-    const uint2* mt_rec;          // [num_mt] {first row, rows = ceil(deepest marker / 4)}
+    const uint32_t* codes;        // [sum_t mt_rows[t]][16] dwords = two (code, count) runs each
+    const uint2* mt_rec;          // [num_mt] {first row, rows = ceil(most runs in the tile / 2)}
     const double* ud;             // [num_pc][m_pad]  (SoA)
     const double* mu;             // [m_pad]
     const double* ediag;          // [4][m_pad]: c_other, exp(c_other+D[g]) for g = 0,1,2

@@ -6,9 +6,9 @@
 //     the BTL candidate points of slot g (BTL = 1 or 2 -> 4 or 8 points per launch);
 //     markers are sorted by depth at context creation and grouped in 16-marker
 //     micro-tiles so all lanes of a wave run the same number of steps;
-//   * reads are dictionary codes (class x quality), 4 per dword, stored
-//     [micro-tile][step/4][marker]: a wave load is one contiguous 64-byte row,
-//     rows are prefetched two deep;
+//   * a marker's reads are run-length coded over the (class x quality) dictionary:
+//     (code, count) byte pairs, two per dword, stored [micro-tile][step/2][marker]:
+//     a wave load is one contiguous 64-byte row, rows are prefetched two deep;
 //   * the per-alpha log-likelihood table (h:213-229) is rebuilt per launch in LDS,
 //     restricted to the codes that occur in the data and to the six OFF-diagonal
 //     genotype pairs: the diagonal (g1==g2) and the "other base" class do not
@@ -240,7 +240,7 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     // -- so no work list has to be fetched before the first load of a tile can issue.
     const uint32_t nslot = gridDim.x * (uint32_t)nwave;
     const uint32_t u = (uint32_t)wave * gridDim.x + blockIdx.x;
-    const uint32_t padw = 0x01010101u * (uint32_t)L.num_code;
+    const uint32_t padw = 0x00010001u * (uint32_t)L.num_code;
     const double* my_tab = tab + g * (6 * BTL);
     const double* my_pts = pts + (g * BTL) * stride;
     const size_t mp = L.m_pad;
@@ -261,7 +261,7 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
 #pragma unroll
         for (int i = 0; i < BTL * 6; ++i) acc[i] = 0.0;
 
-        // ---- per-read accumulate (h:288-303); code rows prefetched two deep ----
+        // ---- per-read accumulate (h:288-303), one step per run; rows prefetched two deep ----
         const uint32_t* cp = L.codes + (size_t)rec.x * kMtMarkers + m;
         const int rows = (L.ablate & 2) ? 0 : (int)rec.y;
         uint32_t w_cur = rows > 0 ? cp[0] : padw;
@@ -269,14 +269,16 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
         for (int s = 0; s < rows; ++s) {
             const uint32_t w_n2 = (s + 2 < rows) ? cp[(size_t)(s + 2) * kMtMarkers] : padw;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = (w_cur >> (8 * j)) & 0xffu;
+            for (int j = 0; j < 2; ++j) {
+                // one run: `n` reads of the same (class, quality) -> n * table row
+                const uint32_t c = (w_cur >> (16 * j)) & 0xffu;
+                const double n = (double)((w_cur >> (16 * j + 8)) & 0xffu);
                 const double2* row = reinterpret_cast<const double2*>(my_tab + c * RS);
 #pragma unroll
                 for (int i = 0; i < 3 * BTL; ++i) {
                     const double2 t = row[i];
-                    acc[2 * i] += t.x;
-                    acc[2 * i + 1] += t.y;
+                    acc[2 * i] = fma(n, t.x, acc[2 * i]);
+                    acc[2 * i + 1] = fma(n, t.y, acc[2 * i + 1]);
                 }
             }
             w_cur = w_nxt;
