@@ -99,6 +99,14 @@ int vb2_llk_eval_batch_device(vb2_ctx* ctx, int32_t num_point, const double* d_p
     return ctx->impl->eval_device(num_point, d_points, d_llk_out, (hipStream_t)stream);
 }
 
+// Profiling aid (not part of the public header): per-workgroup wall-clock stamps of the
+// last launch when the context was created with VB2_STAMPS set.
+int vb2_debug_read_stamps(vb2_ctx* ctx, unsigned long long* out, int max_blocks)
+{
+    if (guard_ctx(ctx)) return 0;
+    return ctx->impl->read_stamps(out, max_blocks);
+}
+
 int vb2_optimize_llk(vb2_eval_fn eval, void* user, int32_t num_pc, const vb2_model* model,
                      vb2_estimate* out, vb2_trace* trace)
 {

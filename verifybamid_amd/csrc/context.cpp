@@ -92,7 +92,7 @@ Context::~Context()
     auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
     fr(L.codes); fr(L.mt_rec); fr(L.ud); fr(L.mu); fr(L.ediag);
     fr(L.known_af); fr(L.dict_perr);
-    fr(d_partials);
+    fr(d_partials); fr(d_ticket); fr(d_stamps);
     if (h_points) (void)hipHostFree(h_points);
     if (h_out) (void)hipHostFree(h_out);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -316,6 +316,14 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
 
     const int nb = kMaxGridPerCU * num_cu;
     VB2_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * (size_t)kMaxPointsPerLaunch * nb));
+    VB2_HIP(hipMalloc((void**)&c->d_ticket, sizeof(unsigned int)));
+    VB2_HIP(hipMemset(c->d_ticket, 0, sizeof(unsigned int)));
+    if (std::getenv("VB2_STAMPS")) {
+        VB2_HIP(hipMalloc((void**)&c->d_stamps, sizeof(unsigned long long) * 8 * nb));
+        VB2_HIP(hipMemset(c->d_stamps, 0, sizeof(unsigned long long) * 8 * nb));
+        L.stamps = c->d_stamps;
+    }
+    if (const char* sl = std::getenv("VB2_SINGLE_LAUNCH")) set_single_launch(std::atoi(sl) != 0);
     // Host <-> device hand-off of the (tiny) parameter and result vectors goes through
     // pinned, device-mapped host memory that the kernels access directly: no copy
     // commands on the evaluation path.
@@ -353,7 +361,7 @@ int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipS
         VB2_HIP(launch_fill_zero(d_llk, num_point, s));
         return VB2_OK;
     }
-    VB2_HIP(launch_llk_eval(L, num_point, d_pts, d_partials, d_llk, s));
+    VB2_HIP(launch_llk_eval(L, num_point, d_pts, d_partials, d_llk, d_ticket, s));
     return VB2_OK;
 }
 
@@ -380,6 +388,15 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
         std::memcpy(llk_out + done, h_out, sizeof(double) * n);
     }
     return VB2_OK;
+}
+
+int Context::read_stamps(unsigned long long* out, int max_blocks)
+{
+    if (!d_stamps) return 0;
+    const int nb = std::min(max_blocks, kMaxGridPerCU * L.num_cu);
+    if (hipMemcpy(out, d_stamps, sizeof(unsigned long long) * 8 * nb, hipMemcpyDeviceToHost) != hipSuccess)
+        return 0;
+    return nb;
 }
 
 void Context::fill_info(vb2_info* info) const

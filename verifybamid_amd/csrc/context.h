@@ -29,6 +29,7 @@ public:
     int eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,
                   double* llk_out);
     void fill_info(vb2_info* info) const;
+    int read_stamps(unsigned long long* out, int max_blocks);
 
     int device = -1;
     int num_marker = 0;
@@ -37,6 +38,8 @@ public:
     hipStream_t stream = nullptr;
     bool own_stream = false;
     double* d_partials = nullptr;
+    unsigned int* d_ticket = nullptr;
+    unsigned long long* d_stamps = nullptr;   // VB2_STAMPS profiling aid
     double* h_points = nullptr;   // pinned + device-mapped staging (host view)
     double* h_out = nullptr;
     double* d_points = nullptr;   // device view of the same memory

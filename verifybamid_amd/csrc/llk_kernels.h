@@ -30,6 +30,7 @@ struct DeviceLayout {
     int32_t num_pc;
     int32_t num_cu;               // compute units of the device
     int32_t ablate;               // profiling aid (VB2_ABLATE): 1 no table math, 2 no read loop, 4 no epilogue math
+    unsigned long long* stamps;   // profiling aid: [grid][8] wall-clock stamps, or nullptr
     int64_t num_active;
     int64_t m_pad;                // num_mt * 16
 };
@@ -41,8 +42,11 @@ constexpr int kMaxGridPerCU = 2;
 
 // Enqueue evaluation of num_point candidate rows (pc1 | pc2 | alpha) on stream.
 // d_partials: >= kMaxPointsPerLaunch * kMaxGridPerCU * L.num_cu doubles of scratch.
+// d_ticket: one zero-initialised unsigned int (arrival counter of the single-launch mode).
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
-                           double* d_partials, double* d_out, hipStream_t stream);
+                           double* d_partials, double* d_out, unsigned int* d_ticket,
+                           hipStream_t stream);
+void set_single_launch(bool on);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 // A/B switch: lanes of one ds_read_b128 service group share a candidate slot (default) or plain
 void set_lane_mapping(bool hardware_groups);

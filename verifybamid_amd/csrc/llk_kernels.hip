@@ -21,7 +21,8 @@
 //     depth-sorted micro-tiles are dealt to the wave slots round-robin across
 //     workgroups, so every CU sees the same depth mix;
 //   * deterministic reduction: 16-lane butterfly -> waves of the block -> per-block
-//     partial; a one-block finalize kernel sums the partials in a fixed order.
+//     partial; the last workgroup to arrive (agent-scope ticket) sums the partials in a
+//     fixed order (or, two-kernel mode, a one-block finalize kernel does).
 #include "llk_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -187,7 +188,8 @@ template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU =
 template <int BTL, bool HWMAP>
 __global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPerSimd)
 llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid,
-                double* __restrict__ partials)
+                double* __restrict__ partials, double* __restrict__ llk_out,
+                unsigned int* __restrict__ ticket)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NP = 4 * BTL;
@@ -206,6 +208,9 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     const int wave = tid >> 6;
     int m, g;
     lane_map<HWMAP>(lane, m, g);
+    // profiling aid: 100 MHz wall-clock stamps per workgroup (L.stamps == nullptr normally)
+    unsigned long long* stamps = L.stamps ? L.stamps + (size_t)blockIdx.x * 8 : nullptr;
+    if (stamps && tid == 0) stamps[0] = wall_clock64();
 
     // parameter rows -> LDS with one coalesced load (they may live in mapped host memory)
     for (int e = tid; e < NP * stride; e += nthread) {
@@ -214,6 +219,7 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
         pts[e] = points[src * stride + (e - b * stride)];
     }
     __syncthreads();
+    if (stamps && tid == 0) stamps[1] = wall_clock64();
 
     // ---- per-alpha table, off-diagonal pairs only (h:213-229) ----
     for (int e = tid; e < nrow * 6 * NP; e += nthread) {
@@ -230,6 +236,7 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
         tab[d * RS + bp] = v;
     }
     __syncthreads();
+    if (stamps && tid == 0) stamps[2] = wall_clock64();
 
     double llk_lane[BTL];
 #pragma unroll
@@ -339,6 +346,10 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
         }
     }
 
+    if (stamps && lane == 0) {
+        if (wave == 0) stamps[3] = wall_clock64();           // wave 0 done with its tiles
+        if (wave == nwave - 1) stamps[4] = wall_clock64();   // last wave done with its tiles
+    }
     // ---- deterministic block reduction -> one partial per (point, block) ----
     // butterfly over the 16 lanes that share candidate slot g
 #pragma unroll
@@ -352,11 +363,55 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
         for (int t = 0; t < BTL; ++t) red[wave * NP + g * BTL + t] = llk_lane[t];
     }
     __syncthreads();
+    if (stamps && tid == 0) stamps[5] = wall_clock64();
+    if (ticket == nullptr) {                     // two-kernel mode: llk_finalize_kernel follows
+        if (tid < NP) {
+            double s = 0;
+            for (int w = 0; w < nwave; ++w) s += red[w * NP + tid];
+            partials[(size_t)tid * gridDim.x + blockIdx.x] = s;
+        }
+        return;
+    }
+    // ---- single-launch mode: the last workgroup to arrive sums all partials ----
+    // Hand-off through 8-byte agent-scope atomics on both sides (write-through stores,
+    // L1-bypassing loads), drained before the ticket is drawn: placement independent.
     if (tid < NP) {
         double s = 0;
         for (int w = 0; w < nwave; ++w) s += red[w * NP + tid];
-        partials[(size_t)tid * gridDim.x + blockIdx.x] = s;
+        __hip_atomic_store(&partials[(size_t)tid * gridDim.x + blockIdx.x], s, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned int* last_flag = reinterpret_cast<unsigned int*>(red);      // red is dead now
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+        *last_flag = (t == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*last_flag == 0u) return;
+    // same summation order as llk_finalize_kernel: lane-strided, then a wave butterfly
+    const int nb = (int)gridDim.x;
+    for (int b = wave; b < num_valid; b += nwave) {
+        const double* p = partials + (size_t)b * nb;
+        double s = 0;
+        for (int base = 0; base < nb; base += 8 * 64) {
+            double x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = base + q * 64 + lane;
+                x[q] = i < nb ? __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += x[q];
+        }
+        s = wave_sum(s);
+        if (lane == 0) llk_out[b] = s;
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamps && tid == 0) stamps[6] = wall_clock64();
 }
 
 // Sums the per-block partials in a fixed order -> bitwise reproducible: wave w takes
@@ -416,20 +471,26 @@ void set_lane_mapping(bool hw) { g_hwmap = hw; }
 
 template <int BTL, bool HWMAP>
 static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int num_valid,
-                             double* d_partials, hipStream_t stream)
+                             double* d_partials, double* d_out, unsigned int* d_ticket,
+                             hipStream_t stream)
 {
     constexpr int NP = 4 * BTL;
     const size_t shmem = sizeof(double) * (size_t)((L.num_code + 1) * row_stride(NP) +
                                                    kMaxBlockWaves * NP + NP * (2 * L.num_pc + 1));
     const LaunchGeom gm = launch_geom(L, BTL);
     hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
-                       stream, L, d_points, num_valid, d_partials);
+                       stream, L, d_points, num_valid, d_partials, d_out, d_ticket);
     return hipGetLastError();
 }
 
+static bool g_single_launch = true;
+void set_single_launch(bool on) { g_single_launch = on; }
+
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
-                           double* d_partials, double* d_out, hipStream_t stream)
+                           double* d_partials, double* d_out, unsigned int* d_ticket,
+                           hipStream_t stream)
 {
+    unsigned int* tk = g_single_launch ? d_ticket : nullptr;
     const int stride = 2 * L.num_pc + 1;
     int done = 0;
     while (done < num_point) {
@@ -438,15 +499,17 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         const int step = left > 4 ? (left < 8 ? left : 8) : left;
         hipError_t e;
         if (step > 4)
-            e = g_hwmap ? launch_btl<2, true>(L, p, step, d_partials, stream)
-                        : launch_btl<2, false>(L, p, step, d_partials, stream);
+            e = g_hwmap ? launch_btl<2, true>(L, p, step, d_partials, d_out + done, tk, stream)
+                        : launch_btl<2, false>(L, p, step, d_partials, d_out + done, tk, stream);
         else
-            e = g_hwmap ? launch_btl<1, true>(L, p, step, d_partials, stream)
-                        : launch_btl<1, false>(L, p, step, d_partials, stream);
+            e = g_hwmap ? launch_btl<1, true>(L, p, step, d_partials, d_out + done, tk, stream)
+                        : launch_btl<1, false>(L, p, step, d_partials, d_out + done, tk, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(256), 0, stream, d_partials,
-                           launch_geom(L, step > 4 ? 2 : 1).grid, step, d_out + done);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (!tk) {
+            hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(256), 0, stream, d_partials,
+                               launch_geom(L, step > 4 ? 2 : 1).grid, step, d_out + done);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
         done += step;
     }
     return hipSuccess;
