@@ -314,7 +314,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     c->num_read_other = num_other;
     c->algorithmic_bytes = 2 * num_read + m_active * (8 * (int64_t)k + 12);
 
-    const int nb = kMaxGridPerCU * num_cu;
+    const int nb = std::max(kMaxGridPerCU * num_cu, (num_mt + kMaxTilesPerBlock - 1) / kMaxTilesPerBlock);
     VB2_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * (size_t)kMaxPointsPerLaunch * nb));
     VB2_HIP(hipMalloc((void**)&c->d_ticket, sizeof(unsigned int)));
     VB2_HIP(hipMemset(c->d_ticket, 0, sizeof(unsigned int)));
@@ -393,7 +393,7 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
 int Context::read_stamps(unsigned long long* out, int max_blocks)
 {
     if (!d_stamps) return 0;
-    const int nb = std::min(max_blocks, kMaxGridPerCU * L.num_cu);
+    const int nb = std::min(max_blocks, max_grid(L));
     if (hipMemcpy(out, d_stamps, sizeof(unsigned long long) * 8 * nb, hipMemcpyDeviceToHost) != hipSuccess)
         return 0;
     return nb;

@@ -39,6 +39,12 @@ struct LaunchGeom { int grid, block_waves; };
 // Workgroups / waves per workgroup used for a launch of 4*btl points.
 LaunchGeom launch_geom(const DeviceLayout& L, int btl);
 constexpr int kMaxGridPerCU = 2;
+constexpr int kMaxTilesPerBlock = 1024;   // per-tile result slots a workgroup keeps in LDS
+inline int max_grid(const DeviceLayout& L)
+{
+    const int a = kMaxGridPerCU * L.num_cu, b = (L.num_mt + kMaxTilesPerBlock - 1) / kMaxTilesPerBlock;
+    return a > b ? a : b;
+}
 
 // Enqueue evaluation of num_point candidate rows (pc1 | pc2 | alpha) on stream.
 // d_partials: >= kMaxPointsPerLaunch * kMaxGridPerCU * L.num_cu doubles of scratch.

@@ -200,8 +200,10 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     const int k = L.num_pc;
     const int stride = 2 * k + 1;
     double* tab = lds;                          // [nrow][RS]
-    double* red = lds + nrow * RS;              // [nwave][NP]
-    double* pts = red + kMaxBlockWaves * NP;    // [NP][2k+1] this launch's parameter rows
+    double* red = lds + nrow * RS;              // [NP] block sums; then the work-queue counter
+    unsigned int* queue = reinterpret_cast<unsigned int*>(red + NP);
+    double* pts = red + NP + 2;                 // [NP][2k+1] this launch's parameter rows
+    double* tile_llk = pts + NP * stride;       // [tiles of this workgroup][NP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -212,6 +214,7 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     unsigned long long* stamps = L.stamps ? L.stamps + (size_t)blockIdx.x * 8 : nullptr;
     if (stamps && tid == 0) stamps[0] = wall_clock64();
 
+    if (tid == 0) *queue = (unsigned int)nwave;      // waves start on tiles 0..nwave-1
     // parameter rows -> LDS with one coalesced load (they may live in mapped host memory)
     for (int e = tid; e < NP * stride; e += nthread) {
         const int b = e / stride;
@@ -238,24 +241,23 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     __syncthreads();
     if (stamps && tid == 0) stamps[2] = wall_clock64();
 
-    double llk_lane[BTL];
-#pragma unroll
-    for (int t = 0; t < BTL; ++t) llk_lane[t] = 0.0;
-
-    // Micro-tiles are dealt to (workgroup, wave) slots arithmetically -- consecutive
-    // (depth-sorted) tiles go to consecutive workgroups, alternate rounds run backwards
-    // -- so no work list has to be fetched before the first load of a tile can issue.
-    const uint32_t nslot = gridDim.x * (uint32_t)nwave;
-    const uint32_t u = (uint32_t)wave * gridDim.x + blockIdx.x;
+    // Work distribution.  Workgroup b owns micro-tiles b, b+grid, b+2*grid, ... (the tiles are
+    // depth-sorted, so every workgroup -- hence every CU, and every XCD's L2 at every launch --
+    // gets the same depth mix of the same data).  Inside the workgroup the waves pull tiles
+    // from that list longest-first through an LDS counter, which evens out the 1-vs-2-tiles
+    // imbalance a static deal leaves.  Each tile's result goes to its own LDS slot and the
+    // slots are summed in index order afterwards, so the dynamic schedule does not change
+    // a single bit of the result.
+    const uint32_t ntile_blk = ((uint32_t)L.num_mt + gridDim.x - 1 - blockIdx.x) / gridDim.x;
     const uint32_t padw = 0x00010001u * (uint32_t)L.num_code;
     const double* my_tab = tab + g * (6 * BTL);
     const double* my_pts = pts + (g * BTL) * stride;
     const size_t mp = L.m_pad;
-    const uint32_t nround = ((uint32_t)L.num_mt + nslot - 1) / nslot;
-    for (uint32_t round = 0; round < nround; ++round) {
-        const uint64_t t64 = (uint64_t)round * nslot + ((round & 1) ? nslot - 1 - u : u);
-        if (t64 >= (uint64_t)L.num_mt) continue;             // wave-uniform
-        const uint32_t mt = (uint32_t)t64;
+    for (uint32_t it = (uint32_t)wave; it < ntile_blk;) {
+        const uint32_t mt = blockIdx.x + it * gridDim.x;
+        double llk_lane[BTL];
+#pragma unroll
+        for (int t = 0; t < BTL; ++t) llk_lane[t] = 0.0;
         const uint2 rec = L.mt_rec[mt];                      // {first row, rows}
         // per-marker constants: issued now, consumed after the read loop
         const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
@@ -344,6 +346,21 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
                 if (lk > 0) llk_lane[t] += log_nonneg(lk);
             }
         }
+        // tile result: butterfly over the 16 lanes (markers) that share candidate slot g
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const int partner = lane_of<HWMAP>(m ^ off, g);
+#pragma unroll
+            for (int t = 0; t < BTL; ++t) llk_lane[t] += __shfl(llk_lane[t], partner, 64);
+        }
+        if (m == 0) {
+#pragma unroll
+            for (int t = 0; t < BTL; ++t) tile_llk[(size_t)it * NP + g * BTL + t] = llk_lane[t];
+        }
+        // next tile of this workgroup, whichever wave gets there first
+        uint32_t nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1u);
+        it = __builtin_amdgcn_readfirstlane(nxt);
     }
 
     if (stamps && lane == 0) {
@@ -351,39 +368,28 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
         if (wave == nwave - 1) stamps[4] = wall_clock64();   // last wave done with its tiles
     }
     // ---- deterministic block reduction -> one partial per (point, block) ----
-    // butterfly over the 16 lanes that share candidate slot g
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        const int partner = lane_of<HWMAP>(m ^ off, g);
-#pragma unroll
-        for (int t = 0; t < BTL; ++t) llk_lane[t] += __shfl(llk_lane[t], partner, 64);
-    }
-    if (m == 0) {
-#pragma unroll
-        for (int t = 0; t < BTL; ++t) red[wave * NP + g * BTL + t] = llk_lane[t];
+    __syncthreads();
+    for (int b = wave; b < NP; b += nwave) {         // tiles in index order, then a butterfly
+        double s = 0;
+        for (uint32_t i = lane; i < ntile_blk; i += 64) s += tile_llk[(size_t)i * NP + b];
+        s = wave_sum(s);
+        if (lane == 0) red[b] = s;
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[5] = wall_clock64();
     if (ticket == nullptr) {                     // two-kernel mode: llk_finalize_kernel follows
-        if (tid < NP) {
-            double s = 0;
-            for (int w = 0; w < nwave; ++w) s += red[w * NP + tid];
-            partials[(size_t)tid * gridDim.x + blockIdx.x] = s;
-        }
+        if (tid < NP) partials[(size_t)tid * gridDim.x + blockIdx.x] = red[tid];
         return;
     }
     // ---- single-launch mode: the last workgroup to arrive sums all partials ----
     // Hand-off through 8-byte agent-scope atomics on both sides (write-through stores,
     // L1-bypassing loads), drained before the ticket is drawn: placement independent.
-    if (tid < NP) {
-        double s = 0;
-        for (int w = 0; w < nwave; ++w) s += red[w * NP + tid];
-        __hip_atomic_store(&partials[(size_t)tid * gridDim.x + blockIdx.x], s, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid < NP)
+        __hip_atomic_store(&partials[(size_t)tid * gridDim.x + blockIdx.x], red[tid],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned int* last_flag = reinterpret_cast<unsigned int*>(red);      // red is dead now
+    unsigned int* last_flag = queue;                                    // the queue is drained
     if (tid == 0) {
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED,
                                                       __HIP_MEMORY_SCOPE_AGENT);
@@ -463,6 +469,8 @@ LaunchGeom launch_geom(const DeviceLayout& L, int btl)
     bw = bw < 4 ? 4 : (bw > max_waves ? max_waves : bw);
     int grid = (L.num_mt + bw - 1) / bw;
     grid = grid < 1 ? 1 : (grid > grid_target ? grid_target : grid);
+    const int min_grid = (L.num_mt + kMaxTilesPerBlock - 1) / kMaxTilesPerBlock;   // LDS slots per tile
+    if (grid < min_grid) grid = min_grid;
     return LaunchGeom{grid, bw};
 }
 
@@ -475,9 +483,10 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int 
                              hipStream_t stream)
 {
     constexpr int NP = 4 * BTL;
-    const size_t shmem = sizeof(double) * (size_t)((L.num_code + 1) * row_stride(NP) +
-                                                   kMaxBlockWaves * NP + NP * (2 * L.num_pc + 1));
     const LaunchGeom gm = launch_geom(L, BTL);
+    const size_t tiles_per_block = (size_t)(L.num_mt + gm.grid - 1) / gm.grid;
+    const size_t shmem = sizeof(double) * ((size_t)(L.num_code + 1) * row_stride(NP) + NP + 2 +
+                                           (size_t)NP * (2 * L.num_pc + 1) + tiles_per_block * NP);
     hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
                        stream, L, d_points, num_valid, d_partials, d_out, d_ticket);
     return hipGetLastError();
