@@ -24,7 +24,8 @@ public:
     ~Context();
     static int create(const vb2_input* in, const vb2_options* opt, Context** out);
     // device pointers, asynchronous on s (nullptr = own stream)
-    int eval_device(int num_point, const double* d_points, double* d_llk, hipStream_t s);
+    int eval_device(int num_point, const double* d_points, double* d_llk, hipStream_t s,
+                    unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0);
     // host pointers, synchronous
     int eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,
                   double* llk_out);
@@ -44,6 +45,10 @@ public:
     double* h_out = nullptr;
     double* d_points = nullptr;   // device view of the same memory
     double* d_out = nullptr;
+    unsigned long long* h_done = nullptr;   // completion sequence number (mapped host memory)
+    unsigned long long* d_done = nullptr;
+    unsigned long long done_seq_ = 0;
+    bool spin_wait = true;
     int64_t num_read = 0, num_read_other = 0, device_bytes = 0, algorithmic_bytes = 0;
     char device_name[64] = {0};
     char arch[32] = {0};

@@ -49,8 +49,11 @@ inline int max_grid(const DeviceLayout& L)
 // Enqueue evaluation of num_point candidate rows (pc1 | pc2 | alpha) on stream.
 // d_partials: >= kMaxPointsPerLaunch * kMaxGridPerCU * L.num_cu doubles of scratch.
 // d_ticket: one zero-initialised unsigned int (arrival counter of the single-launch mode).
+// done_flag: optional word in mapped host memory that receives done_seq after the results of
+// the LAST launch are written (lets the host wait without hipStreamSynchronize).
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
                            double* d_partials, double* d_out, unsigned int* d_ticket,
+                           unsigned long long* done_flag, unsigned long long done_seq,
                            hipStream_t stream);
 void set_single_launch(bool on);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);

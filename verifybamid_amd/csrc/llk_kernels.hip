@@ -189,7 +189,8 @@ template <int BTL, bool HWMAP>
 __global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPerSimd)
 llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid,
                 double* __restrict__ partials, double* __restrict__ llk_out,
-                unsigned int* __restrict__ ticket)
+                unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
+                unsigned long long done_seq)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NP = 4 * BTL;
@@ -418,6 +419,15 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     }
     if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (stamps && tid == 0) stamps[6] = wall_clock64();
+    if (done_flag) {
+        // host hand-off without a stream synchronisation: results (in mapped host memory)
+        // first, then the sequence number the host is spinning on
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();
+            __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // Sums the per-block partials in a fixed order -> bitwise reproducible: wave w takes
@@ -425,7 +435,8 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
 // then a butterfly over the wave.
 __global__ void __launch_bounds__(256)
 llk_finalize_kernel(const double* __restrict__ partials, int nb, int num_point,
-                    double* __restrict__ llk_out)
+                    double* __restrict__ llk_out, unsigned long long* __restrict__ done_flag,
+                    unsigned long long done_seq)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int b = wave; b < num_point; b += 4) {
@@ -443,6 +454,13 @@ llk_finalize_kernel(const double* __restrict__ partials, int nb, int num_point,
         }
         s = wave_sum(s);
         if (lane == 0) llk_out[b] = s;
+    }
+    if (done_flag) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -480,6 +498,7 @@ void set_lane_mapping(bool hw) { g_hwmap = hw; }
 template <int BTL, bool HWMAP>
 static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int num_valid,
                              double* d_partials, double* d_out, unsigned int* d_ticket,
+                             unsigned long long* done_flag, unsigned long long done_seq,
                              hipStream_t stream)
 {
     constexpr int NP = 4 * BTL;
@@ -488,7 +507,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int 
     const size_t shmem = sizeof(double) * ((size_t)(L.num_code + 1) * row_stride(NP) + NP + 2 +
                                            (size_t)NP * (2 * L.num_pc + 1) + tiles_per_block * NP);
     hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
-                       stream, L, d_points, num_valid, d_partials, d_out, d_ticket);
+                       stream, L, d_points, num_valid, d_partials, d_out, d_ticket, done_flag, done_seq);
     return hipGetLastError();
 }
 
@@ -497,6 +516,7 @@ void set_single_launch(bool on) { g_single_launch = on; }
 
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
                            double* d_partials, double* d_out, unsigned int* d_ticket,
+                           unsigned long long* done_flag, unsigned long long done_seq,
                            hipStream_t stream)
 {
     unsigned int* tk = g_single_launch ? d_ticket : nullptr;
@@ -506,17 +526,19 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         const int left = num_point - done;
         const double* p = d_points + (size_t)done * stride;
         const int step = left > 4 ? (left < 8 ? left : 8) : left;
+        unsigned long long* df = (done + step >= num_point) ? done_flag : nullptr;   // last launch signals
+        unsigned long long* df_eval = tk ? df : nullptr;
         hipError_t e;
         if (step > 4)
-            e = g_hwmap ? launch_btl<2, true>(L, p, step, d_partials, d_out + done, tk, stream)
-                        : launch_btl<2, false>(L, p, step, d_partials, d_out + done, tk, stream);
+            e = g_hwmap ? launch_btl<2, true>(L, p, step, d_partials, d_out + done, tk, df_eval, done_seq, stream)
+                        : launch_btl<2, false>(L, p, step, d_partials, d_out + done, tk, df_eval, done_seq, stream);
         else
-            e = g_hwmap ? launch_btl<1, true>(L, p, step, d_partials, d_out + done, tk, stream)
-                        : launch_btl<1, false>(L, p, step, d_partials, d_out + done, tk, stream);
+            e = g_hwmap ? launch_btl<1, true>(L, p, step, d_partials, d_out + done, tk, df_eval, done_seq, stream)
+                        : launch_btl<1, false>(L, p, step, d_partials, d_out + done, tk, df_eval, done_seq, stream);
         if (e != hipSuccess) return e;
         if (!tk) {
             hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(256), 0, stream, d_partials,
-                               launch_geom(L, step > 4 ? 2 : 1).grid, step, d_out + done);
+                               launch_geom(L, step > 4 ? 2 : 1).grid, step, d_out + done, df, done_seq);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         done += step;
