@@ -177,10 +177,12 @@ __device__ __forceinline__ int lane_of(int m, int g)
     return (g << 4) + m;
 }
 
-// Occupancy targets: BTL=1 fits 80 VGPRs -> 6 waves/SIMD = two 768-thread workgroups
-// per CU; BTL=2 needs ~128 VGPRs -> 4 waves/SIMD = one 1024-thread workgroup per CU.
+// Occupancy target: one 1024-thread workgroup per CU (4 waves/SIMD, <=128 VGPRs).  Two
+// smaller workgroups per CU were measured slower: the per-alpha table is built once per
+// workgroup, and that redundant work is 9 % of a launch's transcendentals at one
+// workgroup per CU but 18 % at two.
 template <int BTL> struct Geom;
-template <> struct Geom<1> { static constexpr int kMaxWaves = 12, kBlocksPerCU = 2, kWavesPerSimd = 6; };
+template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 
 // BTL = candidate points per lane; a launch evaluates NP = 4*BTL points
