@@ -178,6 +178,24 @@ int vb2_ctx_optimize_llk(vb2_ctx *ctx, const vb2_model *model, vb2_estimate *out
                          vb2_trace *trace);
 
 /* ------------------------------------------------------------------------- *
+ * 2b. Cohorts: several samples (contexts on one device, same --NumPC) advancing in
+ *     lock-step -- every Nelder-Mead step of every sample goes into ONE kernel launch
+ *     (BASELINE.json configs[4]; the reference would run them as separate processes).
+ * ------------------------------------------------------------------------- */
+typedef struct vb2_batch vb2_batch;
+#define VB2_BATCH_SLOTS 8      /* parameter points per sample and step */
+
+int vb2_batch_create(vb2_ctx *const *ctxs, int32_t num_sample, vb2_batch **out);
+void vb2_batch_destroy(vb2_batch *b);
+/* One step: sample s evaluates num_point[s] (0..8) points.  pc1/pc2 are
+ * [num_sample][8][num_pc], alpha and llk_out [num_sample][8]; unused slots are ignored. */
+int vb2_batch_eval(vb2_batch *b, const int32_t *num_point, const double *pc1, const double *pc2,
+                   const double *alpha, double *llk_out);
+/* OptimizeLLK for every sample; models has 1 entry (shared) or num_sample entries. */
+int vb2_batch_optimize_llk(vb2_batch *b, const vb2_model *models, int32_t num_model,
+                           vb2_estimate *out);
+
+/* ------------------------------------------------------------------------- *
  * 3. File level: the --SVDPrefix/--PileupFile flow of execute()
  *    (main.cpp:283-411): panel + pileup readers, sanity check, OptimizeLLK,
  *    <out>.Ancestry and <out>.selfSM writers.

@@ -372,6 +372,42 @@ def test_marker_sharded_single_process(c2):
     assert abs(est["llk1"] - one["llk1"]) <= 1e-9 * abs(one["llk1"])
 
 
+def test_cohort_batch_lockstep_matches_individual_runs():
+    """vb2_batch: samples of different sizes (one of them with no reads at all) evaluated and
+    optimised in lock-step give each sample the result of its own single-context run."""
+    specs = [(3000, 25, 0.02, 61), (1200, 8, 0.15, 62), (5000, 40, 0.3, 63), (64, 5, 0.1, 64),
+             (2000, 30, 0.0, 65)]
+    datas = [vb.synth.make_pileup(M, dep, 3, alpha_true=a, seed=sd) for (M, dep, a, sd) in specs]
+    empty = vb.synth.make_pileup(50, 10, 3, seed=66, missing_frac=1.0)
+    datas.insert(2, empty)
+    ctxs = [vb.LikelihoodContext(d) for d in datas]
+    try:
+        rng = np.random.default_rng(9)
+        S, k = len(ctxs), 3
+        with vb.CohortBatch(ctxs) as batch:
+            npt = np.array([8, 3, 2, 0, 5, 1], dtype=np.int32)
+            pc1 = rng.normal(0, 0.03, size=(S, 8, k))
+            pc2 = rng.normal(0, 0.03, size=(S, 8, k))
+            al = rng.uniform(0, 0.5, size=(S, 8))
+            got = batch.eval(npt, pc1, pc2, al)
+            for s in range(S):
+                n = int(npt[s])
+                if n:
+                    want = ctxs[s].llk(pc1[s, :n], pc2[s, :n], al[s, :n])
+                    assert rel_err(got[s, :n], want) <= LLK_RTOL if np.any(want != 0) else np.all(got[s, :n] == 0)
+            again = batch.eval(npt, pc1, pc2, al)
+            assert np.array_equal(got, again)
+            ests = batch.optimize()
+        for s in range(S):
+            one = ctxs[s].optimize()
+            assert abs(ests[s]["alpha"] - one["alpha"]) <= 1e-6, s
+            assert abs(ests[s]["llk1"] - one["llk1"]) <= 1e-9 * max(1.0, abs(one["llk1"])), s
+            assert ests[s]["num_eval"] > 0
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_device_pointer_api_on_torch_stream(c2):
     import torch
     d, _ = c2

@@ -93,6 +93,7 @@ SYMBOLS = [
     "vb2_llk_eval_batch_device", "vb2_optimize_llk", "vb2_ctx_optimize_llk", "vb2_run",
     "vb2_flat_load", "vb2_flat_input", "vb2_flat_stats", "vb2_flat_free", "vb2_last_error",
     "vb2_abi_version", "vb2_device_count",
+    "vb2_batch_create", "vb2_batch_destroy", "vb2_batch_eval", "vb2_batch_optimize_llk",
 ]
 
 _lib = None
@@ -140,6 +141,11 @@ def lib():
     L.vb2_flat_stats.argtypes = [C.c_void_p, C.POINTER(RunResult)]
     L.vb2_flat_free.argtypes = [C.c_void_p]
     L.vb2_flat_free.restype = None
+    L.vb2_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]
+    L.vb2_batch_destroy.argtypes = [C.c_void_p]
+    L.vb2_batch_destroy.restype = None
+    L.vb2_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vb2_batch_optimize_llk.argtypes = [C.c_void_p, C.POINTER(Model), C.c_int32, C.POINTER(Estimate)]
     _lib = L
     return L
 

@@ -218,6 +218,55 @@ class LikelihoodContext:
         return out
 
 
+class CohortBatch:
+    """vb2_batch: several LikelihoodContexts (one device, same --NumPC) evaluated and
+    optimised in lock-step, one kernel launch per step for the whole cohort."""
+    SLOTS = 8
+
+    def __init__(self, contexts):
+        self._lib = _abi.lib()
+        self.contexts = list(contexts)
+        self.num_pc = self.contexts[0].num_pc
+        n = len(self.contexts)
+        arr = (C.c_void_p * n)(*[c._h for c in self.contexts])
+        h = C.c_void_p()
+        _abi.check(self._lib.vb2_batch_create(arr, n, C.byref(h)), "vb2_batch_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vb2_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def eval(self, num_point, pc1, pc2, alpha):
+        """num_point: [S] ints (0..8); pc1/pc2: [S,8,k]; alpha: [S,8] -> llk [S,8]."""
+        S, k = len(self.contexts), self.num_pc
+        npt = np.ascontiguousarray(num_point, dtype=np.int32)
+        pc1 = np.ascontiguousarray(pc1, dtype=np.float64).reshape(S, self.SLOTS, k)
+        pc2 = np.ascontiguousarray(pc2, dtype=np.float64).reshape(S, self.SLOTS, k)
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64).reshape(S, self.SLOTS)
+        out = np.zeros((S, self.SLOTS))
+        _abi.check(self._lib.vb2_batch_eval(self._h, _p(npt), _p(pc1), _p(pc2), _p(alpha), _p(out)),
+                   "vb2_batch_eval")
+        return out
+
+    def optimize(self, **model_kw):
+        S = len(self.contexts)
+        m, keep = _model(**model_kw)
+        est = (_abi.Estimate * S)()
+        _abi.check(self._lib.vb2_batch_optimize_llk(self._h, C.byref(m), 1, est),
+                   "vb2_batch_optimize_llk")
+        return [_estimate_dict(est[s], self.num_pc) for s in range(S)]
+
+
 def optimize_with_evaluator(evaluate, num_pc, trace_capacity=0, known_af=False, **model_kw):
     """OptimizeLLK over an arbitrary batched evaluator
         evaluate(pc1[B,k], pc2[B,k], alpha[B]) -> llk[B]

@@ -5,6 +5,7 @@
 #include <memory>
 #include <new>
 
+#include "batch.h"
 #include "context.h"
 #include "estimator.h"
 #include "hostio.h"
@@ -133,6 +134,53 @@ int vb2_ctx_optimize_llk(vb2_ctx* ctx, const vb2_model* model, vb2_estimate* out
 {
     if (int rc = guard_ctx(ctx)) return rc;
     return vb2_optimize_llk(ctx_eval_cb, ctx->impl, ctx->impl->num_pc, model, out, trace);
+}
+
+int vb2_batch_create(vb2_ctx* const* ctxs, int32_t num_sample, vb2_batch** out)
+{
+    if (!out) return VB2_ERR_INVALID;
+    *out = nullptr;
+    try {
+        vb2::Batch* b = nullptr;
+        const int rc = vb2::Batch::create(ctxs, num_sample, &b);
+        if (rc) return rc;
+        *out = new vb2_batch{b};
+        return VB2_OK;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_NOMEM;
+    }
+}
+
+void vb2_batch_destroy(vb2_batch* b)
+{
+    if (!b) return;
+    delete b->impl;
+    delete b;
+}
+
+int vb2_batch_eval(vb2_batch* b, const int32_t* num_point, const double* pc1, const double* pc2,
+                   const double* alpha, double* llk_out)
+{
+    if (!b || !b->impl || !num_point || !pc1 || !pc2 || !alpha || !llk_out) {
+        set_error("vb2_batch_eval: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    return b->impl->eval(num_point, pc1, pc2, alpha, llk_out);
+}
+
+int vb2_batch_optimize_llk(vb2_batch* b, const vb2_model* models, int32_t num_model, vb2_estimate* out)
+{
+    if (!b || !b->impl) {
+        set_error("vb2_batch_optimize_llk: null batch");
+        return VB2_ERR_INVALID;
+    }
+    try {
+        return b->impl->optimize(models, num_model, out);
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
 }
 
 int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)

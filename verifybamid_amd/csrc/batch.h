@@ -1,0 +1,49 @@
+// batch.h -- a cohort of samples evaluated / optimised in lock-step on one GPU
+// (BASELINE.json configs[4]): every Nelder-Mead step of every sample
+// goes into ONE kernel launch, so the per-launch fixed costs (launch, per-alpha table,
+// cross-workgroup reduction) are paid once per step for the whole cohort.
+#ifndef VB2_BATCH_H_
+#define VB2_BATCH_H_
+
+#include <vector>
+
+#include "context.h"
+
+namespace vb2 {
+
+class Batch {
+public:
+    ~Batch();
+    static int create(vb2_ctx* const* ctxs, int num_sample, Batch** out);
+    // num_point[s] in [0, 8]; pc1/pc2: [S][8][k]; alpha, llk_out: [S][8]
+    int eval(const int32_t* num_point, const double* pc1, const double* pc2, const double* alpha,
+             double* llk_out);
+    // OptimizeLLK for every sample, searches advancing in lock-step; models: 1 or S entries
+    int optimize(const vb2_model* models, int num_model, vb2_estimate* out);
+
+    int num_sample = 0, num_pc = 0, device = -1;
+    int64_t num_launch = 0;
+
+private:
+    std::vector<Context*> ctx_;
+    hipStream_t stream_ = nullptr;
+    DeviceLayout* d_layouts_ = nullptr;
+    double* d_partials_ = nullptr;
+    unsigned int* d_tickets_ = nullptr;
+    unsigned int* d_batch_done_ = nullptr;
+    double *h_points_ = nullptr, *d_points_ = nullptr;     // mapped host memory, both views
+    double *h_out_ = nullptr, *d_out_ = nullptr;
+    int *h_nv_ = nullptr, *d_nv_ = nullptr;
+    unsigned long long *h_done_ = nullptr, *d_done_ = nullptr;
+    unsigned long long seq_ = 0;
+    int bps_ = 1, block_waves_ = 16;
+    size_t shmem_[2] = {0, 0};
+};
+
+}  // namespace vb2
+
+struct vb2_batch {
+    vb2::Batch* impl;
+};
+
+#endif

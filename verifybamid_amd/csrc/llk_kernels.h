@@ -55,7 +55,25 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            double* d_partials, double* d_out, unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
                            hipStream_t stream);
-void set_single_launch(bool on);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
+void set_single_launch(bool on);
+
+// One launch over several samples (contexts on the same device): see llk_eval_multi_kernel.
+struct MultiLaunch {
+    const DeviceLayout* d_layouts;   // [num_sample] in HBM
+    const double* d_points;          // [num_sample][4*btl][2k+1]
+    const int* d_num_valid;          // [num_sample] 0 = sample sits this step out
+    double* d_partials;              // [num_sample][4*btl][bps]
+    double* d_out;                   // [num_sample][4*btl]
+    unsigned int* d_tickets;         // [num_sample], zero-initialised
+    unsigned int* d_batch_done;      // one zero-initialised counter
+    unsigned long long* done_flag;   // mapped host word or nullptr
+    unsigned long long done_seq;
+    unsigned int batch_active;       // samples with num_valid > 0
+    int num_sample, bps, block_waves, btl;
+    size_t shmem;
+};
+size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk);
+hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 // A/B switch: lanes of one ds_read_b128 service group share a candidate slot (default) or plain
 void set_lane_mapping(bool hardware_groups);

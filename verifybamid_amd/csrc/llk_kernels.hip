@@ -187,12 +187,15 @@ template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU =
 
 // BTL = candidate points per lane; a launch evaluates NP = 4*BTL points
 // (num_valid <= NP of them real; the rest replicate the last real point).
+// The body is shared by the single-sample kernel (blk = blk, nblk = nblk) and
+// the multi-sample kernel (blk/nblk = this workgroup's index among its sample's workgroups).
 template <int BTL, bool HWMAP>
-__global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPerSimd)
-llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid,
-                double* __restrict__ partials, double* __restrict__ llk_out,
-                unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
-                unsigned long long done_seq)
+__device__ __forceinline__ void
+eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_valid,
+          double* __restrict__ partials, double* __restrict__ llk_out,
+          unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
+          unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
+          unsigned int* __restrict__ batch_done, unsigned int batch_active)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NP = 4 * BTL;
@@ -214,7 +217,7 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     int m, g;
     lane_map<HWMAP>(lane, m, g);
     // profiling aid: 100 MHz wall-clock stamps per workgroup (L.stamps == nullptr normally)
-    unsigned long long* stamps = L.stamps ? L.stamps + (size_t)blockIdx.x * 8 : nullptr;
+    unsigned long long* stamps = L.stamps ? L.stamps + (size_t)blk * 8 : nullptr;
     if (stamps && tid == 0) stamps[0] = wall_clock64();
 
     if (tid == 0) *queue = (unsigned int)nwave;      // waves start on tiles 0..nwave-1
@@ -251,13 +254,13 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     // imbalance a static deal leaves.  Each tile's result goes to its own LDS slot and the
     // slots are summed in index order afterwards, so the dynamic schedule does not change
     // a single bit of the result.
-    const uint32_t ntile_blk = ((uint32_t)L.num_mt + gridDim.x - 1 - blockIdx.x) / gridDim.x;
+    const uint32_t ntile_blk = ((uint32_t)L.num_mt + nblk - 1 - blk) / nblk;
     const uint32_t padw = 0x00010001u * (uint32_t)L.num_code;
     const double* my_tab = tab + g * (6 * BTL);
     const double* my_pts = pts + (g * BTL) * stride;
     const size_t mp = L.m_pad;
     for (uint32_t it = (uint32_t)wave; it < ntile_blk;) {
-        const uint32_t mt = blockIdx.x + it * gridDim.x;
+        const uint32_t mt = blk + it * nblk;
         double llk_lane[BTL];
 #pragma unroll
         for (int t = 0; t < BTL; ++t) llk_lane[t] = 0.0;
@@ -381,14 +384,14 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     __syncthreads();
     if (stamps && tid == 0) stamps[5] = wall_clock64();
     if (ticket == nullptr) {                     // two-kernel mode: llk_finalize_kernel follows
-        if (tid < NP) partials[(size_t)tid * gridDim.x + blockIdx.x] = red[tid];
+        if (tid < NP) partials[(size_t)tid * nblk + blk] = red[tid];
         return;
     }
     // ---- single-launch mode: the last workgroup to arrive sums all partials ----
     // Hand-off through 8-byte agent-scope atomics on both sides (write-through stores,
     // L1-bypassing loads), drained before the ticket is drawn: placement independent.
     if (tid < NP)
-        __hip_atomic_store(&partials[(size_t)tid * gridDim.x + blockIdx.x], red[tid],
+        __hip_atomic_store(&partials[(size_t)tid * nblk + blk], red[tid],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -396,12 +399,12 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     if (tid == 0) {
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED,
                                                       __HIP_MEMORY_SCOPE_AGENT);
-        *last_flag = (t == gridDim.x - 1) ? 1u : 0u;
+        *last_flag = (t == nblk - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (*last_flag == 0u) return;
     // same summation order as llk_finalize_kernel: lane-strided, then a wave butterfly
-    const int nb = (int)gridDim.x;
+    const int nb = (int)nblk;
     for (int b = wave; b < num_valid; b += nwave) {
         const double* p = partials + (size_t)b * nb;
         double s = 0;
@@ -423,14 +426,59 @@ llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num
     if (stamps && tid == 0) stamps[6] = wall_clock64();
     if (done_flag) {
         // host hand-off without a stream synchronisation: results (in mapped host memory)
-        // first, then the sequence number the host is spinning on
+        // first, then the sequence number the host is spinning on.  In a multi-sample launch
+        // the sample that completes last (batch_done counter) is the one that signals.
         __syncthreads();
         if (tid == 0) {
             __threadfence_system();
-            __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            bool signal = true;
+            if (batch_done) {
+                const unsigned int t = __hip_atomic_fetch_add(batch_done, 1u, __ATOMIC_ACQ_REL,
+                                                              __HIP_MEMORY_SCOPE_AGENT);
+                signal = (t == batch_active - 1);
+                if (signal) __hip_atomic_store(batch_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (signal)
+                __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
+
+template <int BTL, bool HWMAP>
+__global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPerSimd)
+llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid,
+                double* __restrict__ partials, double* __restrict__ llk_out,
+                unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
+                unsigned long long done_seq)
+{
+    eval_body<BTL, HWMAP>(L, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
+                          blockIdx.x, gridDim.x, nullptr, 0u);
+}
+
+// Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
+// w / bps as that sample's workgroup w % bps.  Every sample has its own layout, parameter rows,
+// partials, ticket and output slot; samples with num_valid == 0 sit this step out.
+template <int BTL, bool HWMAP>
+__global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPerSimd)
+llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __restrict__ points,
+                      const int* __restrict__ num_valid, double* __restrict__ partials,
+                      double* __restrict__ llk_out, unsigned int* __restrict__ tickets, int bps,
+                      unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
+                      unsigned int* __restrict__ batch_done, unsigned int batch_active)
+{
+    constexpr int NP = 4 * BTL;
+    const int s = blockIdx.x / bps;
+    const int nv = num_valid[s];
+    if (nv <= 0) return;                                   // uniform for the workgroup
+    const DeviceLayout L = layouts[s];
+    const int stride = 2 * L.num_pc + 1;
+    eval_body<BTL, HWMAP>(L, points + (size_t)s * NP * stride, nv,
+                          partials + (size_t)s * NP * bps, llk_out + (size_t)s * NP, tickets + s,
+                          done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
+                          batch_done, batch_active);
+}
+
+
 
 // Sums the per-block partials in a fixed order -> bitwise reproducible: wave w takes
 // points w, w+4, ...; lane l adds blocks l, l+64, ... (8 independent loads in flight),
@@ -505,9 +553,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int 
 {
     constexpr int NP = 4 * BTL;
     const LaunchGeom gm = launch_geom(L, BTL);
-    const size_t tiles_per_block = (size_t)(L.num_mt + gm.grid - 1) / gm.grid;
-    const size_t shmem = sizeof(double) * ((size_t)(L.num_code + 1) * row_stride(NP) + NP + 2 +
-                                           (size_t)NP * (2 * L.num_pc + 1) + tiles_per_block * NP);
+    const size_t shmem = eval_shmem_bytes(L, BTL, gm.grid);
     hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
                        stream, L, d_points, num_valid, d_partials, d_out, d_ticket, done_flag, done_seq);
     return hipGetLastError();
@@ -546,6 +592,39 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         done += step;
     }
     return hipSuccess;
+}
+
+size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk)
+{
+    const int NP = 4 * btl;
+    const size_t tiles_per_block = (size_t)(L.num_mt + nblk - 1) / nblk;
+    return sizeof(double) * ((size_t)(L.num_code + 1) * row_stride(NP) + NP + 2 +
+                             (size_t)NP * (2 * L.num_pc + 1) + tiles_per_block * NP);
+}
+
+hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
+{
+    const dim3 grid(ml.num_sample * ml.bps), block(ml.block_waves * 64);
+    if (ml.btl == 2) {
+        if (g_hwmap)
+            hipLaunchKernelGGL((llk_eval_multi_kernel<2, true>), grid, block, ml.shmem, stream, ml.d_layouts,
+                               ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,
+                               ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active);
+        else
+            hipLaunchKernelGGL((llk_eval_multi_kernel<2, false>), grid, block, ml.shmem, stream, ml.d_layouts,
+                               ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,
+                               ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active);
+    } else {
+        if (g_hwmap)
+            hipLaunchKernelGGL((llk_eval_multi_kernel<1, true>), grid, block, ml.shmem, stream, ml.d_layouts,
+                               ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,
+                               ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active);
+        else
+            hipLaunchKernelGGL((llk_eval_multi_kernel<1, false>), grid, block, ml.shmem, stream, ml.d_layouts,
+                               ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,
+                               ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active);
+    }
+    return hipGetLastError();
 }
 
 // Zero-marker case: LLK of an empty sum.
