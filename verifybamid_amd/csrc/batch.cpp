@@ -23,7 +23,6 @@ namespace vb2 {
 
 namespace {
 constexpr int kSlot = kMaxPointsPerLaunch;   // point slots per sample and step
-constexpr size_t kLdsBudget = 60 * 1024;     // stay under the default 64 KiB dynamic-LDS limit
 }
 
 Batch::~Batch()
@@ -74,13 +73,7 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
 
     // geometry: ~one workgroup per CU in total; more workgroups per sample when the per-tile
     // result slots would not fit in LDS
-    int bps = std::max(1, num_cu / num_sample);
-    bps = std::max(bps, (max_mt + kMaxTilesPerBlock - 1) / kMaxTilesPerBlock);
-    for (;; ++bps) {
-        size_t need = 0;
-        for (int s = 0; s < num_sample; ++s) need = std::max(need, eval_shmem_bytes(layouts[s], 2, bps));
-        if (need <= kLdsBudget || bps >= std::max(1, max_mt)) break;
-    }
+    const int bps = std::max(1, num_cu / num_sample);
     b->bps_ = bps;
     const int tiles_per_block = (max_mt + bps - 1) / bps;
     const int k = b->num_pc;
@@ -88,7 +81,8 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
     b->block_waves_ = std::max(min_bw, std::min(kMaxBlockWaves, tiles_per_block));
     for (int btl = 1; btl <= 2; ++btl) {
         size_t need = 0;
-        for (int s = 0; s < num_sample; ++s) need = std::max(need, eval_shmem_bytes(layouts[s], btl, bps));
+        for (int s = 0; s < num_sample; ++s)
+            need = std::max(need, eval_shmem_bytes(layouts[s], btl, bps, b->block_waves_));
         b->shmem_[btl - 1] = need;
     }
     if (b->shmem_[1] > 64 * 1024) {

@@ -316,7 +316,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     c->num_read_other = num_other;
     c->algorithmic_bytes = 2 * num_read + m_active * (8 * (int64_t)k + 12);
 
-    const int nb = std::max(kMaxGridPerCU * num_cu, (num_mt + kMaxTilesPerBlock - 1) / kMaxTilesPerBlock);
+    const int nb = kMaxGridPerCU * num_cu;
     VB2_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * (size_t)kMaxPointsPerLaunch * nb));
     VB2_HIP(hipMalloc((void**)&c->d_ticket, sizeof(unsigned int)));
     VB2_HIP(hipMemset(c->d_ticket, 0, sizeof(unsigned int)));

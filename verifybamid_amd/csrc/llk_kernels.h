@@ -39,12 +39,8 @@ struct LaunchGeom { int grid, block_waves; };
 // Workgroups / waves per workgroup used for a launch of 4*btl points.
 LaunchGeom launch_geom(const DeviceLayout& L, int btl);
 constexpr int kMaxGridPerCU = 2;
-constexpr int kMaxTilesPerBlock = 1024;   // per-tile result slots a workgroup keeps in LDS
-inline int max_grid(const DeviceLayout& L)
-{
-    const int a = kMaxGridPerCU * L.num_cu, b = (L.num_mt + kMaxTilesPerBlock - 1) / kMaxTilesPerBlock;
-    return a > b ? a : b;
-}
+constexpr int kDynTilesPerWave = 8;       // up to this many tiles per wave: dynamic queue + per-tile slots
+inline int max_grid(const DeviceLayout& L) { return kMaxGridPerCU * L.num_cu; }
 
 // Enqueue evaluation of num_point candidate rows (pc1 | pc2 | alpha) on stream.
 // d_partials: >= kMaxPointsPerLaunch * kMaxGridPerCU * L.num_cu doubles of scratch.
@@ -72,7 +68,7 @@ struct MultiLaunch {
     int num_sample, bps, block_waves, btl;
     size_t shmem;
 };
-size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk);
+size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves);
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 // A/B switch: lanes of one ds_read_b128 service group share a candidate slot (default) or plain

@@ -259,6 +259,12 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
     const double* my_tab = tab + g * (6 * BTL);
     const double* my_pts = pts + (g * BTL) * stride;
     const size_t mp = L.m_pad;
+    // With many tiles per wave a static deal (wave w takes tiles w, w+nwave, ...) is already
+    // balanced and needs no per-tile result slots; the queue is for the few-tiles case.
+    const bool dyn = ntile_blk <= (uint32_t)(kDynTilesPerWave * nwave);
+    double llk_wave[BTL];                                 // static mode: this lane's running sums
+#pragma unroll
+    for (int t = 0; t < BTL; ++t) llk_wave[t] = 0.0;
     for (uint32_t it = (uint32_t)wave; it < ntile_blk;) {
         const uint32_t mt = blk + it * nblk;
         double llk_lane[BTL];
@@ -352,6 +358,12 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
                 if (lk > 0) llk_lane[t] += log_nonneg(lk);
             }
         }
+        if (!dyn) {
+#pragma unroll
+            for (int t = 0; t < BTL; ++t) llk_wave[t] += llk_lane[t];
+            it += (uint32_t)nwave;
+            continue;
+        }
         // tile result: butterfly over the 16 lanes (markers) that share candidate slot g
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) {
@@ -368,6 +380,18 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
         if (lane == 0) nxt = atomicAdd(queue, 1u);
         it = __builtin_amdgcn_readfirstlane(nxt);
     }
+    if (!dyn) {                                           // one result slot per wave (zeros if idle)
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const int partner = lane_of<HWMAP>(m ^ off, g);
+#pragma unroll
+            for (int t = 0; t < BTL; ++t) llk_wave[t] += __shfl(llk_wave[t], partner, 64);
+        }
+        if (m == 0) {
+#pragma unroll
+            for (int t = 0; t < BTL; ++t) tile_llk[(size_t)wave * NP + g * BTL + t] = llk_wave[t];
+        }
+    }
 
     if (stamps && lane == 0) {
         if (wave == 0) stamps[3] = wall_clock64();           // wave 0 done with its tiles
@@ -375,9 +399,10 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
     }
     // ---- deterministic block reduction -> one partial per (point, block) ----
     __syncthreads();
-    for (int b = wave; b < NP; b += nwave) {         // tiles in index order, then a butterfly
+    const uint32_t nres = dyn ? ntile_blk : (uint32_t)nwave;
+    for (int b = wave; b < NP; b += nwave) {         // slots in index order, then a butterfly
         double s = 0;
-        for (uint32_t i = lane; i < ntile_blk; i += 64) s += tile_llk[(size_t)i * NP + b];
+        for (uint32_t i = lane; i < nres; i += 64) s += tile_llk[(size_t)i * NP + b];
         s = wave_sum(s);
         if (lane == 0) red[b] = s;
     }
@@ -537,8 +562,6 @@ LaunchGeom launch_geom(const DeviceLayout& L, int btl)
     bw = bw < 4 ? 4 : (bw > max_waves ? max_waves : bw);
     int grid = (L.num_mt + bw - 1) / bw;
     grid = grid < 1 ? 1 : (grid > grid_target ? grid_target : grid);
-    const int min_grid = (L.num_mt + kMaxTilesPerBlock - 1) / kMaxTilesPerBlock;   // LDS slots per tile
-    if (grid < min_grid) grid = min_grid;
     return LaunchGeom{grid, bw};
 }
 
@@ -553,7 +576,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int 
 {
     constexpr int NP = 4 * BTL;
     const LaunchGeom gm = launch_geom(L, BTL);
-    const size_t shmem = eval_shmem_bytes(L, BTL, gm.grid);
+    const size_t shmem = eval_shmem_bytes(L, BTL, gm.grid, gm.block_waves);
     hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
                        stream, L, d_points, num_valid, d_partials, d_out, d_ticket, done_flag, done_seq);
     return hipGetLastError();
@@ -594,12 +617,14 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
     return hipSuccess;
 }
 
-size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk)
+size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves)
 {
     const int NP = 4 * btl;
     const size_t tiles_per_block = (size_t)(L.num_mt + nblk - 1) / nblk;
+    const size_t slots = tiles_per_block <= (size_t)kDynTilesPerWave * block_waves ? tiles_per_block
+                                                                                   : (size_t)block_waves;
     return sizeof(double) * ((size_t)(L.num_code + 1) * row_stride(NP) + NP + 2 +
-                             (size_t)NP * (2 * L.num_pc + 1) + tiles_per_block * NP);
+                             (size_t)NP * (2 * L.num_pc + 1) + slots * NP);
 }
 
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
