@@ -22,7 +22,7 @@ namespace vb2 {
     } while (0)
 
 namespace {
-constexpr int kSlot = kMaxPointsPerLaunch;   // point slots per sample and step
+constexpr int kSlot = 8;                     // point slots per sample and step (VB2_BATCH_SLOTS)
 }
 
 Batch::~Batch()

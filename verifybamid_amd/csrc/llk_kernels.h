@@ -13,7 +13,9 @@ constexpr int kMaxCode = 2 * kNumQual;   // classes ref/alt x qualities
 constexpr int kPadCode = 255;            // never a real dictionary index
 constexpr int kMtMarkers = 16;           // markers per micro-tile (one 16-lane group)
 constexpr int kMaxBlockWaves = 16;       // 1024-thread blocks at most
-constexpr int kMaxPointsPerLaunch = 8;
+constexpr int kMaxGroups = 4;             // groups of 8 points per launch
+constexpr int kMaxPointsPerLaunch = 8 * kMaxGroups;
+constexpr int kLdsLimitBytes = 160 * 1024;
 
 // Everything the kernels read, in HBM.  "Sorted order" = active markers sorted by
 // (non-"other") depth, descending; position = micro_tile*16 + m.
@@ -68,7 +70,8 @@ struct MultiLaunch {
     int num_sample, bps, block_waves, btl;
     size_t shmem;
 };
-size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves);
+size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);
+int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves);
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 // A/B switch: lanes of one ds_read_b128 service group share a candidate slot (default) or plain

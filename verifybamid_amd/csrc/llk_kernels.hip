@@ -195,7 +195,7 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
           double* __restrict__ partials, double* __restrict__ llk_out,
           unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
           unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
-          unsigned int* __restrict__ batch_done, unsigned int batch_active)
+          unsigned int* __restrict__ batch_done, unsigned int batch_active, const int ngrp)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NP = 4 * BTL;
@@ -205,11 +205,15 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
     const int nwave = nthread >> 6;
     const int k = L.num_pc;
     const int stride = 2 * k + 1;
-    double* tab = lds;                          // [nrow][RS]
-    double* red = lds + nrow * RS;              // [NP] block sums; then the work-queue counter
-    unsigned int* queue = reinterpret_cast<unsigned int*>(red + NP);
-    double* pts = red + NP + 2;                 // [NP][2k+1] this launch's parameter rows
-    double* tile_llk = pts + NP * stride;       // [tiles of this workgroup][NP]
+    // A launch carries ngrp groups of NP points; each group has its own table and the
+    // (tile, group) pairs are the work items, so a bigger batch re-reads the pileup from
+    // L2 per group but pays launch, prologue and reduction once.
+    const int NPT = NP * ngrp;                  // points of this launch
+    double* tab = lds;                          // [ngrp][nrow][RS]
+    double* red = lds + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
+    unsigned int* queue = reinterpret_cast<unsigned int*>(red + NPT);
+    double* pts = red + NPT + 2;                // [NPT][2k+1] this launch's parameter rows
+    double* tile_llk = pts + NPT * stride;      // [work items or waves][NP] result slots
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -222,7 +226,7 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
 
     if (tid == 0) *queue = (unsigned int)nwave;      // waves start on tiles 0..nwave-1
     // parameter rows -> LDS with one coalesced load (they may live in mapped host memory)
-    for (int e = tid; e < NP * stride; e += nthread) {
+    for (int e = tid; e < NPT * stride; e += nthread) {
         const int b = e / stride;
         const int src = b < num_valid ? b : num_valid - 1;
         pts[e] = points[src * stride + (e - b * stride)];
@@ -231,16 +235,18 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
     if (stamps && tid == 0) stamps[1] = wall_clock64();
 
     // ---- per-alpha table, off-diagonal pairs only (h:213-229) ----
-    for (int e = tid; e < nrow * 6 * NP; e += nthread) {
-        const int d = e / (6 * NP);
+    for (int e = tid; e < ngrp * nrow * 6 * NP; e += nthread) {
+        const int d = e / (6 * NP);              // row index over all groups: grp*nrow + code
         const int bp = e - d * (6 * NP);
-        const int b = bp / 6, p = bp - b * 6;
+        const int grp_e = d / nrow;
+        const int b = grp_e * NP + bp / 6, p = bp % 6;
+        const int dc = d - grp_e * nrow;         // dictionary code of this row
         double v = 0.0;
-        if (d < L.num_code) {
+        if (dc < L.num_code) {
             int g1, g2;
             pair_of(p, g1, g2);
-            v = (L.ablate & 1) ? -0.01 * (d + p)
-                               : table_entry(pts[b * stride + 2 * k], L.dict_perr[d], g1, g2);
+            v = (L.ablate & 1) ? -0.01 * (dc + p)
+                               : table_entry(pts[b * stride + 2 * k], L.dict_perr[dc], g1, g2);
         }
         tab[d * RS + bp] = v;
     }
@@ -256,17 +262,40 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
     // a single bit of the result.
     const uint32_t ntile_blk = ((uint32_t)L.num_mt + nblk - 1 - blk) / nblk;
     const uint32_t padw = 0x00010001u * (uint32_t)L.num_code;
-    const double* my_tab = tab + g * (6 * BTL);
-    const double* my_pts = pts + (g * BTL) * stride;
     const size_t mp = L.m_pad;
+    const uint32_t nitem = ntile_blk * (uint32_t)ngrp;       // (tile, group) work items
     // With many tiles per wave a static deal (wave w takes tiles w, w+nwave, ...) is already
     // balanced and needs no per-tile result slots; the queue is for the few-tiles case.
-    const bool dyn = ntile_blk <= (uint32_t)(kDynTilesPerWave * nwave);
+    const bool dyn = nitem <= (uint32_t)(kDynTilesPerWave * nwave);
     double llk_wave[BTL];                                 // static mode: this lane's running sums
 #pragma unroll
     for (int t = 0; t < BTL; ++t) llk_wave[t] = 0.0;
-    for (uint32_t it = (uint32_t)wave; it < ntile_blk;) {
+    uint32_t grp_wave = 0;                                // static mode: group llk_wave belongs to
+    auto flush_wave = [&](uint32_t grp) {                 // static mode: one slot per (wave, group)
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const int partner = lane_of<HWMAP>(m ^ off, g);
+#pragma unroll
+            for (int t = 0; t < BTL; ++t) llk_wave[t] += __shfl(llk_wave[t], partner, 64);
+        }
+        if (m == 0) {
+#pragma unroll
+            for (int t = 0; t < BTL; ++t)
+                tile_llk[((size_t)grp * nwave + wave) * NP + g * BTL + t] = llk_wave[t];
+        }
+#pragma unroll
+        for (int t = 0; t < BTL; ++t) llk_wave[t] = 0.0;
+    };
+    for (uint32_t idx = (uint32_t)wave; idx < nitem;) {
+        const uint32_t grp = idx / ntile_blk;
+        const uint32_t it = idx - grp * ntile_blk;
         const uint32_t mt = blk + it * nblk;
+        const double* my_tab = tab + (size_t)grp * nrow * RS + g * (6 * BTL);
+        const double* my_pts = pts + ((size_t)grp * NP + g * BTL) * stride;
+        while (!dyn && grp_wave < grp) {                     // wave-uniform
+            flush_wave(grp_wave);
+            ++grp_wave;
+        }
         double llk_lane[BTL];
 #pragma unroll
         for (int t = 0; t < BTL; ++t) llk_lane[t] = 0.0;
@@ -361,7 +390,7 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
         if (!dyn) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) llk_wave[t] += llk_lane[t];
-            it += (uint32_t)nwave;
+            idx += (uint32_t)nwave;
             continue;
         }
         // tile result: butterfly over the 16 lanes (markers) that share candidate slot g
@@ -373,24 +402,15 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
         }
         if (m == 0) {
 #pragma unroll
-            for (int t = 0; t < BTL; ++t) tile_llk[(size_t)it * NP + g * BTL + t] = llk_lane[t];
+            for (int t = 0; t < BTL; ++t) tile_llk[(size_t)idx * NP + g * BTL + t] = llk_lane[t];
         }
-        // next tile of this workgroup, whichever wave gets there first
+        // next work item of this workgroup, whichever wave gets there first
         uint32_t nxt = 0;
         if (lane == 0) nxt = atomicAdd(queue, 1u);
-        it = __builtin_amdgcn_readfirstlane(nxt);
+        idx = __builtin_amdgcn_readfirstlane(nxt);
     }
-    if (!dyn) {                                           // one result slot per wave (zeros if idle)
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
-            const int partner = lane_of<HWMAP>(m ^ off, g);
-#pragma unroll
-            for (int t = 0; t < BTL; ++t) llk_wave[t] += __shfl(llk_wave[t], partner, 64);
-        }
-        if (m == 0) {
-#pragma unroll
-            for (int t = 0; t < BTL; ++t) tile_llk[(size_t)wave * NP + g * BTL + t] = llk_wave[t];
-        }
+    if (!dyn) {                                           // slots (wave, group): zeros if idle
+        for (uint32_t grp = grp_wave; grp < (uint32_t)ngrp; ++grp) flush_wave(grp);
     }
 
     if (stamps && lane == 0) {
@@ -399,23 +419,24 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
     }
     // ---- deterministic block reduction -> one partial per (point, block) ----
     __syncthreads();
-    const uint32_t nres = dyn ? ntile_blk : (uint32_t)nwave;
-    for (int b = wave; b < NP; b += nwave) {         // slots in index order, then a butterfly
+    const uint32_t nres = dyn ? ntile_blk : (uint32_t)nwave;   // result slots per group
+    for (int b = wave; b < NPT; b += nwave) {         // slots in index order, then a butterfly
+        const int grp = b / NP, bb = b - grp * NP;
         double s = 0;
-        for (uint32_t i = lane; i < nres; i += 64) s += tile_llk[(size_t)i * NP + b];
+        for (uint32_t i = lane; i < nres; i += 64) s += tile_llk[((size_t)grp * nres + i) * NP + bb];
         s = wave_sum(s);
         if (lane == 0) red[b] = s;
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[5] = wall_clock64();
     if (ticket == nullptr) {                     // two-kernel mode: llk_finalize_kernel follows
-        if (tid < NP) partials[(size_t)tid * nblk + blk] = red[tid];
+        if (tid < NPT) partials[(size_t)tid * nblk + blk] = red[tid];
         return;
     }
     // ---- single-launch mode: the last workgroup to arrive sums all partials ----
     // Hand-off through 8-byte agent-scope atomics on both sides (write-through stores,
     // L1-bypassing loads), drained before the ticket is drawn: placement independent.
-    if (tid < NP)
+    if (tid < NPT)
         __hip_atomic_store(&partials[(size_t)tid * nblk + blk], red[tid],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -474,10 +495,10 @@ __global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPe
 llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid,
                 double* __restrict__ partials, double* __restrict__ llk_out,
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
-                unsigned long long done_seq)
+                unsigned long long done_seq, int ngrp)
 {
     eval_body<BTL, HWMAP>(L, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
-                          blockIdx.x, gridDim.x, nullptr, 0u);
+                          blockIdx.x, gridDim.x, nullptr, 0u, ngrp);
 }
 
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
@@ -500,7 +521,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
     eval_body<BTL, HWMAP>(L, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * NP * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
-                          batch_done, batch_active);
+                          batch_done, batch_active, 1);
 }
 
 
@@ -569,16 +590,23 @@ static bool g_hwmap = true;
 void set_lane_mapping(bool hw) { g_hwmap = hw; }
 
 template <int BTL, bool HWMAP>
-static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int num_valid,
+static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int num_valid, int ngrp,
                              double* d_partials, double* d_out, unsigned int* d_ticket,
                              unsigned long long* done_flag, unsigned long long done_seq,
                              hipStream_t stream)
 {
-    constexpr int NP = 4 * BTL;
     const LaunchGeom gm = launch_geom(L, BTL);
-    const size_t shmem = eval_shmem_bytes(L, BTL, gm.grid, gm.block_waves);
+    const size_t shmem = eval_shmem_bytes(L, BTL, gm.grid, gm.block_waves, ngrp);
+    static bool raised = false;          // per instantiation: allow more than 64 KiB of dynamic LDS
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&llk_eval_kernel<BTL, HWMAP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
     hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
-                       stream, L, d_points, num_valid, d_partials, d_out, d_ticket, done_flag, done_seq);
+                       stream, L, d_points, num_valid, d_partials, d_out, d_ticket, done_flag, done_seq,
+                       ngrp);
     return hipGetLastError();
 }
 
@@ -596,16 +624,20 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
     while (done < num_point) {
         const int left = num_point - done;
         const double* p = d_points + (size_t)done * stride;
-        const int step = left > 4 ? (left < 8 ? left : 8) : left;
+        // up to max_groups x 8 points per launch (more points amortise the fixed costs)
+        const LaunchGeom gm2 = launch_geom(L, 2);
+        const int cap = 8 * max_groups(L, 2, gm2.grid, gm2.block_waves);
+        const int step = left < cap ? left : cap;
+        const int ngrp = step > 4 ? (step + 7) / 8 : 1;
         unsigned long long* df = (done + step >= num_point) ? done_flag : nullptr;   // last launch signals
         unsigned long long* df_eval = tk ? df : nullptr;
         hipError_t e;
         if (step > 4)
-            e = g_hwmap ? launch_btl<2, true>(L, p, step, d_partials, d_out + done, tk, df_eval, done_seq, stream)
-                        : launch_btl<2, false>(L, p, step, d_partials, d_out + done, tk, df_eval, done_seq, stream);
+            e = g_hwmap ? launch_btl<2, true>(L, p, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream)
+                        : launch_btl<2, false>(L, p, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream);
         else
-            e = g_hwmap ? launch_btl<1, true>(L, p, step, d_partials, d_out + done, tk, df_eval, done_seq, stream)
-                        : launch_btl<1, false>(L, p, step, d_partials, d_out + done, tk, df_eval, done_seq, stream);
+            e = g_hwmap ? launch_btl<1, true>(L, p, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, stream)
+                        : launch_btl<1, false>(L, p, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, stream);
         if (e != hipSuccess) return e;
         if (!tk) {
             hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(256), 0, stream, d_partials,
@@ -617,14 +649,21 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
     return hipSuccess;
 }
 
-size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves)
+size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp)
 {
-    const int NP = 4 * btl;
-    const size_t tiles_per_block = (size_t)(L.num_mt + nblk - 1) / nblk;
-    const size_t slots = tiles_per_block <= (size_t)kDynTilesPerWave * block_waves ? tiles_per_block
-                                                                                   : (size_t)block_waves;
-    return sizeof(double) * ((size_t)(L.num_code + 1) * row_stride(NP) + NP + 2 +
-                             (size_t)NP * (2 * L.num_pc + 1) + slots * NP);
+    const size_t NP = 4 * (size_t)btl, G = (size_t)ngrp;
+    const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;
+    const size_t slots = items <= (size_t)kDynTilesPerWave * block_waves ? items : (size_t)block_waves * G;
+    return sizeof(double) * (G * (L.num_code + 1) * row_stride((int)NP) + G * NP + 2 +
+                             G * NP * (2 * L.num_pc + 1) + slots * NP);
+}
+
+// Largest number of point groups one launch may carry: LDS (160 KiB per CU) and 4 at most.
+int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves)
+{
+    int g = kMaxGroups;
+    while (g > 1 && eval_shmem_bytes(L, btl, nblk, block_waves, g) > kLdsLimitBytes) --g;
+    return g;
 }
 
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
