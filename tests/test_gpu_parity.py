@@ -347,6 +347,38 @@ def test_run_files_with_sanity_check_and_pileup_roundtrip(tmp_path):
     assert lines[1].split("\t")[3] == "3000" and lines[1].split("\t")[6] == cxx_default(r1["alpha"])
 
 
+def test_known_af_file_flow(tmp_path):
+    """--KnownAF: per-marker allele frequencies from a file, 1-D search over alpha
+    (main.cpp:314-319 forces isPCFixed and WithinAncestry)."""
+    d = vb.synth.make_pileup(1500, 20, 2, alpha_true=0.06, seed=13)
+    pre = vb.synth.write_files(d, str(tmp_path / "kaf"))
+    rng = np.random.default_rng(14)
+    af = np.clip(d.means / 2 + rng.normal(0, 0.02, size=d.num_marker), 0.001, 0.999)
+    with open(pre + ".af", "w") as f:
+        for i in range(d.num_marker):
+            p = 1000 + 10 * i
+            f.write("1\t%d\t%d\t%s\t%s\t%r\n" % (p - 1, p, chr(d.meta["ref_base"][i]),
+                                                   chr(d.alt_base[i]), float(af[i])))
+    out = str(tmp_path / "o")
+    r = vb.run_files(pre, pre + ".pileup", out, num_pc=2, disable_sanity=True, known_af_path=pre + ".af")
+    from oracle import binding, refio
+    flat, _, _ = refio.load_flat(pre, pre + ".pileup", 2, sanity_disabled=True, known_af_path=pre + ".af")
+    assert flat.af_known and np.allclose(flat.known_af, af)
+    ref = binding.OracleData(flat).optimize()
+    assert abs(r["alpha"] - ref["alpha"]) <= NORTH_STAR_ALPHA_ATOL
+    assert abs(r["llk1"] - ref["llk1"]) <= 1e-9 * abs(ref["llk1"])
+    assert r["num_eval"] == ref["num_eval"]
+    # the command line takes the same path
+    exe = os.path.join(ROOT, "verifybamid_amd", "bin", "VerifyBamID")
+    p = subprocess.run([exe, "--SVDPrefix", pre, "--PileupFile", pre + ".pileup", "--Reference", "x.fa",
+                        "--NumPC", "2", "--DisableSanityCheck", "--KnownAF", pre + ".af", "--Output",
+                        str(tmp_path / "cli")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "Estimation from OptimizeHomoFixedPC:" in p.stdout
+    row = open(str(tmp_path / "cli") + ".selfSM").read().splitlines()[1].split("\t")
+    assert row[6] == cxx_default(r["alpha"] if r["alpha"] < 0.5 else 1 - r["alpha"])
+
+
 def test_insufficient_markers_fails_sanity(golden_dir, tmp_path):
     with pytest.raises(_abi.Vb2Error) as ei:
         vb.run_files(os.path.join(golden_dir, HAPMAP), os.path.join(golden_dir, "test.LongRead.pileup"),

@@ -85,8 +85,8 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
             need = std::max(need, eval_shmem_bytes(layouts[s], btl, bps, b->block_waves_));
         b->shmem_[btl - 1] = need;
     }
-    if (b->shmem_[1] > 64 * 1024) {
-        set_error("vb2_batch_create: per-workgroup LDS need exceeds 64 KiB");
+    if (b->shmem_[1] > (size_t)kLdsLimitBytes) {
+        set_error("vb2_batch_create: per-workgroup LDS need exceeds 160 KiB");
         return VB2_ERR_INVALID;
     }
 

@@ -669,6 +669,18 @@ int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves)
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
 {
     const dim3 grid(ml.num_sample * ml.bps), block(ml.block_waves * 64);
+    static bool raised = false;          // allow more than 64 KiB of dynamic LDS (wide dictionaries)
+    if (!raised) {
+        const void* fns[4] = {reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, true>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, false>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, true>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, false>)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+            if (e != hipSuccess) return e;
+        }
+        raised = true;
+    }
     if (ml.btl == 2) {
         if (g_hwmap)
             hipLaunchKernelGGL((llk_eval_multi_kernel<2, true>), grid, block, ml.shmem, stream, ml.d_layouts,
