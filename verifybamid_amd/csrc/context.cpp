@@ -17,7 +17,9 @@
 #include <cstring>
 #include <numeric>
 #include <queue>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace vb2 {
@@ -59,10 +61,13 @@ const double kCond[2][3][3] = {
     {{0.0, 1.0 / 3.0, 2.0 / 3.0}, {1.0 / 6.0, 1.0 / 6.0, 2.0 / 3.0}, {1.0 / 3.0, 0.0, 2.0 / 3.0}},
 };
 
+inline unsigned char ascii_upper(unsigned char c) { return (c >= 'a' && c <= 'z') ? (unsigned char)(c - 32) : c; }
+
+// classifyBase (h:180-184); toupper() in the "C" locale, without the libc call per read
 inline int classify_base(char base, char alt)
 {
     if (base == '.' || base == ',') return 0;
-    if (std::toupper((unsigned char)base) == std::toupper((unsigned char)alt)) return 1;
+    if (ascii_upper((unsigned char)base) == ascii_upper((unsigned char)alt)) return 1;
     return 2;
 }
 
@@ -137,6 +142,12 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
 
     const int M = in->num_marker, k = in->num_pc;
+    const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_start = tnow();
 
     // ---- Phred table, exactly the reference's pow() (h:65-74) ----
     double phred[kNumQual];
@@ -159,32 +170,67 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     int64_t num_read = 0, num_other = 0;
     std::vector<int32_t> eff_depth;     // runs per marker (see below)
     eff_depth.reserve(M);
-    std::vector<int64_t> local_hist(kMaxCode, 0);
-    for (int i = 0; i < M; ++i) {
-        const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
-        if (depth < 0) {
+    std::vector<uint8_t> raw((size_t)(M > 0 ? in->read_off[M] : 0));   // (class, q) per read; 255 = other
+    for (int i = 0; i < M; ++i)
+        if (in->read_off[i + 1] < in->read_off[i]) {
             set_error("vb2_ctx_create: read_off not monotone");
             return VB2_ERR_INVALID;
         }
-        if (depth == 0) continue;
-        if (!in->sanity_disabled && ((double)depth < lo || (double)depth > hi)) continue;
-        // steps of this marker in the kernel = runs of equal (class, quality): one
-        // (code, count) pair per distinct code, counts above 255 split
-        const char alt = in->alt_base[i];
-        std::fill(local_hist.begin(), local_hist.end(), 0);
-        for (int64_t j = 0; j < depth; ++j) {
-            const int bc = classify_base(in->bases[beg + j], alt);
-            if (bc == 2) { ++num_other; continue; }
-            const int c2 = bc * kNumQual + clamp_qual(in->quals[beg + j]);
-            ++code_hist[c2];
-            ++local_hist[c2];
+    // The flattening is embarrassingly parallel over markers: a few host threads for big inputs.
+    const int64_t total_reads = M > 0 ? in->read_off[M] - in->read_off[0] : 0;
+    int nthr = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, total_reads / 200000));
+    if (const char* ft = std::getenv("VB2_FLATTEN_THREADS")) nthr = std::max(1, std::atoi(ft));
+    auto parallel_for = [&](int64_t n, const std::function<void(int, int64_t, int64_t)>& fn) {
+        if (nthr == 1 || n < nthr) { fn(0, 0, n); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; ++t) th.emplace_back(fn, t, n * t / nthr, n * (t + 1) / nthr);
+        for (auto& x : th) x.join();
+    };
+    std::vector<int32_t> eff_all(M, -1);                       // -1: marker does not count
+    {
+        std::vector<std::vector<int64_t>> hist_t(nthr, std::vector<int64_t>(kMaxCode, 0));
+        std::vector<int64_t> reads_t(nthr, 0), other_t(nthr, 0);
+        parallel_for(M, [&](int t, int64_t i0, int64_t i1) {
+            std::vector<int32_t> local_hist(kMaxCode, 0);
+            std::vector<int> touched;
+            touched.reserve(kMaxCode);
+            for (int64_t i = i0; i < i1; ++i) {
+                const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
+                if (depth == 0) continue;
+                if (!in->sanity_disabled && ((double)depth < lo || (double)depth > hi)) continue;
+                // steps of this marker in the kernel = runs of equal (class, quality): one
+                // (code, count) pair per distinct code, counts above 255 split
+                const char alt = in->alt_base[i];
+                touched.clear();
+                for (int64_t j = 0; j < depth; ++j) {
+                    const int bc = classify_base(in->bases[beg + j], alt);
+                    if (bc == 2) { ++other_t[t]; raw[beg + j] = 255; continue; }
+                    const int c2 = bc * kNumQual + clamp_qual(in->quals[beg + j]);
+                    raw[beg + j] = (uint8_t)c2;
+                    ++hist_t[t][c2];
+                    if (local_hist[c2]++ == 0) touched.push_back(c2);
+                }
+                int32_t eff = 0;
+                for (int c2 : touched) {
+                    eff += (local_hist[c2] + 254) / 255;
+                    local_hist[c2] = 0;
+                }
+                reads_t[t] += depth;
+                eff_all[i] = eff;
+            }
+        });
+        for (int t = 0; t < nthr; ++t) {
+            num_read += reads_t[t];
+            num_other += other_t[t];
+            for (int c2 = 0; c2 < kMaxCode; ++c2) code_hist[c2] += hist_t[t][c2];
         }
-        int32_t eff = 0;
-        for (int c2 = 0; c2 < kMaxCode; ++c2) eff += (int32_t)((local_hist[c2] + 254) / 255);
-        num_read += depth;
-        active.push_back(i);
-        eff_depth.push_back(eff);
     }
+    for (int i = 0; i < M; ++i)
+        if (eff_all[i] >= 0) {
+            active.push_back(i);
+            eff_depth.push_back(eff_all[i]);
+        }
     const int64_t m_active = (int64_t)active.size();
 
     // ---- dictionary: observed (class, q) pairs, most frequent first ----
@@ -234,30 +280,33 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     std::vector<double> ud_s((size_t)k * m_pad, 0.0), mu_s(m_pad, 0.0), cdiag((size_t)4 * m_pad, 0.0);
     std::vector<double> kaf_s;
     if (in->known_af) kaf_s.assign(m_pad, 0.0);
+    parallel_for(m_active, [&](int, int64_t m0, int64_t m1) {
     std::vector<uint32_t> run_of(num_code + 1, 0);
-    for (int64_t m = 0; m < m_active; ++m) {
+    std::vector<int> touched;
+    touched.reserve(kMaxCode);
+    for (int64_t m = m0; m < m1; ++m) {
         const int i = active[perm[m]];
         const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
-        const char alt = in->alt_base[i];
         double c_other = 0.0, dg[3] = {0.0, 0.0, 0.0};
-        std::fill(run_of.begin(), run_of.end(), 0);
+        touched.clear();
         for (int64_t j = 0; j < depth; ++j) {
-            const int bc = classify_base(in->bases[beg + j], alt);
-            const int q = clamp_qual(in->quals[beg + j]);
-            const double* lc = &logc[(bc * kNumQual + q) * 3];
-            if (bc == 2) {
-                c_other += lc[0];           // same for every genotype pair
+            const int c2 = raw[beg + j];
+            if (c2 == 255) {                // class "other": same term for every genotype pair
+                c_other += logc[(2 * kNumQual + clamp_qual(in->quals[beg + j])) * 3];
             } else {
+                const double* lc = &logc[c2 * 3];
                 dg[0] += lc[0]; dg[1] += lc[1]; dg[2] += lc[2];
-                ++run_of[dict_of[bc * kNumQual + q]];
+                const int d = dict_of[c2];
+                if (run_of[d]++ == 0) touched.push_back(d);
             }
         }
+        std::sort(touched.begin(), touched.end());
         // runs in dictionary order: lanes of a wave then tend to hit the same or
         // neighbouring LDS table rows at the same step (bank-friendly)
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
         uint8_t* row0 = reinterpret_cast<uint8_t*>(&codes[(size_t)mt_row_off[t] * kMtMarkers]);
         size_t j = 0;
-        for (int d = 0; d < num_code; ++d) {
+        for (int d : touched) {
             for (uint32_t left = run_of[d]; left > 0;) {
                 const uint32_t n = left > 255 ? 255 : left;
                 uint8_t* slot = row0 + ((j >> 1) * kMtMarkers + lane) * 4 + (j & 1) * 2;
@@ -266,6 +315,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
                 left -= n;
                 ++j;
             }
+            run_of[d] = 0;
         }
         if (in->known_af) {
             kaf_s[m] = in->known_af[i];
@@ -279,7 +329,9 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         cdiag[2 * m_pad + m] = std::exp(dg[1] + c_other);
         cdiag[3 * m_pad + m] = std::exp(dg[2] + c_other);
     }
+    });
 
+    const auto t_flat = tnow();
     // ---- upload ----
     int rc;
     DeviceLayout& L = c->L;
@@ -354,6 +406,9 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     }
     if (const char* lm = std::getenv("VB2_LANE_MAP")) set_lane_mapping(std::strcmp(lm, "plain") != 0);
     VB2_HIP(hipDeviceSynchronize());
+    if (timing)
+        std::fprintf(stderr, "vb2_ctx_create: flatten %.1f ms, device alloc+upload %.1f ms\n",
+                     tms(t_start, t_flat), tms(t_flat, tnow()));
     *out = c.release();
     return VB2_OK;
 }
