@@ -440,6 +440,25 @@ def test_cohort_batch_lockstep_matches_individual_runs():
             c.close()
 
 
+def test_in_kernel_reduction_is_stable_under_stress(c2, c3):
+    """The cross-workgroup hand-off (agent-scope atomics + ticket, last arriver sums) must
+    return the same bits on every launch, also when launches of different shapes and
+    contexts interleave (stale partials would show up as a changed sum)."""
+    d, _ = c2
+    rng = np.random.default_rng(21)
+    with vb.LikelihoodContext(d) as small, vb.LikelihoodContext(c3) as big:
+        sets = []
+        for ctx, k in ((small, 2), (big, 4)):
+            for B in (1, 4, 8, 13, 32):
+                pc1, pc2, al = _random_points(rng, B, k)
+                sets.append((ctx, pc1, pc2, al, ctx.llk(pc1, pc2, al)))
+        order = rng.integers(0, len(sets), size=6000)
+        for i in order:
+            ctx, pc1, pc2, al, want = sets[i]
+            got = ctx.llk(pc1, pc2, al)
+            assert np.array_equal(got, want), i
+
+
 def test_device_pointer_api_on_torch_stream(c2):
     import torch
     d, _ = c2
