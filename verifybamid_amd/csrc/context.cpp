@@ -414,7 +414,8 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
 }
 
 int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipStream_t s,
-                         unsigned long long* done_flag, unsigned long long done_seq)
+                         unsigned long long* done_flag, unsigned long long done_seq,
+                         const double* h_pts)
 {
     if (num_point <= 0) return VB2_OK;
     VB2_HIP(hipSetDevice(device));
@@ -423,7 +424,7 @@ int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipS
         VB2_HIP(launch_fill_zero(d_llk, num_point, s));
         return VB2_OK;
     }
-    VB2_HIP(launch_llk_eval(L, num_point, d_pts, d_partials, d_llk, d_ticket, done_flag, done_seq, s));
+    VB2_HIP(launch_llk_eval(L, num_point, d_pts, h_pts, d_partials, d_llk, d_ticket, done_flag, done_seq, s));
     return VB2_OK;
 }
 
@@ -448,7 +449,8 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
         // mapped host memory; spinning on it costs a few microseconds less per call than
         // hipStreamSynchronize (which matters: a search is ~350 dependent calls).
         const unsigned long long seq = ++done_seq_;
-        int rc = eval_device(n, d_points, d_out, stream, L.num_mt > 0 && spin_wait ? d_done : nullptr, seq);
+        int rc = eval_device(n, d_points, d_out, stream, L.num_mt > 0 && spin_wait ? d_done : nullptr, seq,
+                             h_points);
         if (rc) return rc;
         bool seen = false;
         if (L.num_mt > 0 && spin_wait) {

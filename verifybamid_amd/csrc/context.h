@@ -25,7 +25,8 @@ public:
     static int create(const vb2_input* in, const vb2_options* opt, Context** out);
     // device pointers, asynchronous on s (nullptr = own stream)
     int eval_device(int num_point, const double* d_points, double* d_llk, hipStream_t s,
-                    unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0);
+                    unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0,
+                    const double* h_points = nullptr);
     // host pointers, synchronous
     int eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,
                   double* llk_out);

@@ -16,6 +16,7 @@ constexpr int kMaxBlockWaves = 16;       // 1024-thread blocks at most
 constexpr int kMaxGroups = 4;             // groups of 8 points per launch
 constexpr int kMaxPointsPerLaunch = 8 * kMaxGroups;
 constexpr int kLdsLimitBytes = 160 * 1024;
+constexpr int kInlinePointDoubles = 96;    // parameter rows that travel as kernel arguments (768 B)
 
 // Everything the kernels read, in HBM.  "Sorted order" = active markers sorted by
 // (non-"other") depth, descending; position = micro_tile*16 + m.
@@ -49,8 +50,11 @@ inline int max_grid(const DeviceLayout& L) { return kMaxGridPerCU * L.num_cu; }
 // d_ticket: one zero-initialised unsigned int (arrival counter of the single-launch mode).
 // done_flag: optional word in mapped host memory that receives done_seq after the results of
 // the LAST launch are written (lets the host wait without hipStreamSynchronize).
+// h_points: the same rows readable by the host (or nullptr): small batches then travel as
+// kernel arguments instead of being read from (possibly mapped host) memory.
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
-                           double* d_partials, double* d_out, unsigned int* d_ticket,
+                           const double* h_points, double* d_partials, double* d_out,
+                           unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
                            hipStream_t stream);
 void set_single_launch(bool on);

@@ -189,9 +189,16 @@ template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU =
 // (num_valid <= NP of them real; the rest replicate the last real point).
 // The body is shared by the single-sample kernel (blk = blk, nblk = nblk) and
 // the multi-sample kernel (blk/nblk = this workgroup's index among its sample's workgroups).
+// Parameter rows passed inside the kernel-argument segment (host-pointer path with few
+// points): saves the PCIe round trip of reading them from mapped host memory.
+struct InlinePoints {
+    int count;                       // doubles valid in v (0 = read from the pointer)
+    double v[kInlinePointDoubles];
+};
+
 template <int BTL, bool HWMAP>
 __device__ __forceinline__ void
-eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_valid,
+eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
           unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
           unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
@@ -229,7 +236,8 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
     for (int e = tid; e < NPT * stride; e += nthread) {
         const int b = e / stride;
         const int src = b < num_valid ? b : num_valid - 1;
-        pts[e] = points[src * stride + (e - b * stride)];
+        const int idx = src * stride + (e - b * stride);
+        pts[e] = ip.count > 0 ? ip.v[idx] : points[idx];
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[1] = wall_clock64();
@@ -492,12 +500,12 @@ eval_body(const DeviceLayout& L, const double* __restrict__ points, int num_vali
 
 template <int BTL, bool HWMAP>
 __global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPerSimd)
-llk_eval_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid,
-                double* __restrict__ partials, double* __restrict__ llk_out,
+llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
+                int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
                 unsigned long long done_seq, int ngrp)
 {
-    eval_body<BTL, HWMAP>(L, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
+    eval_body<BTL, HWMAP>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
                           blockIdx.x, gridDim.x, nullptr, 0u, ngrp);
 }
 
@@ -518,7 +526,9 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
     if (nv <= 0) return;                                   // uniform for the workgroup
     const DeviceLayout L = layouts[s];
     const int stride = 2 * L.num_pc + 1;
-    eval_body<BTL, HWMAP>(L, points + (size_t)s * NP * stride, nv,
+    InlinePoints ip;
+    ip.count = 0;
+    eval_body<BTL, HWMAP>(L, ip, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * NP * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1);
@@ -590,7 +600,8 @@ static bool g_hwmap = true;
 void set_lane_mapping(bool hw) { g_hwmap = hw; }
 
 template <int BTL, bool HWMAP>
-static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int num_valid, int ngrp,
+static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, const double* h_points,
+                             int num_valid, int ngrp,
                              double* d_partials, double* d_out, unsigned int* d_ticket,
                              unsigned long long* done_flag, unsigned long long done_seq,
                              hipStream_t stream)
@@ -604,9 +615,16 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, int 
         if (e != hipSuccess) return e;
         raised = true;
     }
+    InlinePoints ip;
+    ip.count = 0;
+    const int ndbl = num_valid * (2 * L.num_pc + 1);
+    if (h_points && ndbl <= kInlinePointDoubles) {      // small batch with host-visible values
+        ip.count = ndbl;
+        for (int i = 0; i < ndbl; ++i) ip.v[i] = h_points[i];
+    }
     hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
-                       stream, L, d_points, num_valid, d_partials, d_out, d_ticket, done_flag, done_seq,
-                       ngrp);
+                       stream, L, ip, d_points, num_valid, d_partials, d_out, d_ticket, done_flag,
+                       done_seq, ngrp);
     return hipGetLastError();
 }
 
@@ -614,7 +632,8 @@ static bool g_single_launch = true;
 void set_single_launch(bool on) { g_single_launch = on; }
 
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
-                           double* d_partials, double* d_out, unsigned int* d_ticket,
+                           const double* h_points, double* d_partials, double* d_out,
+                           unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
                            hipStream_t stream)
 {
@@ -624,6 +643,7 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
     while (done < num_point) {
         const int left = num_point - done;
         const double* p = d_points + (size_t)done * stride;
+        const double* hp = h_points ? h_points + (size_t)done * stride : nullptr;
         // up to max_groups x 8 points per launch (more points amortise the fixed costs)
         const LaunchGeom gm2 = launch_geom(L, 2);
         const int cap = 8 * max_groups(L, 2, gm2.grid, gm2.block_waves);
@@ -633,11 +653,11 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         unsigned long long* df_eval = tk ? df : nullptr;
         hipError_t e;
         if (step > 4)
-            e = g_hwmap ? launch_btl<2, true>(L, p, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream)
-                        : launch_btl<2, false>(L, p, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream);
+            e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream)
+                        : launch_btl<2, false>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream);
         else
-            e = g_hwmap ? launch_btl<1, true>(L, p, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, stream)
-                        : launch_btl<1, false>(L, p, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, stream);
+            e = g_hwmap ? launch_btl<1, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, stream)
+                        : launch_btl<1, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, stream);
         if (e != hipSuccess) return e;
         if (!tk) {
             hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(256), 0, stream, d_partials,
