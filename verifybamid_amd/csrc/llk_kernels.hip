@@ -53,6 +53,9 @@ __device__ __forceinline__ double exp_nonpos(double x)
     const double kLog2e = 1.4426950408889634074;
     const double kLn2Hi = 6.93147180369123816490e-01;   // ln2 split (fdlibm constants)
     const double kLn2Lo = 1.90821492927058770002e-10;
+    // below -800 the result is 0 anyway (2^-1154); the clamp also maps -inf to a finite
+    // argument, so no special case is needed after the ldexp
+    x = fmax(x, -800.0);
     const double kd = rint(x * kLog2e);
     double r = fma(-kd, kLn2Hi, x);
     r = fma(-kd, kLn2Lo, r);
@@ -70,8 +73,7 @@ __device__ __forceinline__ double exp_nonpos(double x)
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    const double y = ldexp(p, (int)kd);
-    return x < -746.0 ? 0.0 : y;                        // also covers x = -inf
+    return ldexp(p, (int)kd);
 }
 
 // log(x) for x >= 0, FP64 (fdlibm's e_log algorithm with explicit FMAs, ~1 ulp):
