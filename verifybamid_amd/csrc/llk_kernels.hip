@@ -113,6 +113,19 @@ __device__ __forceinline__ double log_nonneg(double x)
     return x == 0.0 ? -__builtin_huge_val() : res;
 }
 
+// A positive value as (mantissa in [0.5,1), binary exponent): products of likelihoods are
+// kept in this form so that a marker's log is never taken -- one log per (workgroup, point)
+// replaces one per (marker, point).
+struct ScaledProd {
+    double m;     // mantissa product
+    double e;     // exponent sum (exact integer)
+};
+__device__ __forceinline__ void sp_renorm(ScaledProd& p)
+{
+    p.e += (double)__builtin_amdgcn_frexp_exp(p.m);
+    p.m = __builtin_amdgcn_frexp_mant(p.m);
+}
+
 // One table entry, with the reference's expression order (h:223-225).
 // perr_signed = +pErr(q) for class ref, -pErr(q) for class alt (one load per code;
 // the alt class is the ref class with genotypes mirrored, g -> 2-g: h:164-177).
@@ -222,7 +235,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     double* red = lds + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
     unsigned int* queue = reinterpret_cast<unsigned int*>(red + NPT);
     double* pts = red + NPT + 2;                // [NPT][2k+1] this launch's parameter rows
-    double* tile_llk = pts + NPT * stride;      // [work items or waves][NP] result slots
+    double* tile_llk = pts + NPT * stride;      // [work items or waves][NP] {mantissa, exponent}
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -277,24 +290,35 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // With many tiles per wave a static deal (wave w takes tiles w, w+nwave, ...) is already
     // balanced and needs no per-tile result slots; the queue is for the few-tiles case.
     const bool dyn = nitem <= (uint32_t)(kDynTilesPerWave * nwave);
-    double llk_wave[BTL];                                 // static mode: this lane's running sums
-#pragma unroll
-    for (int t = 0; t < BTL; ++t) llk_wave[t] = 0.0;
-    uint32_t grp_wave = 0;                                // static mode: group llk_wave belongs to
-    auto flush_wave = [&](uint32_t grp) {                 // static mode: one slot per (wave, group)
+    // The per-marker likelihoods of a work item are MULTIPLIED (mantissa x 2^exponent): over
+    // the 16 markers of the tile by a butterfly, then slot by slot in the block reduction.
+    auto tile_product = [&](ScaledProd* p) {              // over the 16 lanes sharing slot g
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) {
             const int partner = lane_of<HWMAP>(m ^ off, g);
 #pragma unroll
-            for (int t = 0; t < BTL; ++t) llk_wave[t] += __shfl(llk_wave[t], partner, 64);
+            for (int t = 0; t < BTL; ++t) {
+                p[t].m *= __shfl(p[t].m, partner, 64);    // 16 factors in [0.5,1): no underflow
+                p[t].e += __shfl(p[t].e, partner, 64);
+            }
         }
+    };
+    ScaledProd wave_prod[BTL];                            // static mode: this lane's running product
+#pragma unroll
+    for (int t = 0; t < BTL; ++t) wave_prod[t] = ScaledProd{1.0, 0.0};
+    uint32_t grp_wave = 0;                                // static mode: group wave_prod belongs to
+    auto flush_wave = [&](uint32_t grp) {                 // static mode: one slot per (wave, group)
+        tile_product(wave_prod);
         if (m == 0) {
 #pragma unroll
-            for (int t = 0; t < BTL; ++t)
-                tile_llk[((size_t)grp * nwave + wave) * NP + g * BTL + t] = llk_wave[t];
+            for (int t = 0; t < BTL; ++t) {
+                const size_t o = (((size_t)grp * nwave + wave) * NP + g * BTL + t) * 2;
+                tile_llk[o] = wave_prod[t].m;
+                tile_llk[o + 1] = wave_prod[t].e;
+            }
         }
 #pragma unroll
-        for (int t = 0; t < BTL; ++t) llk_wave[t] = 0.0;
+        for (int t = 0; t < BTL; ++t) wave_prod[t] = ScaledProd{1.0, 0.0};
     };
     for (uint32_t idx = (uint32_t)wave; idx < nitem;) {
         const uint32_t grp = idx / ntile_blk;
@@ -306,9 +330,9 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             flush_wave(grp_wave);
             ++grp_wave;
         }
-        double llk_lane[BTL];
+        ScaledProd lane_prod[BTL];                           // this marker's likelihood per point
 #pragma unroll
-        for (int t = 0; t < BTL; ++t) llk_lane[t] = 0.0;
+        for (int t = 0; t < BTL; ++t) lane_prod[t] = ScaledProd{1.0, 0.0};
         const uint2 rec = L.mt_rec[mt];                      // {first row, rows}
         // per-marker constants: issued now, consumed after the read loop
         const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
@@ -349,8 +373,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (live && (L.ablate & 4)) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t)
-                llk_lane[t] += acc[t * 6] + acc[t * 6 + 1] + acc[t * 6 + 2] + acc[t * 6 + 3] +
-                               acc[t * 6 + 4] + acc[t * 6 + 5] + cst + e0 + e1 + e2;
+                lane_prod[t].e += acc[t * 6] + acc[t * 6 + 1] + acc[t * 6 + 2] + acc[t * 6 + 3] +
+                                  acc[t * 6 + 4] + acc[t * 6 + 5] + cst + e0 + e1 + e2;
         } else if (live) {
             double af1[BTL], af2[BTL];
             if (L.known_af) {
@@ -394,25 +418,31 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 lk += exp_nonpos(a[4] + cst) * gf[2] * gf2[0];
                 lk += exp_nonpos(a[5] + cst) * gf[2] * gf2[1];
                 lk += e2 * gf[2] * gf2[2];
-                if (lk > 0) llk_lane[t] += log_nonneg(lk);
+                // the reference adds log(lk) only if lk > 0 (h:310-311): a dropped marker is
+                // the factor 1
+                const bool keep = lk > 0;
+                lane_prod[t].m = keep ? __builtin_amdgcn_frexp_mant(lk) : 1.0;
+                lane_prod[t].e = keep ? (double)__builtin_amdgcn_frexp_exp(lk) : 0.0;
             }
         }
         if (!dyn) {
 #pragma unroll
-            for (int t = 0; t < BTL; ++t) llk_wave[t] += llk_lane[t];
+            for (int t = 0; t < BTL; ++t) {               // running product, renormalised per tile
+                wave_prod[t].m *= lane_prod[t].m;
+                wave_prod[t].e += lane_prod[t].e;
+                sp_renorm(wave_prod[t]);
+            }
             idx += (uint32_t)nwave;
             continue;
         }
-        // tile result: butterfly over the 16 lanes (markers) that share candidate slot g
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
-            const int partner = lane_of<HWMAP>(m ^ off, g);
-#pragma unroll
-            for (int t = 0; t < BTL; ++t) llk_lane[t] += __shfl(llk_lane[t], partner, 64);
-        }
+        tile_product(lane_prod);
         if (m == 0) {
 #pragma unroll
-            for (int t = 0; t < BTL; ++t) tile_llk[(size_t)idx * NP + g * BTL + t] = llk_lane[t];
+            for (int t = 0; t < BTL; ++t) {
+                const size_t o = ((size_t)idx * NP + g * BTL + t) * 2;
+                tile_llk[o] = lane_prod[t].m;
+                tile_llk[o + 1] = lane_prod[t].e;
+            }
         }
         // next work item of this workgroup, whichever wave gets there first
         uint32_t nxt = 0;
@@ -432,10 +462,21 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const uint32_t nres = dyn ? ntile_blk : (uint32_t)nwave;   // result slots per group
     for (int b = wave; b < NPT; b += nwave) {         // slots in index order, then a butterfly
         const int grp = b / NP, bb = b - grp * NP;
-        double s = 0;
-        for (uint32_t i = lane; i < nres; i += 64) s += tile_llk[((size_t)grp * nres + i) * NP + bb];
-        s = wave_sum(s);
-        if (lane == 0) red[b] = s;
+        ScaledProd p{1.0, 0.0};
+        for (uint32_t i = lane; i < nres; i += 64) {
+            const size_t o = (((size_t)grp * nres + i) * NP + bb) * 2;
+            p.m *= tile_llk[o];
+            p.e += tile_llk[o + 1];
+            sp_renorm(p);                              // a slot can be as small as 2^-16
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            p.m *= __shfl_xor(p.m, off, 64);
+            p.e += __shfl_xor(p.e, off, 64);
+            sp_renorm(p);
+        }
+        // the only logarithm of this (workgroup, point): log(prod lk) = log(m) + e*ln2
+        if (lane == 0) red[b] = log_nonneg(p.m) + p.e * 6.93147180559945286227e-01;
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[5] = wall_clock64();
@@ -677,7 +718,7 @@ size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_wave
     const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;
     const size_t slots = items <= (size_t)kDynTilesPerWave * block_waves ? items : (size_t)block_waves * G;
     return sizeof(double) * (G * (L.num_code + 1) * row_stride((int)NP) + G * NP + 2 +
-                             G * NP * (2 * L.num_pc + 1) + slots * NP);
+                             G * NP * (2 * L.num_pc + 1) + 2 * slots * NP);
 }
 
 // Largest number of point groups one launch may carry: LDS (160 KiB per CU) and 4 at most.
