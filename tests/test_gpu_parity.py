@@ -325,6 +325,45 @@ def test_missing_markers_and_batch_chunking():
     _check(d, B=21, k=4)
 
 
+def test_randomized_shapes_sweep():
+    """Seeded sweep over marker counts, depths, quality ranges, k, batch sizes, missing markers,
+    depth filter and known-AF mode: every geometry decision of the launcher (static vs queued
+    tiles, 1-4 point groups, narrow vs wide tables, grid smaller than the CU count) is hit with
+    the oracle beside it."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(36):
+        M = int(rng.choice([1, 15, 16, 17, 255, 900, 4097, 12000]))
+        k = int(rng.integers(1, 7))
+        depth = float(rng.choice([1, 3, 12, 40, 90]))
+        q_lo = int(rng.integers(0, 40))
+        q_hi = int(rng.integers(q_lo, 94))
+        d = vb.synth.make_pileup(M, depth, k, alpha_true=float(rng.uniform(0, 0.3)), seed=1000 + case,
+                                 q_lo=q_lo, q_hi=q_hi, missing_frac=float(rng.choice([0.0, 0.0, 0.4])))
+        if case % 3 == 1:
+            d = vb.synth.with_sanity_stats(d)         # +-3 sd depth filter on
+        if case % 4 == 2:
+            d = vb.PileupData(k, d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base,
+                              rng.uniform(0, 1, size=M), d.avg_depth, d.sd_depth, d.sanity_disabled)
+        B = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 17, 31, 32, 33, 70]))
+        od = oracle_data(d)
+        pc1, pc2, al = _random_points(rng, B, k)
+        al[0] = 0.0                                   # alpha = 0 and alpha -> 1 rows of the table
+        if B > 1:
+            al[-1] = 0.999
+        with vb.LikelihoodContext(d) as ctx:
+            got = ctx.llk(pc1, pc2, al)
+        idx = list(range(B)) if B <= 9 else [0, 1, B // 2, B - 2, B - 1]
+        want = np.array([od.llk(pc1[i], pc2[i], al[i]) for i in idx])
+        if np.all(want == 0):
+            assert np.all(got[idx] == 0), case
+        else:
+            err = rel_err(got[idx], want)
+            worst = max(worst, err)
+            assert err <= LLK_RTOL, (case, M, k, depth, q_lo, q_hi, B, err)
+    assert worst < LLK_RTOL
+
+
 # ------------------------------------------------------------------ file flow and device pointers
 
 def test_run_files_with_sanity_check_and_pileup_roundtrip(tmp_path):
