@@ -1,0 +1,26 @@
+"""In-kernel timeline of one command of the resident search kernel (VB2_STAMPS=1): the stamps
+left behind are those of the last evaluation of the search."""
+import os, sys, ctypes as C
+os.environ["VB2_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import verifybamid_amd as vb
+from verifybamid_amd import _abi
+M = int(os.environ.get("VB2_M", 100000))
+d = vb.synth.make_pileup(M, 30, 4, 0.05, 2)
+ctx = vb.LikelihoodContext(d)
+ctx.optimize()
+lib = _abi.lib()
+buf = (C.c_ulonglong * (8 * 512))()
+lib.vb2_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+nb = lib.vb2_debug_read_stamps(ctx._h, buf, 512)
+s = np.array(buf[:8 * nb], dtype=np.float64).reshape(nb, 8)
+t0 = s[0, 7]
+s = s[s[:, 0] > 0]
+us = (s - t0) / 100.0
+names = ["entry", "points in LDS", "table built", "wave0 tiles done", "last wave tiles done", "block reduced", "finalized (last block)"]
+print("blocks:", len(s), " t=0: workgroup 0 has a valid command image")
+for i, n in enumerate(names):
+    col = us[:, i][s[:, i] > 0]
+    if len(col): print("%-24s min %6.2f  median %6.2f  max %6.2f us" % (n, col.min(), np.median(col), col.max()))
+ctx.close()

@@ -108,6 +108,13 @@ int vb2_debug_read_stamps(vb2_ctx* ctx, unsigned long long* out, int max_blocks)
     return ctx->impl->read_stamps(out, max_blocks);
 }
 
+// Test aid (not part of the public header): batches served by the resident search kernel.
+long long vb2_debug_resident_evals(vb2_ctx* ctx)
+{
+    if (guard_ctx(ctx)) return -1;
+    return (long long)ctx->impl->resident_evals;
+}
+
 int vb2_optimize_llk(vb2_eval_fn eval, void* user, int32_t num_pc, const vb2_model* model,
                      vb2_estimate* out, vb2_trace* trace)
 {
@@ -133,7 +140,11 @@ int vb2_optimize_llk(vb2_eval_fn eval, void* user, int32_t num_pc, const vb2_mod
 int vb2_ctx_optimize_llk(vb2_ctx* ctx, const vb2_model* model, vb2_estimate* out, vb2_trace* trace)
 {
     if (int rc = guard_ctx(ctx)) return rc;
-    return vb2_optimize_llk(ctx_eval_cb, ctx->impl, ctx->impl->num_pc, model, out, trace);
+    // the whole search runs against one resident kernel when that mode is available
+    const bool resident = ctx->impl->resident_begin();
+    const int rc = vb2_optimize_llk(ctx_eval_cb, ctx->impl, ctx->impl->num_pc, model, out, trace);
+    if (resident) ctx->impl->resident_end();
+    return rc;
 }
 
 int vb2_batch_create(vb2_ctx* const* ctxs, int32_t num_sample, vb2_batch** out)

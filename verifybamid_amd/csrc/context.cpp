@@ -11,6 +11,7 @@
 #include "context.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -95,6 +96,7 @@ int upload(const std::vector<T>& h, T** d, int64_t* bytes)
 Context::~Context()
 {
     if (device >= 0) (void)hipSetDevice(device);
+    if (resident_active) resident_end();
     auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
     fr(L.codes); fr(L.mt_rec); fr(L.ud); fr(L.mu); fr(L.ediag);
     fr(L.known_af); fr(L.dict_perr);
@@ -102,6 +104,9 @@ Context::~Context()
     if (h_points) (void)hipHostFree(h_points);
     if (h_out) (void)hipHostFree(h_out);
     if (h_done) (void)hipHostFree(h_done);
+    if (h_cmd) (void)hipHostFree(h_cmd);
+    if (h_state) (void)hipHostFree(h_state);
+    fr(d_relay);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -390,6 +395,17 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     *c->h_done = 0;
     VB2_HIP(hipHostGetDevicePointer((void**)&c->d_done, c->h_done, 0));
     if (const char* sw = std::getenv("VB2_SPIN_WAIT")) c->spin_wait = std::atoi(sw) != 0;
+    if (const char* rs = std::getenv("VB2_RESIDENT")) c->resident_enabled = std::atoi(rs) != 0;
+    {
+        const size_t words = (size_t)resident_words(k);
+        VB2_HIP(hipHostMalloc((void**)&c->h_cmd, sizeof(unsigned long long) * words, hipHostMallocMapped));
+        std::memset(c->h_cmd, 0, sizeof(unsigned long long) * words);
+        VB2_HIP(hipHostGetDevicePointer((void**)&c->d_cmd, c->h_cmd, 0));
+        VB2_HIP(hipMalloc((void**)&c->d_relay, sizeof(unsigned long long) * words));
+        VB2_HIP(hipHostMalloc((void**)&c->h_state, sizeof(unsigned int), hipHostMallocMapped));
+        *c->h_state = 0;
+        VB2_HIP(hipHostGetDevicePointer((void**)&c->d_state, c->h_state, 0));
+    }
     c->device_bytes += (int64_t)(sizeof(double) * (size_t)kMaxPointsPerLaunch * nb);
     if (opt && opt->stream) {
         c->stream = (hipStream_t)opt->stream;
@@ -428,6 +444,64 @@ int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipS
     return VB2_OK;
 }
 
+// One resident search per device at a time (all its workgroups must be on the CUs together).
+static std::atomic<int> g_resident_busy[64];
+
+bool Context::resident_begin()
+{
+    if (!resident_enabled || resident_active || L.num_mt == 0 || !spin_wait || device < 0 || device >= 64)
+        return false;
+    int expected = 0;
+    if (!g_resident_busy[device].compare_exchange_strong(expected, 1)) return false;
+    bool ok = hipSetDevice(device) == hipSuccess;
+    const size_t words = (size_t)resident_words(num_pc);
+    if (ok) {
+        std::memset(h_cmd, 0, sizeof(unsigned long long) * words);
+        __atomic_store_n(h_state, 0u, __ATOMIC_RELEASE);
+        ok = hipMemsetAsync(d_relay, 0, sizeof(unsigned long long) * words, stream) == hipSuccess;
+    }
+    if (ok) {
+        ResidentArgs ra;
+        ra.h_cmd = d_cmd;
+        ra.relay = d_relay;
+        ra.h_out = d_out;
+        ra.h_done = d_done;
+        ra.h_state = d_state;
+        ra.first_seq = done_seq_ + 1;
+        ra.timeout_ticks = 100000000ull;                  // 1 s without a command: give up
+        ok = launch_llk_resident(L, ra, d_partials, d_ticket, stream) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+    }
+    if (!ok) {
+        g_resident_busy[device].store(0);
+        return false;
+    }
+    resident_active = true;
+    return true;
+}
+
+// Posts rows (or the exit command, n = 0) under sequence number seq.
+static void resident_post(unsigned long long* cmd, int words, unsigned long long seq, int n, int stride,
+                          const double* rows)
+{
+    unsigned long long x = 0;
+    if (n > 0) std::memcpy(cmd + 2, rows, sizeof(double) * (size_t)n * stride);
+    cmd[1] = (unsigned long long)n;
+    for (int w = 1; w < words - 1; ++w) x ^= cmd[w];
+    cmd[words - 1] = x ^ resident_mix(seq);
+    __atomic_store_n(&cmd[0], seq, __ATOMIC_RELEASE);
+}
+
+void Context::resident_end()
+{
+    if (!resident_active) return;
+    (void)hipSetDevice(device);
+    resident_post(h_cmd, resident_words(num_pc), ++done_seq_, 0, 2 * num_pc + 1, nullptr);
+    (void)hipStreamSynchronize(stream);                    // the kernel leaves on the exit command
+    resident_active = false;
+    g_resident_busy[device].store(0);
+}
+
 int Context::eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,
                        double* llk_out)
 {
@@ -437,6 +511,48 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
     }
     VB2_HIP(hipSetDevice(device));
     const int k = num_pc, stride = 2 * k + 1;
+    int served = 0;
+    while (resident_active && served < num_point) {
+        // the search kernel is already on the CUs: post <= 4 rows, spin on the sequence number
+        const int n = std::min(4, num_point - served);
+        double rows[4 * (2 * VB2_MAX_PC + 1)];
+        for (int b = 0; b < n; ++b) {
+            double* row = rows + (size_t)b * stride;
+            std::memcpy(row, pc1 + (size_t)(served + b) * k, sizeof(double) * k);
+            std::memcpy(row + k, pc2 + (size_t)(served + b) * k, sizeof(double) * k);
+            row[2 * k] = alpha[served + b];
+        }
+        const unsigned long long seq = ++done_seq_;
+        resident_post(h_cmd, resident_words(k), seq, n, stride, rows);
+        bool seen = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+            if ((spins & 0x3ff) == 0x3ff) {
+                if (__atomic_load_n(h_state, __ATOMIC_ACQUIRE) == 3u) break;       // kernel gave up
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) break;
+            }
+            __builtin_ia32_pause();
+        }
+        if (!seen) {
+            // Give up on the mode: the kernel leaves on its idle limit (or already has); the
+            // batch is redone with plain launches below.
+            (void)hipStreamSynchronize(stream);
+            resident_active = false;
+            resident_enabled = false;
+            g_resident_busy[device].store(0);
+            VB2_HIP(hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream));
+            break;
+        }
+        std::memcpy(llk_out + served, h_out, sizeof(double) * n);
+        served += n;
+        ++resident_evals;
+    }
+    pc1 += (size_t)served * k;
+    pc2 += (size_t)served * k;
+    alpha += served;
+    llk_out += served;
+    num_point -= served;
     for (int done = 0; done < num_point; done += kStagePoints) {
         const int n = std::min(kStagePoints, num_point - done);
         for (int b = 0; b < n; ++b) {

@@ -30,6 +30,12 @@ public:
     // host pointers, synchronous
     int eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,
                   double* llk_out);
+    // Resident search mode (llk_resident_kernel): between begin and end, eval_host posts its
+    // batches to the kernel that is already on the CUs instead of launching one per call.
+    // begin() returns false (and changes nothing) when the mode is unavailable; any failure
+    // later falls back to plain launches on its own.
+    bool resident_begin();
+    void resident_end();
     void fill_info(vb2_info* info) const;
     int read_stamps(unsigned long long* out, int max_blocks);
 
@@ -50,6 +56,14 @@ public:
     unsigned long long* d_done = nullptr;
     unsigned long long done_seq_ = 0;
     bool spin_wait = true;
+    bool resident_enabled = true;            // VB2_RESIDENT=0 turns the mode off
+    bool resident_active = false;
+    unsigned long long* h_cmd = nullptr;     // mailbox (mapped host memory) + device view
+    unsigned long long* d_cmd = nullptr;
+    unsigned long long* d_relay = nullptr;
+    unsigned int* h_state = nullptr;
+    unsigned int* d_state = nullptr;
+    int64_t resident_evals = 0;              // batches served by the resident kernel
     int64_t num_read = 0, num_read_other = 0, device_bytes = 0, algorithmic_bytes = 0;
     char device_name[64] = {0};
     char arch[32] = {0};

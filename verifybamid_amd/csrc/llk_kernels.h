@@ -78,6 +78,26 @@ size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_wave
 int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves);
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
+
+// Resident search kernel (llk_resident_kernel): launched once per search, fed through a mailbox.
+// Word layout of h_cmd / relay: [0] seq, [1] rows valid (0 = exit), [2..2+4*(2k+1)) rows
+// (pc1 | pc2 | alpha), [2+4*(2k+1)] check word: XOR of words [1, last) ^ resident_mix(seq).
+struct ResidentArgs {
+    const unsigned long long* h_cmd;     // mailbox in mapped host memory (device view)
+    unsigned long long* relay;           // same layout in device memory, zero-initialised
+    double* h_out;                       // [4] results, mapped host memory (device view)
+    unsigned long long* h_done;          // completion sequence number, mapped host memory
+    unsigned int* h_state;               // 1 running, 2 exited on command, 3 gave up (idle timeout)
+    unsigned long long first_seq;        // sequence number of the first command
+    unsigned long long timeout_ticks;    // idle limit in 100 MHz wall-clock ticks
+};
+__host__ __device__ inline unsigned long long resident_mix(unsigned long long seq)
+{
+    return seq * 0x9E3779B97F4A7C15ull;      // spreads consecutive sequence numbers over 64 bits
+}
+inline int resident_words(int num_pc) { return 2 + 4 * (2 * num_pc + 1) + 1; }
+hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, double* d_partials,
+                               unsigned int* d_ticket, hipStream_t stream);
 // A/B switch: lanes of one ds_read_b128 service group share a candidate slot (default) or plain
 void set_lane_mapping(bool hardware_groups);
 void set_geom_override(int btl, int max_waves, int blocks_per_cu);

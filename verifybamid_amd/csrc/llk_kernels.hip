@@ -217,7 +217,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
           double* __restrict__ partials, double* __restrict__ llk_out,
           unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
           unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
-          unsigned int* __restrict__ batch_done, unsigned int batch_active, const int ngrp)
+          unsigned int* __restrict__ batch_done, unsigned int batch_active, const int ngrp,
+          const bool coherent_points = false)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NP = 4 * BTL;
@@ -252,7 +253,10 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         const int b = e / stride;
         const int src = b < num_valid ? b : num_valid - 1;
         const int idx = src * stride + (e - b * stride);
-        pts[e] = ip.count > 0 ? ip.v[idx] : points[idx];
+        // resident mode: the rows were just written by another workgroup -> L1-bypassing loads
+        pts[e] = ip.count > 0 ? ip.v[idx]
+                 : coherent_points ? __hip_atomic_load(&points[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : points[idx];
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[1] = wall_clock64();
@@ -579,6 +583,105 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
 
 
 
+// ---------------------------------------------------------------------------------------------
+// Resident search kernel.  A Nelder-Mead search is ~480 DEPENDENT launches of 4 points, and at
+// 17 us of kernel per launch the ~7 us of launch submission + dispatch per iteration is a third
+// of the wall-clock.  This kernel is launched once per search and stays on the CUs: the host
+// posts each batch of <= 4 parameter rows in a mailbox in mapped host memory, workgroup 0 polls
+// it over PCIe and relays it through device memory, every workgroup evaluates its tiles exactly
+// as llk_eval_kernel<1> does, and the last workgroup writes the results + sequence number back
+// to mapped host memory.  The host optimiser keeps every decision (bit-identical trajectory).
+//
+// Mailbox / relay layout (64-bit words): [0] sequence number, [1] rows valid (0 = exit),
+// [2 .. 2+4*(2k+1)) parameter rows, [last] check word = XOR of words 1.. ^ mix(sequence).  The
+// check word makes one PCIe read pass self-validating: a torn read (host mid-write) fails the
+// test and is retried, so no second round trip is needed after seeing a new sequence number.
+// Both sides give up after a bounded wait (the kernel when idle for timeout_ticks of the
+// 100 MHz wall clock, the host after a few seconds) and the host falls back to plain launches.
+__device__ __forceinline__ double* lds_base()
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    return lds;
+}
+
+template <bool HWMAP>
+__global__ void __launch_bounds__(Geom<1>::kMaxWaves * 64, Geom<1>::kWavesPerSimd)
+llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restrict__ partials,
+                    unsigned int* __restrict__ ticket)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stride = 2 * L.num_pc + 1;
+    const int nword = 2 + 4 * stride + 1;
+    InlinePoints ip;
+    ip.count = 0;
+    if (blockIdx.x == 0 && tid == 0)
+        __hip_atomic_store(ra.h_state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (unsigned long long seq = ra.first_seq;; ++seq) {
+        __syncthreads();                       // everyone is out of the previous evaluation's LDS
+        const unsigned long long t_wait = wall_clock64();
+        bool timed_out = false;
+        if (blockIdx.x == 0 && wave == 0) {
+            // ---- host mailbox -> relay (one wave; retried until a consistent image arrives) ----
+            for (unsigned it = 0;; ++it) {
+                unsigned long long x = 0, w0 = 0;
+                for (int w = lane; w < nword; w += 64) {
+                    const unsigned long long v =
+                        __hip_atomic_load(&ra.h_cmd[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (w == 0) {
+                        w0 = v;
+                    } else {
+                        x ^= v;
+                        __hip_atomic_store(&ra.relay[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off, 64);
+                w0 = __shfl(w0, 0, 64);
+                if (w0 == seq && x == resident_mix(seq)) break;
+                if ((it & 15) == 15 && wall_clock64() - t_wait > ra.timeout_ticks) { timed_out = true; break; }
+            }
+            if (!timed_out) {
+                if (L.stamps && lane == 0) L.stamps[7] = wall_clock64();     // command seen
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(&ra.relay[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (lane == 0) {
+                // tell the other workgroups (and the host) to give up as well
+                __hip_atomic_store(&ra.relay[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- one thread per workgroup waits for the relayed command ----
+        // (relaxed L1-bypassing loads: an acquire here would invalidate caches under the
+        // workgroups that are still evaluating; the rows are read with bypassing loads too)
+        unsigned long long* lds_flag = reinterpret_cast<unsigned long long*>(lds_base());
+        if (tid == 0) {
+            unsigned long long got = 0;
+            for (unsigned it = 0;; ++it) {
+                got = __hip_atomic_load(&ra.relay[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got == seq || got == ~0ull) break;
+                if ((it & 63) == 63 && wall_clock64() - t_wait > 2 * ra.timeout_ticks) { got = ~0ull; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            *lds_flag = got;
+        }
+        __syncthreads();
+        timed_out = (*lds_flag == ~0ull);       // eval_body's first barrier orders this read before its LDS writes
+        if (timed_out) {
+            if (blockIdx.x == 0 && tid == 0)
+                __hip_atomic_store(ra.h_state, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        const int nv = (int)__hip_atomic_load(&ra.relay[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nv <= 0) {                          // exit command
+            if (blockIdx.x == 0 && tid == 0)
+                __hip_atomic_store(ra.h_state, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        eval_body<1, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
+                            ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, true);
+    }
+}
+
 // Sums the per-block partials in a fixed order -> bitwise reproducible: wave w takes
 // points w, w+4, ...; lane l adds blocks l, l+64, ... (8 independent loads in flight),
 // then a butterfly over the wave.
@@ -764,6 +867,25 @@ hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
                                ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, double* d_partials,
+                               unsigned int* d_ticket, hipStream_t stream)
+{
+    const LaunchGeom gm = launch_geom(L, 1);
+    const size_t shmem = eval_shmem_bytes(L, 1, gm.grid, gm.block_waves, 1);
+    if (shmem > (size_t)kLdsLimitBytes || gm.grid > L.num_cu) return hipErrorInvalidConfiguration;
+    const void* fn = g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<true>)
+                             : reinterpret_cast<const void*>(&llk_resident_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e != hipSuccess) return e;
+    // every workgroup must be on a CU at the same time (they all wait for the host): the
+    // cooperative launch guarantees that or fails
+    DeviceLayout Lc = L;
+    ResidentArgs rc = ra;
+    void* args[] = {&Lc, &rc, &d_partials, &d_ticket};
+    return hipLaunchCooperativeKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args,
+                                      (unsigned int)shmem, stream);
 }
 
 // Zero-marker case: LLK of an empty sum.
