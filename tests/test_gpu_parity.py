@@ -480,22 +480,60 @@ def test_cohort_batch_lockstep_matches_individual_runs():
 
 
 def test_in_kernel_reduction_is_stable_under_stress(c2, c3):
-    """The cross-workgroup hand-off (agent-scope atomics + ticket, last arriver sums) must
-    return the same bits on every launch, also when launches of different shapes and
-    contexts interleave (stale partials would show up as a changed sum)."""
-    d, _ = c2
+    """The cross-workgroup hand-off (tagged partial sums collected by workgroup 0) must return
+    the same bits on every launch, also when launches of different shapes and contexts
+    interleave.  One- and two-point launches and rows with pc1 == pc2 are the hard cases: their
+    partial sums / parameter words repeat, which a weak check word would not tell from the
+    stale set of the launch before."""
+    d, od = c2
     rng = np.random.default_rng(21)
     with vb.LikelihoodContext(d) as small, vb.LikelihoodContext(c3) as big:
         sets = []
         for ctx, k in ((small, 2), (big, 4)):
-            for B in (1, 4, 8, 13, 32):
+            for B in (1, 1, 2, 4, 8, 13, 32):
                 pc1, pc2, al = _random_points(rng, B, k)
+                if B == 2:
+                    pc2 = pc1.copy()
                 sets.append((ctx, pc1, pc2, al, ctx.llk(pc1, pc2, al)))
+        for ctx, pc1, pc2, al, want in sets:
+            if ctx is small:                       # anchor the reference values on the oracle
+                ref = np.array([od.llk(pc1[i], pc2[i], al[i]) for i in range(len(al))])
+                assert rel_err(want, ref) <= LLK_RTOL
         order = rng.integers(0, len(sets), size=6000)
         for i in order:
             ctx, pc1, pc2, al, want = sets[i]
             got = ctx.llk(pc1, pc2, al)
             assert np.array_equal(got, want), i
+
+
+def test_resident_search_matches_plain_launches(c2):
+    """vb2_ctx_optimize_llk runs against the resident kernel (commands through the mailbox);
+    with the mode off it launches one kernel per step.  Same evaluations, same bits -- for the
+    Heter model and for the within-ancestry one, whose rows have pc1 == pc2."""
+    import ctypes as C
+    d, od = c2
+    lib = _abi.lib()
+    lib.vb2_debug_resident_evals.restype = C.c_longlong
+    lib.vb2_debug_resident_evals.argtypes = [C.c_void_p]
+    lib.vb2_debug_set_resident.argtypes = [C.c_void_p, C.c_int]
+    with vb.LikelihoodContext(d) as ctx:
+        for kw in (dict(), dict(within_ancestry=True)):
+            lib.vb2_debug_set_resident(ctx._h, 0)
+            plain = ctx.optimize(trace_capacity=4096, **kw)
+            n0 = lib.vb2_debug_resident_evals(ctx._h)
+            lib.vb2_debug_set_resident(ctx._h, 1)
+            for _ in range(6):
+                res = ctx.optimize(trace_capacity=4096, **kw)
+                assert res["alpha"] == plain["alpha"] and res["llk1"] == plain["llk1"]
+                assert res["llk0"] == plain["llk0"] and res["num_eval"] == plain["num_eval"]
+                assert np.array_equal(res["trace"]["llk"], plain["trace"]["llk"])
+            assert lib.vb2_debug_resident_evals(ctx._h) > n0 + 6 * 20      # the mode was really used
+        ref = od.optimize()
+        assert abs(plain["alpha"] - ref["alpha"]) <= NORTH_STAR_ALPHA_ATOL
+        # plain evaluations still work between searches
+        pc1, pc2, al = _random_points(np.random.default_rng(3), 3, 2)
+        want = np.array([od.llk(pc1[i], pc2[i], al[i]) for i in range(3)])
+        assert rel_err(ctx.llk(pc1, pc2, al), want) <= LLK_RTOL
 
 
 def test_device_pointer_api_on_torch_stream(c2):

@@ -115,6 +115,13 @@ long long vb2_debug_resident_evals(vb2_ctx* ctx)
     return (long long)ctx->impl->resident_evals;
 }
 
+// Test aid: turn the resident search mode off/on for one context (VB2_RESIDENT does it globally).
+void vb2_debug_set_resident(vb2_ctx* ctx, int on)
+{
+    if (guard_ctx(ctx)) return;
+    ctx->impl->resident_enabled = on != 0;
+}
+
 int vb2_optimize_llk(vb2_eval_fn eval, void* user, int32_t num_pc, const vb2_model* model,
                      vb2_estimate* out, vb2_trace* trace)
 {

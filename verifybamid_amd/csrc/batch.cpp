@@ -93,7 +93,8 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
     const size_t S = (size_t)num_sample, stride = 2 * (size_t)k + 1;
     VB2_HIP(hipMalloc((void**)&b->d_layouts_, sizeof(DeviceLayout) * S));
     VB2_HIP(hipMemcpy(b->d_layouts_, layouts.data(), sizeof(DeviceLayout) * S, hipMemcpyHostToDevice));
-    VB2_HIP(hipMalloc((void**)&b->d_partials_, sizeof(double) * S * kSlot * bps));
+    VB2_HIP(hipMalloc((void**)&b->d_partials_, sizeof(double) * S * (kSlot + 1) * bps));
+    VB2_HIP(hipMemset(b->d_partials_, 0, sizeof(double) * S * (kSlot + 1) * bps));
     VB2_HIP(hipMalloc((void**)&b->d_tickets_, sizeof(unsigned int) * S));
     VB2_HIP(hipMemset(b->d_tickets_, 0, sizeof(unsigned int) * S));
     VB2_HIP(hipMalloc((void**)&b->d_batch_done_, sizeof(unsigned int)));

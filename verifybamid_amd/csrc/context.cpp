@@ -374,7 +374,8 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     c->algorithmic_bytes = 2 * num_read + m_active * (8 * (int64_t)k + 12);
 
     const int nb = kMaxGridPerCU * num_cu;
-    VB2_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * (size_t)kMaxPointsPerLaunch * nb));
+    VB2_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb));
+    VB2_HIP(hipMemset(c->d_partials, 0, sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb));
     VB2_HIP(hipMalloc((void**)&c->d_ticket, sizeof(unsigned int)));
     VB2_HIP(hipMemset(c->d_ticket, 0, sizeof(unsigned int)));
     if (std::getenv("VB2_STAMPS")) {
@@ -383,6 +384,8 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         L.stamps = c->d_stamps;
     }
     if (const char* sl = std::getenv("VB2_SINGLE_LAUNCH")) set_single_launch(std::atoi(sl) != 0);
+    if (const char* rm = std::getenv("VB2_REDUCE"))
+        set_reduce_mode(!std::strcmp(rm, "ticket") ? 1 : !std::strcmp(rm, "tagged") ? 2 : 0);
     // Host <-> device hand-off of the (tiny) parameter and result vectors goes through
     // pinned, device-mapped host memory that the kernels access directly: no copy
     // commands on the evaluation path.
@@ -396,6 +399,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     VB2_HIP(hipHostGetDevicePointer((void**)&c->d_done, c->h_done, 0));
     if (const char* sw = std::getenv("VB2_SPIN_WAIT")) c->spin_wait = std::atoi(sw) != 0;
     if (const char* rs = std::getenv("VB2_RESIDENT")) c->resident_enabled = std::atoi(rs) != 0;
+    c->dbg_timing = timing;
     {
         const size_t words = (size_t)resident_words(k);
         VB2_HIP(hipHostMalloc((void**)&c->h_cmd, sizeof(unsigned long long) * words, hipHostMallocMapped));
@@ -440,7 +444,8 @@ int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipS
         VB2_HIP(launch_fill_zero(d_llk, num_point, s));
         return VB2_OK;
     }
-    VB2_HIP(launch_llk_eval(L, num_point, d_pts, h_pts, d_partials, d_llk, d_ticket, done_flag, done_seq, s));
+    VB2_HIP(launch_llk_eval(L, num_point, d_pts, h_pts, d_partials, d_llk, d_ticket, done_flag, done_seq,
+                            &done_seq_, s));
     return VB2_OK;
 }
 
@@ -487,7 +492,7 @@ static void resident_post(unsigned long long* cmd, int words, unsigned long long
     unsigned long long x = 0;
     if (n > 0) std::memcpy(cmd + 2, rows, sizeof(double) * (size_t)n * stride);
     cmd[1] = (unsigned long long)n;
-    for (int w = 1; w < words - 1; ++w) x ^= cmd[w];
+    for (int w = 1; w < words - 1; ++w) x ^= word_hash(cmd[w], (unsigned)w);
     cmd[words - 1] = x ^ resident_mix(seq);
     __atomic_store_n(&cmd[0], seq, __ATOMIC_RELEASE);
 }
@@ -498,6 +503,12 @@ void Context::resident_end()
     (void)hipSetDevice(device);
     resident_post(h_cmd, resident_words(num_pc), ++done_seq_, 0, 2 * num_pc + 1, nullptr);
     (void)hipStreamSynchronize(stream);                    // the kernel leaves on the exit command
+    if (dbg_timing && dbg_cmds > 0) {
+        std::fprintf(stderr, "resident search: %lld commands, host between result and next post %.2f us avg, "
+                     "post -> result seen %.2f us avg\n", (long long)dbg_cmds,
+                     1e-3 * dbg_host_ns / dbg_cmds, 1e-3 * dbg_wait_ns / dbg_cmds);
+        dbg_cmds = 0; dbg_host_ns = dbg_wait_ns = 0; dbg_have_prev = false;
+    }
     resident_active = false;
     g_resident_busy[device].store(0);
 }
@@ -526,6 +537,8 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
         resident_post(h_cmd, resident_words(k), seq, n, stride, rows);
         bool seen = false;
         const auto t0 = std::chrono::steady_clock::now();
+        if (dbg_timing && dbg_have_prev)
+            dbg_host_ns += std::chrono::duration<double, std::nano>(t0 - dbg_prev_seen).count();
         for (unsigned spins = 0;; ++spins) {
             if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
             if ((spins & 0x3ff) == 0x3ff) {
@@ -547,6 +560,12 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
         std::memcpy(llk_out + served, h_out, sizeof(double) * n);
         served += n;
         ++resident_evals;
+        if (dbg_timing) {
+            dbg_prev_seen = std::chrono::steady_clock::now();
+            dbg_wait_ns += std::chrono::duration<double, std::nano>(dbg_prev_seen - t0).count();
+            dbg_have_prev = true;
+            ++dbg_cmds;
+        }
     }
     pc1 += (size_t)served * k;
     pc2 += (size_t)served * k;

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -64,6 +65,11 @@ public:
     unsigned int* h_state = nullptr;
     unsigned int* d_state = nullptr;
     int64_t resident_evals = 0;              // batches served by the resident kernel
+    // VB2_DEBUG_TIMING: where a resident search's wall-clock goes (host logic vs device round trip)
+    bool dbg_timing = false, dbg_have_prev = false;
+    int64_t dbg_cmds = 0;
+    double dbg_host_ns = 0, dbg_wait_ns = 0;
+    std::chrono::steady_clock::time_point dbg_prev_seen;
     int64_t num_read = 0, num_read_other = 0, device_bytes = 0, algorithmic_bytes = 0;
     char device_name[64] = {0};
     char arch[32] = {0};

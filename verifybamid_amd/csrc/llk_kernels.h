@@ -46,7 +46,8 @@ constexpr int kDynTilesPerWave = 8;       // up to this many tiles per wave: dyn
 inline int max_grid(const DeviceLayout& L) { return kMaxGridPerCU * L.num_cu; }
 
 // Enqueue evaluation of num_point candidate rows (pc1 | pc2 | alpha) on stream.
-// d_partials: >= kMaxPointsPerLaunch * kMaxGridPerCU * L.num_cu doubles of scratch.
+// d_partials: >= (kMaxPointsPerLaunch + 1) * kMaxGridPerCU * L.num_cu doubles of scratch.
+// tag_counter: incremented per kernel launch; tags must never repeat on one partials buffer.
 // d_ticket: one zero-initialised unsigned int (arrival counter of the single-launch mode).
 // done_flag: optional word in mapped host memory that receives done_seq after the results of
 // the LAST launch are written (lets the host wait without hipStreamSynchronize).
@@ -56,15 +57,16 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            const double* h_points, double* d_partials, double* d_out,
                            unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
-                           hipStream_t stream);
+                           unsigned long long* tag_counter, hipStream_t stream);
 void set_single_launch(bool on);
+void set_reduce_mode(int mode);     // 0 auto, 1 arrival ticket, 2 tagged sets (VB2_REDUCE)
 
 // One launch over several samples (contexts on the same device): see llk_eval_multi_kernel.
 struct MultiLaunch {
     const DeviceLayout* d_layouts;   // [num_sample] in HBM
     const double* d_points;          // [num_sample][4*btl][2k+1]
     const int* d_num_valid;          // [num_sample] 0 = sample sits this step out
-    double* d_partials;              // [num_sample][4*btl][bps]
+    double* d_partials;              // [num_sample][4*btl + 1][bps]; done_seq doubles as the launch tag
     double* d_out;                   // [num_sample][4*btl]
     unsigned int* d_tickets;         // [num_sample], zero-initialised
     unsigned int* d_batch_done;      // one zero-initialised counter
@@ -81,7 +83,7 @@ hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 
 // Resident search kernel (llk_resident_kernel): launched once per search, fed through a mailbox.
 // Word layout of h_cmd / relay: [0] seq, [1] rows valid (0 = exit), [2..2+4*(2k+1)) rows
-// (pc1 | pc2 | alpha), [2+4*(2k+1)] check word: XOR of words [1, last) ^ resident_mix(seq).
+// (pc1 | pc2 | alpha), [2+4*(2k+1)] check word: XOR of word_hash(word w, w) over [1, last) ^ resident_mix(seq).
 struct ResidentArgs {
     const unsigned long long* h_cmd;     // mailbox in mapped host memory (device view)
     unsigned long long* relay;           // same layout in device memory, zero-initialised
@@ -94,6 +96,16 @@ struct ResidentArgs {
 __host__ __device__ inline unsigned long long resident_mix(unsigned long long seq)
 {
     return seq * 0x9E3779B97F4A7C15ull;      // spreads consecutive sequence numbers over 64 bits
+}
+// Position-dependent 64-bit hash of one word (xor-shift, multiply, xor-shift).  The check words of the
+// mailbox and of the partial-sum hand-off are the XOR of these over the payload, ^ mix(tag):
+// a plain XOR of the payload would be blind to equal words (pc1 == pc2 rows, the four equal
+// sums of a one-point launch), i.e. to exactly the stale/new mixtures it has to catch.
+__host__ __device__ inline unsigned long long word_hash(unsigned long long v, unsigned int pos)
+{
+    unsigned long long z = v + 0x9E3779B97F4A7C15ull * (unsigned long long)(pos + 1);
+    z = (z ^ (z >> 32)) * 0xBF58476D1CE4E5B9ull;
+    return z ^ (z >> 29);
 }
 inline int resident_words(int num_pc) { return 2 + 4 * (2 * num_pc + 1) + 1; }
 hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, double* d_partials,

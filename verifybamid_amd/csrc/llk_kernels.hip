@@ -218,7 +218,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
           unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
           unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
           unsigned int* __restrict__ batch_done, unsigned int batch_active, const int ngrp,
-          const bool coherent_points = false)
+          const unsigned long long tag, const bool coherent_points = false)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NP = 4 * BTL;
@@ -488,42 +488,115 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (tid < NPT) partials[(size_t)tid * nblk + blk] = red[tid];
         return;
     }
-    // ---- single-launch mode: the last workgroup to arrive sums all partials ----
-    // Hand-off through 8-byte agent-scope atomics on both sides (write-through stores,
-    // L1-bypassing loads), drained before the ticket is drawn: placement independent.
-    if (tid < NPT)
-        __hip_atomic_store(&partials[(size_t)tid * nblk + blk], red[tid],
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned int* last_flag = queue;                                    // the queue is drained
-    if (tid == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT);
-        *last_flag = (t == nblk - 1) ? 1u : 0u;
+    if (tag == 0) {
+        // ---- single-launch mode A (large batches): the last workgroup to arrive sums all partials ----
+        // Hand-off through 8-byte agent-scope atomics on both sides (write-through stores,
+        // L1-bypassing loads), drained before the ticket is drawn: placement independent.
+        if (tid < NPT)
+            __hip_atomic_store(&partials[(size_t)tid * nblk + blk], red[tid],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned int* last_flag = queue;                                    // the queue is drained
+        if (tid == 0) {
+            const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+            *last_flag = (t == nblk - 1) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*last_flag == 0u) return;
+        // same summation order as llk_finalize_kernel: lane-strided, then a wave butterfly
+        const int nbt = (int)nblk;
+        for (int b = wave; b < num_valid; b += nwave) {
+            const double* p = partials + (size_t)b * nbt;
+            double s = 0;
+            for (int base = 0; base < nbt; base += 8 * 64) {
+                double x[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = base + q * 64 + lane;
+                    x[q] = i < nbt ? __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += x[q];
+            }
+            s = wave_sum(s);
+            if (lane == 0) llk_out[b] = s;
+        }
+        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+    // ---- single-launch mode B (small batches, resident search): workgroup 0 collects all partials ----
+    // Every workgroup publishes its NPT sums plus a check word (XOR of position-dependent word
+    // hashes ^ mix(launch tag)) with write-through stores and is done: no drain, no arrival counter.
+    // Workgroup 0 polls the NPT+1 words of each workgroup with L1-bypassing loads until the
+    // check word fits -- stale words of an earlier launch or a half-arrived set fail it -- so
+    // the hand-off costs one store propagation plus one read instead of three dependent
+    // round trips through the fabric (store drain, ticket atomic, reload).
+    unsigned long long* pw = reinterpret_cast<unsigned long long*>(partials);
+    if (wave == 0) {
+        const unsigned long long bits = lane < NPT ? (unsigned long long)__double_as_longlong(red[lane]) : 0ull;
+        unsigned long long x = lane < NPT ? word_hash(bits, (unsigned)lane) : 0ull;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off, 64);
+        if (lane < NPT)
+            __hip_atomic_store(&pw[(size_t)lane * nblk + blk], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == NPT)
+            __hip_atomic_store(&pw[(size_t)NPT * nblk + blk], x ^ resident_mix(tag), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (blk != 0) return;
+    __syncthreads();                                   // the table is dead: its space stages the partials
+    const int nb = (int)nblk;
+    double* stage = lds;                               // [NPT][nb]
+    {
+        const unsigned long long want = resident_mix(tag);
+        const unsigned long long t_wait = wall_clock64();
+        for (int b = tid; b < nb; b += nthread) {      // one thread per workgroup's set
+            for (unsigned it = 0;; ++it) {
+                // check word and the first words are requested together, NP + 1 loads in flight
+                unsigned long long x = __hip_atomic_load(&pw[(size_t)NPT * nb + b], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                for (int w0 = 0; w0 < NPT; w0 += NP) {       // NPT is a multiple of NP (4 or 8)
+                    unsigned long long v[NP];
+#pragma unroll
+                    for (int u = 0; u < NP; ++u)
+                        v[u] = __hip_atomic_load(&pw[(size_t)(w0 + u) * nb + b], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        x ^= word_hash(v[u], (unsigned)(w0 + u));
+                        stage[(size_t)(w0 + u) * nb + b] = __longlong_as_double((long long)v[u]);
+                    }
+                }
+                if (x == want) break;
+                if ((it & 63) == 63 && wall_clock64() - t_wait > 200000000ull) {   // 2 s: a workgroup is missing
+                    for (int w = 0; w < NPT; ++w) stage[(size_t)w * nb + b] = __builtin_nan("");
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
     }
     __syncthreads();
-    if (*last_flag == 0u) return;
     // same summation order as llk_finalize_kernel: lane-strided, then a wave butterfly
-    const int nb = (int)nblk;
     for (int b = wave; b < num_valid; b += nwave) {
-        const double* p = partials + (size_t)b * nb;
+        const double* p = stage + (size_t)b * nb;
         double s = 0;
         for (int base = 0; base < nb; base += 8 * 64) {
             double x[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int i = base + q * 64 + lane;
-                x[q] = i < nb ? __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                              : 0.0;
+                x[q] = i < nb ? p[i] : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) s += x[q];
         }
         s = wave_sum(s);
-        if (lane == 0) llk_out[b] = s;
+        if (lane == 0) llk_out[b] = s;                   // NaN if a workgroup never reported
     }
-    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (stamps && tid == 0) stamps[6] = wall_clock64();
     if (done_flag) {
         // host hand-off without a stream synchronisation: results (in mapped host memory)
@@ -550,10 +623,10 @@ __global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPe
 llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
                 int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
-                unsigned long long done_seq, int ngrp)
+                unsigned long long done_seq, int ngrp, unsigned long long tag)
 {
     eval_body<BTL, HWMAP>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
-                          blockIdx.x, gridDim.x, nullptr, 0u, ngrp);
+                          blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag);
 }
 
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
@@ -576,9 +649,9 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
     InlinePoints ip;
     ip.count = 0;
     eval_body<BTL, HWMAP>(L, ip, points + (size_t)s * NP * stride, nv,
-                          partials + (size_t)s * NP * bps, llk_out + (size_t)s * NP, tickets + s,
+                          partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
-                          batch_done, batch_active, 1);
+                          batch_done, batch_active, 1, done_seq);
 }
 
 
@@ -593,7 +666,8 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
 // to mapped host memory.  The host optimiser keeps every decision (bit-identical trajectory).
 //
 // Mailbox / relay layout (64-bit words): [0] sequence number, [1] rows valid (0 = exit),
-// [2 .. 2+4*(2k+1)) parameter rows, [last] check word = XOR of words 1.. ^ mix(sequence).  The
+// [2 .. 2+4*(2k+1)) parameter rows, [last] check word = XOR of word_hash(word, position) ^
+// mix(sequence).  The
 // check word makes one PCIe read pass self-validating: a torn read (host mid-write) fails the
 // test and is retried, so no second round trip is needed after seeing a new sequence number.
 // Both sides give up after a bounded wait (the kernel when idle for timeout_ticks of the
@@ -630,7 +704,8 @@ llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restr
                     if (w == 0) {
                         w0 = v;
                     } else {
-                        x ^= v;
+                        if (w < nword - 1) x ^= word_hash(v, (unsigned)w);
+                        else x ^= v;                       // the check word itself
                         __hip_atomic_store(&ra.relay[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
@@ -678,7 +753,7 @@ llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restr
             return;
         }
         eval_body<1, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
-                            ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, true);
+                            ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, true);
     }
 }
 
@@ -750,7 +825,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
                              int num_valid, int ngrp,
                              double* d_partials, double* d_out, unsigned int* d_ticket,
                              unsigned long long* done_flag, unsigned long long done_seq,
-                             hipStream_t stream)
+                             unsigned long long tag, hipStream_t stream)
 {
     const LaunchGeom gm = launch_geom(L, BTL);
     const size_t shmem = eval_shmem_bytes(L, BTL, gm.grid, gm.block_waves, ngrp);
@@ -770,10 +845,12 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
     }
     hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
                        stream, L, ip, d_points, num_valid, d_partials, d_out, d_ticket, done_flag,
-                       done_seq, ngrp);
+                       done_seq, ngrp, tag);
     return hipGetLastError();
 }
 
+static int g_reduce_mode = 0;          // 0 auto, 1 ticket, 2 tagged
+void set_reduce_mode(int m) { g_reduce_mode = m; }
 static bool g_single_launch = true;
 void set_single_launch(bool on) { g_single_launch = on; }
 
@@ -781,7 +858,7 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            const double* h_points, double* d_partials, double* d_out,
                            unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
-                           hipStream_t stream)
+                           unsigned long long* tag_counter, hipStream_t stream)
 {
     unsigned int* tk = g_single_launch ? d_ticket : nullptr;
     const int stride = 2 * L.num_pc + 1;
@@ -798,12 +875,16 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         unsigned long long* df = (done + step >= num_point) ? done_flag : nullptr;   // last launch signals
         unsigned long long* df_eval = tk ? df : nullptr;
         hipError_t e;
+        // hand-off protocol: tagged sets for <= 4 points (one fabric round trip less, latency
+        // matters), arrival ticket for bigger batches (cheaper per point); VB2_REDUCE overrides
+        const bool tagged = g_reduce_mode == 2 || (g_reduce_mode == 0 && step <= 4);
+        const unsigned long long tag = tagged ? ++*tag_counter : 0ull;   // unique per launch on this buffer
         if (step > 4)
-            e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream)
-                        : launch_btl<2, false>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream);
+            e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
+                        : launch_btl<2, false>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
         else
-            e = g_hwmap ? launch_btl<1, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, stream)
-                        : launch_btl<1, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, stream);
+            e = g_hwmap ? launch_btl<1, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
+                        : launch_btl<1, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
         if (e != hipSuccess) return e;
         if (!tk) {
             hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(256), 0, stream, d_partials,
@@ -820,8 +901,11 @@ size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_wave
     const size_t NP = 4 * (size_t)btl, G = (size_t)ngrp;
     const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;
     const size_t slots = items <= (size_t)kDynTilesPerWave * block_waves ? items : (size_t)block_waves * G;
-    return sizeof(double) * (G * (L.num_code + 1) * row_stride((int)NP) + G * NP + 2 +
-                             G * NP * (2 * L.num_pc + 1) + 2 * slots * NP);
+    const size_t bytes = sizeof(double) * (G * (L.num_code + 1) * row_stride((int)NP) + G * NP + 2 +
+                                           G * NP * (2 * L.num_pc + 1) + 2 * slots * NP);
+    // workgroup 0 stages every workgroup's partial sums ([points][workgroups]) over the dead table
+    const size_t stage = sizeof(double) * G * NP * (size_t)nblk;
+    return bytes > stage ? bytes : stage;
 }
 
 // Largest number of point groups one launch may carry: LDS (160 KiB per CU) and 4 at most.
