@@ -693,6 +693,7 @@ llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restr
     for (unsigned long long seq = ra.first_seq;; ++seq) {
         __syncthreads();                       // everyone is out of the previous evaluation's LDS
         const unsigned long long t_wait = wall_clock64();
+        unsigned long long t_seen = 0;
         bool timed_out = false;
         if (blockIdx.x == 0 && wave == 0) {
             // ---- host mailbox -> relay (one wave; retried until a consistent image arrives) ----
@@ -716,7 +717,7 @@ llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restr
                 if ((it & 15) == 15 && wall_clock64() - t_wait > ra.timeout_ticks) { timed_out = true; break; }
             }
             if (!timed_out) {
-                if (L.stamps && lane == 0) L.stamps[7] = wall_clock64();     // command seen
+                t_seen = wall_clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0)
                     __hip_atomic_store(&ra.relay[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -752,6 +753,7 @@ llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restr
                 __hip_atomic_store(ra.h_state, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
+        if (L.stamps && blockIdx.x == 0 && tid == 0) L.stamps[7] = t_seen;     // profiling: command seen
         eval_body<1, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
                             ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, true);
     }
