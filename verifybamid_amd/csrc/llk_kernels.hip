@@ -955,6 +955,9 @@ hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
     return hipGetLastError();
 }
 
+static bool g_coop_launch = false;
+void set_coop_launch(bool on) { g_coop_launch = on; }
+
 hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, double* d_partials,
                                unsigned int* d_ticket, hipStream_t stream)
 {
@@ -965,13 +968,26 @@ hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, do
                              : reinterpret_cast<const void*>(&llk_resident_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
-    // every workgroup must be on a CU at the same time (they all wait for the host): the
-    // cooperative launch guarantees that or fails
+    // Every workgroup must be on a CU at the same time (they all wait for the host).  The grid
+    // is at most one 1024-thread workgroup per CU, so on a device that is not running other
+    // kernels a plain launch is resident as a whole; VB2_COOP=1 asks the runtime to guarantee
+    // it (hipLaunchCooperativeKernel).  Not the default: under rocprofv3 a process that made a
+    // cooperative launch crashes in the profiler's exit handler (ROCm 7.2), and the bounded
+    // waits on both sides already turn a partly resident grid into a fallback, not a hang.
     DeviceLayout Lc = L;
     ResidentArgs rc = ra;
-    void* args[] = {&Lc, &rc, &d_partials, &d_ticket};
-    return hipLaunchCooperativeKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args,
-                                      (unsigned int)shmem, stream);
+    if (g_coop_launch) {
+        void* args[] = {&Lc, &rc, &d_partials, &d_ticket};
+        return hipLaunchCooperativeKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args,
+                                          (unsigned int)shmem, stream);
+    }
+    if (g_hwmap)
+        hipLaunchKernelGGL(llk_resident_kernel<true>, dim3(gm.grid), dim3(gm.block_waves * 64), shmem, stream,
+                           Lc, rc, d_partials, d_ticket);
+    else
+        hipLaunchKernelGGL(llk_resident_kernel<false>, dim3(gm.grid), dim3(gm.block_waves * 64), shmem, stream,
+                           Lc, rc, d_partials, d_ticket);
+    return hipGetLastError();
 }
 
 // Zero-marker case: LLK of an empty sum.
