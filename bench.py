@@ -157,7 +157,7 @@ def main():
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "llk_eval_kernel<%d,true>" % (2 if B > 4 else 1),
+            "kernel": "llk_eval_kernel<%d,true>" % (2 if B > 4 else 3),
             "launches_per_step": (B + 31) // 32,
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "device_us_per_launch": step_us,

@@ -400,6 +400,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     if (const char* sw = std::getenv("VB2_SPIN_WAIT")) c->spin_wait = std::atoi(sw) != 0;
     if (const char* rs = std::getenv("VB2_RESIDENT")) c->resident_enabled = std::atoi(rs) != 0;
     if (const char* co = std::getenv("VB2_COOP")) set_coop_launch(std::atoi(co) != 0);
+    if (const char* pm = std::getenv("VB2_PAIRED")) set_paired_mode(std::atoi(pm) != 0);
     c->dbg_timing = timing;
     {
         const size_t words = (size_t)resident_words(k);

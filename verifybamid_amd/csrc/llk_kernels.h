@@ -108,6 +108,7 @@ __host__ __device__ inline unsigned long long word_hash(unsigned long long v, un
     return z ^ (z >> 29);
 }
 inline int resident_words(int num_pc) { return 2 + 4 * (2 * num_pc + 1) + 1; }
+void set_paired_mode(bool on);     // VB2_PAIRED=0: 4-point launches use MODE 1 instead of MODE 3
 void set_coop_launch(bool on);     // VB2_COOP=1: cooperative launch of the resident kernel
 hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, double* d_partials,
                                unsigned int* d_ticket, hipStream_t stream);

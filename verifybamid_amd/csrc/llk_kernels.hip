@@ -196,12 +196,18 @@ __device__ __forceinline__ int lane_of(int m, int g)
 // smaller workgroups per CU were measured slower: the per-alpha table is built once per
 // workgroup, and that redundant work is 9 % of a launch's transcendentals at one
 // workgroup per CU but 18 % at two.
-template <int BTL> struct Geom;
+template <int MODE> struct Geom;
 template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
+template <> struct Geom<3> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 
-// BTL = candidate points per lane; a launch evaluates NP = 4*BTL points
-// (num_valid <= NP of them real; the rest replicate the last real point).
+// MODE picks the wave shape.  BTL = candidate points per lane, SLOTS = candidate slots per wave:
+//   MODE 1: 16 markers x 4 slots x 1 point   (NP = 4 points per group; A/B alternative to 3)
+//   MODE 2: 16 markers x 4 slots x 2 points  (NP = 8)
+//   MODE 3: 2 x 16 markers x 2 slots x 2 points (NP = 4): the wave takes TWO micro-tiles, so a
+//           4-point launch (a Nelder-Mead iteration) amortises the per-run bookkeeping over two
+//           points per lane like MODE 2 does, instead of one.
+// A launch evaluates groups of NP points (num_valid of them real; the rest replicate the last).
 // The body is shared by the single-sample kernel (blk = blk, nblk = nblk) and
 // the multi-sample kernel (blk/nblk = this workgroup's index among its sample's workgroups).
 // Parameter rows passed inside the kernel-argument segment (host-pointer path with few
@@ -211,7 +217,7 @@ struct InlinePoints {
     double v[kInlinePointDoubles];
 };
 
-template <int BTL, bool HWMAP>
+template <int MODE, bool HWMAP>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -221,7 +227,9 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
           const unsigned long long tag, const bool coherent_points = false)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int NP = 4 * BTL;
+    constexpr int BTL = MODE == 1 ? 1 : 2;
+    constexpr bool PAIRED = MODE == 3;
+    constexpr int NP = (PAIRED ? 2 : 4) * BTL;
     constexpr int RS = row_stride(NP);
     const int nrow = L.num_code + 1;
     const int nthread = blockDim.x;
@@ -241,8 +249,10 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    int m, g;
-    lane_map<HWMAP>(lane, m, g);
+    int m, g4;
+    lane_map<HWMAP>(lane, m, g4);
+    const int g = PAIRED ? (g4 & 1) : g4;        // candidate slot
+    const int half = PAIRED ? (g4 >> 1) : 0;     // PAIRED: which of the item's two micro-tiles
     // profiling aid: 100 MHz wall-clock stamps per workgroup (L.stamps == nullptr normally)
     unsigned long long* stamps = L.stamps ? L.stamps + (size_t)blk * 8 : nullptr;
     if (stamps && tid == 0) stamps[0] = wall_clock64();
@@ -290,19 +300,30 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const uint32_t ntile_blk = ((uint32_t)L.num_mt + nblk - 1 - blk) / nblk;
     const uint32_t padw = 0x00010001u * (uint32_t)L.num_code;
     const size_t mp = L.m_pad;
-    const uint32_t nitem = ntile_blk * (uint32_t)ngrp;       // (tile, group) work items
+    // work items: (tile, group), or (pair of consecutive owned tiles, group) in PAIRED mode
+    const uint32_t nunit = PAIRED ? (ntile_blk + 1) / 2 : ntile_blk;
+    const uint32_t nitem = nunit * (uint32_t)ngrp;
     // With many tiles per wave a static deal (wave w takes tiles w, w+nwave, ...) is already
     // balanced and needs no per-tile result slots; the queue is for the few-tiles case.
-    const bool dyn = nitem <= (uint32_t)(kDynTilesPerWave * nwave);
+    // (decided on the tile count, like eval_shmem_bytes sizes the slots)
+    const bool dyn = ntile_blk * (uint32_t)ngrp <= (uint32_t)(kDynTilesPerWave * nwave);
     // The per-marker likelihoods of a work item are MULTIPLIED (mantissa x 2^exponent): over
     // the 16 markers of the tile by a butterfly, then slot by slot in the block reduction.
     auto tile_product = [&](ScaledProd* p) {              // over the 16 lanes sharing slot g
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) {
-            const int partner = lane_of<HWMAP>(m ^ off, g);
+            const int partner = lane_of<HWMAP>(m ^ off, g4);
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
                 p[t].m *= __shfl(p[t].m, partner, 64);    // 16 factors in [0.5,1): no underflow
+                p[t].e += __shfl(p[t].e, partner, 64);
+            }
+        }
+        if (PAIRED) {                                     // the item's other micro-tile
+            const int partner = lane_of<HWMAP>(m, g4 ^ 2);
+#pragma unroll
+            for (int t = 0; t < BTL; ++t) {
+                p[t].m *= __shfl(p[t].m, partner, 64);    // two factors >= 2^-16
                 p[t].e += __shfl(p[t].e, partner, 64);
             }
         }
@@ -313,7 +334,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     uint32_t grp_wave = 0;                                // static mode: group wave_prod belongs to
     auto flush_wave = [&](uint32_t grp) {                 // static mode: one slot per (wave, group)
         tile_product(wave_prod);
-        if (m == 0) {
+        if (m == 0 && half == 0) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
                 const size_t o = (((size_t)grp * nwave + wave) * NP + g * BTL + t) * 2;
@@ -325,9 +346,11 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         for (int t = 0; t < BTL; ++t) wave_prod[t] = ScaledProd{1.0, 0.0};
     };
     for (uint32_t idx = (uint32_t)wave; idx < nitem;) {
-        const uint32_t grp = idx / ntile_blk;
-        const uint32_t it = idx - grp * ntile_blk;
-        const uint32_t mt = blk + it * nblk;
+        const uint32_t grp = idx / nunit;
+        const uint32_t unit = idx - grp * nunit;
+        const uint32_t it = PAIRED ? 2 * unit + (uint32_t)half : unit;   // index in this workgroup's tile list
+        const bool have_tile = it < ntile_blk;               // PAIRED: an odd list leaves one half idle
+        const uint32_t mt = have_tile ? blk + it * nblk : blk;
         const double* my_tab = tab + (size_t)grp * nrow * RS + g * (6 * BTL);
         const double* my_pts = pts + ((size_t)grp * NP + g * BTL) * stride;
         while (!dyn && grp_wave < grp) {                     // wave-uniform
@@ -340,7 +363,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         const uint2 rec = L.mt_rec[mt];                      // {first row, rows}
         // per-marker constants: issued now, consumed after the read loop
         const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
-        const bool live = pos < (size_t)L.num_active;
+        const bool live = have_tile && pos < (size_t)L.num_active;
         const size_t posc = live ? pos : 0;
         const double cst = L.ediag[posc];
         const double e0 = L.ediag[mp + posc], e1 = L.ediag[2 * mp + posc], e2 = L.ediag[3 * mp + posc];
@@ -351,7 +374,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
 
         // ---- per-read accumulate (h:288-303), one step per run; rows prefetched two deep ----
         const uint32_t* cp = L.codes + (size_t)rec.x * kMtMarkers + m;
-        const int rows = (L.ablate & 2) ? 0 : (int)rec.y;
+        const int rows = ((L.ablate & 2) || !have_tile) ? 0 : (int)rec.y;
         uint32_t w_cur = rows > 0 ? cp[0] : padw;
         uint32_t w_nxt = rows > 1 ? cp[kMtMarkers] : padw;
         for (int s = 0; s < rows; ++s) {
@@ -440,7 +463,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             continue;
         }
         tile_product(lane_prod);
-        if (m == 0) {
+        if (m == 0 && half == 0) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
                 const size_t o = ((size_t)idx * NP + g * BTL + t) * 2;
@@ -463,7 +486,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     }
     // ---- deterministic block reduction -> one partial per (point, block) ----
     __syncthreads();
-    const uint32_t nres = dyn ? ntile_blk : (uint32_t)nwave;   // result slots per group
+    const uint32_t nres = dyn ? nunit : (uint32_t)nwave;       // result slots per group
     for (int b = wave; b < NPT; b += nwave) {         // slots in index order, then a butterfly
         const int grp = b / NP, bb = b - grp * NP;
         ScaledProd p{1.0, 0.0};
@@ -618,29 +641,29 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     }
 }
 
-template <int BTL, bool HWMAP>
-__global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPerSimd)
+template <int MODE, bool HWMAP>
+__global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
                 int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
                 unsigned long long done_seq, int ngrp, unsigned long long tag)
 {
-    eval_body<BTL, HWMAP>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
-                          blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag);
+    eval_body<MODE, HWMAP>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
+                           blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag);
 }
 
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
 // w / bps as that sample's workgroup w % bps.  Every sample has its own layout, parameter rows,
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
-template <int BTL, bool HWMAP>
-__global__ void __launch_bounds__(Geom<BTL>::kMaxWaves * 64, Geom<BTL>::kWavesPerSimd)
+template <int MODE, bool HWMAP>
+__global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __restrict__ points,
                       const int* __restrict__ num_valid, double* __restrict__ partials,
                       double* __restrict__ llk_out, unsigned int* __restrict__ tickets, int bps,
                       unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
                       unsigned int* __restrict__ batch_done, unsigned int batch_active)
 {
-    constexpr int NP = 4 * BTL;
+    constexpr int NP = MODE == 2 ? 8 : 4;
     const int s = blockIdx.x / bps;
     const int nv = num_valid[s];
     if (nv <= 0) return;                                   // uniform for the workgroup
@@ -648,7 +671,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
     const int stride = 2 * L.num_pc + 1;
     InlinePoints ip;
     ip.count = 0;
-    eval_body<BTL, HWMAP>(L, ip, points + (size_t)s * NP * stride, nv,
+    eval_body<MODE, HWMAP>(L, ip, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1, done_seq);
@@ -678,8 +701,8 @@ __device__ __forceinline__ double* lds_base()
     return lds;
 }
 
-template <bool HWMAP>
-__global__ void __launch_bounds__(Geom<1>::kMaxWaves * 64, Geom<1>::kWavesPerSimd)
+template <int MODE, bool HWMAP>
+__global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restrict__ partials,
                     unsigned int* __restrict__ ticket)
 {
@@ -754,7 +777,7 @@ llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restr
             return;
         }
         if (L.stamps && blockIdx.x == 0 && tid == 0) L.stamps[7] = t_seen;     // profiling: command seen
-        eval_body<1, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
+        eval_body<MODE, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
                             ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, true);
     }
 }
@@ -822,18 +845,22 @@ LaunchGeom launch_geom(const DeviceLayout& L, int btl)
 static bool g_hwmap = true;
 void set_lane_mapping(bool hw) { g_hwmap = hw; }
 
-template <int BTL, bool HWMAP>
+static bool g_paired = true;          // 4-point launches: MODE 3 (two micro-tiles per wave) or MODE 1
+void set_paired_mode(bool on) { g_paired = on; }
+
+template <int MODE, bool HWMAP>
 static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, const double* h_points,
                              int num_valid, int ngrp,
                              double* d_partials, double* d_out, unsigned int* d_ticket,
                              unsigned long long* done_flag, unsigned long long done_seq,
                              unsigned long long tag, hipStream_t stream)
 {
+    constexpr int BTL = MODE == 2 ? 2 : 1;               // NP = 4 * BTL points per group
     const LaunchGeom gm = launch_geom(L, BTL);
     const size_t shmem = eval_shmem_bytes(L, BTL, gm.grid, gm.block_waves, ngrp);
     static bool raised = false;          // per instantiation: allow more than 64 KiB of dynamic LDS
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&llk_eval_kernel<BTL, HWMAP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
         if (e != hipSuccess) return e;
         raised = true;
@@ -845,7 +872,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
         ip.count = ndbl;
         for (int i = 0; i < ndbl; ++i) ip.v[i] = h_points[i];
     }
-    hipLaunchKernelGGL((llk_eval_kernel<BTL, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
+    hipLaunchKernelGGL((llk_eval_kernel<MODE, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
                        stream, L, ip, d_points, num_valid, d_partials, d_out, d_ticket, done_flag,
                        done_seq, ngrp, tag);
     return hipGetLastError();
@@ -884,6 +911,9 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         if (step > 4)
             e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
                         : launch_btl<2, false>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
+        else if (g_paired)
+            e = g_hwmap ? launch_btl<3, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
+                        : launch_btl<3, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
         else
             e = g_hwmap ? launch_btl<1, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
                         : launch_btl<1, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
@@ -923,35 +953,27 @@ hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
     const dim3 grid(ml.num_sample * ml.bps), block(ml.block_waves * 64);
     static bool raised = false;          // allow more than 64 KiB of dynamic LDS (wide dictionaries)
     if (!raised) {
-        const void* fns[4] = {reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, true>),
+        const void* fns[6] = {reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, true>),
                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, false>),
                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, true>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, false>)};
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, false>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, true>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, false>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
             if (e != hipSuccess) return e;
         }
         raised = true;
     }
-    if (ml.btl == 2) {
-        if (g_hwmap)
-            hipLaunchKernelGGL((llk_eval_multi_kernel<2, true>), grid, block, ml.shmem, stream, ml.d_layouts,
-                               ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,
-                               ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active);
-        else
-            hipLaunchKernelGGL((llk_eval_multi_kernel<2, false>), grid, block, ml.shmem, stream, ml.d_layouts,
-                               ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,
-                               ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active);
-    } else {
-        if (g_hwmap)
-            hipLaunchKernelGGL((llk_eval_multi_kernel<1, true>), grid, block, ml.shmem, stream, ml.d_layouts,
-                               ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,
-                               ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active);
-        else
-            hipLaunchKernelGGL((llk_eval_multi_kernel<1, false>), grid, block, ml.shmem, stream, ml.d_layouts,
-                               ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,
-                               ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active);
-    }
+    const int mode = ml.btl == 2 ? 2 : (g_paired ? 3 : 1);
+#define VB2_MULTI_LAUNCH(MODE, HW)                                                                       \
+    hipLaunchKernelGGL((llk_eval_multi_kernel<MODE, HW>), grid, block, ml.shmem, stream, ml.d_layouts,   \
+                       ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,       \
+                       ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active)
+    if (mode == 2) { if (g_hwmap) VB2_MULTI_LAUNCH(2, true); else VB2_MULTI_LAUNCH(2, false); }
+    else if (mode == 3) { if (g_hwmap) VB2_MULTI_LAUNCH(3, true); else VB2_MULTI_LAUNCH(3, false); }
+    else { if (g_hwmap) VB2_MULTI_LAUNCH(1, true); else VB2_MULTI_LAUNCH(1, false); }
+#undef VB2_MULTI_LAUNCH
     return hipGetLastError();
 }
 
@@ -964,8 +986,10 @@ hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, do
     const LaunchGeom gm = launch_geom(L, 1);
     const size_t shmem = eval_shmem_bytes(L, 1, gm.grid, gm.block_waves, 1);
     if (shmem > (size_t)kLdsLimitBytes || gm.grid > L.num_cu) return hipErrorInvalidConfiguration;
-    const void* fn = g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<true>)
-                             : reinterpret_cast<const void*>(&llk_resident_kernel<false>);
+    const void* fn = g_paired ? (g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true>)
+                                         : reinterpret_cast<const void*>(&llk_resident_kernel<3, false>))
+                              : (g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<1, true>)
+                                         : reinterpret_cast<const void*>(&llk_resident_kernel<1, false>));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     // Every workgroup must be on a CU at the same time (they all wait for the host).  The grid
@@ -981,13 +1005,10 @@ hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, do
         return hipLaunchCooperativeKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args,
                                           (unsigned int)shmem, stream);
     }
-    if (g_hwmap)
-        hipLaunchKernelGGL(llk_resident_kernel<true>, dim3(gm.grid), dim3(gm.block_waves * 64), shmem, stream,
-                           Lc, rc, d_partials, d_ticket);
-    else
-        hipLaunchKernelGGL(llk_resident_kernel<false>, dim3(gm.grid), dim3(gm.block_waves * 64), shmem, stream,
-                           Lc, rc, d_partials, d_ticket);
-    return hipGetLastError();
+    {   // the plain launch goes through the same entry point with explicit arguments
+        void* args[] = {&Lc, &rc, &d_partials, &d_ticket};
+        return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
+    }
 }
 
 // Zero-marker case: LLK of an empty sum.
