@@ -150,6 +150,69 @@ def test_reader_quirks(tmp_path):
     assert d2.sd_depth == flat2.sd_depth and not d2.sanity_disabled
 
 
+def _load_arrays(pre, k, **kw):
+    d = vb.PileupData.from_files(pre, pre + ".pileup", k, **kw)
+    return dict(M=d.num_marker, ud=d.ud.tobytes(), mu=d.means.tobytes(), off=d.read_off.tobytes(),
+                bases=d.bases.tobytes(), quals=d.quals.tobytes(), alt=d.alt_base.tobytes(),
+                avg=np.float64(d.avg_depth).tobytes(), sd=np.float64(d.sd_depth).tobytes(),
+                nb=d.meta["num_bases"])
+
+
+def test_fast_scanner_equals_stringstream_statements(tmp_path, monkeypatch):
+    """The readers parse plainly formatted lines with a hand-written scanner and everything else
+    with the original `stringstream >> field` statements.  Differential test on deliberately
+    odd files (CRLF, blank and short lines, signs, exponents, junk after numbers, hex, nan,
+    huge values, multi-character alleles, tabs/spaces mixes): VB2_SLOW_PARSE=1 sends every
+    line through the stringstream statements; the two must agree byte for byte."""
+    rng = np.random.default_rng(77)
+    nums = ["0.5", "-0.25", "+1.5", "1e-3", "2.5E+2", ".5", "5.", "1e5x", "0x10", "nan", "inf", "1e999",
+            "1e-320", "-0", "12abc", "", "3,4", "1.2.3", "+", "-.e5", "00012.5000", "7e", "1e+", "９"]
+    ints = ["100", "+200", "-5", "0300", "12x", "4294967296", "99999999999", "", "1.5", "0x1F", "7", "8"]
+    alle = ["A", "C", "G", "T", "AC", "A,G", "a", "N", "", ".", "<DEL>"]
+    seps = ["\t", " ", "  ", "\t ", " \t\t"]
+    eols = ["\n", "\r\n", "\n", "\n"]
+
+    def sep():
+        return str(rng.choice(seps))
+
+    for trial in range(int(os.environ.get("VB2_FUZZ_TRIALS", "25"))):
+        pre = str(tmp_path / ("f%d" % trial))
+        M = int(rng.integers(1, 40))
+        odd = trial >= 5                       # the first files are clean apart from spacing/CRLF
+        rows_bed, rows_ud, rows_mu, rows_pl = [], [], [], []
+        for i in range(M):
+            pos = 100 + 10 * i
+            e = str(rng.choice(eols))
+            pick = lambda pool, plain: str(rng.choice(pool)) if odd and rng.random() < 0.25 else plain
+            rows_bed.append("1" + sep() + pick(ints, str(pos - 1)) + sep() + pick(ints, str(pos)) + sep() +
+                            pick(alle, "A") + sep() + pick(alle, "C") + e)
+            rows_ud.append(sep().join(pick(nums, "%r" % float(rng.normal())) for _ in range(3)) + e)
+            rows_mu.append("m%d" % i + sep() + pick(nums, "%r" % float(rng.uniform(0.1, 1.9))) + e)
+            depth = int(rng.integers(0, 8))
+            seq = "".join(rng.choice(list(".,ACGTacgtN*$^+-1#"), size=depth)) if depth else "*"
+            qual = "".join(chr(int(x)) for x in rng.integers(33, 100, size=max(depth, 1)))
+            fields = ["1", pick(ints, str(pos)), "A", pick(ints, str(depth)), seq, qual]
+            if odd and rng.random() < 0.15:
+                fields = fields[:int(rng.integers(0, 6))]          # short / blank line
+            rows_pl.append(sep().join(fields) + e)
+        if odd and rng.random() < 0.5:
+            rows_pl[-1] = rows_pl[-1].rstrip("\r\n")              # unterminated last pileup line counts
+        if odd and rng.random() < 0.5:
+            rows_bed[-1] = rows_bed[-1].rstrip("\r\n")            # ... but not the last panel line
+        for ext, rows in ((".bed", rows_bed), (".UD", rows_ud), (".mu", rows_mu), (".pileup", rows_pl)):
+            with open(pre + ext, "w", newline="") as f:
+                f.write("".join(rows))
+        out = []
+        for slow in ("0", "1"):
+            monkeypatch.setenv("VB2_SLOW_PARSE", slow)
+            try:
+                out.append(_load_arrays(pre, 2, disable_sanity=True))
+            except Exception as exc:             # both paths must fail alike, too
+                out.append(("error", str(exc)))
+        assert out[0] == out[1], trial
+    monkeypatch.delenv("VB2_SLOW_PARSE")
+
+
 def test_ud_with_too_few_columns(tmp_path):
     pre = str(tmp_path / "q")
     open(pre + ".bed", "w").write("1\t0\t1\tA\tC\n")

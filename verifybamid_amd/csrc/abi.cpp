@@ -1,5 +1,8 @@
 // abi.cpp -- the extern "C" surface declared in include/vb2_abi.h.
 #include <chrono>
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <memory>
@@ -214,15 +217,43 @@ int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
         f->panel.numPC = a->num_pc;
         int rc;
         // constructor reads the .bed (ContaminationEstimator.cpp:47), then ReadSVDMatrix
-        if ((rc = vb2::read_bed(a->bed_path, &f->panel))) return rc;
-        if (a->known_af_path && (rc = vb2::read_known_af(a->known_af_path, &f->panel))) return rc;
-        if ((rc = vb2::read_ud(a->ud_path, &f->panel))) return rc;
-        if ((rc = vb2::read_mean(a->mean_path, &f->panel))) return rc;
+        // The four files are independent until the markers are resolved: .UD and .mu are parsed
+        // on two helper threads while this one reads the .bed (the pileup reader needs it) and
+        // the pileup.  Errors are reported in the reference's reading order (.bed, AF, .UD, .mu).
+        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+        const double tl0 = now_s();
+        double tl_bed = 0, tl_pile = 0, tl_join = 0;
+        int rc_ud = VB2_OK, rc_mu = VB2_OK;
+        std::string err_ud, err_mu;
+        std::thread t_ud([&] {
+            rc_ud = vb2::read_ud(a->ud_path, &f->panel);
+            if (rc_ud) err_ud = vb2::g_last_error;
+        });
+        std::thread t_mu([&] {
+            rc_mu = vb2::read_mean(a->mean_path, &f->panel);
+            if (rc_mu) err_mu = vb2::g_last_error;
+        });
+        rc = vb2::read_bed(a->bed_path, &f->panel);
+        if (!rc && a->known_af_path) rc = vb2::read_known_af(a->known_af_path, &f->panel);
+        tl_bed = now_s();
+        int rc_pile = VB2_OK;
+        std::string err_main = rc ? vb2::g_last_error : std::string(), err_pile;
+        if (!rc) {
+            rc_pile = vb2::read_pileup(a->pileup_path, f->panel.ChooseBed, &f->viewer);
+            if (rc_pile) err_pile = vb2::g_last_error;
+        }
+        tl_pile = now_s();
+        t_ud.join();
+        t_mu.join();
+        tl_join = now_s();
+        if (rc) { set_error(err_main); return rc; }
+        if (rc_ud) { set_error(err_ud); return rc_ud; }
+        if (rc_mu) { set_error(err_mu); return rc_mu; }
         if (f->panel.means.size() < f->panel.NumMarker || f->panel.PosVec.size() < f->panel.NumMarker) {
             set_error(".UD has more rows than .mu/.bed");
             return VB2_ERR_INVALID;
         }
-        if ((rc = vb2::read_pileup(a->pileup_path, f->panel.ChooseBed, &f->viewer))) return rc;
+        if (rc_pile) { set_error(err_pile); return rc_pile; }
         f->sanity_disabled = a->disable_sanity != 0;
         if (!f->sanity_disabled && !vb2::sanity_check(f->panel, &f->viewer)) {
             set_error("Insufficient Available markers, check input bam depth distribution in "
@@ -231,7 +262,12 @@ int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
             *out = f.release();
             return VB2_ERR_SANITY;
         }
+        const double tl_san = now_s();
         f->resolve();
+        if (timing)
+            std::fprintf(stderr, "vb2_flat_load: .bed %.1f ms, pileup %.1f ms, wait for .UD/.mu %.1f ms, "
+                         "sanity %.1f ms, resolve %.1f ms\n", 1e3 * (tl_bed - tl0), 1e3 * (tl_pile - tl_bed),
+                         1e3 * (tl_join - tl_pile), 1e3 * (tl_san - tl_join), 1e3 * (now_s() - tl_san));
         *out = f.release();
         return VB2_OK;
     } catch (const std::bad_alloc&) {

@@ -4,6 +4,8 @@
 #include <cctype>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -14,28 +16,149 @@ namespace vb2 {
 
 namespace {
 
-// The reference reads panel files through statgen's InputFile::readLine, which
-// reports EOF (and so drops the data) for a last line that lacks '\n'
-// (statgen/InputFile.cpp:112-130).  Same here.
-bool terminated_lines(const std::string& path, std::vector<std::string>* lines)
-{
-    std::ifstream fin(path, std::ios::binary);
-    if (!fin.is_open()) return false;
-    std::string all((std::istreambuf_iterator<char>(fin)), std::istreambuf_iterator<char>());
-    size_t beg = 0;
-    for (;;) {
-        const size_t nl = all.find('\n', beg);
-        if (nl == std::string::npos) break;
-        lines->emplace_back(all, beg, nl - beg);
-        beg = nl + 1;
-    }
-    return true;
-}
-
 int io_error(const std::string& what)
 {
     set_error(what);
     return VB2_ERR_IO;
+}
+
+bool slurp(const std::string& path, std::string* all)
+{
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) all->append(buf, n);
+    std::fclose(f);
+    return true;
+}
+
+// ---- fast field scanner -------------------------------------------------------------------
+// The readers below restate code that parses every line with `std::stringstream >> field`.
+// That is exact but slow (≈2 µs per field).  The scanner handles the lines whose fields are
+// plainly formatted -- whitespace-separated tokens, decimal numbers -- with the same results
+// (strtod is what libstdc++'s num_get ends in), and reports anything else as "not plain": the
+// caller then runs the original stringstream statements on that line, so odd input (short
+// lines, "1e", hex, overflow, locale digits, ...) keeps the iostream behaviour bit for bit.
+// VB2_SLOW_PARSE=1 (read per call): every line takes the stringstream statements -- the
+// differential tests compare the two paths on deliberately odd files.
+inline bool slow_parse() { const char* e = std::getenv("VB2_SLOW_PARSE"); return e && e[0] == '1'; }
+
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
+
+struct Scan {
+    const char* p;
+    const char* end;
+    void skip_ws() { while (p < end && is_ws(*p)) ++p; }
+    // next whitespace-delimited token; false at end of line
+    bool token(const char** b, const char** e)
+    {
+        skip_ws();
+        if (p >= end) return false;
+        *b = p;
+        while (p < end && !is_ws(*p)) ++p;
+        *e = p;
+        return true;
+    }
+    // `ss >> char`: the next non-blank character (tokens do not matter)
+    bool one_char(char* c)
+    {
+        skip_ws();
+        if (p >= end) return false;
+        *c = *p++;
+        return true;
+    }
+};
+
+// [+-]?digits, at most 9 digits (no overflow question) -> int
+inline bool plain_int(const char* b, const char* e, int* out)
+{
+    const char* q = b;
+    bool neg = false;
+    if (q < e && (*q == '+' || *q == '-')) neg = (*q++ == '-');
+    if (q >= e || e - q > 9) return false;
+    int v = 0;
+    for (; q < e; ++q) {
+        if (*q < '0' || *q > '9') return false;
+        v = v * 10 + (*q - '0');
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+// [+-]?(digits[.digits*] | .digits)([eE][+-]?digits)? -> double.
+// Up to 15 significant digits and a decimal exponent within +-22 (what R / awk / printf("%.15g")
+// panels contain) take Clinger's exact path: the digit string as an integer (< 2^53) times or
+// divided by an exactly representable power of ten is ONE correctly rounded IEEE operation,
+// i.e. the strtod result.  Everything else goes to strtod itself.
+inline bool plain_double(const char* b, const char* e, double* out)
+{
+    static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                      1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char* q = b;
+    bool neg = false;
+    if (q < e && (*q == '+' || *q == '-')) neg = (*q++ == '-');
+    int nd = 0, nsig = 0, frac = 0;
+    unsigned long long sig = 0;
+    bool lead = true;
+    while (q < e && *q >= '0' && *q <= '9') {
+        if (!(lead && *q == '0')) { lead = false; if (nsig < 19) sig = sig * 10 + (unsigned)(*q - '0'); ++nsig; }
+        ++q; ++nd;
+    }
+    if (q < e && *q == '.') {
+        ++q;
+        while (q < e && *q >= '0' && *q <= '9') {
+            if (!(lead && *q == '0')) { lead = false; if (nsig < 19) sig = sig * 10 + (unsigned)(*q - '0'); ++nsig; }
+            ++q; ++nd; ++frac;
+        }
+    }
+    if (nd == 0) return false;
+    int ex = 0;
+    if (q < e && (*q == 'e' || *q == 'E')) {
+        ++q;
+        bool eneg = false;
+        if (q < e && (*q == '+' || *q == '-')) eneg = (*q++ == '-');
+        int ne = 0;
+        while (q < e && *q >= '0' && *q <= '9') { ex = ex * 10 + (*q - '0'); ++q; ++ne; }
+        if (ne == 0 || ne > 3) return false;
+        if (eneg) ex = -ex;
+    }
+    if (q != e || e - b > 60) return false;
+    const int e10 = ex - frac;                  // value = sig * 10^e10
+    if (nsig <= 15 && e10 >= -22 && e10 <= 22) {
+        double v = (double)sig;                 // exact: sig < 10^15 < 2^53
+        v = e10 < 0 ? v / kPow10[-e10] : v * kPow10[e10];
+        *out = neg ? -v : v;
+        return true;
+    }
+    char tmp[64];
+    std::memcpy(tmp, b, (size_t)(e - b));
+    tmp[e - b] = 0;
+    char* endp = nullptr;
+    const double v = std::strtod(tmp, &endp);
+    if (endp != tmp + (e - b) || !std::isfinite(v)) return false;
+    *out = v;
+    return true;
+}
+
+// Calls fn(begin, end) for every '\n'-terminated line.  The reference reads panel files
+// through statgen's InputFile::readLine, which reports EOF (and so drops the data) for a last
+// line that lacks '\n' (statgen/InputFile.cpp:112-130); with_unterminated = true is the
+// std::getline behaviour instead (an unterminated last line counts).
+template <class F>
+void for_each_line(const std::string& all, bool with_unterminated, F fn)
+{
+    const char* p = all.data();
+    const char* end = p + all.size();
+    while (p < end) {
+        const char* nl = static_cast<const char*>(std::memchr(p, '\n', (size_t)(end - p)));
+        if (!nl) {
+            if (with_unterminated) fn(p, end);
+            break;
+        }
+        fn(p, nl);
+        p = nl + 1;
+    }
 }
 
 }  // namespace
@@ -44,58 +167,100 @@ int io_error(const std::string& what)
 // character of an allele column is kept ("A,G" -> 'A').
 int read_bed(const std::string& path, Panel* p)
 {
-    std::vector<std::string> lines;
-    if (!terminated_lines(path, &lines)) return io_error("Open file:" + path + "\t failed");
+    std::string all;
+    if (!slurp(path, &all)) return io_error("Open file:" + path + "\t failed");
     std::string chr;
     int pos = 0;
     char ref = 0, alt = 0;
-    for (const std::string& line : lines) {
-        std::stringstream ss(line);
-        ss >> chr >> pos >> pos;
-        ss >> ref >> alt;
+    std::unordered_map<int, std::pair<char, char>>* inner = nullptr;    // ChooseBed[chr] of the last line
+    std::string inner_chr;
+    const bool slow = slow_parse();
+    for_each_line(all, false, [&](const char* b, const char* e) {
+        Scan sc{b, e};
+        const char *t0, *t1, *u0, *u1, *v0, *v1;
+        int p1 = 0, p2 = 0;
+        char r = 0, a = 0;
+        if (!slow && sc.token(&t0, &t1) && sc.token(&u0, &u1) && plain_int(u0, u1, &p1) && sc.token(&v0, &v1) &&
+            plain_int(v0, v1, &p2) && sc.one_char(&r) && sc.one_char(&a)) {
+            chr.assign(t0, t1);
+            pos = p2;
+            ref = r;
+            alt = a;
+        } else {                                   // not plain: the original statements
+            std::stringstream ss(std::string(b, e));
+            ss >> chr >> pos >> pos;
+            ss >> ref >> alt;
+        }
         p->PosVec.push_back(std::make_pair(chr, pos));
-        p->ChooseBed[chr][pos] = std::make_pair(ref, alt);
-    }
+        if (!inner || inner_chr != chr) {
+            inner = &p->ChooseBed[chr];
+            inner_chr = chr;
+        }
+        (*inner)[pos] = std::make_pair(ref, alt);
+    });
     return VB2_OK;
 }
 
 // ContaminationEstimator.cpp:342-373: first numPC columns; fewer is fatal.
 int read_ud(const std::string& path, Panel* p)
 {
-    std::vector<std::string> lines;
-    if (!terminated_lines(path, &lines)) return io_error("Open file:" + path + "\t failed");
+    std::string all;
+    if (!slurp(path, &all)) return io_error("Open file:" + path + "\t failed");
     std::vector<double> row(p->numPC, 0.);
-    for (const std::string& line : lines) {
-        std::stringstream ss(line);
+    int rc = VB2_OK;
+    const bool slow = slow_parse();
+    for_each_line(all, false, [&](const char* b, const char* e) {
+        if (rc) return;
         int index = 0;
-        while (index < p->numPC && ss >> row[index]) index++;
+        Scan sc{b, e};
+        const char *t0, *t1;
+        bool plain = !slow;
+        while (plain && index < p->numPC) {
+            if (!sc.token(&t0, &t1)) break;                     // short line: the error below
+            if (!plain_double(t0, t1, &row[index])) { plain = false; break; }
+            index++;
+        }
+        if (!plain) {
+            std::stringstream ss(std::string(b, e));
+            index = 0;
+            while (index < p->numPC && ss >> row[index]) index++;
+        }
         if (index < p->numPC) {
             char msg[256];
             std::snprintf(msg, sizeof(msg),
                           "--NumPC should be less than or equal to the number of PCs in SVD files "
                           "provided by --SVDPrefix! (Expected:%d vs Observed:%d)", p->numPC, index);
             set_error(msg);
-            return VB2_ERR_INVALID;
+            rc = VB2_ERR_INVALID;
+            return;
         }
         p->UD.insert(p->UD.end(), row.begin(), row.end());
         p->NumMarker++;
-    }
-    return VB2_OK;
+    });
+    return rc;
 }
 
 // ContaminationEstimator.cpp:440-459: second column.
 int read_mean(const std::string& path, Panel* p)
 {
-    std::vector<std::string> lines;
-    if (!terminated_lines(path, &lines)) return io_error("Open file:" + path + "\t failed");
+    std::string all;
+    if (!slurp(path, &all)) return io_error("Open file:" + path + "\t failed");
     double mu = 0;
     std::string name;
-    for (const std::string& line : lines) {
-        std::stringstream ss(line);
-        ss >> name;
-        ss >> mu;
+    const bool slow = slow_parse();
+    for_each_line(all, false, [&](const char* b, const char* e) {
+        Scan sc{b, e};
+        const char *t0, *t1, *u0, *u1;
+        double v = 0;
+        if (!slow && sc.token(&t0, &t1) && sc.token(&u0, &u1) && plain_double(u0, u1, &v)) {
+            mu = v;                                 // (the name is not used)
+        } else {
+            std::stringstream ss(std::string(b, e));
+            ss >> name;
+            ss >> mu;
+        }
         p->means.push_back(mu);
-    }
+    });
     return VB2_OK;
 }
 
@@ -127,56 +292,113 @@ namespace {
 void parse_bases(const std::string& seq, const std::string& qual, std::string* pseq,
                  std::string* pqual)
 {
-    pseq->clear();
-    pqual->clear();
-    size_t iq = 0;
-    for (size_t i = 0; i < seq.size(); ++i) {
+    // character classes: 1 keep (one quality each), 2 '*' '#' (consume a quality), 3 '+' '-'
+    // (indel: skip the length and that many characters), 4 '^' (skip the next character)
+    static const struct Table {
+        unsigned char cls[256];
+        Table()
+        {
+            std::memset(cls, 0, sizeof(cls));
+            for (const char* k = ".,AGCTNagctn"; *k; ++k) cls[(unsigned char)*k] = 1;
+            cls[(unsigned char)'*'] = cls[(unsigned char)'#'] = 2;
+            cls[(unsigned char)'+'] = cls[(unsigned char)'-'] = 3;
+            cls[(unsigned char)'^'] = 4;
+        }
+    } table;
+    const size_t n = seq.size(), nq = qual.size();
+    pseq->resize(n);
+    pqual->resize(n);
+    char* ps = &(*pseq)[0];
+    char* pq = &(*pqual)[0];
+    size_t iq = 0, o = 0;
+    for (size_t i = 0; i < n; ++i) {
         const char c = seq[i];
-        if (c == '+' || c == '-') {
+        switch (table.cls[(unsigned char)c]) {
+        case 1:
+            ps[o] = c;
+            pq[o] = iq < nq ? qual[iq] : '!';
+            ++o;
+            ++iq;
+            break;
+        case 2:
+            ++iq;
+            break;
+        case 3: {
             size_t j = i + 1;
-            while (j != seq.size() && std::isdigit((unsigned char)seq[j])) j++;
+            while (j != n && std::isdigit((unsigned char)seq[j])) j++;
             const size_t digit_len = j - (i + 1);
             const int clip = digit_len ? std::stoi(seq.substr(i + 1, digit_len)) : 0;
             i += digit_len + clip;
-        } else if (c == '^') {
+            break;
+        }
+        case 4:
             i += 1;
-        } else if (c == '.' || c == ',' || c == 'A' || c == 'G' || c == 'C' || c == 'T' || c == 'N' ||
-                   c == 'a' || c == 'g' || c == 'c' || c == 't' || c == 'n') {
-            *pseq += c;
-            *pqual += iq < qual.size() ? qual[iq] : '!';
-            ++iq;
-        } else if (c == '*' || c == '#') {
-            ++iq;
+            break;
+        default:
+            break;
         }
     }
+    pseq->resize(o);
+    pqual->resize(o);
 }
 }  // namespace
 
 // SimplePileupViewer.cpp:748-833.
 int read_pileup(const std::string& path, const BedTable& bed, PileupViewer* v)
 {
-    std::ifstream fin(path);
-    if (!fin.is_open()) return io_error("open file " + path + " failed!");
+    std::string all;
+    if (!slurp(path, &all)) return io_error("open file " + path + " failed!");
     int global_index = 0;
-    std::string chr, ref, seq, qual, line, pseq, pqual;
+    std::string chr, ref, seq, qual, pseq, pqual;
     int pos = 0, depth = 0;
     v->numBases = 0;
-    while (std::getline(fin, line)) {
-        std::stringstream ss(line);
-        ss >> chr >> pos >> ref >> depth >> seq >> qual;   // fields persist across malformed lines
+    int rc = VB2_OK;
+    // per-chromosome tables of the last line (consecutive lines share the chromosome)
+    std::string cur_chr;
+    const std::unordered_map<int, std::pair<char, char>>* bed_chr = nullptr;
+    std::unordered_map<int32_t, int32_t>* idx_chr = nullptr;
+    bool have_cur = false;
+    const bool slow = slow_parse();
+    for_each_line(all, true, [&](const char* b, const char* e) {
+        if (rc) return;
+        Scan sc{b, e};
+        const char *c0, *c1, *p0, *p1, *r0, *r1, *d0, *d1, *s0, *s1, *q0, *q1;
+        int ppos = 0, pdepth = 0;
+        if (!slow && sc.token(&c0, &c1) && sc.token(&p0, &p1) && plain_int(p0, p1, &ppos) && sc.token(&r0, &r1) &&
+            sc.token(&d0, &d1) && plain_int(d0, d1, &pdepth) && sc.token(&s0, &s1) && sc.token(&q0, &q1)) {
+            chr.assign(c0, c1);
+            pos = ppos;
+            ref.assign(r0, r1);
+            depth = pdepth;
+            seq.assign(s0, s1);
+            qual.assign(q0, q1);
+        } else {                                    // fields persist across malformed lines
+            std::stringstream ss(std::string(b, e));
+            ss >> chr >> pos >> ref >> depth >> seq >> qual;
+        }
         if (seq.find_first_of(".,") != std::string::npos && ref == ".") {
             set_error("Pileup format error: cannot find ref allele, exit!");
-            return VB2_ERR_INVALID;
+            rc = VB2_ERR_INVALID;
+            return;
         }
         parse_bases(seq, qual, &pseq, &pqual);
         depth = (int)pqual.length();                        // SNP bases only
-        auto bc = bed.find(chr);
-        if (bc == bed.end() || bc->second.find(pos) == bc->second.end()) continue;
+        if (!have_cur || cur_chr != chr) {
+            cur_chr = chr;
+            have_cur = true;
+            auto bc = bed.find(chr);
+            bed_chr = bc == bed.end() ? nullptr : &bc->second;
+            auto pc = v->posIndex.find(chr);
+            idx_chr = pc == v->posIndex.end() ? nullptr : &pc->second;
+        }
+        if (!bed_chr || bed_chr->find(pos) == bed_chr->end()) return;
 
         bool existed = false;
-        auto pc = v->posIndex.find(chr);
-        if (pc != v->posIndex.end() && pc->second.find(pos) != pc->second.end()) existed = true;
-        else v->posIndex[chr][pos] = global_index++;
+        if (idx_chr && idx_chr->find(pos) != idx_chr->end()) existed = true;
+        else {
+            if (!idx_chr) idx_chr = &v->posIndex[chr];
+            (*idx_chr)[pos] = global_index++;
+        }
         if (existed) {
             std::cerr << "[WARNING] The pileup file has duplicated lines! Merged here" << std::endl;
             // the reference builds a merged copy and then drops it (quirk vii)
@@ -189,7 +411,8 @@ int read_pileup(const std::string& path, const BedTable& bed, PileupViewer* v)
         seq = "";
         qual = "";
         v->effectiveNumSite++;
-    }
+    });
+    if (rc) return rc;
     v->avgDepth = (double)v->numBases / v->effectiveNumSite;
     return VB2_OK;
 }
