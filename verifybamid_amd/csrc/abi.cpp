@@ -1,4 +1,6 @@
 // abi.cpp -- the extern "C" surface declared in include/vb2_abi.h.
+#include <hip/hip_runtime_api.h>
+
 #include <chrono>
 #include <thread>
 #include <cstdio>
@@ -302,8 +304,16 @@ int vb2_run(const vb2_run_args* a, vb2_run_result* out)
         return VB2_ERR_INVALID;
     }
     const double t0 = now_s();
+    // The HIP runtime takes ~0.2 s to come up in a fresh process: start that now, on a helper
+    // thread, while this one reads the input files (errors surface later, in vb2_ctx_create).
+    std::thread warm([dev = a->device] {
+        if (dev >= 0) (void)hipSetDevice(dev);
+        (void)hipFree(nullptr);
+        (void)hipGetLastError();
+    });
     vb2_flat* flat = nullptr;
     int rc = vb2_flat_load(a, &flat);
+    warm.join();
     std::unique_ptr<vb2_flat> holder(flat);
     if (rc == VB2_ERR_SANITY && flat && a->output_pileup && a->output_prefix)
         vb2::write_pileup(a->output_prefix, *flat);
