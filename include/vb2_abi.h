@@ -173,7 +173,11 @@ typedef struct vb2_trace {
 /* OptimizeLLK over an arbitrary evaluator (e.g. marker shards + all-reduce). */
 int vb2_optimize_llk(vb2_eval_fn eval, void *user, int32_t num_pc, const vb2_model *model,
                      vb2_estimate *out, vb2_trace *trace);
-/* OptimizeLLK on a context (evaluator = vb2_llk_eval_batch on ctx). */
+/* OptimizeLLK on a context (evaluator = vb2_llk_eval_batch on ctx).  The search runs against ONE
+ * kernel that stays resident on the device and receives each iteration's points through a mailbox
+ * in pinned host memory; the calling thread spins until the search is over and
+ * the context's stream is busy for that time.  Falls back to one launch per iteration on its own
+ * when the mode is unavailable (VB2_RESIDENT=0 forces that).  Same results either way. */
 int vb2_ctx_optimize_llk(vb2_ctx *ctx, const vb2_model *model, vb2_estimate *out,
                          vb2_trace *trace);
 
