@@ -200,6 +200,8 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
             std::vector<int32_t> local_hist(kMaxCode, 0);
             std::vector<int> touched;
             touched.reserve(kMaxCode);
+            std::vector<int64_t>& hist = hist_t[t];
+            int64_t n_read = 0, n_other = 0;          // thread-local: no shared cache lines in the loop
             for (int64_t i = i0; i < i1; ++i) {
                 const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
                 if (depth == 0) continue;
@@ -210,10 +212,10 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
                 touched.clear();
                 for (int64_t j = 0; j < depth; ++j) {
                     const int bc = classify_base(in->bases[beg + j], alt);
-                    if (bc == 2) { ++other_t[t]; raw[beg + j] = 255; continue; }
+                    if (bc == 2) { ++n_other; raw[beg + j] = 255; continue; }
                     const int c2 = bc * kNumQual + clamp_qual(in->quals[beg + j]);
                     raw[beg + j] = (uint8_t)c2;
-                    ++hist_t[t][c2];
+                    ++hist[c2];
                     if (local_hist[c2]++ == 0) touched.push_back(c2);
                 }
                 int32_t eff = 0;
@@ -221,9 +223,11 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
                     eff += (local_hist[c2] + 254) / 255;
                     local_hist[c2] = 0;
                 }
-                reads_t[t] += depth;
+                n_read += depth;
                 eff_all[i] = eff;
             }
+            reads_t[t] = n_read;
+            other_t[t] = n_other;
         });
         for (int t = 0; t < nthr; ++t) {
             num_read += reads_t[t];
@@ -231,6 +235,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
             for (int c2 = 0; c2 < kMaxCode; ++c2) code_hist[c2] += hist_t[t][c2];
         }
     }
+    const auto t_pass1 = tnow();
     for (int i = 0; i < M; ++i)
         if (eff_all[i] >= 0) {
             active.push_back(i);
@@ -254,10 +259,16 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     }
 
     // ---- sort markers by effective depth (descending, stable); 16-marker micro-tiles ----
+    // counting sort = the stable descending sort by run count (ties keep panel order)
     std::vector<int64_t> perm(m_active);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(),
-                     [&](int64_t a, int64_t b) { return eff_depth[a] > eff_depth[b]; });
+    {
+        int32_t dmax = 0;
+        for (int64_t a = 0; a < m_active; ++a) dmax = std::max(dmax, eff_depth[a]);
+        std::vector<int64_t> start((size_t)dmax + 2, 0);
+        for (int64_t a = 0; a < m_active; ++a) ++start[(size_t)(dmax - eff_depth[a]) + 1];
+        for (size_t d = 1; d < start.size(); ++d) start[d] += start[d - 1];
+        for (int64_t a = 0; a < m_active; ++a) perm[start[(size_t)(dmax - eff_depth[a])]++] = a;
+    }
     const int num_mt = (int)((m_active + kMtMarkers - 1) / kMtMarkers);
     const int64_t m_pad = (int64_t)num_mt * kMtMarkers;
 
@@ -274,6 +285,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         return VB2_ERR_INVALID;
     }
 
+    const auto t_sort = tnow();
     const int num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     std::vector<uint2> mt_rec(num_mt);
     for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rows[t]);
@@ -429,8 +441,10 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     if (const char* lm = std::getenv("VB2_LANE_MAP")) set_lane_mapping(std::strcmp(lm, "plain") != 0);
     VB2_HIP(hipDeviceSynchronize());
     if (timing)
-        std::fprintf(stderr, "vb2_ctx_create: flatten %.1f ms, device alloc+upload %.1f ms\n",
-                     tms(t_start, t_flat), tms(t_flat, tnow()));
+        std::fprintf(stderr, "vb2_ctx_create: flatten %.1f ms (classify %.1f, dictionary+sort %.1f, pack %.1f; "
+                     "%d threads), device alloc+upload %.1f ms\n",
+                     tms(t_start, t_flat), tms(t_start, t_pass1), tms(t_pass1, t_sort), tms(t_sort, t_flat), nthr,
+                     tms(t_flat, tnow()));
     *out = c.release();
     return VB2_OK;
 }
