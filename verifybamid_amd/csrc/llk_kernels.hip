@@ -2,10 +2,11 @@
 // (reference: FullLLKFunc::ComputeMixLLKs, ContaminationEstimator.h:194-314).
 //
 // Work decomposition:
-//   * a wave = 16 markers x 4 candidate slots: lane (m, g) walks marker m's reads for
-//     the BTL candidate points of slot g (BTL = 1 or 2 -> 4 or 8 points per launch);
-//     markers are sorted by depth at context creation and grouped in 16-marker
-//     micro-tiles so all lanes of a wave run the same number of steps;
+//   * a wave = 16 markers x 4 candidate slots: lane (m, g) walks marker m's reads for the BTL
+//     candidate points of slot g (MODE 2: 8 points per group); 4-point launches use two
+//     16-marker micro-tiles x 2 slots x 2 points instead (MODE 3).  Markers are sorted by depth
+//     at context creation and grouped in 16-marker micro-tiles so all lanes of a wave run about
+//     the same number of steps;
 //   * a marker's reads are run-length coded over the (class x quality) dictionary:
 //     (code, count) byte pairs, two per dword, stored [micro-tile][step/2][marker]:
 //     a wave load is one contiguous 64-byte row, rows are prefetched two deep;
@@ -16,13 +17,18 @@
 //   * each lane keeps 6 FP64 accumulators per candidate point in registers and
 //     gathers its table row from LDS with ds_read_b128 (row = 6 values per point);
 //   * epilogue per lane: UD*PC projection (h:251-267), HWE priors (h:186-192),
-//     9-term exp-sum and log with the reference's `> 0` test (h:307-311);
-//   * persistent launch: <= two workgroups per CU (table built once per workgroup);
-//     depth-sorted micro-tiles are dealt to the wave slots round-robin across
-//     workgroups, so every CU sees the same depth mix;
-//   * deterministic reduction: 16-lane butterfly -> waves of the block -> per-block
-//     partial; the last workgroup to arrive (agent-scope ticket) sums the partials in a
-//     fixed order (or, two-kernel mode, a one-block finalize kernel does).
+//     9-term exp-sum with the reference's `> 0` test (h:307-311); the marker likelihoods are
+//     multiplied as (mantissa, exponent) and the log is taken once per (workgroup, point);
+//   * persistent launch: one 1024-thread workgroup per CU (table built once per workgroup);
+//     depth-sorted micro-tiles are dealt round-robin across workgroups, so every CU sees the
+//     same depth mix, and pulled by the waves of a workgroup through an LDS work queue;
+//   * deterministic reduction: 16-lane butterfly -> work-item slots -> per-workgroup partial;
+//     the partials cross workgroups inside the launch, either collected by workgroup 0 from
+//     tagged, self-validating sets (<= 4 points, cohorts, resident search) or summed by the last
+//     workgroup to arrive at an agent-scope ticket (bigger batches), always in the same fixed
+//     order (or, two-kernel mode, by llk_finalize_kernel);
+//   * llk_resident_kernel keeps the same body on the CUs for a whole Nelder-Mead search and
+//     takes its batches from a mailbox in mapped host memory.
 #include "llk_kernels.h"
 
 #include <hip/hip_runtime.h>
