@@ -536,6 +536,51 @@ def test_resident_search_matches_plain_launches(c2):
         assert rel_err(ctx.llk(pc1, pc2, al), want) <= LLK_RTOL
 
 
+def test_resident_mode_concurrency_and_idle_timeout(c2):
+    """Only one resident search per device: a second context searching at the same time uses
+    plain launches (same result).  And the safety net: a resident kernel that hears nothing for a
+    second leaves on its own; the next evaluation notices, falls back to plain launches and is
+    still right."""
+    import ctypes as C
+    import threading
+    import time
+    d, od = c2
+    lib = _abi.lib()
+    lib.vb2_debug_resident_evals.restype = C.c_longlong
+    lib.vb2_debug_resident_evals.argtypes = [C.c_void_p]
+    lib.vb2_debug_resident_begin.argtypes = [C.c_void_p]
+    lib.vb2_debug_resident_begin.restype = C.c_int
+    lib.vb2_debug_resident_end.argtypes = [C.c_void_p]
+    with vb.LikelihoodContext(d) as a, vb.LikelihoodContext(d) as b:
+        want = a.optimize()
+        res = {}
+
+        def run(name, ctx):
+            res[name] = [ctx.optimize() for _ in range(4)]
+
+        ta, tb = threading.Thread(target=run, args=("a", a)), threading.Thread(target=run, args=("b", b))
+        ta.start(); tb.start(); ta.join(); tb.join()
+        for name in ("a", "b"):
+            for r in res[name]:
+                assert r["alpha"] == want["alpha"] and r["llk1"] == want["llk1"] and r["num_eval"] == want["num_eval"]
+
+        # idle timeout: enter the mode by hand and stay silent for longer than the kernel waits
+        pc1, pc2, al = _random_points(np.random.default_rng(8), 3, 2)
+        ref = np.array([od.llk(pc1[i], pc2[i], al[i]) for i in range(3)])
+        assert lib.vb2_debug_resident_begin(a._h) == 1
+        assert lib.vb2_debug_resident_begin(b._h) == 0            # the device is taken
+        n0 = lib.vb2_debug_resident_evals(a._h)
+        assert rel_err(a.llk(pc1, pc2, al), ref) <= LLK_RTOL     # served by the resident kernel
+        assert lib.vb2_debug_resident_evals(a._h) == n0 + 1
+        time.sleep(2.5)                                           # kernel gives up after 1-2 s
+        assert rel_err(a.llk(pc1, pc2, al), ref) <= LLK_RTOL     # noticed, redone with plain launches
+        assert lib.vb2_debug_resident_evals(a._h) == n0 + 1
+        lib.vb2_debug_resident_end(a._h)
+        assert rel_err(b.llk(pc1, pc2, al), ref) <= LLK_RTOL
+        again = a.optimize()                                      # the mode stays off for this context
+        assert again["alpha"] == want["alpha"] and again["llk1"] == want["llk1"]
+
+
 def test_device_pointer_api_on_torch_stream(c2):
     import torch
     d, _ = c2

@@ -120,6 +120,18 @@ long long vb2_debug_resident_evals(vb2_ctx* ctx)
     return (long long)ctx->impl->resident_evals;
 }
 
+// Test aid: enter / leave the resident mode by hand (vb2_ctx_optimize_llk does it around a search).
+int vb2_debug_resident_begin(vb2_ctx* ctx)
+{
+    if (guard_ctx(ctx)) return 0;
+    return ctx->impl->resident_begin() ? 1 : 0;
+}
+void vb2_debug_resident_end(vb2_ctx* ctx)
+{
+    if (guard_ctx(ctx)) return;
+    ctx->impl->resident_end();
+}
+
 // Test aid: turn the resident search mode off/on for one context (VB2_RESIDENT does it globally).
 void vb2_debug_set_resident(vb2_ctx* ctx, int on)
 {
