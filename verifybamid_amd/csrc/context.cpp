@@ -99,7 +99,7 @@ Context::~Context()
     if (resident_active) resident_end();
     auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
     fr(L.codes); fr(L.mt_rec); fr(L.ud); fr(L.mu); fr(L.ediag);
-    fr(L.known_af); fr(L.dict_perr);
+    fr(L.known_af); fr(L.dict_perr); fr(L.prim);
     fr(d_partials); fr(d_ticket); fr(d_stamps);
     if (h_points) (void)hipHostFree(h_points);
     if (h_out) (void)hipHostFree(h_out);
@@ -373,6 +373,28 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     L.ediag = d_cd;
     if ((rc = upload(dict_perr, &d_dpe, &c->device_bytes))) return rc;
     L.dict_perr = d_dpe;
+    // primary codes of the per-alpha table: all ref codes (with the alt code of the same quality
+    // as twin, if that occurs) and the alt codes without a ref partner
+    std::vector<double2> prim;
+    auto prim_rec = [&](int d, uint32_t twin) {
+        const unsigned long long bits = (unsigned long long)((uint32_t)d | (twin << 16));
+        double y;
+        std::memcpy(&y, &bits, sizeof(y));
+        prim.push_back(make_double2(dict_perr[d], y));
+    };
+    for (int d = 0; d < num_code; ++d) {
+        const int cls = order[d] / kNumQual, q = order[d] % kNumQual;
+        if (cls == 0) {
+            const int t = dict_of[kNumQual + q];
+            prim_rec(d, t == kPadCode ? 0xffffu : (uint32_t)t);
+        } else if (dict_of[q] == kPadCode) {
+            prim_rec(d, 0xffffu);
+        }
+    }
+    double2* d_prim;
+    if ((rc = upload(prim, &d_prim, &c->device_bytes))) return rc;
+    L.prim = d_prim;
+    L.num_prim = (int32_t)prim.size();
     L.num_code = num_code;
     L.num_mt = num_mt;
     L.num_cu = num_cu;

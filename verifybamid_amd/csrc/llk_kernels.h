@@ -28,7 +28,11 @@ struct DeviceLayout {
     const double* ediag;          // [4][m_pad]: c_other, exp(c_other+D[g]) for g = 0,1,2
     const double* known_af;       // [m_pad] or nullptr
     const double* dict_perr;      // [num_code] +10^(-q/10) class ref, -10^(-q/10) class alt
+    const double2* prim;          // [num_prim] codes whose table rows are computed: {signed pErr, bits: code |
+                                  // twin << 16}, twin = the alt code of the same quality (its row is the mirror
+                                  // image of this one) or 0xffff
     int32_t num_code;
+    int32_t num_prim;
     int32_t num_mt;
     int32_t num_pc;
     int32_t num_cu;               // compute units of the device

@@ -40,7 +40,8 @@ __device__ __forceinline__ void pair_of(int p, int& g1, int& g2)
 {
     // p: 0:(0,1) 1:(0,2) 2:(1,0) 3:(1,2) 4:(2,0) 5:(2,1)
     g1 = p >> 1;
-    g2 = (p == 0) ? 1 : (p == 1) ? 2 : (p == 2) ? 0 : (p == 3) ? 2 : (p == 4) ? 0 : 1;
+    const int lo = p & 1;
+    g2 = lo + (lo >= g1 ? 1 : 0);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -141,11 +142,11 @@ __device__ __forceinline__ double table_entry(double alpha, double perr_signed, 
     const double p_err = fabs(perr_signed);
     const double p_ok = 1.0 - p_err;
     if (alt) { g1 = 2 - g1; g2 = 2 - g2; }
-    // class ref: P(ref | g, error) = {0, 1/6, 1/3}[g], P(ref | g, no error) = {1, .5, 0}[g]
-    const double e1 = g1 == 0 ? 0.0 : (g1 == 1 ? 1.0 / 6.0 : 1.0 / 3.0);
-    const double e2 = g2 == 0 ? 0.0 : (g2 == 1 ? 1.0 / 6.0 : 1.0 / 3.0);
-    const double n1 = g1 == 0 ? 1.0 : (g1 == 1 ? 0.5 : 0.0);
-    const double n2 = g2 == 0 ? 1.0 : (g2 == 1 ? 0.5 : 0.0);
+    // class ref: P(ref | g, error) = {0, 1/6, 1/3}[g], P(ref | g, no error) = {1, .5, 0}[g].
+    // As arithmetic on g (exact: fl(1/3) = 2*fl(1/6), the same mantissa one binade up; 1 - g/2
+    // is exact), which is cheaper than selecting among 64-bit constants:
+    const double e1 = (double)g1 * (1.0 / 6.0), e2 = (double)g2 * (1.0 / 6.0);
+    const double n1 = 1.0 - 0.5 * (double)g1, n2 = 1.0 - 0.5 * (double)g2;
     const double one_minus_alpha = 1.0 - alpha;
     const double val = (alpha * e1 + one_minus_alpha * e2) * p_err +
                        (alpha * n1 + one_minus_alpha * n2) * p_ok;
@@ -250,7 +251,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     double* red = lds + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
     unsigned int* queue = reinterpret_cast<unsigned int*>(red + NPT);
     double* pts = red + NPT + 2;                // [NPT][2k+1] this launch's parameter rows
-    double* tile_llk = pts + NPT * stride;      // [work items or waves][NP] {mantissa, exponent}
+    double2* prim_lds = reinterpret_cast<double2*>(pts + NPT * stride + ((NPT * stride) & 1));   // [num_prim], 16-B aligned
+    double* tile_llk = reinterpret_cast<double*>(prim_lds + L.num_prim);   // [work items or waves][NP] {mantissa, exponent}
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -274,24 +276,49 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                  : coherent_points ? __hip_atomic_load(&points[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                    : points[idx];
     }
+    // With several groups a thread builds several table entries: the primary-code records (a
+    // few dozen) go to LDS first so that the loop below does not wait on a global load per
+    // entry.  With one group each thread builds about one entry and loads its record directly.
+    const bool staged = ngrp > 1;
+    if (staged)
+        for (int e = tid; e < L.num_prim; e += nthread) prim_lds[e] = L.prim[e];
     __syncthreads();
     if (stamps && tid == 0) stamps[1] = wall_clock64();
 
     // ---- per-alpha table, off-diagonal pairs only (h:213-229) ----
-    for (int e = tid; e < ngrp * nrow * 6 * NP; e += nthread) {
-        const int d = e / (6 * NP);              // row index over all groups: grp*nrow + code
-        const int bp = e - d * (6 * NP);
-        const int grp_e = d / nrow;
-        const int b = grp_e * NP + bp / 6, p = bp % 6;
-        const int dc = d - grp_e * nrow;         // dictionary code of this row
-        double v = 0.0;
-        if (dc < L.num_code) {
-            int g1, g2;
-            pair_of(p, g1, g2);
-            v = (L.ablate & 1) ? -0.01 * (dc + p)
-                               : table_entry(pts[b * stride + 2 * k], L.dict_perr[dc], g1, g2);
-        }
-        tab[d * RS + bp] = v;
+    // Class alt is class ref with the genotypes mirrored (g -> 2-g, h:164-177): the entry of
+    // (alt, q) for pair p IS the entry of (ref, q) for pair 5-p, the same expression on the same
+    // numbers.  So only the "primary" codes are computed -- every ref code, and alt codes whose
+    // quality has no ref code in the data -- and the thread that computes a ref entry also stores
+    // it into the alt twin's row: half the logarithms, and no barrier in between.
+    // (a thread's entries for the different groups are independent: computed side by side so
+    // that their long dependent logarithm chains overlap)
+    for (int e = tid; e < L.num_prim * 6 * NP; e += nthread) {
+        const int pi = e / (6 * NP);
+        const int bp = e - pi * (6 * NP);
+        const int bb = bp / 6, p = bp - bb * 6;
+        const double2 rec = staged ? prim_lds[pi] : L.prim[pi];       // {signed pErr, code | twin << 16}
+        const uint32_t pr = (uint32_t)__double_as_longlong(rec.y);
+        const int dc = (int)(pr & 0xffffu), twin = (int)(pr >> 16);
+        int g1, g2;
+        pair_of(p, g1, g2);
+        double v[kMaxGroups];
+#pragma unroll
+        for (int grp_e = 0; grp_e < kMaxGroups; ++grp_e)
+            if (grp_e < ngrp)
+                v[grp_e] = (L.ablate & 1) ? -0.01 * (dc + p)
+                                          : table_entry(pts[(grp_e * NP + bb) * stride + 2 * k], rec.x, g1, g2);
+#pragma unroll
+        for (int grp_e = 0; grp_e < kMaxGroups; ++grp_e)
+            if (grp_e < ngrp) {
+                double* gtab = tab + (size_t)grp_e * nrow * RS;
+                gtab[dc * RS + bp] = v[grp_e];
+                if (twin != 0xffff) gtab[twin * RS + bb * 6 + (5 - p)] = v[grp_e];
+            }
+    }
+    for (int e = tid; e < ngrp * RS; e += nthread) {                  // padding code: zero rows
+        const int grp_e = e / RS;
+        tab[((size_t)grp_e * nrow + L.num_code) * RS + (e - grp_e * RS)] = 0.0;
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[2] = wall_clock64();
@@ -940,7 +967,8 @@ size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_wave
     const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;
     const size_t slots = items <= (size_t)kDynTilesPerWave * block_waves ? items : (size_t)block_waves * G;
     const size_t bytes = sizeof(double) * (G * (L.num_code + 1) * row_stride((int)NP) + G * NP + 2 +
-                                           G * NP * (2 * L.num_pc + 1) + 2 * slots * NP);
+                                           G * NP * (2 * L.num_pc + 1) + 1 + 2 * (size_t)L.num_prim +
+                                           2 * slots * NP);
     // workgroup 0 stages every workgroup's partial sums ([points][workgroups]) over the dead table
     const size_t stage = sizeof(double) * G * NP * (size_t)nblk;
     return bytes > stage ? bytes : stage;
