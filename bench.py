@@ -7,7 +7,7 @@
 Workload (config.workload): synthetic pileup of 100 000 markers x depth 30, --NumPC 4
 (BASELINE.json configs[2], the shape the metric is quoted on), resident in HBM before the
 timed region.  One STEP = one pass of the hot path over that pileup for a batch of
-`--batch` parameter points (default 32, the most one launch carries): one
+`--batch` parameter points (default 48, the most one launch carries): one
 `vb2_llk_eval_batch_device` call = one launch of the dominant kernel
 (llk_eval_kernel<2,true>: 8 points per group, 4 groups).  One "eval" = one
 (pc1, pc2, alpha) point = one call of the reference's ComputeMixLLKs.
@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=32, help="parameter points per step (one launch carries up to 32)")
+    ap.add_argument("--batch", type=int, default=48, help="parameter points per step (one launch carries up to 48)")
     ap.add_argument("--markers", type=int, default=100000)
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--num-pc", type=int, default=4)
@@ -158,7 +158,7 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "llk_eval_kernel<%d,true>" % (2 if B > 4 else 3),
-            "launches_per_step": (B + 31) // 32,
+            "launches_per_step": (B + 47) // 48,
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "device_us_per_launch": step_us,
             "note": "device time = HIP events on the launch stream over the timed region / steps; "

@@ -13,7 +13,7 @@ constexpr int kMaxCode = 2 * kNumQual;   // classes ref/alt x qualities
 constexpr int kPadCode = 255;            // never a real dictionary index
 constexpr int kMtMarkers = 16;           // markers per micro-tile (one 16-lane group)
 constexpr int kMaxBlockWaves = 16;       // 1024-thread blocks at most
-constexpr int kMaxGroups = 4;             // groups of 8 points per launch
+constexpr int kMaxGroups = 6;             // groups of 8 points per launch
 constexpr int kMaxPointsPerLaunch = 8 * kMaxGroups;
 constexpr int kLdsLimitBytes = 160 * 1024;
 constexpr int kInlinePointDoubles = 96;    // parameter rows that travel as kernel arguments (768 B)
@@ -46,7 +46,7 @@ struct LaunchGeom { int grid, block_waves; };
 // Workgroups / waves per workgroup used for a launch of 4*btl points.
 LaunchGeom launch_geom(const DeviceLayout& L, int btl);
 constexpr int kMaxGridPerCU = 2;
-constexpr int kDynTilesPerWave = 8;       // up to this many tiles per wave: dynamic queue + per-tile slots
+constexpr int kDynTilesPerWave = 10;      // up to this many tiles per wave: dynamic queue + per-tile slots
 inline int max_grid(const DeviceLayout& L) { return kMaxGridPerCU * L.num_cu; }
 
 // Enqueue evaluation of num_point candidate rows (pc1 | pc2 | alpha) on stream.
