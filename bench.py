@@ -36,8 +36,11 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 a
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--prewarm-ms", type=float, default=100.0,
+                    help="keep the GPU busy this long before the warmup steps: an idle MI355X needs ~40 ms of "
+                         "load to reach its sustained clocks (tools/warm_curve.py: 113 -> 87 us per launch)")
     ap.add_argument("--batch", type=int, default=48, help="parameter points per step (one launch carries up to 48)")
     ap.add_argument("--markers", type=int, default=100000)
     ap.add_argument("--depth", type=float, default=30.0)
@@ -93,6 +96,12 @@ def main():
         if dist is not None and args.mode == "marker":
             dist.all_reduce(out)      # sum of per-shard partial LLKs over RCCL
 
+    # untimed: bring the clocks up (same work as a step), then the W warmup steps
+    t_pw = time.perf_counter()
+    while 1e3 * (time.perf_counter() - t_pw) < args.prewarm_ms:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -128,7 +137,7 @@ def main():
         "config": {
             "workload": "synthetic pileup %d markers x depth %g, --NumPC %d (BASELINE.json configs[2] shape)"
                         % (args.markers, args.depth, k),
-            "batch_points_per_step": B,
+            "batch_points_per_step": B, "prewarm_ms": args.prewarm_ms,
             "parallelism": ("1 GPU" if world == 1 else
                             ("sample-parallel x%d (one sample per GPU, no collective)" % world
                              if args.mode == "sample" else
