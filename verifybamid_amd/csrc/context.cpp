@@ -101,10 +101,6 @@ Context::~Context()
     fr(L.codes); fr(L.mt_rec); fr(L.ud); fr(L.mu); fr(L.ediag);
     fr(L.known_af); fr(L.dict_perr); fr(L.prim);
     fr(d_partials); fr(d_ticket); fr(d_stamps);
-    fr(lane2.d_partials); fr(lane2.d_ticket);
-    if (lane2.fork) (void)hipEventDestroy(lane2.fork);
-    if (lane2.join) (void)hipEventDestroy(lane2.join);
-    if (lane2.stream) (void)hipStreamDestroy(lane2.stream);
     if (h_points) (void)hipHostFree(h_points);
     if (h_out) (void)hipHostFree(h_out);
     if (h_done) (void)hipHostFree(h_done);
@@ -438,15 +434,6 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     if (const char* sw = std::getenv("VB2_SPIN_WAIT")) c->spin_wait = std::atoi(sw) != 0;
     if (const char* rs = std::getenv("VB2_RESIDENT")) c->resident_enabled = std::atoi(rs) != 0;
     if (const char* co = std::getenv("VB2_COOP")) set_coop_launch(std::atoi(co) != 0);
-    if (const char* ov = std::getenv("VB2_OVERLAP")) set_overlap(std::atoi(ov) != 0);
-    // second lane for batches of several launches (see launch_llk_eval)
-    VB2_HIP(hipStreamCreateWithFlags(&c->lane2.stream, hipStreamNonBlocking));
-    VB2_HIP(hipEventCreateWithFlags(&c->lane2.fork, hipEventDisableTiming));
-    VB2_HIP(hipEventCreateWithFlags(&c->lane2.join, hipEventDisableTiming));
-    VB2_HIP(hipMalloc((void**)&c->lane2.d_partials, sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb));
-    VB2_HIP(hipMemset(c->lane2.d_partials, 0, sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb));
-    VB2_HIP(hipMalloc((void**)&c->lane2.d_ticket, sizeof(unsigned int)));
-    VB2_HIP(hipMemset(c->lane2.d_ticket, 0, sizeof(unsigned int)));
     if (const char* pm = std::getenv("VB2_PAIRED")) set_paired_mode(std::atoi(pm) != 0);
     c->dbg_timing = timing;
     {
@@ -496,7 +483,7 @@ int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipS
         return VB2_OK;
     }
     VB2_HIP(launch_llk_eval(L, num_point, d_pts, h_pts, d_partials, d_llk, d_ticket, done_flag, done_seq,
-                            &done_seq_, s, lane2.stream ? &lane2 : nullptr));
+                            &done_seq_, s));
     return VB2_OK;
 }
 

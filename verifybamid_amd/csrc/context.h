@@ -48,7 +48,6 @@ public:
     bool own_stream = false;
     double* d_partials = nullptr;
     unsigned int* d_ticket = nullptr;
-    OverlapLane lane2{};                      // second stream + buffers for multi-launch batches
     unsigned long long* d_stamps = nullptr;   // VB2_STAMPS profiling aid
     double* h_points = nullptr;   // pinned + device-mapped staging (host view)
     double* h_out = nullptr;

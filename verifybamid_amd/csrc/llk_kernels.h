@@ -57,21 +57,11 @@ inline int max_grid(const DeviceLayout& L) { return kMaxGridPerCU * L.num_cu; }
 // the LAST launch are written (lets the host wait without hipStreamSynchronize).
 // h_points: the same rows readable by the host (or nullptr): small batches then travel as
 // kernel arguments instead of being read from (possibly mapped host) memory.
-// lane2 (optional): a second stream with its own partial-sum buffer and ticket; batches that need
-// several launches alternate between the two so that consecutive launches overlap head to tail.
-struct OverlapLane {
-    hipStream_t stream;
-    hipEvent_t fork, join;
-    double* d_partials;
-    unsigned int* d_ticket;
-};
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
                            const double* h_points, double* d_partials, double* d_out,
                            unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
-                           unsigned long long* tag_counter, hipStream_t stream,
-                           const OverlapLane* lane2 = nullptr);
-void set_overlap(bool on);          // VB2_OVERLAP=0: multi-launch batches stay on one stream
+                           unsigned long long* tag_counter, hipStream_t stream);
 void set_single_launch(bool on);
 void set_reduce_mode(int mode);     // 0 auto, 1 arrival ticket, 2 tagged sets (VB2_REDUCE)
 

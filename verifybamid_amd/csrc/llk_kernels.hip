@@ -916,49 +916,16 @@ void set_reduce_mode(int m) { g_reduce_mode = m; }
 static bool g_single_launch = true;
 void set_single_launch(bool on) { g_single_launch = on; }
 
-__global__ void signal_kernel(unsigned long long* done_flag, unsigned long long done_seq)
-{
-    __threadfence_system();
-    __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-static bool g_overlap = true;
-void set_overlap(bool on) { g_overlap = on; }
-
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
                            const double* h_points, double* d_partials, double* d_out,
                            unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
-                           unsigned long long* tag_counter, hipStream_t stream, const OverlapLane* lane2)
+                           unsigned long long* tag_counter, hipStream_t stream)
 {
     unsigned int* tk = g_single_launch ? d_ticket : nullptr;
     const int stride = 2 * L.num_pc + 1;
-    // A batch that needs several launches alternates them between the caller's stream and a second
-    // one (own partial-sum buffer and ticket): the launches are independent, so the head of one
-    // (parameter rows, table) and the tail of the other (last workgroups, reduction) overlap
-    // instead of leaving most CUs idle twice per launch.
-    const LaunchGeom gm_cap = launch_geom(L, 2);
-    const int cap_all = 8 * max_groups(L, 2, gm_cap.grid, gm_cap.block_waves);
-    const bool overlap = g_overlap && lane2 && tk && num_point > cap_all;
-    hipError_t eo;
-    if (overlap) {
-        if ((eo = hipEventRecord(lane2->fork, stream)) != hipSuccess) return eo;
-        if ((eo = hipStreamWaitEvent(lane2->stream, lane2->fork, 0)) != hipSuccess) return eo;
-    }
-    unsigned long long* const done_flag_final = done_flag;
-    if (overlap) done_flag = nullptr;                // signalled after the join instead
-    int launch_no = 0;
-    hipStream_t const stream0 = stream;
-    double* const partials0 = d_partials;
     int done = 0;
     while (done < num_point) {
-        if (overlap) {
-            const bool second = (launch_no & 1) != 0;
-            stream = second ? lane2->stream : stream0;
-            d_partials = second ? lane2->d_partials : partials0;
-            tk = second ? lane2->d_ticket : d_ticket;
-            ++launch_no;
-        }
         const int left = num_point - done;
         const double* p = d_points + (size_t)done * stride;
         const double* hp = h_points ? h_points + (size_t)done * stride : nullptr;
@@ -990,14 +957,6 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         done += step;
-    }
-    if (overlap) {
-        if ((eo = hipEventRecord(lane2->join, lane2->stream)) != hipSuccess) return eo;
-        if ((eo = hipStreamWaitEvent(stream0, lane2->join, 0)) != hipSuccess) return eo;
-        if (done_flag_final) {
-            hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, stream0, done_flag_final, done_seq);
-            if ((eo = hipGetLastError()) != hipSuccess) return eo;
-        }
     }
     return hipSuccess;
 }
