@@ -536,6 +536,27 @@ def test_resident_search_matches_plain_launches(c2):
         assert rel_err(ctx.llk(pc1, pc2, al), want) <= LLK_RTOL
 
 
+@pytest.mark.parametrize("k", [1, 10, 40])
+def test_resident_search_with_wide_parameter_rows(k):
+    """The mailbox image is 4*(2k+1)+3 words; beyond 64 words wave 0 reads it in several passes
+    (k = 10: 87 words, k = 40: 327).  Resident and plain searches must agree bit for bit."""
+    import ctypes as C
+    lib = _abi.lib()
+    lib.vb2_debug_set_resident.argtypes = [C.c_void_p, C.c_int]
+    lib.vb2_debug_resident_evals.restype = C.c_longlong
+    lib.vb2_debug_resident_evals.argtypes = [C.c_void_p]
+    d = vb.synth.make_pileup(3000, 12, k, alpha_true=0.08, seed=300 + k)
+    with vb.LikelihoodContext(d) as ctx:
+        lib.vb2_debug_set_resident(ctx._h, 0)
+        plain = ctx.optimize(within_ancestry=True, epsilon=1e-6)
+        lib.vb2_debug_set_resident(ctx._h, 1)
+        n0 = lib.vb2_debug_resident_evals(ctx._h)
+        res = ctx.optimize(within_ancestry=True, epsilon=1e-6)
+        assert lib.vb2_debug_resident_evals(ctx._h) > n0
+        assert res["alpha"] == plain["alpha"] and res["llk1"] == plain["llk1"] and res["llk0"] == plain["llk0"]
+        assert res["num_eval"] == plain["num_eval"] and np.array_equal(res["pc"], plain["pc"])
+
+
 def test_resident_mode_concurrency_and_idle_timeout(c2):
     """Only one resident search per device: a second context searching at the same time uses
     plain launches (same result).  And the safety net: a resident kernel that hears nothing for a
