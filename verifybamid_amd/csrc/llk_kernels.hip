@@ -378,6 +378,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
 #pragma unroll
         for (int t = 0; t < BTL; ++t) wave_prod[t] = ScaledProd{1.0, 0.0};
     };
+    uint32_t round = 0;                                   // static mode: items are dealt in snake order
     for (uint32_t idx = (uint32_t)wave; idx < nitem;) {
         const uint32_t grp = idx / nunit;
         const uint32_t unit = idx - grp * nunit;
@@ -492,7 +493,10 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 wave_prod[t].e += lane_prod[t].e;
                 sp_renorm(wave_prod[t]);
             }
-            idx += (uint32_t)nwave;
+            // next round, direction reversed: the items are depth-sorted, and a plain deal would
+            // hand wave 0 the deepest tile of every round
+            ++round;
+            idx = round * (uint32_t)nwave + ((round & 1u) ? (uint32_t)(nwave - 1 - wave) : (uint32_t)wave);
             continue;
         }
         tile_product(lane_prod);
