@@ -406,28 +406,36 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
 #pragma unroll
         for (int i = 0; i < BTL * 6; ++i) acc[i] = 0.0;
 
-        // ---- per-read accumulate (h:288-303), one step per run; rows prefetched two deep ----
+        // ---- per-read accumulate (h:288-303), one step per run ----
+        // Rows are prefetched kPrefetch deep: with one sample its pileup sits in L2, but a cohort
+        // launch streams every sample's rows from HBM once, and two rows ahead (~0.6 us of work)
+        // does not cover that latency.
         const uint32_t* cp = L.codes + (size_t)rec.x * kMtMarkers + m;
         const int rows = ((L.ablate & 2) || !have_tile) ? 0 : (int)rec.y;
-        uint32_t w_cur = rows > 0 ? cp[0] : padw;
-        uint32_t w_nxt = rows > 1 ? cp[kMtMarkers] : padw;
-        for (int s = 0; s < rows; ++s) {
-            const uint32_t w_n2 = (s + 2 < rows) ? cp[(size_t)(s + 2) * kMtMarkers] : padw;
+        constexpr int kPrefetch = 8;
+        uint32_t w[kPrefetch];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // one run: `n` reads of the same (class, quality) -> n * table row
-                const uint32_t c = (w_cur >> (16 * j)) & 0xffu;
-                const double n = (double)((w_cur >> (16 * j + 8)) & 0xffu);
-                const double2* row = reinterpret_cast<const double2*>(my_tab + c * RS);
+        for (int j = 0; j < kPrefetch; ++j) w[j] = j < rows ? cp[(size_t)j * kMtMarkers] : padw;
+        for (int s0 = 0; s0 < rows; s0 += kPrefetch) {
 #pragma unroll
-                for (int i = 0; i < 3 * BTL; ++i) {
-                    const double2 t = row[i];
-                    acc[2 * i] = fma(n, t.x, acc[2 * i]);
-                    acc[2 * i + 1] = fma(n, t.y, acc[2 * i + 1]);
+            for (int u = 0; u < kPrefetch; ++u) {
+                if (s0 + u >= rows) break;
+                const uint32_t w_cur = w[u];
+                w[u] = (s0 + u + kPrefetch < rows) ? cp[(size_t)(s0 + u + kPrefetch) * kMtMarkers] : padw;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // one run: `n` reads of the same (class, quality) -> n * table row
+                    const uint32_t c = (w_cur >> (16 * j)) & 0xffu;
+                    const double n = (double)((w_cur >> (16 * j + 8)) & 0xffu);
+                    const double2* row = reinterpret_cast<const double2*>(my_tab + c * RS);
+#pragma unroll
+                    for (int i = 0; i < 3 * BTL; ++i) {
+                        const double2 t = row[i];
+                        acc[2 * i] = fma(n, t.x, acc[2 * i]);
+                        acc[2 * i + 1] = fma(n, t.y, acc[2 * i + 1]);
+                    }
                 }
             }
-            w_cur = w_nxt;
-            w_nxt = w_n2;
         }
 
         // ---- per-marker epilogue ----
