@@ -402,9 +402,11 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         const double cst = L.ediag[posc];
         const double e0 = L.ediag[mp + posc], e1 = L.ediag[2 * mp + posc], e2 = L.ediag[3 * mp + posc];
 
+        // the six off-diagonal sums start from the marker's "other base" constant (it is part of
+        // every genotype pair's sum, h:299-303), so the epilogue needs no separate addition
         double acc[BTL * 6];
 #pragma unroll
-        for (int i = 0; i < BTL * 6; ++i) acc[i] = 0.0;
+        for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
 
         // ---- per-read accumulate (h:288-303), one step per run ----
         // Rows are prefetched kPrefetch deep: with one sample its pileup sits in L2, but a cohort
@@ -443,7 +445,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
 #pragma unroll
             for (int t = 0; t < BTL; ++t)
                 lane_prod[t].e += acc[t * 6] + acc[t * 6 + 1] + acc[t * 6 + 2] + acc[t * 6 + 3] +
-                                  acc[t * 6 + 4] + acc[t * 6 + 5] + cst + e0 + e1 + e2;
+                                  acc[t * 6 + 4] + acc[t * 6 + 5] + e0 + e1 + e2;
         } else if (live) {
             double af1[BTL], af2[BTL];
             if (L.known_af) {
@@ -479,13 +481,13 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 // do not depend on (alpha, PC) and were taken at context creation
                 double lk = 0;
                 lk += e0 * gf[0] * gf2[0];
-                lk += exp_nonpos(a[0] + cst) * gf[0] * gf2[1];
-                lk += exp_nonpos(a[1] + cst) * gf[0] * gf2[2];
-                lk += exp_nonpos(a[2] + cst) * gf[1] * gf2[0];
+                lk += exp_nonpos(a[0]) * gf[0] * gf2[1];
+                lk += exp_nonpos(a[1]) * gf[0] * gf2[2];
+                lk += exp_nonpos(a[2]) * gf[1] * gf2[0];
                 lk += e1 * gf[1] * gf2[1];
-                lk += exp_nonpos(a[3] + cst) * gf[1] * gf2[2];
-                lk += exp_nonpos(a[4] + cst) * gf[2] * gf2[0];
-                lk += exp_nonpos(a[5] + cst) * gf[2] * gf2[1];
+                lk += exp_nonpos(a[3]) * gf[1] * gf2[2];
+                lk += exp_nonpos(a[4]) * gf[2] * gf2[0];
+                lk += exp_nonpos(a[5]) * gf[2] * gf2[1];
                 lk += e2 * gf[2] * gf2[2];
                 // the reference adds log(lk) only if lk > 0 (h:310-311): a dropped marker is
                 // the factor 1
