@@ -557,6 +557,36 @@ def test_resident_search_with_wide_parameter_rows(k):
         assert res["num_eval"] == plain["num_eval"] and np.array_equal(res["pc"], plain["pc"])
 
 
+def test_search_bracket_serves_the_callers_own_optimiser(c2):
+    """INTEGRATION.md option A: the reference's optimiser calls Evaluate once per point.  Inside
+    vb2_ctx_search_begin/end those single-point calls are served by the resident kernel; the values
+    are the ones unbracketed calls return, bit for bit, and faster."""
+    import ctypes as C
+    import time
+    d, od = c2
+    lib = _abi.lib()
+    lib.vb2_debug_resident_evals.restype = C.c_longlong
+    lib.vb2_debug_resident_evals.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(31)
+    pts = [_random_points(rng, 1, 2) for _ in range(300)]
+    with vb.LikelihoodContext(d) as ctx:
+        t0 = time.perf_counter()
+        plain = [ctx.llk(*p)[0] for p in pts]
+        t_plain = time.perf_counter() - t0
+        n0 = lib.vb2_debug_resident_evals(ctx._h)
+        with ctx.search():
+            t0 = time.perf_counter()
+            bracketed = [ctx.llk(*p)[0] for p in pts]
+            t_br = time.perf_counter() - t0
+        assert lib.vb2_debug_resident_evals(ctx._h) == n0 + len(pts)
+        assert bracketed == plain
+        want = [od.llk(p[0][0], p[1][0], p[2][0]) for p in pts[:5]]
+        assert rel_err(plain[:5], want) <= LLK_RTOL
+        assert rel_err(ctx.llk(*pts[0]), want[0]) <= LLK_RTOL        # and plain calls work again afterwards
+        print("300 single-point evaluations: %.2f ms unbracketed, %.2f ms inside search_begin/end"
+              % (1e3 * t_plain, 1e3 * t_br))
+
+
 def test_resident_mode_concurrency_and_idle_timeout(c2):
     """Only one resident search per device: a second context searching at the same time uses
     plain launches (same result).  And the safety net: a resident kernel that hears nothing for a
@@ -569,9 +599,8 @@ def test_resident_mode_concurrency_and_idle_timeout(c2):
     lib = _abi.lib()
     lib.vb2_debug_resident_evals.restype = C.c_longlong
     lib.vb2_debug_resident_evals.argtypes = [C.c_void_p]
-    lib.vb2_debug_resident_begin.argtypes = [C.c_void_p]
-    lib.vb2_debug_resident_begin.restype = C.c_int
-    lib.vb2_debug_resident_end.argtypes = [C.c_void_p]
+    lib.vb2_debug_resident_active.argtypes = [C.c_void_p]
+    lib.vb2_debug_resident_active.restype = C.c_int
     with vb.LikelihoodContext(d) as a, vb.LikelihoodContext(d) as b:
         want = a.optimize()
         res = {}
@@ -588,15 +617,16 @@ def test_resident_mode_concurrency_and_idle_timeout(c2):
         # idle timeout: enter the mode by hand and stay silent for longer than the kernel waits
         pc1, pc2, al = _random_points(np.random.default_rng(8), 3, 2)
         ref = np.array([od.llk(pc1[i], pc2[i], al[i]) for i in range(3)])
-        assert lib.vb2_debug_resident_begin(a._h) == 1
-        assert lib.vb2_debug_resident_begin(b._h) == 0            # the device is taken
+        assert lib.vb2_ctx_search_begin(a._h) == 0 and lib.vb2_debug_resident_active(a._h) == 1
+        assert lib.vb2_ctx_search_begin(b._h) == 0 and lib.vb2_debug_resident_active(b._h) == 0   # the device is taken
         n0 = lib.vb2_debug_resident_evals(a._h)
         assert rel_err(a.llk(pc1, pc2, al), ref) <= LLK_RTOL     # served by the resident kernel
         assert lib.vb2_debug_resident_evals(a._h) == n0 + 1
         time.sleep(2.5)                                           # kernel gives up after 1-2 s
         assert rel_err(a.llk(pc1, pc2, al), ref) <= LLK_RTOL     # noticed, redone with plain launches
         assert lib.vb2_debug_resident_evals(a._h) == n0 + 1
-        lib.vb2_debug_resident_end(a._h)
+        lib.vb2_ctx_search_end(a._h)
+        lib.vb2_ctx_search_end(b._h)
         assert rel_err(b.llk(pc1, pc2, al), ref) <= LLK_RTOL
         again = a.optimize()                                      # the mode stays off for this context
         assert again["alpha"] == want["alpha"] and again["llk1"] == want["llk1"]

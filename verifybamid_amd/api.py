@@ -204,6 +204,22 @@ class LikelihoodContext:
                                                        C.c_void_p(stream) if stream else None),
                    "vb2_llk_eval_batch_device")
 
+    def search(self):
+        """Context manager around a series of dependent llk() calls (a search driven by the
+        caller): vb2_ctx_search_begin / vb2_ctx_search_end."""
+        ctx = self
+
+        class _Search:
+            def __enter__(self_inner):
+                _abi.check(ctx._lib.vb2_ctx_search_begin(ctx._h), "vb2_ctx_search_begin")
+                return ctx
+
+            def __exit__(self_inner, *exc):
+                ctx._lib.vb2_ctx_search_end(ctx._h)
+                return False
+
+        return _Search()
+
     def optimize(self, trace_capacity=0, **model_kw):
         """OptimizeLLK on this context.  model_kw: within_ancestry, fix_pc, fix_alpha, epsilon..."""
         m, keep = _model(known_af=self.data.known_af is not None, **model_kw)

@@ -120,16 +120,24 @@ long long vb2_debug_resident_evals(vb2_ctx* ctx)
     return (long long)ctx->impl->resident_evals;
 }
 
-// Test aid: enter / leave the resident mode by hand (vb2_ctx_optimize_llk does it around a search).
-int vb2_debug_resident_begin(vb2_ctx* ctx)
+int vb2_ctx_search_begin(vb2_ctx* ctx)
 {
-    if (guard_ctx(ctx)) return 0;
-    return ctx->impl->resident_begin() ? 1 : 0;
+    if (int rc = guard_ctx(ctx)) return rc;
+    (void)ctx->impl->resident_begin();         // unavailable -> plain launches, still a success
+    return VB2_OK;
 }
-void vb2_debug_resident_end(vb2_ctx* ctx)
+
+void vb2_ctx_search_end(vb2_ctx* ctx)
 {
     if (guard_ctx(ctx)) return;
     ctx->impl->resident_end();
+}
+
+// Test aid: is the context in resident mode right now?
+int vb2_debug_resident_active(vb2_ctx* ctx)
+{
+    if (guard_ctx(ctx)) return 0;
+    return ctx->impl->resident_active ? 1 : 0;
 }
 
 // Test aid: turn the resident search mode off/on for one context (VB2_RESIDENT does it globally).
