@@ -80,7 +80,8 @@ struct MultiLaunch {
     int num_sample, bps, block_waves, btl;
     size_t shmem;
 };
-size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);
+size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);   // groups of 4*btl points
+size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp);
 int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves);
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);

@@ -207,6 +207,7 @@ template <int MODE> struct Geom;
 template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<3> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
+template <> struct Geom<4> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 
 // MODE picks the wave shape.  BTL = candidate points per lane, SLOTS = candidate slots per wave:
 //   MODE 1: 16 markers x 4 slots x 1 point   (NP = 4 points per group; A/B alternative to 3)
@@ -214,6 +215,9 @@ template <> struct Geom<3> { static constexpr int kMaxWaves = 16, kBlocksPerCU =
 //   MODE 3: 2 x 16 markers x 2 slots x 2 points (NP = 4): the wave takes TWO micro-tiles, so a
 //           4-point launch (a Nelder-Mead iteration) amortises the per-run bookkeeping over two
 //           points per lane like MODE 2 does, instead of one.
+//   MODE 4: 4 x 16 markers x 1 slot x 1 point (NP = 1): a single-point evaluation (a caller's own
+//           optimiser, Initialize, LLK0) does a quarter of the work of a 4-point launch instead of
+//           evaluating the point four times.
 // A launch evaluates groups of NP points (num_valid of them real; the rest replicate the last).
 // The body is shared by the single-sample kernel (blk = blk, nblk = nblk) and
 // the multi-sample kernel (blk/nblk = this workgroup's index among its sample's workgroups).
@@ -234,9 +238,10 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
           const unsigned long long tag, const bool coherent_points = false)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int BTL = MODE == 1 ? 1 : 2;
-    constexpr bool PAIRED = MODE == 3;
-    constexpr int NP = (PAIRED ? 2 : 4) * BTL;
+    constexpr int BTL = (MODE == 1 || MODE == 4) ? 1 : 2;
+    constexpr int TPW = MODE == 3 ? 2 : MODE == 4 ? 4 : 1;   // micro-tiles per wave
+    constexpr int SLOTS = 4 / TPW;                           // candidate slots per wave
+    constexpr int NP = SLOTS * BTL;
     constexpr int RS = row_stride(NP);
     const int nrow = L.num_code + 1;
     const int nthread = blockDim.x;
@@ -251,7 +256,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     double* red = lds + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
     unsigned int* queue = reinterpret_cast<unsigned int*>(red + NPT);
     double* pts = red + NPT + 2;                // [NPT][2k+1] this launch's parameter rows
-    double2* prim_lds = reinterpret_cast<double2*>(pts + NPT * stride + ((NPT * stride) & 1));   // [num_prim], 16-B aligned
+    const size_t prim_off = (size_t)(pts - lds) + (size_t)NPT * stride;
+    double2* prim_lds = reinterpret_cast<double2*>(lds + prim_off + (prim_off & 1));   // [num_prim], 16-B aligned
     double* tile_llk = reinterpret_cast<double*>(prim_lds + L.num_prim);   // [work items or waves][NP] {mantissa, exponent}
 
     const int tid = threadIdx.x;
@@ -259,8 +265,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const int wave = tid >> 6;
     int m, g4;
     lane_map<HWMAP>(lane, m, g4);
-    const int g = PAIRED ? (g4 & 1) : g4;        // candidate slot
-    const int half = PAIRED ? (g4 >> 1) : 0;     // PAIRED: which of the item's two micro-tiles
+    const int g = g4 & (SLOTS - 1);              // candidate slot
+    const int half = g4 / SLOTS;                 // which of the item's TPW micro-tiles
     // profiling aid: 100 MHz wall-clock stamps per workgroup (L.stamps == nullptr normally)
     unsigned long long* stamps = L.stamps ? L.stamps + (size_t)blk * 8 : nullptr;
     if (stamps && tid == 0) stamps[0] = wall_clock64();
@@ -334,7 +340,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const uint32_t padw = 0x00010001u * (uint32_t)L.num_code;
     const size_t mp = L.m_pad;
     // work items: (tile, group), or (pair of consecutive owned tiles, group) in PAIRED mode
-    const uint32_t nunit = PAIRED ? (ntile_blk + 1) / 2 : ntile_blk;
+    const uint32_t nunit = (ntile_blk + TPW - 1) / TPW;
     const uint32_t nitem = nunit * (uint32_t)ngrp;
     // With many tiles per wave a static deal (wave w takes tiles w, w+nwave, ...) is already
     // balanced and needs no per-tile result slots; the queue is for the few-tiles case.
@@ -352,11 +358,12 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 p[t].e += __shfl(p[t].e, partner, 64);
             }
         }
-        if (PAIRED) {                                     // the item's other micro-tile
-            const int partner = lane_of<HWMAP>(m, g4 ^ 2);
+#pragma unroll
+        for (int off = SLOTS; off < 4; off <<= 1) {       // the item's other micro-tiles
+            const int partner = lane_of<HWMAP>(m, g4 ^ off);
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
-                p[t].m *= __shfl(p[t].m, partner, 64);    // two factors >= 2^-16
+                p[t].m *= __shfl(p[t].m, partner, 64);    // factors >= 2^-16 each: no underflow
                 p[t].e += __shfl(p[t].e, partner, 64);
             }
         }
@@ -382,8 +389,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     for (uint32_t idx = (uint32_t)wave; idx < nitem;) {
         const uint32_t grp = idx / nunit;
         const uint32_t unit = idx - grp * nunit;
-        const uint32_t it = PAIRED ? 2 * unit + (uint32_t)half : unit;   // index in this workgroup's tile list
-        const bool have_tile = it < ntile_blk;               // PAIRED: an odd list leaves one half idle
+        const uint32_t it = TPW * unit + (uint32_t)half;     // index in this workgroup's tile list
+        const bool have_tile = it < ntile_blk;               // TPW > 1: the list's end may leave lanes idle
         const uint32_t mt = have_tile ? blk + it * nblk : blk;
         const double* my_tab = tab + (size_t)grp * nrow * RS + g * (6 * BTL);
         const double* my_pts = pts + ((size_t)grp * NP + g * BTL) * stride;
@@ -710,7 +717,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
                       unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
                       unsigned int* __restrict__ batch_done, unsigned int batch_active)
 {
-    constexpr int NP = MODE == 2 ? 8 : 4;
+    constexpr int NP = MODE == 2 ? 8 : MODE == 4 ? 1 : 4;
     const int s = blockIdx.x / bps;
     const int nv = num_valid[s];
     if (nv <= 0) return;                                   // uniform for the workgroup
@@ -824,8 +831,12 @@ llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restr
             return;
         }
         if (L.stamps && blockIdx.x == 0 && tid == 0) L.stamps[7] = t_seen;     // profiling: command seen
-        eval_body<MODE, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
-                            ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, true);
+        if (MODE == 3 && nv == 1)       // a single point: the one-point wave shape (a quarter of the work)
+            eval_body<4, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
+                                ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, true);
+        else
+            eval_body<MODE, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
+                                   ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, true);
     }
 }
 
@@ -902,9 +913,9 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
                              unsigned long long* done_flag, unsigned long long done_seq,
                              unsigned long long tag, hipStream_t stream)
 {
-    constexpr int BTL = MODE == 2 ? 2 : 1;               // NP = 4 * BTL points per group
-    const LaunchGeom gm = launch_geom(L, BTL);
-    const size_t shmem = eval_shmem_bytes(L, BTL, gm.grid, gm.block_waves, ngrp);
+    constexpr int NP = MODE == 2 ? 8 : MODE == 4 ? 1 : 4;     // points per group
+    const LaunchGeom gm = launch_geom(L, MODE == 2 ? 2 : 1);
+    const size_t shmem = eval_shmem_np(L, NP, gm.grid, gm.block_waves, ngrp);
     static bool raised = false;          // per instantiation: allow more than 64 KiB of dynamic LDS
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP>),
@@ -958,6 +969,9 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         if (step > 4)
             e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
                         : launch_btl<2, false>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
+        else if (g_paired && step == 1)
+            e = g_hwmap ? launch_btl<4, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
+                        : launch_btl<4, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
         else if (g_paired)
             e = g_hwmap ? launch_btl<3, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
                         : launch_btl<3, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
@@ -975,9 +989,9 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
     return hipSuccess;
 }
 
-size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp)
+size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp)
 {
-    const size_t NP = 4 * (size_t)btl, G = (size_t)ngrp;
+    const size_t NP = (size_t)np, G = (size_t)ngrp;
     const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;
     const size_t slots = items <= (size_t)kDynTilesPerWave * block_waves ? items : (size_t)block_waves * G;
     const size_t bytes = sizeof(double) * (G * (L.num_code + 1) * row_stride((int)NP) + G * NP + 2 +
@@ -986,6 +1000,11 @@ size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_wave
     // workgroup 0 stages every workgroup's partial sums ([points][workgroups]) over the dead table
     const size_t stage = sizeof(double) * G * NP * (size_t)nblk;
     return bytes > stage ? bytes : stage;
+}
+
+size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp)
+{
+    return eval_shmem_np(L, 4 * btl, nblk, block_waves, ngrp);
 }
 
 // Largest number of point groups one launch may carry: LDS (160 KiB per CU) and 4 at most.
