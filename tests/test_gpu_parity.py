@@ -506,10 +506,16 @@ def test_in_kernel_reduction_is_stable_under_stress(c2, c3):
             assert np.array_equal(got, want), i
 
 
+def _needs_resident_mode():
+    if os.environ.get("VB2_RESIDENT") == "0" or os.environ.get("VB2_SPIN_WAIT") == "0":
+        pytest.skip("resident search mode switched off through the environment")
+
+
 def test_resident_search_matches_plain_launches(c2):
     """vb2_ctx_optimize_llk runs against the resident kernel (commands through the mailbox);
     with the mode off it launches one kernel per step.  Same evaluations, same bits -- for the
     Heter model and for the within-ancestry one, whose rows have pc1 == pc2."""
+    _needs_resident_mode()
     import ctypes as C
     d, od = c2
     lib = _abi.lib()
@@ -540,6 +546,7 @@ def test_resident_search_matches_plain_launches(c2):
 def test_resident_search_with_wide_parameter_rows(k):
     """The mailbox image is 4*(2k+1)+3 words; beyond 64 words wave 0 reads it in several passes
     (k = 10: 87 words, k = 40: 327).  Resident and plain searches must agree bit for bit."""
+    _needs_resident_mode()
     import ctypes as C
     lib = _abi.lib()
     lib.vb2_debug_set_resident.argtypes = [C.c_void_p, C.c_int]
@@ -561,6 +568,7 @@ def test_search_bracket_serves_the_callers_own_optimiser(c2):
     """INTEGRATION.md option A: the reference's optimiser calls Evaluate once per point.  Inside
     vb2_ctx_search_begin/end those single-point calls are served by the resident kernel; the values
     are the ones unbracketed calls return, bit for bit, and faster."""
+    _needs_resident_mode()
     import ctypes as C
     import time
     d, od = c2
@@ -592,6 +600,7 @@ def test_resident_mode_concurrency_and_idle_timeout(c2):
     plain launches (same result).  And the safety net: a resident kernel that hears nothing for a
     second leaves on its own; the next evaluation notices, falls back to plain launches and is
     still right."""
+    _needs_resident_mode()
     import ctypes as C
     import threading
     import time
