@@ -243,6 +243,25 @@ typedef struct vb2_run_result {
 
 int vb2_run(const vb2_run_args *args, vb2_run_result *out);
 
+/* Cohort form of vb2_run (BASELINE configs[4]: many samples against one panel).  The reference
+ * runs one process per sample; here the panel (.UD/.mu/.bed, optional AF file) is read once, the
+ * pileups are read and flattened by host threads while the device searches the previous group of
+ * samples in lock-step (one kernel launch per search step for the whole group, vb2_batch_*), and
+ * every sample gets the outputs vb2_run would write (<prefix>.Ancestry, <prefix>.selfSM, optional
+ * <prefix>.Pileup).  args->pileup_path / output_prefix of `base` are ignored.
+ * status[s] receives the sample's own VB2_* code (e.g. VB2_ERR_SANITY); the call itself fails only
+ * for errors that concern all samples (panel, device). */
+typedef struct vb2_cohort_args {
+    vb2_run_args base;                   /* panel paths, num_pc, flags, model, device          */
+    int32_t num_sample;
+    const char *const *pileup_paths;     /* [num_sample]                                      */
+    const char *const *output_prefixes;  /* [num_sample], or NULL = write nothing             */
+    int32_t group_size;                  /* samples searched together; 0 = 32                 */
+    int32_t num_host_thread;             /* pileup readers/flatteners; 0 = up to 16           */
+} vb2_cohort_args;
+int vb2_cohort_run(const vb2_cohort_args *args, vb2_run_result *out /* [num_sample] */,
+                   int32_t *status /* [num_sample] */);
+
 /* Host-side flattening only (no device): reads panel + pileup, resolves markers
  * and returns the arrays of vb2_input in library-owned memory; free with
  * vb2_flat_free.  Lets callers (tests, shard planners) inspect or slice them. */

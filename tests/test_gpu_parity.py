@@ -418,6 +418,50 @@ def test_known_af_file_flow(tmp_path):
     assert row[6] == cxx_default(r["alpha"] if r["alpha"] < 0.5 else 1 - r["alpha"])
 
 
+def test_cohort_run_equals_per_sample_runs(tmp_path):
+    """vb2_cohort_run (one panel, many pileups, lock-step groups, host reader threads) writes for
+    every sample the files vb2_run writes for it alone (6 significant digits: byte for byte) and
+    reports a sample that fails its own sanity check without disturbing the others."""
+    k, M = 3, 2500
+    base = vb.synth.with_sanity_stats(vb.synth.make_pileup(M, 14, k, alpha_true=0.03, seed=50))
+    pre = vb.synth.write_files(base, str(tmp_path / "panel"))
+    piles, singles = [], []
+    for s in range(7):
+        d = vb.synth.make_pileup(M, 10 + 2 * s, k, alpha_true=0.02 * (s + 1), seed=60 + s)
+        # same panel (seeded ud/mu/alleles differ per seed, so re-use the base panel's rows)
+        d = vb.PileupData(k, base.ud, base.means, d.read_off, d.bases, d.quals, base.alt_base, None,
+                          d.avg_depth, d.sd_depth, True, dict(base.meta))
+        f = vb.synth.write_files(d, str(tmp_path / ("s%d" % s)))
+        piles.append(f + ".pileup")
+    # sample 7: only a handful of sites -> fails the sanity check (needs > 1000 sites)
+    few = str(tmp_path / "few.pileup")
+    with open(piles[0]) as fin, open(few, "w") as fout:
+        for i, line in enumerate(fin):
+            if i < 40:
+                fout.write(line)
+    piles.append(few)
+    for s, ppath in enumerate(piles):
+        out = str(tmp_path / ("single%d" % s))
+        try:
+            r = vb.run_files(pre, ppath, out, num_pc=k)
+            singles.append((r, out))
+        except _abi.Vb2Error as exc:
+            assert exc.code == _abi.VB2_ERR_SANITY and s == 7
+            singles.append((None, out))
+    outs = [str(tmp_path / ("cohort%d" % s)) for s in range(len(piles))]
+    res = vb.run_cohort_files(pre, piles, outs, num_pc=k, group_size=3, num_host_thread=4)
+    assert [r["status"] for r in res] == [0] * 7 + [_abi.VB2_ERR_SANITY]
+    for s in range(7):
+        one, out1 = singles[s]
+        # the lock-step launch gives a sample fewer workgroups than a launch of its own, so the
+        # likelihood sums differ in the last bits; the search itself must come out the same
+        assert abs(res[s]["alpha"] - one["alpha"]) <= 1e-9
+        assert rel_err([res[s]["llk1"], res[s]["llk0"]], [one["llk1"], one["llk0"]]) <= LLK_RTOL
+        for ext in (".Ancestry", ".selfSM"):
+            assert open(outs[s] + ext).read() == open(out1 + ext).read(), (s, ext)
+    assert not os.path.exists(outs[7] + ".Ancestry")
+
+
 def test_insufficient_markers_fails_sanity(golden_dir, tmp_path):
     with pytest.raises(_abi.Vb2Error) as ei:
         vb.run_files(os.path.join(golden_dir, HAPMAP), os.path.join(golden_dir, "test.LongRead.pileup"),

@@ -5,7 +5,8 @@ The product is libvb2.so (HIP kernels + C++ host, C-ABI in include/vb2_abi.h) an
 tests, the bench and multi-GPU (torch.distributed) drivers.
 """
 from .api import (CohortBatch, LikelihoodContext, PileupData, optimize_with_evaluator,  # noqa: F401
-                  run_files)
+                  run_cohort_files, run_files)
 from . import synth  # noqa: F401
 
-__all__ = ["CohortBatch", "LikelihoodContext", "PileupData", "optimize_with_evaluator", "run_files", "synth"]
+__all__ = ["CohortBatch", "LikelihoodContext", "PileupData", "optimize_with_evaluator", "run_cohort_files",
+           "run_files", "synth"]

@@ -84,13 +84,20 @@ class RunResult(C.Structure):
     ]
 
 
+class CohortArgs(C.Structure):
+    _fields_ = [
+        ("base", RunArgs), ("num_sample", C.c_int32), ("pileup_paths", C.POINTER(C.c_char_p)),
+        ("output_prefixes", C.POINTER(C.c_char_p)), ("group_size", C.c_int32), ("num_host_thread", C.c_int32),
+    ]
+
+
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                       C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 # every symbol include/vb2_abi.h declares
 SYMBOLS = [
     "vb2_ctx_create", "vb2_ctx_destroy", "vb2_ctx_info", "vb2_llk_eval_batch",
-    "vb2_llk_eval_batch_device", "vb2_ctx_search_begin", "vb2_ctx_search_end", "vb2_optimize_llk", "vb2_ctx_optimize_llk", "vb2_run",
+    "vb2_llk_eval_batch_device", "vb2_ctx_search_begin", "vb2_ctx_search_end", "vb2_optimize_llk", "vb2_ctx_optimize_llk", "vb2_run", "vb2_cohort_run",
     "vb2_flat_load", "vb2_flat_input", "vb2_flat_stats", "vb2_flat_free", "vb2_last_error",
     "vb2_abi_version", "vb2_device_count",
     "vb2_batch_create", "vb2_batch_destroy", "vb2_batch_eval", "vb2_batch_optimize_llk",
@@ -130,6 +137,7 @@ def lib():
                                      C.c_void_p]
     L.vb2_llk_eval_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    L.vb2_cohort_run.argtypes = [C.POINTER(CohortArgs), C.POINTER(RunResult), C.POINTER(C.c_int32)]
     L.vb2_ctx_search_begin.argtypes = [C.c_void_p]
     L.vb2_ctx_search_end.argtypes = [C.c_void_p]
     L.vb2_ctx_search_end.restype = None

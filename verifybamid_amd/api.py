@@ -328,3 +328,36 @@ def run_files(svd_prefix, pileup_path, output_prefix=None, num_pc=2, disable_san
                avg_depth=res.avg_depth, sd_depth=res.sd_depth, seconds_load=res.seconds_load,
                seconds_optimize=res.seconds_optimize)
     return out
+
+
+def run_cohort_files(svd_prefix, pileup_paths, output_prefixes=None, num_pc=2, disable_sanity=False,
+                     known_af_path=None, device=-1, output_pileup=False, group_size=0, num_host_thread=0,
+                     **model_kw):
+    """Many pileups against one panel (vb2_cohort_run): the panel is read once, the pileups are read
+    and flattened by host threads while the device searches the previous group in lock-step.
+    Returns one dict per sample (with its own "status" code)."""
+    S = len(pileup_paths)
+    args, keep = _run_args(svd_prefix, pileup_paths[0], num_pc, disable_sanity, known_af_path, None,
+                           device, output_pileup, **model_kw)
+    ca = _abi.CohortArgs()
+    ca.base = args
+    ca.num_sample = S
+    piles = (C.c_char_p * S)(*[str(p).encode() for p in pileup_paths])
+    ca.pileup_paths = piles
+    prefs = None
+    if output_prefixes is not None:
+        prefs = (C.c_char_p * S)(*[str(p).encode() for p in output_prefixes])
+        ca.output_prefixes = prefs
+    ca.group_size = int(group_size)
+    ca.num_host_thread = int(num_host_thread)
+    res = (_abi.RunResult * S)()
+    status = (C.c_int32 * S)()
+    _abi.check(_abi.lib().vb2_cohort_run(C.byref(ca), res, status), "vb2_cohort_run")
+    out = []
+    for s in range(S):
+        d = _estimate_dict(res[s].est, num_pc)
+        d.update(status=int(status[s]), num_marker=res[s].num_marker, num_site=res[s].num_site,
+                 num_bases=int(res[s].num_bases), avg_depth=res[s].avg_depth, sd_depth=res[s].sd_depth,
+                 seconds_load=res[s].seconds_load, seconds_optimize=res[s].seconds_optimize)
+        out.append(d)
+    return out

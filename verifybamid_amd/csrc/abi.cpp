@@ -1,6 +1,11 @@
 // abi.cpp -- the extern "C" surface declared in include/vb2_abi.h.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <vector>
 #include <chrono>
 #include <thread>
 #include <cstdio>
@@ -32,6 +37,46 @@ int ctx_eval_cb(void* user, int32_t n, const double* pc1, const double* pc2, con
                 double* out)
 {
     return static_cast<vb2::Context*>(user)->eval_host(n, pc1, pc2, alpha, out);
+}
+
+// which "Estimation from ..." header the reference prints (ContaminationEstimator.cpp:98-150)
+const char* estimation_title(const vb2_model& model)
+{
+    const bool heter = model.is_heter && !model.is_af_known;
+    const bool pcfix = (model.is_pc_fixed && model.fix_pc) || model.is_af_known;
+    const bool afix = !pcfix && model.is_alpha_fixed;
+    if (!heter) return pcfix ? "Estimation from OptimizeHomoFixedPC:" : afix ? nullptr : "Estimation from OptimizeHomo:";
+    return pcfix ? "Estimation from OptimizeHeterFixedPC:"
+                 : afix ? "Estimation from OptimizeHeterFixedAlpha:" : "Estimation from OptimizeHeter:";
+}
+
+// The panel files of a run (reference order of errors: .bed, AF, .UD, .mu); .UD and .mu are parsed
+// on helper threads while this one reads the .bed.
+int load_panel(const vb2_run_args* a, vb2::Panel* panel)
+{
+    int rc_ud = VB2_OK, rc_mu = VB2_OK;
+    std::string err_ud, err_mu;
+    std::thread t_ud([&] {
+        rc_ud = vb2::read_ud(a->ud_path, panel);
+        if (rc_ud) err_ud = vb2::g_last_error;
+    });
+    std::thread t_mu([&] {
+        rc_mu = vb2::read_mean(a->mean_path, panel);
+        if (rc_mu) err_mu = vb2::g_last_error;
+    });
+    int rc = vb2::read_bed(a->bed_path, panel);
+    if (!rc && a->known_af_path) rc = vb2::read_known_af(a->known_af_path, panel);
+    const std::string err_main = rc ? vb2::g_last_error : std::string();
+    t_ud.join();
+    t_mu.join();
+    if (rc) { set_error(err_main); return rc; }
+    if (rc_ud) { set_error(err_ud); return rc_ud; }
+    if (rc_mu) { set_error(err_mu); return rc_mu; }
+    if (panel->means.size() < panel->NumMarker || panel->PosVec.size() < panel->NumMarker) {
+        set_error(".UD has more rows than .mu/.bed");
+        return VB2_ERR_INVALID;
+    }
+    return VB2_OK;
 }
 
 double now_s()
@@ -356,19 +401,176 @@ int vb2_run(const vb2_run_args* a, vb2_run_result* out)
     vb2_ctx_destroy(ctx);
     if (rc) return rc;
 
-    // stdout block: which "Estimation from ..." header the reference prints
-    const bool heter = model.is_heter && !model.is_af_known;
-    const bool pcfix = (model.is_pc_fixed && model.fix_pc) || model.is_af_known;
-    const bool afix = !pcfix && model.is_alpha_fixed;
-    const char* title = nullptr;
-    if (!heter) title = pcfix ? "Estimation from OptimizeHomoFixedPC:" : afix ? nullptr : "Estimation from OptimizeHomo:";
-    else title = pcfix ? "Estimation from OptimizeHeterFixedPC:" : afix ? "Estimation from OptimizeHeterFixedAlpha:" : "Estimation from OptimizeHeter:";
-    vb2::print_summary(title, a->num_pc, out->est);
+    vb2::print_summary(estimation_title(model), a->num_pc, out->est);
     if (a->output_prefix) {
         if ((rc = vb2::write_ancestry(a->output_prefix, a->num_pc, out->est.pc, out->est.pc2))) return rc;
         if ((rc = vb2::write_selfsm(a->output_prefix, *flat, out->est, true))) return rc;
     }
     return VB2_OK;
+}
+
+int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* status)
+{
+    if (!a || !out || !status || a->num_sample < 1 || !a->pileup_paths || !a->base.ud_path ||
+        !a->base.mean_path || !a->base.bed_path || a->base.num_pc < 1 || a->base.num_pc > VB2_MAX_PC) {
+        set_error("vb2_cohort_run: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    try {
+        const int S = a->num_sample;
+        const int G = std::max(1, std::min(a->group_size > 0 ? a->group_size : 32, 64));
+        const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+        const int T = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : 16, hw, S}));
+        for (int s = 0; s < S; ++s) {
+            std::memset(&out[s], 0, sizeof(out[s]));
+            status[s] = VB2_ERR_INVALID;
+        }
+        std::thread warm([dev = a->base.device] {      // HIP runtime start-up behind the panel reading
+            if (dev >= 0) (void)hipSetDevice(dev);
+            (void)hipFree(nullptr);
+            (void)hipGetLastError();
+        });
+        auto panel = std::make_shared<vb2::Panel>();
+        panel->numPC = a->base.num_pc;
+        int rc = load_panel(&a->base, panel.get());
+        warm.join();
+        if (rc) return rc;
+
+        struct Slot {
+            std::unique_ptr<vb2_flat> flat;
+            vb2_ctx* ctx = nullptr;
+            int rc = VB2_OK;
+            bool ready = false;
+        };
+        std::vector<Slot> slots(S);
+        std::mutex mu;
+        std::condition_variable cv;
+        int next = 0, groups_done = 0;
+        bool stop = false;
+        vb2::g_flatten_thread_cap.store(std::max(1, 16 / T));
+        const bool sanity_off = a->base.disable_sanity != 0;
+
+        auto prepare = [&](int s) {
+            Slot& sl = slots[s];
+            const double t0 = now_s();
+            sl.flat.reset(new vb2_flat(panel));
+            vb2_flat& f = *sl.flat;
+            sl.rc = vb2::read_pileup(a->pileup_paths[s], panel->ChooseBed, &f.viewer);
+            if (sl.rc) return;
+            f.sanity_disabled = sanity_off;
+            const bool sane = sanity_off || vb2::sanity_check(*panel, &f.viewer);
+            f.resolve();
+            vb2_flat_stats(&f, &out[s]);
+            const char* prefix = a->output_prefixes ? a->output_prefixes[s] : nullptr;
+            if (a->base.output_pileup && prefix) (void)vb2::write_pileup(prefix, f);
+            if (!sane) {
+                sl.rc = VB2_ERR_SANITY;
+                return;
+            }
+            vb2_options opt{};
+            opt.device = a->base.device;
+            sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
+            out[s].seconds_load = now_s() - t0;
+        };
+        auto worker = [&] {
+            for (;;) {
+                int s;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    // stay at most two groups ahead of the device (bounds host and device memory)
+                    cv.wait(lk, [&] { return stop || next >= S || next < (groups_done + 2) * G; });
+                    if (stop || next >= S) return;
+                    s = next++;
+                }
+                try {
+                    prepare(s);
+                } catch (const std::exception&) {
+                    slots[s].rc = VB2_ERR_INVALID;
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    slots[s].ready = true;
+                }
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back(worker);
+
+        vb2_model model = a->base.model;
+        if (panel->isAFknown) model.is_af_known = 1;
+        int rc_all = VB2_OK;
+        for (int g0 = 0; g0 < S && rc_all == VB2_OK; g0 += G) {
+            const int g1 = std::min(S, g0 + G);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] {
+                    for (int s = g0; s < g1; ++s)
+                        if (!slots[s].ready) return false;
+                    return true;
+                });
+            }
+            std::vector<vb2_ctx*> ctxs;
+            std::vector<int> who;
+            for (int s = g0; s < g1; ++s) {
+                status[s] = slots[s].rc;
+                if (slots[s].rc == VB2_OK && slots[s].ctx) {
+                    ctxs.push_back(slots[s].ctx);
+                    who.push_back(s);
+                }
+            }
+            if (!ctxs.empty()) {
+                const double t1 = now_s();
+                std::vector<vb2_estimate> est(ctxs.size());
+                vb2_batch* batch = nullptr;
+                int rcb = vb2_batch_create(ctxs.data(), (int32_t)ctxs.size(), &batch);
+                if (!rcb) rcb = vb2_batch_optimize_llk(batch, &model, 1, est.data());
+                if (batch) vb2_batch_destroy(batch);
+                const double dt = (now_s() - t1) / (double)ctxs.size();
+                if (rcb) {
+                    rc_all = rcb;                      // device-level failure: concerns every sample
+                } else {
+                    for (size_t i = 0; i < who.size(); ++i) {
+                        const int s = who[i];
+                        out[s].est = est[i];
+                        out[s].seconds_optimize = dt;
+                        const char* prefix = a->output_prefixes ? a->output_prefixes[s] : nullptr;
+                        if (prefix) {
+                            int rw = vb2::write_ancestry(prefix, a->base.num_pc, est[i].pc, est[i].pc2);
+                            if (!rw) rw = vb2::write_selfsm(prefix, *slots[s].flat, est[i], true);
+                            if (rw) status[s] = rw;
+                        }
+                    }
+                }
+            }
+            for (int s = g0; s < g1; ++s) {
+                if (slots[s].ctx) vb2_ctx_destroy(slots[s].ctx);
+                slots[s].ctx = nullptr;
+                slots[s].flat.reset();
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ++groups_done;
+            }
+            cv.notify_all();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& th : pool) th.join();
+        for (auto& sl : slots)
+            if (sl.ctx) vb2_ctx_destroy(sl.ctx);
+        vb2::g_flatten_thread_cap.store(0);
+        return rc_all;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return VB2_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
 }
 
 }  // extern "C"

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <limits>
 #include <map>
 #include <sstream>
@@ -46,7 +47,7 @@ int main(int argc, char** argv)
     // defaults: main.cpp:58-79
     std::string UDPath("Empty"), MeanPath("Empty"), BedPath("Empty"), BamFile("Empty"),
         RefPath("Empty"), outputPrefix("result"), PileupFile("Empty"), SVDPrefix("Empty"),
-        knownAF("Empty"), fixPC("Empty");
+        knownAF("Empty"), fixPC("Empty"), PileupList("Empty");
     double fixAlpha = -1., epsilon = 1e-8;
     bool withinAncestry = false, outputPileup = false, verbose = false, disableSanityCheck = false;
     int seed = 12345, nPC = 2, nthread = 4, device = -1;
@@ -72,6 +73,9 @@ int main(int argc, char** argv)
         {"MeanPath", {Flag::kString, &MeanPath, false}},
         {"BedPath", {Flag::kString, &BedPath, false}},
         {"Device", {Flag::kInt, &device, false}},
+        // not in the reference: a cohort against one panel.  File of lines "<pileup>\t<output prefix>";
+        // the panel is read once and the samples are searched in lock-step groups (vb2_cohort_run).
+        {"PileupList", {Flag::kString, &PileupList, false}},
     };
     for (int i = 1; i < argc; ++i) {
         const char* a = argv[i];
@@ -120,7 +124,8 @@ int main(int argc, char** argv)
     if (BamFile != "Empty")
         fatal("--BamFile needs htslib, which this build does not have; run the reference once with "
               "--OutputPileup and pass the result with --PileupFile");
-    if (PileupFile == "Empty") fatal("--BamFile or --PileupFile is required");   // main.cpp:278-281
+    if (PileupFile == "Empty" && PileupList == "Empty")
+        fatal("--BamFile or --PileupFile is required");                // main.cpp:278-281
 
     vb2_run_args args;
     std::memset(&args, 0, sizeof(args));
@@ -157,6 +162,46 @@ int main(int argc, char** argv)
         args.model.fix_alpha = fixAlpha;
     }
     if (args.known_af_path) args.model.is_af_known = 1;               // main.cpp:314-319
+
+    if (PileupList != "Empty") {
+        std::ifstream fl(PileupList);
+        if (!fl.is_open()) fatal("cannot open --PileupList file");
+        std::vector<std::string> pile, pref;
+        std::string line;
+        while (std::getline(fl, line)) {
+            if (line.empty()) continue;
+            const size_t tab = line.find('\t');
+            pile.push_back(line.substr(0, tab));
+            pref.push_back(tab == std::string::npos ? line + ".vb2" : line.substr(tab + 1));
+        }
+        if (pile.empty()) fatal("--PileupList file names no sample");
+        std::vector<const char*> cpile, cpref;
+        for (size_t i = 0; i < pile.size(); ++i) { cpile.push_back(pile[i].c_str()); cpref.push_back(pref[i].c_str()); }
+        vb2_cohort_args ca;
+        std::memset(&ca, 0, sizeof(ca));
+        ca.base = args;
+        ca.num_sample = (int32_t)pile.size();
+        ca.pileup_paths = cpile.data();
+        ca.output_prefixes = cpref.data();
+        ca.num_host_thread = nthread > 4 ? nthread : 0;               // --NumThread above its default: reader threads
+        std::vector<vb2_run_result> cres(pile.size());
+        std::vector<int32_t> cst(pile.size());
+        const int rcc = vb2_cohort_run(&ca, cres.data(), cst.data());
+        if (rcc != VB2_OK) {
+            std::fprintf(stderr, "\nFATAL ERROR - \n%s\n\n", vb2_last_error());
+            return EXIT_FAILURE;
+        }
+        int bad = 0;
+        std::printf("#PILEUP\tOUTPUT\tSTATUS\tFREEMIX\tFREELK1\tFREELK0\tAVG_DP\n");
+        for (size_t i = 0; i < pile.size(); ++i) {
+            const double al = cres[i].est.alpha;
+            std::printf("%s\t%s\t%d\t%g\t%g\t%g\t%g\n", pile[i].c_str(), pref[i].c_str(), (int)cst[i],
+                        al < 0.5 ? al : 1 - al, cres[i].est.llk1, cres[i].est.llk0, cres[i].avg_depth);
+            if (cst[i] != VB2_OK) ++bad;
+        }
+        std::fprintf(stderr, "NOTICE - cohort of %zu samples done, %d failed their own checks\n", pile.size(), bad);
+        return bad ? EXIT_FAILURE : 0;
+    }
 
     vb2_run_result res;
     const int rc = vb2_run(&args, &res);

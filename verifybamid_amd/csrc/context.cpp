@@ -38,6 +38,8 @@ void set_error(const std::string& msg) { g_last_error = msg; }
         }                                                                              \
     } while (0)
 
+std::atomic<int> g_flatten_thread_cap{0};
+
 int usable_device_count()
 {
     int n = 0;
@@ -185,6 +187,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     const int64_t total_reads = M > 0 ? in->read_off[M] - in->read_off[0] : 0;
     int nthr = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
     nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, total_reads / 200000));
+    if (const int cap = g_flatten_thread_cap.load()) nthr = std::min(nthr, cap);     // cohort runner: many creates at once
     if (const char* ft = std::getenv("VB2_FLATTEN_THREADS")) nthr = std::max(1, std::atoi(ft));
     auto parallel_for = [&](int64_t n, const std::function<void(int, int64_t, int64_t)>& fn) {
         if (nthr == 1 || n < nthr) { fn(0, 0, n); return; }

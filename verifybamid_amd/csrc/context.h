@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <memory>
@@ -17,6 +18,7 @@ namespace vb2 {
 void set_error(const std::string& msg);
 extern thread_local std::string g_last_error;
 int usable_device_count();
+extern std::atomic<int> g_flatten_thread_cap;   // 0 = no cap on the flatten threads of vb2_ctx_create
 
 constexpr int kStagePoints = 256;   // points per host<->device staging round
 

@@ -541,8 +541,16 @@ void vb2_flat::resolve()
         ++num_site;
         bases += viewer.baseInfo[s->second];
         quals += viewer.qualInfo[s->second];
-        alt_base[i] = panel.ChooseBed[chr][pos].second;
-        if (panel.isAFknown) known_af[i] = panel.knownAF[chr][(uint32_t)pos];
+        // lookups only: the panel may be shared by several samples being resolved at once
+        alt_base[i] = panel.ChooseBed.at(chr).at(pos).second;
+        if (panel.isAFknown) {
+            // the reference's knownAF[chr][pos] yields 0 for a site the AF file does not list
+            auto ac = panel.knownAF.find(chr);
+            if (ac != panel.knownAF.end()) {
+                auto ap = ac->second.find((uint32_t)pos);
+                if (ap != ac->second.end()) known_af[i] = ap->second;
+            }
+        }
     }
     read_off[M] = (int64_t)bases.size();
     input = vb2_input{};

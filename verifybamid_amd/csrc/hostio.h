@@ -11,6 +11,7 @@
 #define VB2_HOSTIO_H_
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -54,7 +55,12 @@ bool sanity_check(const Panel& p, PileupViewer* v);
 
 // The flattened, panel-ordered arrays behind a vb2_input (owned here).
 struct vb2_flat {
-    vb2::Panel panel;
+    std::shared_ptr<vb2::Panel> panel_ptr;    // one panel can serve a whole cohort of samples
+    vb2::Panel& panel;                        // = *panel_ptr
+    vb2_flat() : panel_ptr(std::make_shared<vb2::Panel>()), panel(*panel_ptr) {}
+    explicit vb2_flat(std::shared_ptr<vb2::Panel> shared) : panel_ptr(std::move(shared)), panel(*panel_ptr) {}
+    vb2_flat(const vb2_flat&) = delete;
+    vb2_flat& operator=(const vb2_flat&) = delete;
     vb2::PileupViewer viewer;
     std::vector<int64_t> read_off;
     std::string bases, quals;
