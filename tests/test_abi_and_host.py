@@ -37,6 +37,28 @@ def test_header_symbols_exported():
     assert lib.vb2_abi_version() == 1
 
 
+def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
+    """include/vb2_abi.h must compile as C99 (it is the FFI boundary: extern "C", PODs, no C++), and
+    the ctypes structs of the Python binding must have the sizes the C compiler gives them."""
+    import subprocess
+    src = tmp_path / "abi_check.c"
+    names = ["vb2_input", "vb2_options", "vb2_info", "vb2_model", "vb2_estimate", "vb2_trace",
+             "vb2_run_args", "vb2_run_result", "vb2_cohort_args"]
+    src.write_text('#include <stdio.h>\n#include "vb2_abi.h"\nint main(void) {\n' +
+                   "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) +
+                   "  return 0;\n}\n")
+    exe = tmp_path / "abi_check"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe)], check=True)
+    sizes = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True,
+                                                         check=True).stdout.splitlines())
+    binding = dict(vb2_input=_abi.Input, vb2_options=_abi.Options, vb2_info=_abi.Info, vb2_model=_abi.Model,
+                   vb2_estimate=_abi.Estimate, vb2_trace=_abi.Trace, vb2_run_args=_abi.RunArgs,
+                   vb2_run_result=_abi.RunResult, vb2_cohort_args=_abi.CohortArgs)
+    for n, cls in binding.items():
+        assert int(sizes[n]) == C.sizeof(cls), (n, sizes[n], C.sizeof(cls))
+
+
 def test_no_device_fails_loudly():
     lib = _abi.lib()
     if lib.vb2_device_count() > 0:
