@@ -523,6 +523,34 @@ def test_cohort_batch_lockstep_matches_individual_runs():
             c.close()
 
 
+def test_cohort_at_the_queue_vs_static_deal_boundary():
+    """32 samples -> 8 workgroups of 16 waves per sample; the work queue with per-item result
+    slots is used up to 10 tiles per wave = 160 tiles per workgroup, the static deal above.  A
+    sample of 1284 micro-tiles gives four workgroups 161 tiles and four 160: all of them must take
+    the same decision, the one the LDS was sized for (regression: they used to decide per
+    workgroup).  Neighbouring sizes cover both sides of the boundary."""
+    rng = np.random.default_rng(13)
+    k, S = 2, 32
+    for tiles in (1279, 1284, 1290):
+        M = 16 * tiles
+        datas = [vb.synth.make_pileup(M, 3, k, alpha_true=0.05, seed=500 + s % 3) for s in range(S)]
+        ctxs = [vb.LikelihoodContext(d) for d in datas]
+        try:
+            with vb.CohortBatch(ctxs) as batch:
+                npt = np.full(S, 4, dtype=np.int32)
+                pc1 = rng.normal(0, 0.03, size=(S, 8, k))
+                pc2 = rng.normal(0, 0.03, size=(S, 8, k))
+                al = rng.uniform(0, 0.5, size=(S, 8))
+                got = batch.eval(npt, pc1, pc2, al)
+                assert np.array_equal(got, batch.eval(npt, pc1, pc2, al))
+                for s in (0, 1, 2, 31):
+                    want = ctxs[s].llk(pc1[s, :4], pc2[s, :4], al[s, :4])
+                    assert rel_err(got[s, :4], want) <= LLK_RTOL, (tiles, s)
+        finally:
+            for c in ctxs:
+                c.close()
+
+
 def test_in_kernel_reduction_is_stable_under_stress(c2, c3):
     """The cross-workgroup hand-off (tagged partial sums collected by workgroup 0) must return
     the same bits on every launch, also when launches of different shapes and contexts

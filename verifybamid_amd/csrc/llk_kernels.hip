@@ -344,8 +344,11 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const uint32_t nitem = nunit * (uint32_t)ngrp;
     // With many tiles per wave a static deal (wave w takes tiles w, w+nwave, ...) is already
     // balanced and needs no per-tile result slots; the queue is for the few-tiles case.
-    // (decided on the tile count, like eval_shmem_bytes sizes the slots)
-    const bool dyn = ntile_blk * (uint32_t)ngrp <= (uint32_t)(kDynTilesPerWave * nwave);
+    // Decided on ceil(tiles / workgroups), the same for every workgroup and exactly what
+    // eval_shmem_np sized the result slots for (a workgroup with one tile fewer must not choose
+    // differently: the queue needs a slot per item, the static deal only one per wave).
+    const uint32_t max_tiles_blk = ((uint32_t)L.num_mt + nblk - 1) / nblk;
+    const bool dyn = max_tiles_blk * (uint32_t)ngrp <= (uint32_t)(kDynTilesPerWave * nwave);
     // The per-marker likelihoods of a work item are MULTIPLIED (mantissa x 2^exponent): over
     // the 16 markers of the tile by a butterfly, then slot by slot in the block reduction.
     auto tile_product = [&](ScaledProd* p) {              // over the 16 lanes sharing slot g
