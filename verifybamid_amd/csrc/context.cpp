@@ -588,9 +588,16 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
             }
             __builtin_ia32_pause();
         }
+        // A NaN can only be the kernel's own "a workgroup never reported" marker (the partial-sum
+        // hand-off waited two seconds): part of the grid is not on the CUs.  Same treatment as no
+        // answer at all.
+        if (seen)
+            for (int b = 0; b < n; ++b)
+                if (std::isnan(h_out[b])) seen = false;
         if (!seen) {
-            // Give up on the mode: the kernel leaves on its idle limit (or already has); the
-            // batch is redone with plain launches below.
+            // Give up on the mode: tell the kernel to leave (it may already have, on its idle
+            // limit), wait for it, and redo the batch with plain launches below.
+            resident_post(h_cmd, resident_words(k), ++done_seq_, 0, stride, nullptr);
             (void)hipStreamSynchronize(stream);
             resident_active = false;
             resident_enabled = false;
