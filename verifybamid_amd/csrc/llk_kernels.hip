@@ -814,14 +814,16 @@ llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restr
             unsigned long long got = 0;
             for (unsigned it = 0;; ++it) {
                 got = __hip_atomic_load(&ra.relay[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (got == seq || got == ~0ull) break;
+                // (a relay already past this workgroup's sequence number: it started late, after the
+                // others gave up on it -- leave at once)
+                if (got >= seq) break;
                 if ((it & 63) == 63 && wall_clock64() - t_wait > 2 * ra.timeout_ticks) { got = ~0ull; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             *lds_flag = got;
         }
         __syncthreads();
-        timed_out = (*lds_flag == ~0ull);       // eval_body's first barrier orders this read before its LDS writes
+        timed_out = (*lds_flag != seq);         // eval_body's first barrier orders this read before its LDS writes
         if (timed_out) {
             if (blockIdx.x == 0 && tid == 0)
                 __hip_atomic_store(ra.h_state, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
