@@ -10,16 +10,18 @@ base = vb.synth.with_sanity_stats(vb.synth.make_pileup(M, 30, k, 0.05, 2))
 pre = vb.synth.write_files(base, os.path.join(tmp, "panel"))
 t0 = time.perf_counter()
 piles = []
-for s in range(S):
+DISTINCT = int(os.environ.get("VB2_DISTINCT", S))      # fewer distinct files than samples: reuse them cyclically
+for s in range(min(S, DISTINCT)):
     d = vb.synth.make_pileup(M, 30, k, alpha_true=0.01 * (1 + s % 20), seed=1000 + s)
     d = vb.PileupData(k, base.ud, base.means, d.read_off, d.bases, d.quals, base.alt_base, None,
                       d.avg_depth, d.sd_depth, True, dict(base.meta))
     piles.append(vb.synth.write_files(d, os.path.join(tmp, "s%d" % s)) + ".pileup")
-print("wrote %d pileups in %.1f s" % (S, time.perf_counter() - t0))
+print("wrote %d pileups in %.1f s" % (len(piles), time.perf_counter() - t0))
+piles = [piles[s % len(piles)] for s in range(S)]
 outs = [os.path.join(tmp, "out%d" % s) for s in range(S)]
 t0 = time.perf_counter(); one = vb.run_files(pre, piles[0], os.path.join(tmp, "single"), num_pc=k); t_one = time.perf_counter() - t0
-for threads in (4, 16):
-    for group in (8, 32):
+for threads in [int(x) for x in os.environ.get("VB2_THREADS", "4,16").split(",")]:
+    for group in [int(x) for x in os.environ.get("VB2_GROUPS", "8,32").split(",")]:
         t0 = time.perf_counter()
         res = vb.run_cohort_files(pre, piles, outs, num_pc=k, group_size=group, num_host_thread=threads)
         dt = time.perf_counter() - t0

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <deque>
 #include <chrono>
 #include <thread>
 #include <cstdio>
@@ -497,11 +498,32 @@ int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* statu
         std::vector<std::thread> pool;
         for (int t = 0; t < T; ++t) pool.emplace_back(worker);
 
+        std::mutex rel_mu;
+        std::condition_variable rel_cv;
+        std::deque<std::pair<vb2_ctx*, std::unique_ptr<vb2_flat>>> rel_queue;
+        bool rel_stop = false;
+        std::thread releaser([&] {
+            for (;;) {
+                std::pair<vb2_ctx*, std::unique_ptr<vb2_flat>> item;
+                {
+                    std::unique_lock<std::mutex> lk(rel_mu);
+                    rel_cv.wait(lk, [&] { return rel_stop || !rel_queue.empty(); });
+                    if (rel_queue.empty()) return;
+                    item = std::move(rel_queue.front());
+                    rel_queue.pop_front();
+                }
+                if (item.first) vb2_ctx_destroy(item.first);
+            }
+        });
+
         vb2_model model = a->base.model;
         if (panel->isAFknown) model.is_af_known = 1;
         int rc_all = VB2_OK;
+        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
         for (int g0 = 0; g0 < S && rc_all == VB2_OK; g0 += G) {
             const int g1 = std::min(S, g0 + G);
+            const double tg0 = now_s();
+            double tg_wait = 0, tg_opt = 0, tg_out = 0;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] {
@@ -510,6 +532,7 @@ int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* statu
                     return true;
                 });
             }
+            tg_wait = now_s();
             std::vector<vb2_ctx*> ctxs;
             std::vector<int> who;
             for (int s = g0; s < g1; ++s) {
@@ -526,7 +549,8 @@ int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* statu
                 int rcb = vb2_batch_create(ctxs.data(), (int32_t)ctxs.size(), &batch);
                 if (!rcb) rcb = vb2_batch_optimize_llk(batch, &model, 1, est.data());
                 if (batch) vb2_batch_destroy(batch);
-                const double dt = (now_s() - t1) / (double)ctxs.size();
+                tg_opt = now_s();
+                const double dt = (tg_opt - t1) / (double)ctxs.size();
                 if (rcb) {
                     rc_all = rcb;                      // device-level failure: concerns every sample
                 } else {
@@ -543,11 +567,20 @@ int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* statu
                     }
                 }
             }
-            for (int s = g0; s < g1; ++s) {
-                if (slots[s].ctx) vb2_ctx_destroy(slots[s].ctx);
-                slots[s].ctx = nullptr;
-                slots[s].flat.reset();
+            tg_out = now_s();
+            {   // freeing device and pinned memory synchronises with the device and takes milliseconds
+                // per context: hand the group to the releaser thread and move on
+                std::lock_guard<std::mutex> lk(rel_mu);
+                for (int s = g0; s < g1; ++s) {
+                    rel_queue.emplace_back(slots[s].ctx, std::move(slots[s].flat));
+                    slots[s].ctx = nullptr;
+                }
             }
+            rel_cv.notify_one();
+            if (timing)
+                std::fprintf(stderr, "vb2_cohort_run: group %d-%d: waited %.1f ms for the readers, search %.1f ms, "
+                             "outputs %.1f ms, release %.1f ms\n", g0, g1 - 1, 1e3 * (tg_wait - tg0),
+                             1e3 * (tg_opt - tg_wait), 1e3 * (tg_out - tg_opt), 1e3 * (now_s() - tg_out));
             {
                 std::lock_guard<std::mutex> lk(mu);
                 ++groups_done;
@@ -560,6 +593,12 @@ int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* statu
         }
         cv.notify_all();
         for (auto& th : pool) th.join();
+        {
+            std::lock_guard<std::mutex> lk(rel_mu);
+            rel_stop = true;
+        }
+        rel_cv.notify_one();
+        releaser.join();
         for (auto& sl : slots)
             if (sl.ctx) vb2_ctx_destroy(sl.ctx);
         vb2::g_flatten_thread_cap.store(0);

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <queue>
 #include <functional>
@@ -39,6 +40,53 @@ void set_error(const std::string& msg) { g_last_error = msg; }
     } while (0)
 
 std::atomic<int> g_flatten_thread_cap{0};
+
+namespace {
+// Freed device / pinned slabs are kept for the next context of the process instead of going
+// back to the driver: hipFree and hipHostFree synchronise with the device and cost milliseconds
+// each (a cohort run creates and destroys a context per sample: 5 ms per sample went there).
+// Bounded: at most kMaxCached slabs per kind, and a slab is only reused for a request of at
+// least half its size.  VB2_SLAB_CACHE=0 turns the cache off.
+struct SlabCache {
+    struct Entry { void* p; size_t bytes; int device; };
+    static constexpr size_t kMaxCached = 96;
+    std::mutex mu;
+    std::vector<Entry> dev, pin;
+    bool enabled() { static const bool on = !(std::getenv("VB2_SLAB_CACHE") && std::getenv("VB2_SLAB_CACHE")[0] == '0'); return on; }
+    void* take(std::vector<Entry>& v, size_t bytes, int device, size_t* got)
+    {
+        if (!enabled()) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        size_t best = v.size();
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].device == device && v[i].bytes >= bytes && v[i].bytes <= 2 * bytes + (1u << 20) &&
+                (best == v.size() || v[i].bytes < v[best].bytes))
+                best = i;
+        if (best == v.size()) return nullptr;
+        void* p = v[best].p;
+        *got = v[best].bytes;
+        v.erase(v.begin() + (long)best);
+        return p;
+    }
+    bool give(std::vector<Entry>& v, void* p, size_t bytes, int device)
+    {
+        if (!enabled()) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (v.size() >= kMaxCached) return false;
+        v.push_back(Entry{p, bytes, device});
+        return true;
+    }
+    ~SlabCache()
+    {
+        // process exit: the runtime may already be shutting down; leave the memory to it
+    }
+};
+SlabCache& slab_cache()
+{
+    static SlabCache* c = new SlabCache();      // intentionally never destroyed (see ~SlabCache)
+    return *c;
+}
+}  // namespace
 
 int usable_device_count()
 {
@@ -99,16 +147,10 @@ Context::~Context()
 {
     if (device >= 0) (void)hipSetDevice(device);
     if (resident_active) resident_end();
-    auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
-    fr(L.codes); fr(L.mt_rec); fr(L.ud); fr(L.mu); fr(L.ediag);
-    fr(L.known_af); fr(L.dict_perr); fr(L.prim);
-    fr(d_partials); fr(d_ticket); fr(d_stamps);
-    if (h_points) (void)hipHostFree(h_points);
-    if (h_out) (void)hipHostFree(h_out);
-    if (h_done) (void)hipHostFree(h_done);
-    if (h_cmd) (void)hipHostFree(h_cmd);
-    if (h_state) (void)hipHostFree(h_state);
-    fr(d_relay);
+    if (stream) (void)hipStreamSynchronize(stream);       // nothing of this context is in flight any more
+    // every device array / every pinned, device-mapped buffer of the context: back to the cache
+    if (d_slab && !slab_cache().give(slab_cache().dev, d_slab, d_slab_bytes, device)) (void)hipFree(d_slab);
+    if (h_slab && !slab_cache().give(slab_cache().pin, h_slab, h_slab_bytes, device)) (void)hipHostFree(h_slab);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -352,32 +394,8 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     });
 
     const auto t_flat = tnow();
-    // ---- upload ----
-    int rc;
-    DeviceLayout& L = c->L;
-    std::memset(&L, 0, sizeof(L));
-    uint32_t* d_codes; uint2* d_rec;
-    double* d_ud; double* d_mu; double* d_cd;
-    double* d_kaf; double* d_dpe;
-    if ((rc = upload(codes, &d_codes, &c->device_bytes))) return rc;
-    L.codes = d_codes;
-    if ((rc = upload(mt_rec, &d_rec, &c->device_bytes))) return rc;
-    L.mt_rec = d_rec;
-    if (!in->known_af) {
-        if ((rc = upload(ud_s, &d_ud, &c->device_bytes))) return rc;
-        L.ud = d_ud;
-        if ((rc = upload(mu_s, &d_mu, &c->device_bytes))) return rc;
-        L.mu = d_mu;
-    } else {
-        if ((rc = upload(kaf_s, &d_kaf, &c->device_bytes))) return rc;
-        L.known_af = d_kaf;
-    }
-    if ((rc = upload(cdiag, &d_cd, &c->device_bytes))) return rc;
-    L.ediag = d_cd;
-    if ((rc = upload(dict_perr, &d_dpe, &c->device_bytes))) return rc;
-    L.dict_perr = d_dpe;
-    // primary codes of the per-alpha table: all ref codes (with the alt code of the same quality
-    // as twin, if that occurs) and the alt codes without a ref partner
+    // ---- primary codes of the per-alpha table: all ref codes (with the alt code of the same
+    // quality as twin, if that occurs) and the alt codes without a ref partner ----
     std::vector<double2> prim;
     auto prim_rec = [&](int d, uint32_t twin) {
         const unsigned long long bits = (unsigned long long)((uint32_t)d | (twin << 16));
@@ -394,9 +412,72 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
             prim_rec(d, 0xffffu);
         }
     }
-    double2* d_prim;
-    if ((rc = upload(prim, &d_prim, &c->device_bytes))) return rc;
-    L.prim = d_prim;
+
+    // ---- device memory: ONE allocation per context, carved into 256-byte aligned pieces.
+    // (A cohort creates contexts from many host threads; allocation calls go through driver
+    // ioctls under a process-wide lock and were 12 ms per context there, against 0.6 ms alone.)
+    DeviceLayout& L = c->L;
+    std::memset(&L, 0, sizeof(L));
+    const int nb = kMaxGridPerCU * num_cu;
+    const size_t relay_words = (size_t)resident_words(k);
+    const bool want_stamps = std::getenv("VB2_STAMPS") != nullptr;
+    size_t dev_total = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t off = (dev_total + 255) & ~(size_t)255;
+        dev_total = off + bytes;
+        return off;
+    };
+    const size_t o_codes = carve(codes.size() * sizeof(uint32_t));
+    const size_t o_rec = carve(mt_rec.size() * sizeof(uint2));
+    const size_t o_ud = carve(in->known_af ? 0 : ud_s.size() * sizeof(double));
+    const size_t o_mu = carve(in->known_af ? 0 : mu_s.size() * sizeof(double));
+    const size_t o_kaf = carve(kaf_s.size() * sizeof(double));
+    const size_t o_cd = carve(cdiag.size() * sizeof(double));
+    const size_t o_dpe = carve(dict_perr.size() * sizeof(double));
+    const size_t o_prim = carve(prim.size() * sizeof(double2));
+    const size_t o_part = carve(sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb);
+    const size_t o_ticket = carve(sizeof(unsigned int));
+    const size_t o_relay = carve(sizeof(unsigned long long) * relay_words);
+    const size_t o_stamps = carve(want_stamps ? sizeof(unsigned long long) * 8 * nb : 0);
+    dev_total = (dev_total + 255) & ~(size_t)255;
+    c->d_slab = slab_cache().take(slab_cache().dev, dev_total, dev, &c->d_slab_bytes);
+    if (!c->d_slab) {
+        VB2_HIP(hipMalloc((void**)&c->d_slab, dev_total));
+        c->d_slab_bytes = dev_total;
+    }
+    char* const dbase = static_cast<char*>(c->d_slab);
+    // partial sums, ticket, relay and stamps start as zeros; the data arrays are copied over
+    VB2_HIP(hipMemset(dbase + o_part, 0, dev_total - o_part));
+    auto put = [&](size_t off, const void* src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpy(dbase + off, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    VB2_HIP(put(o_codes, codes.data(), codes.size() * sizeof(uint32_t)));
+    VB2_HIP(put(o_rec, mt_rec.data(), mt_rec.size() * sizeof(uint2)));
+    if (!in->known_af) {
+        VB2_HIP(put(o_ud, ud_s.data(), ud_s.size() * sizeof(double)));
+        VB2_HIP(put(o_mu, mu_s.data(), mu_s.size() * sizeof(double)));
+        L.ud = reinterpret_cast<const double*>(dbase + o_ud);
+        L.mu = reinterpret_cast<const double*>(dbase + o_mu);
+    } else {
+        VB2_HIP(put(o_kaf, kaf_s.data(), kaf_s.size() * sizeof(double)));
+        L.known_af = reinterpret_cast<const double*>(dbase + o_kaf);
+    }
+    VB2_HIP(put(o_cd, cdiag.data(), cdiag.size() * sizeof(double)));
+    VB2_HIP(put(o_dpe, dict_perr.data(), dict_perr.size() * sizeof(double)));
+    VB2_HIP(put(o_prim, prim.data(), prim.size() * sizeof(double2)));
+    L.codes = reinterpret_cast<const uint32_t*>(dbase + o_codes);
+    L.mt_rec = reinterpret_cast<const uint2*>(dbase + o_rec);
+    L.ediag = reinterpret_cast<const double*>(dbase + o_cd);
+    L.dict_perr = reinterpret_cast<const double*>(dbase + o_dpe);
+    L.prim = reinterpret_cast<const double2*>(dbase + o_prim);
+    c->d_partials = reinterpret_cast<double*>(dbase + o_part);
+    c->d_ticket = reinterpret_cast<unsigned int*>(dbase + o_ticket);
+    c->d_relay = reinterpret_cast<unsigned long long*>(dbase + o_relay);
+    if (want_stamps) {
+        c->d_stamps = reinterpret_cast<unsigned long long*>(dbase + o_stamps);
+        L.stamps = c->d_stamps;
+    }
+    c->device_bytes = (int64_t)dev_total;
     L.num_prim = (int32_t)prim.size();
     L.num_code = num_code;
     L.num_mt = num_mt;
@@ -410,46 +491,49 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     c->num_read_other = num_other;
     c->algorithmic_bytes = 2 * num_read + m_active * (8 * (int64_t)k + 12);
 
-    const int nb = kMaxGridPerCU * num_cu;
-    VB2_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb));
-    VB2_HIP(hipMemset(c->d_partials, 0, sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb));
-    VB2_HIP(hipMalloc((void**)&c->d_ticket, sizeof(unsigned int)));
-    VB2_HIP(hipMemset(c->d_ticket, 0, sizeof(unsigned int)));
-    if (std::getenv("VB2_STAMPS")) {
-        VB2_HIP(hipMalloc((void**)&c->d_stamps, sizeof(unsigned long long) * 8 * nb));
-        VB2_HIP(hipMemset(c->d_stamps, 0, sizeof(unsigned long long) * 8 * nb));
-        L.stamps = c->d_stamps;
-    }
     if (const char* sl = std::getenv("VB2_SINGLE_LAUNCH")) set_single_launch(std::atoi(sl) != 0);
     if (const char* rm = std::getenv("VB2_REDUCE"))
         set_reduce_mode(!std::strcmp(rm, "ticket") ? 1 : !std::strcmp(rm, "tagged") ? 2 : 0);
     // Host <-> device hand-off of the (tiny) parameter and result vectors goes through
     // pinned, device-mapped host memory that the kernels access directly: no copy
     // commands on the evaluation path.
+    // (one pinned allocation for all of them, for the same reason as the device slab)
     const size_t pt_bytes = sizeof(double) * (size_t)kStagePoints * (2 * k + 1);
-    VB2_HIP(hipHostMalloc((void**)&c->h_points, pt_bytes, hipHostMallocMapped));
-    VB2_HIP(hipHostMalloc((void**)&c->h_out, sizeof(double) * kStagePoints, hipHostMallocMapped));
-    VB2_HIP(hipHostGetDevicePointer((void**)&c->d_points, c->h_points, 0));
-    VB2_HIP(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
-    VB2_HIP(hipHostMalloc((void**)&c->h_done, sizeof(unsigned long long), hipHostMallocMapped));
-    *c->h_done = 0;
-    VB2_HIP(hipHostGetDevicePointer((void**)&c->d_done, c->h_done, 0));
+    size_t pin_total = 0;
+    auto pcarve = [&](size_t bytes) {
+        const size_t off = (pin_total + 127) & ~(size_t)127;
+        pin_total = off + bytes;
+        return off;
+    };
+    const size_t p_points = pcarve(pt_bytes);
+    const size_t p_out = pcarve(sizeof(double) * kStagePoints);
+    const size_t p_done = pcarve(sizeof(unsigned long long) * 8);        // [0] sequence number (+ spare words)
+    const size_t p_cmd = pcarve(sizeof(unsigned long long) * relay_words);
+    const size_t p_state = pcarve(sizeof(unsigned int));
+    c->h_slab = slab_cache().take(slab_cache().pin, pin_total, dev, &c->h_slab_bytes);
+    if (!c->h_slab) {
+        VB2_HIP(hipHostMalloc((void**)&c->h_slab, pin_total, hipHostMallocMapped));
+        c->h_slab_bytes = pin_total;
+    }
+    std::memset(c->h_slab, 0, pin_total);
+    char* hbase = static_cast<char*>(c->h_slab);
+    char* hdev = nullptr;
+    VB2_HIP(hipHostGetDevicePointer((void**)&hdev, c->h_slab, 0));
+    c->h_points = reinterpret_cast<double*>(hbase + p_points);
+    c->d_points = reinterpret_cast<double*>(hdev + p_points);
+    c->h_out = reinterpret_cast<double*>(hbase + p_out);
+    c->d_out = reinterpret_cast<double*>(hdev + p_out);
+    c->h_done = reinterpret_cast<unsigned long long*>(hbase + p_done);
+    c->d_done = reinterpret_cast<unsigned long long*>(hdev + p_done);
+    c->h_cmd = reinterpret_cast<unsigned long long*>(hbase + p_cmd);
+    c->d_cmd = reinterpret_cast<unsigned long long*>(hdev + p_cmd);
+    c->h_state = reinterpret_cast<unsigned int*>(hbase + p_state);
+    c->d_state = reinterpret_cast<unsigned int*>(hdev + p_state);
     if (const char* sw = std::getenv("VB2_SPIN_WAIT")) c->spin_wait = std::atoi(sw) != 0;
     if (const char* rs = std::getenv("VB2_RESIDENT")) c->resident_enabled = std::atoi(rs) != 0;
     if (const char* co = std::getenv("VB2_COOP")) set_coop_launch(std::atoi(co) != 0);
     if (const char* pm = std::getenv("VB2_PAIRED")) set_paired_mode(std::atoi(pm) != 0);
     c->dbg_timing = timing;
-    {
-        const size_t words = (size_t)resident_words(k);
-        VB2_HIP(hipHostMalloc((void**)&c->h_cmd, sizeof(unsigned long long) * words, hipHostMallocMapped));
-        std::memset(c->h_cmd, 0, sizeof(unsigned long long) * words);
-        VB2_HIP(hipHostGetDevicePointer((void**)&c->d_cmd, c->h_cmd, 0));
-        VB2_HIP(hipMalloc((void**)&c->d_relay, sizeof(unsigned long long) * words));
-        VB2_HIP(hipHostMalloc((void**)&c->h_state, sizeof(unsigned int), hipHostMallocMapped));
-        *c->h_state = 0;
-        VB2_HIP(hipHostGetDevicePointer((void**)&c->d_state, c->h_state, 0));
-    }
-    c->device_bytes += (int64_t)(sizeof(double) * (size_t)kMaxPointsPerLaunch * nb);
     if (opt && opt->stream) {
         c->stream = (hipStream_t)opt->stream;
         c->own_stream = false;

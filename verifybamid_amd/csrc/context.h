@@ -48,6 +48,9 @@ public:
     DeviceLayout L{};
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    void* d_slab = nullptr;                   // the one device allocation the pointers below (and L.*) point into
+    void* h_slab = nullptr;                   // the one pinned, device-mapped host allocation
+    size_t d_slab_bytes = 0, h_slab_bytes = 0;   // allocated sizes (slabs are recycled through a cache)
     double* d_partials = nullptr;
     unsigned int* d_ticket = nullptr;
     unsigned long long* d_stamps = nullptr;   // VB2_STAMPS profiling aid
