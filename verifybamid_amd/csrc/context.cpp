@@ -130,17 +130,6 @@ inline int clamp_qual(char qc)
     return q;
 }
 
-template <typename T>
-int upload(const std::vector<T>& h, T** d, int64_t* bytes)
-{
-    *d = nullptr;
-    if (h.empty()) return VB2_OK;
-    VB2_HIP(hipMalloc((void**)d, h.size() * sizeof(T)));
-    VB2_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    *bytes += (int64_t)(h.size() * sizeof(T));
-    return VB2_OK;
-}
-
 }  // namespace
 
 Context::~Context()
@@ -548,7 +537,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
             set_geom_override(btl, mw, bpc);
     }
     if (const char* lm = std::getenv("VB2_LANE_MAP")) set_lane_mapping(std::strcmp(lm, "plain") != 0);
-    VB2_HIP(hipDeviceSynchronize());
+    VB2_HIP(hipStreamSynchronize(nullptr));        // the memset/copies above (null stream); not a device-wide wait
     if (timing)
         std::fprintf(stderr, "vb2_ctx_create: flatten %.1f ms (classify %.1f, dictionary+sort %.1f, pack %.1f; "
                      "%d threads), device alloc+upload %.1f ms\n",
