@@ -149,7 +149,9 @@ typedef struct vb2_model {
     const double *fix_pc;      /* --FixPC values (num_pc) or NULL                  */
     double epsilon;            /* --Epsilon, 1e-8 by default   (main.cpp:76)       */
     int32_t verbose;           /* --Verbose: per-evaluation notice (h:435-440)     */
-    int32_t reserved;
+    int32_t notices;           /* print the reference's stderr lines: PhaseTimer "Starting/Finished
+                                * phase" (ContaminationEstimator.cpp:10-24, 93-155) and the
+                                * non-convergence warning (MathGenMin.cpp:381); vb2_run sets it */
 } vb2_model;
 
 #define VB2_MAX_PC 64

@@ -16,8 +16,17 @@ def _ensure_built():
     need = [os.path.join(ROOT, "verifybamid_amd", "libvb2.so"),
             os.path.join(ROOT, "verifybamid_amd", "bin", "VerifyBamID"),
             os.path.join(ROOT, "oracle", "liboracle.so")]
+    # ... and rebuilds them whenever a source is newer than the oldest artefact: a stale binary
+    # must not mask a broken source file (make itself only recompiles what changed)
+    srcs = []
+    for d in ("verifybamid_amd/csrc", "include", "oracle"):
+        for f in os.listdir(os.path.join(ROOT, d)):
+            if f.endswith((".cpp", ".hip", ".h", ".c", "Makefile")):
+                srcs.append(os.path.join(ROOT, d, f))
     if all(os.path.exists(p) for p in need):
-        return
+        oldest = min(os.path.getmtime(p) for p in need)
+        if all(os.path.getmtime(f) <= oldest for f in srcs):
+            return
     import __graft_entry__
     __graft_entry__.build()
 

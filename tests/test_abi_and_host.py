@@ -235,6 +235,56 @@ def test_fast_scanner_equals_stringstream_statements(tmp_path, monkeypatch):
     monkeypatch.delenv("VB2_SLOW_PARSE")
 
 
+def _tiny_panel(pre):
+    open(pre + ".bed", "w").write("1\t0\t1\tA\tC\n1\t9\t10\tG\tT\n")
+    open(pre + ".UD", "w").write("0.5 0.25\n-0.5 0.125\n")
+    open(pre + ".mu", "w").write("1:1_A/C 0.5\n1:10_G/T 1.0\n")
+
+
+@pytest.mark.parametrize("seq", ["..+99999999999A", ".+A.", "-"])
+def test_indel_marker_without_valid_length_is_an_error_not_a_crash(tmp_path, seq):
+    """The reference's std::stoi throws on these (SimplePileupViewer.cpp:722) and the run dies;
+    the library must report an error code -- with its helper threads joined, not std::terminate."""
+    pre = str(tmp_path / "q")
+    _tiny_panel(pre)
+    open(pre + ".pileup", "w").write("1\t1\tA\t2\t%s\tII\n" % seq)
+    with pytest.raises(_abi.Vb2Error) as ei:
+        vb.PileupData.from_files(pre, pre + ".pileup", 2, disable_sanity=True)
+    assert "indel" in str(ei.value)
+    # the process (and the library's error state) is still usable
+    open(pre + ".pileup", "w").write("1\t1\tA\t2\t.+1AC\tII\n")
+    d = vb.PileupData.from_files(pre, pre + ".pileup", 2, disable_sanity=True)
+    assert bytes(d.bases).decode() == ".C"
+
+
+def test_stale_fields_after_a_line_outside_the_panel_are_the_parsed_ones(tmp_path):
+    """ReadPileup assigns the parsed strings back to seq/qual before the .bed lookup
+    (SimplePileupViewer.cpp:785-786), so a following SHORT line inherits the parsed bases."""
+    pre = str(tmp_path / "q")
+    _tiny_panel(pre)
+    # line 1 is outside the panel (fields persist, parsed: "." / "I"); line 2 has only chr pos
+    open(pre + ".pileup", "w").write("1\t5\tA\t3\t.$*^]\tIJ\n1\t10\n")
+    d = vb.PileupData.from_files(pre, pre + ".pileup", 2, disable_sanity=True)
+    got = bytes(d.bases[d.read_off[1]:d.read_off[2]]).decode()
+    assert got == "." and bytes(d.quals[d.read_off[1]:d.read_off[2]]).decode() == "I"
+
+
+def test_gzipped_panel_files_are_inflated_like_the_reference_inputfile(tmp_path, golden_dir):
+    """statgen's InputFile opens gzip'd .UD/.mu/.bed transparently (InputFile.cpp ifopen)."""
+    import gzip
+    import shutil
+    pre = str(tmp_path / "gz")
+    for ext in (".UD", ".mu", ".bed"):
+        with open(os.path.join(golden_dir, HAPMAP + ext), "rb") as fi, gzip.open(pre + ext, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+    pile = os.path.join(golden_dir, "expected/result.Pileup")
+    a = vb.PileupData.from_files(pre, pile, 2, disable_sanity=True)
+    b = vb.PileupData.from_files(os.path.join(golden_dir, HAPMAP), pile, 2, disable_sanity=True)
+    assert a.num_marker == b.num_marker == 9787
+    assert a.ud.tobytes() == b.ud.tobytes() and a.means.tobytes() == b.means.tobytes()
+    assert a.alt_base.tobytes() == b.alt_base.tobytes() and a.read_off.tobytes() == b.read_off.tobytes()
+
+
 def test_ud_with_too_few_columns(tmp_path):
     pre = str(tmp_path / "q")
     open(pre + ".bed", "w").write("1\t0\t1\tA\tC\n")

@@ -47,7 +47,7 @@ class Model(C.Structure):
     _fields_ = [
         ("is_heter", C.c_int32), ("is_pc_fixed", C.c_int32), ("is_alpha_fixed", C.c_int32),
         ("is_af_known", C.c_int32), ("fix_alpha", C.c_double), ("fix_pc", C.c_void_p),
-        ("epsilon", C.c_double), ("verbose", C.c_int32), ("reserved", C.c_int32),
+        ("epsilon", C.c_double), ("verbose", C.c_int32), ("notices", C.c_int32),
     ]
 
 

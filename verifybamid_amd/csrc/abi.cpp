@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <deque>
+#include <functional>
 #include <chrono>
 #include <thread>
 #include <cstdio>
@@ -24,6 +25,14 @@
 using vb2::set_error;
 
 namespace {
+
+// Joins a helper thread on every path out of a scope: an exception on the main thread must not
+// unwind past a joinable std::thread (that is std::terminate, not an error code).
+struct JoinGuard {
+    std::thread& t;
+    explicit JoinGuard(std::thread& th) : t(th) {}
+    ~JoinGuard() { if (t.joinable()) t.join(); }
+};
 
 int guard_ctx(const vb2_ctx* ctx)
 {
@@ -58,13 +67,14 @@ int load_panel(const vb2_run_args* a, vb2::Panel* panel)
     int rc_ud = VB2_OK, rc_mu = VB2_OK;
     std::string err_ud, err_mu;
     std::thread t_ud([&] {
-        rc_ud = vb2::read_ud(a->ud_path, panel);
-        if (rc_ud) err_ud = vb2::g_last_error;
+        try { rc_ud = vb2::read_ud(a->ud_path, panel); if (rc_ud) err_ud = vb2::g_last_error; }
+        catch (const std::exception& e) { rc_ud = VB2_ERR_NOMEM; err_ud = e.what(); }
     });
     std::thread t_mu([&] {
-        rc_mu = vb2::read_mean(a->mean_path, panel);
-        if (rc_mu) err_mu = vb2::g_last_error;
+        try { rc_mu = vb2::read_mean(a->mean_path, panel); if (rc_mu) err_mu = vb2::g_last_error; }
+        catch (const std::exception& e) { rc_mu = VB2_ERR_NOMEM; err_mu = e.what(); }
     });
+    JoinGuard j_ud(t_ud), j_mu(t_mu);
     int rc = vb2::read_bed(a->bed_path, panel);
     if (!rc && a->known_af_path) rc = vb2::read_known_af(a->known_af_path, panel);
     const std::string err_main = rc ? vb2::g_last_error : std::string();
@@ -294,13 +304,14 @@ int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
         int rc_ud = VB2_OK, rc_mu = VB2_OK;
         std::string err_ud, err_mu;
         std::thread t_ud([&] {
-            rc_ud = vb2::read_ud(a->ud_path, &f->panel);
-            if (rc_ud) err_ud = vb2::g_last_error;
+            try { rc_ud = vb2::read_ud(a->ud_path, &f->panel); if (rc_ud) err_ud = vb2::g_last_error; }
+            catch (const std::exception& e) { rc_ud = VB2_ERR_NOMEM; err_ud = e.what(); }
         });
         std::thread t_mu([&] {
-            rc_mu = vb2::read_mean(a->mean_path, &f->panel);
-            if (rc_mu) err_mu = vb2::g_last_error;
+            try { rc_mu = vb2::read_mean(a->mean_path, &f->panel); if (rc_mu) err_mu = vb2::g_last_error; }
+            catch (const std::exception& e) { rc_mu = VB2_ERR_NOMEM; err_mu = e.what(); }
         });
+        JoinGuard j_ud(t_ud), j_mu(t_mu);
         rc = vb2::read_bed(a->bed_path, &f->panel);
         if (!rc && a->known_af_path) rc = vb2::read_known_af(a->known_af_path, &f->panel);
         tl_bed = now_s();
@@ -378,8 +389,21 @@ int vb2_run(const vb2_run_args* a, vb2_run_result* out)
         (void)hipGetLastError();
     });
     vb2_flat* flat = nullptr;
-    int rc = vb2_flat_load(a, &flat);
-    warm.join();
+    int rc;
+    const bool notices = a->model.notices != 0;
+    // main.cpp:321-378: the reference times "Load SVD reference data", "Read pileup" and "Marker
+    // sanity check" one after the other; here the panel files and the pileup are read
+    // concurrently, so the three are one phase
+    if (notices) std::fprintf(stderr, "NOTICE - Starting phase: Load SVD reference data + Read pileup + Marker sanity check\n");
+    {
+        JoinGuard j_warm(warm);
+        rc = vb2_flat_load(a, &flat);
+    }
+    if (notices) {
+        std::fprintf(stderr, "NOTICE - Finished phase: Load SVD reference data + Read pileup + Marker sanity check  "
+                             "[%.3f seconds]\n", now_s() - t0);
+        if (!rc && !a->disable_sanity) std::fprintf(stderr, "NOTICE - Passing Marker Sanity Check...\n");
+    }
     std::unique_ptr<vb2_flat> holder(flat);
     if (rc == VB2_ERR_SANITY && flat && a->output_pileup && a->output_prefix)
         vb2::write_pileup(a->output_prefix, *flat);
@@ -391,14 +415,20 @@ int vb2_run(const vb2_run_args* a, vb2_run_result* out)
     vb2_options opt{};
     opt.device = a->device;
     vb2_ctx* ctx = nullptr;
+    const double t_flat0 = now_s();
     if ((rc = vb2_ctx_create(&flat->input, &opt, &ctx))) return rc;
     out->seconds_load = now_s() - t0;
 
     vb2_model model = a->model;
     if (flat->panel.isAFknown) model.is_af_known = 1;
+    if (notices)
+        std::fprintf(stderr, "NOTICE - Finished phase: Flatten + upload to %s  [%.3f seconds]\n",
+                     ctx->impl->device_name, now_s() - t_flat0);
     const double t1 = now_s();
+    if (notices) std::fprintf(stderr, "NOTICE - Starting phase: Optimize likelihood\n");      // main.cpp:382
     rc = vb2_ctx_optimize_llk(ctx, &model, &out->est, nullptr);
     out->seconds_optimize = now_s() - t1;
+    if (notices) std::fprintf(stderr, "NOTICE - Finished phase: Optimize likelihood  [%.3f seconds]\n", out->seconds_optimize);
     vb2_ctx_destroy(ctx);
     if (rc) return rc;
 
@@ -433,8 +463,11 @@ int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* statu
         });
         auto panel = std::make_shared<vb2::Panel>();
         panel->numPC = a->base.num_pc;
-        int rc = load_panel(&a->base, panel.get());
-        warm.join();
+        int rc;
+        {
+            JoinGuard j_warm(warm);
+            rc = load_panel(&a->base, panel.get());
+        }
         if (rc) return rc;
 
         struct Slot {
@@ -485,6 +518,8 @@ int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* statu
                 }
                 try {
                     prepare(s);
+                } catch (const std::bad_alloc&) {
+                    slots[s].rc = VB2_ERR_NOMEM;
                 } catch (const std::exception&) {
                     slots[s].rc = VB2_ERR_INVALID;
                 }
@@ -515,6 +550,30 @@ int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* statu
                 if (item.first) vb2_ctx_destroy(item.first);
             }
         });
+
+        // Every way out of this scope (return, exception) stops and joins the reader pool and the
+        // releaser thread, and gives back the contexts that were never handed over.
+        struct Shutdown {
+            std::function<void()> fn;
+            ~Shutdown() { fn(); }
+        } shutdown{[&] {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop = true;
+            }
+            cv.notify_all();
+            for (auto& th : pool)
+                if (th.joinable()) th.join();
+            {
+                std::lock_guard<std::mutex> lk(rel_mu);
+                rel_stop = true;
+            }
+            rel_cv.notify_one();
+            if (releaser.joinable()) releaser.join();
+            for (auto& sl : slots)
+                if (sl.ctx) { vb2_ctx_destroy(sl.ctx); sl.ctx = nullptr; }
+            vb2::g_flatten_thread_cap.store(0);
+        }};
 
         vb2_model model = a->base.model;
         if (panel->isAFknown) model.is_af_known = 1;
@@ -587,21 +646,6 @@ int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* statu
             }
             cv.notify_all();
         }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv.notify_all();
-        for (auto& th : pool) th.join();
-        {
-            std::lock_guard<std::mutex> lk(rel_mu);
-            rel_stop = true;
-        }
-        rel_cv.notify_one();
-        releaser.join();
-        for (auto& sl : slots)
-            if (sl.ctx) vb2_ctx_destroy(sl.ctx);
-        vb2::g_flatten_thread_cap.store(0);
         return rc_all;
     } catch (const std::bad_alloc&) {
         set_error("out of host memory");

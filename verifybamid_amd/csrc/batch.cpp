@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -163,16 +164,26 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
     ml.block_waves = block_waves_;
     ml.btl = btl;
     ml.shmem = shmem_[btl - 1];
-    VB2_HIP(launch_llk_eval_multi(ml, stream_));
-    ++num_launch;
-    bool seen = false;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0;; ++spins) {
-        if (__atomic_load_n(h_done_, __ATOMIC_ACQUIRE) == ml.done_seq) { seen = true; break; }
-        if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
-        __builtin_ia32_pause();
+    // (a NaN is the tagged hand-off's "a workgroup never reported" marker: redo the step once with
+    // the arrival-ticket hand-off, see Context::eval_host -- NaN must not reach the optimisers)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        ml.force_ticket = attempt > 0;
+        if (attempt > 0) ml.done_seq = ++seq_;
+        VB2_HIP(launch_llk_eval_multi(ml, stream_));
+        ++num_launch;
+        bool seen = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(h_done_, __ATOMIC_ACQUIRE) == ml.done_seq) { seen = true; break; }
+            if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+            __builtin_ia32_pause();
+        }
+        if (!seen) VB2_HIP(hipStreamSynchronize(stream_));
+        bool any_nan = false;
+        for (int s = 0; s < num_sample && !any_nan; ++s)
+            for (int j = 0; j < h_nv_[s]; ++j) any_nan |= std::isnan(h_out_[(size_t)s * NP + j]);
+        if (!any_nan) break;
     }
-    if (!seen) VB2_HIP(hipStreamSynchronize(stream_));
     for (int s = 0; s < num_sample; ++s)
         for (int j = 0; j < h_nv_[s]; ++j) llk_out[(size_t)s * kSlot + j] = h_out_[(size_t)s * NP + j];
     return VB2_OK;

@@ -142,6 +142,7 @@ int main(int argc, char** argv)
     args.model.is_heter = !withinAncestry;
     args.model.epsilon = epsilon;
     args.model.verbose = verbose;
+    args.model.notices = 1;
 
     std::vector<double> tmpPC;
     if (fixPC != "Empty") {                                            // main.cpp:291-308
@@ -210,12 +211,8 @@ int main(int argc, char** argv)
         else std::fprintf(stderr, "\nFATAL ERROR - \n%s\n\n", vb2_last_error());
         return EXIT_FAILURE;
     }
-    std::fprintf(stderr, "NOTICE -   Finished phase: Load + flatten  [%.3f seconds]\n", res.seconds_load);
-    std::fprintf(stderr, "NOTICE -   Finished phase: Optimize likelihood  [%.3f seconds] "
-                         "(%lld likelihood evaluations, %lld points launched)\n",
-                 res.seconds_optimize, (long long)res.est.num_eval, (long long)res.est.num_launch_point);
-    if (!res.est.converged)
-        std::fprintf(stderr, "WARNING - Amoeba.Minimize - Couldn't converge in 50000 cycles\n");
+    std::fprintf(stderr, "NOTICE - %lld likelihood evaluations, %lld points launched on the device\n",
+                 (long long)res.est.num_eval, (long long)res.est.num_launch_point);
     std::fprintf(stderr, "NOTICE - Success!\n");
     return 0;
 }

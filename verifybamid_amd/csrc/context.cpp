@@ -88,6 +88,27 @@ SlabCache& slab_cache()
 }
 }  // namespace
 
+// The A/B switches of llk_kernels.hip are process-wide: read the environment once, not from every
+// (possibly concurrent) context creation.
+static void init_process_knobs()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (const char* sl = std::getenv("VB2_SINGLE_LAUNCH")) set_single_launch(std::atoi(sl) != 0);
+        if (const char* rm = std::getenv("VB2_REDUCE"))
+            set_reduce_mode(!std::strcmp(rm, "ticket") ? 1 : !std::strcmp(rm, "tagged") ? 2 : 0);
+        if (const char* co = std::getenv("VB2_COOP")) set_coop_launch(std::atoi(co) != 0);
+        if (const char* pm = std::getenv("VB2_PAIRED")) set_paired_mode(std::atoi(pm) != 0);
+        for (int btl = 1; btl <= 2; ++btl) {
+            const char* gv = std::getenv(btl == 1 ? "VB2_GEOM1" : "VB2_GEOM2");
+            int mw = 0, bpc = 0;
+            if (gv && std::sscanf(gv, "%d,%d", &mw, &bpc) == 2 && mw > 0 && bpc > 0 && bpc <= kMaxGridPerCU)
+                set_geom_override(btl, mw, bpc);
+        }
+        if (const char* lm = std::getenv("VB2_LANE_MAP")) set_lane_mapping(std::strcmp(lm, "plain") != 0);
+    });
+}
+
 int usable_device_count()
 {
     int n = 0;
@@ -480,9 +501,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     c->num_read_other = num_other;
     c->algorithmic_bytes = 2 * num_read + m_active * (8 * (int64_t)k + 12);
 
-    if (const char* sl = std::getenv("VB2_SINGLE_LAUNCH")) set_single_launch(std::atoi(sl) != 0);
-    if (const char* rm = std::getenv("VB2_REDUCE"))
-        set_reduce_mode(!std::strcmp(rm, "ticket") ? 1 : !std::strcmp(rm, "tagged") ? 2 : 0);
+    init_process_knobs();
     // Host <-> device hand-off of the (tiny) parameter and result vectors goes through
     // pinned, device-mapped host memory that the kernels access directly: no copy
     // commands on the evaluation path.
@@ -520,8 +539,6 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     c->d_state = reinterpret_cast<unsigned int*>(hdev + p_state);
     if (const char* sw = std::getenv("VB2_SPIN_WAIT")) c->spin_wait = std::atoi(sw) != 0;
     if (const char* rs = std::getenv("VB2_RESIDENT")) c->resident_enabled = std::atoi(rs) != 0;
-    if (const char* co = std::getenv("VB2_COOP")) set_coop_launch(std::atoi(co) != 0);
-    if (const char* pm = std::getenv("VB2_PAIRED")) set_paired_mode(std::atoi(pm) != 0);
     c->dbg_timing = timing;
     if (opt && opt->stream) {
         c->stream = (hipStream_t)opt->stream;
@@ -530,13 +547,6 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         VB2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    for (int btl = 1; btl <= 2; ++btl) {
-        const char* gv = std::getenv(btl == 1 ? "VB2_GEOM1" : "VB2_GEOM2");
-        int mw = 0, bpc = 0;
-        if (gv && std::sscanf(gv, "%d,%d", &mw, &bpc) == 2 && mw > 0 && bpc > 0 && bpc <= kMaxGridPerCU)
-            set_geom_override(btl, mw, bpc);
-    }
-    if (const char* lm = std::getenv("VB2_LANE_MAP")) set_lane_mapping(std::strcmp(lm, "plain") != 0);
     VB2_HIP(hipStreamSynchronize(nullptr));        // the memset/copies above (null stream); not a device-wide wait
     if (timing)
         std::fprintf(stderr, "vb2_ctx_create: flatten %.1f ms (classify %.1f, dictionary+sort %.1f, pack %.1f; "
@@ -549,7 +559,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
 
 int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipStream_t s,
                          unsigned long long* done_flag, unsigned long long done_seq,
-                         const double* h_pts)
+                         const double* h_pts, int reduce_override)
 {
     if (num_point <= 0) return VB2_OK;
     VB2_HIP(hipSetDevice(device));
@@ -559,7 +569,7 @@ int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipS
         return VB2_OK;
     }
     VB2_HIP(launch_llk_eval(L, num_point, d_pts, h_pts, d_partials, d_llk, d_ticket, done_flag, done_seq,
-                            &done_seq_, s));
+                            &done_seq_, s, reduce_override));
     return VB2_OK;
 }
 
@@ -704,21 +714,32 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
         // The kernel that produces the last result also publishes a sequence number to
         // mapped host memory; spinning on it costs a few microseconds less per call than
         // hipStreamSynchronize (which matters: a search is ~350 dependent calls).
-        const unsigned long long seq = ++done_seq_;
-        int rc = eval_device(n, d_points, d_out, stream, L.num_mt > 0 && spin_wait ? d_done : nullptr, seq,
-                             h_points);
-        if (rc) return rc;
-        bool seen = false;
-        if (L.num_mt > 0 && spin_wait) {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (unsigned spins = 0;; ++spins) {
-                if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
-                if ((spins & 0x3ff) == 0x3ff &&
-                    std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
-                __builtin_ia32_pause();
+        // A NaN result is the tagged hand-off's "a workgroup never reported" marker (the grid was
+        // not co-resident, e.g. a device shared with another process).  It must never reach the
+        // optimiser -- every Nelder-Mead comparison with a NaN is false -- so the launch is redone
+        // once with the arrival-ticket hand-off, which does not need co-residency.  A NaN that
+        // survives that is the input's own (NaN parameters) and is passed on as the value it is.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const unsigned long long seq = ++done_seq_;
+            int rc = eval_device(n, d_points, d_out, stream, L.num_mt > 0 && spin_wait ? d_done : nullptr, seq,
+                                 h_points, attempt == 0 ? 0 : 1);
+            if (rc) return rc;
+            bool seen = false;
+            if (L.num_mt > 0 && spin_wait) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (unsigned spins = 0;; ++spins) {
+                    if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+                    if ((spins & 0x3ff) == 0x3ff &&
+                        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4)) break;
+                    __builtin_ia32_pause();
+                }
             }
+            if (!seen) VB2_HIP(hipStreamSynchronize(stream));
+            bool any_nan = false;
+            for (int b = 0; b < n; ++b) any_nan |= std::isnan(h_out[b]);
+            if (!any_nan) break;
+            if (attempt == 0) ++nan_retries;
         }
-        if (!seen) VB2_HIP(hipStreamSynchronize(stream));
         std::memcpy(llk_out + done, h_out, sizeof(double) * n);
     }
     return VB2_OK;

@@ -29,7 +29,7 @@ public:
     // device pointers, asynchronous on s (nullptr = own stream)
     int eval_device(int num_point, const double* d_points, double* d_llk, hipStream_t s,
                     unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0,
-                    const double* h_points = nullptr);
+                    const double* h_points = nullptr, int reduce_override = 0);
     // host pointers, synchronous
     int eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,
                   double* llk_out);
@@ -70,6 +70,7 @@ public:
     unsigned int* h_state = nullptr;
     unsigned int* d_state = nullptr;
     int64_t resident_evals = 0;              // batches served by the resident kernel
+    int64_t nan_retries = 0;                 // plain launches redone in ticket mode after a "never reported" NaN
     // VB2_DEBUG_TIMING: where a resident search's wall-clock goes (host logic vs device round trip)
     bool dbg_timing = false, dbg_have_prev = false;
     int64_t dbg_cmds = 0;

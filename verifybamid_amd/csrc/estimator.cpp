@@ -1,6 +1,7 @@
 // estimator.cpp -- see estimator.h.
 #include "estimator.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -178,7 +179,13 @@ static bool run_minimizer(Estimator* e, AmoebaMinimizer& m, int dim,
     m.point = start;
     *ret = m.Minimize(e->epsilon);
     if (m.error && !e->error) e->error = m.error;
-    return *ret != std::numeric_limits<double>::max();
+    const bool ok = *ret != std::numeric_limits<double>::max();
+    if (!ok) {                                            // MathGenMin.cpp:381 (statgen warning())
+        e->hit_cycle_limit = true;
+        if (e->notices)
+            std::fprintf(stderr, "WARNING - Amoeba.Minimize - Couldn't converge in %d cycles\n", 50000);
+    }
+    return ok;
 }
 
 bool Estimator::OptimizeHeter(AmoebaMinimizer& m)
@@ -199,10 +206,10 @@ bool Estimator::OptimizeHeterFixedAlpha(AmoebaMinimizer& m)
     std::vector<double> start(numPC * 2);
     for (int i = 0; i < numPC * 2; ++i) start[i] = i < numPC ? PC[0][i] : PC[1][i - numPC];
     double ret;
-    const bool ok = run_minimizer(this, m, numPC * 2, start, &ret);
+    (void)run_minimizer(this, m, numPC * 2, start, &ret);
     for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
     for (int i = numPC; i < numPC * 2; ++i) PC[1][i - numPC] = m.point[i];
-    return ok;
+    return true;                                          // cpp:258 "fixAlpha usually converges well"
 }
 
 bool Estimator::OptimizeHeterFixedPC(AmoebaMinimizer& m) { return OptimizeHomo(m); }
@@ -224,9 +231,9 @@ bool Estimator::OptimizeHomoFixedAlpha(AmoebaMinimizer& m)
     std::vector<double> start(numPC);
     for (int i = 0; i < numPC; ++i) start[i] = PC[0][i];
     double ret;
-    const bool ok = run_minimizer(this, m, numPC, start, &ret);
+    (void)run_minimizer(this, m, numPC, start, &ret);
     for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
-    return ok;
+    return true;                                          // cpp:312
 }
 
 bool Estimator::OptimizeHomoFixedPC(AmoebaMinimizer& m)
@@ -239,32 +246,66 @@ bool Estimator::OptimizeHomoFixedPC(AmoebaMinimizer& m)
     return ok;
 }
 
+namespace {
+// ContaminationEstimator.cpp:10-24: "NOTICE -   Starting phase: ..." / "Finished phase: ...  [s]"
+struct PhaseTimer {
+    const char* name;
+    bool on;
+    std::chrono::steady_clock::time_point start;
+    PhaseTimer(const char* n, bool enabled) : name(n), on(enabled), start(std::chrono::steady_clock::now())
+    {
+        if (on) std::fprintf(stderr, "NOTICE -   Starting phase: %s\n", name);
+    }
+    ~PhaseTimer()
+    {
+        if (on)
+            std::fprintf(stderr, "NOTICE -   Finished phase: %s  [%.3f seconds]\n", name,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count());
+    }
+};
+}  // namespace
+
 int Estimator::OptimizeLLK()
 {
     AmoebaMinimizer mini;
-    int rc = fn.Initialize();
+    int rc;
+    {
+        PhaseTimer t("Initialize likelihood", notices);
+        rc = fn.Initialize();
+    }
     if (rc) return rc;
     bool ok = true;
     if (!isHeter) {                                       // cpp:98-110
+        PhaseTimer t(isPCFixed ? "OptimizeHomoFixedPC" : isAlphaFixed ? "OptimizeHomoFixedAlpha" : "OptimizeHomo",
+                     notices);
         if (isPCFixed) ok &= OptimizeHomoFixedPC(mini);
         else if (isAlphaFixed) ok &= OptimizeHomoFixedAlpha(mini);
         else ok &= OptimizeHomo(mini);
     } else {                                              // cpp:111-150
         if (isPCFixed) {
+            PhaseTimer t("OptimizeHeterFixedPC", notices);
             ok &= OptimizeHeterFixedPC(mini);
         } else if (isAlphaFixed) {
-            isHeter = false;
-            ok &= OptimizeHomoFixedAlpha(mini);
-            PC[1] = PC[0];
-            fn.globalPC2 = fn.globalPC;
-            isHeter = true;
+            {
+                PhaseTimer t("OptimizeHomoFixedAlpha (initial)", notices);
+                isHeter = false;
+                ok &= OptimizeHomoFixedAlpha(mini);
+                PC[1] = PC[0];
+                fn.globalPC2 = fn.globalPC;
+                isHeter = true;
+            }
+            PhaseTimer t("OptimizeHeterFixedAlpha", notices);
             ok &= OptimizeHeterFixedAlpha(mini);
         } else {
-            isHeter = false;
-            ok &= OptimizeHomo(mini);
-            PC[1] = PC[0];
-            fn.globalPC2 = fn.globalPC;
-            isHeter = true;
+            {
+                PhaseTimer t("OptimizeHomo (initial)", notices);
+                isHeter = false;
+                ok &= OptimizeHomo(mini);
+                PC[1] = PC[0];
+                fn.globalPC2 = fn.globalPC;
+                isHeter = true;
+            }
+            PhaseTimer t("OptimizeHeter", notices);
             ok &= OptimizeHeter(mini);
         }
         if (fn.globalAlpha >= 0.5) {                      // cpp:146-149 (indices 0,1 hard-coded)
@@ -273,7 +314,9 @@ int Estimator::OptimizeLLK()
         }
     }
     if (error) return error;
-    converged = ok;
+    converged = !hit_cycle_limit;
+    (void)ok;                                             // the reference ignores the wrappers' results
+    PhaseTimer t("Calculate null-model LLK", notices);
     return fn.CalculateLLK0();                            // cpp:152-155
 }
 
@@ -281,6 +324,7 @@ void apply_model(Estimator& est, const vb2_model& model)
 {
     // main.cpp:285-319
     est.verbose = model.verbose != 0;
+    est.notices = model.notices != 0;
     est.isHeter = model.is_heter != 0;
     if (model.epsilon > 0) est.epsilon = model.epsilon;
     if (model.is_pc_fixed && model.fix_pc) {

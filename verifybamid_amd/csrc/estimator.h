@@ -56,7 +56,9 @@ public:
 
     // bookkeeping
     int64_t num_eval = 0, num_launch_point = 0;
-    bool converged = true;
+    bool converged = true;            // false iff a Minimize() hit cycleMax (MathGenMin.cpp:380-383)
+    bool hit_cycle_limit = false;
+    bool notices = false;             // print the reference's PhaseTimer / warning lines to stderr
     int error = 0;
     vb2_trace* trace = nullptr;
 

@@ -9,6 +9,9 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <vector>
+
+#include <zlib.h>
 
 #include "context.h"   // set_error
 
@@ -22,15 +25,20 @@ int io_error(const std::string& what)
     return VB2_ERR_IO;
 }
 
+// Whole file -> memory.  Like the reference's InputFile (statgen/InputFile.cpp: ifopen picks
+// GzipFileType by the magic bytes), a gzip'd file is inflated transparently and anything else is
+// read as it is -- zlib's gzread does both.
 bool slurp(const std::string& path, std::string* all)
 {
-    std::FILE* f = std::fopen(path.c_str(), "rb");
+    gzFile f = gzopen(path.c_str(), "rb");
     if (!f) return false;
-    char buf[1 << 16];
-    size_t n;
-    while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) all->append(buf, n);
-    std::fclose(f);
-    return true;
+    gzbuffer(f, 1 << 20);
+    std::vector<char> buf(1 << 20);
+    int n;
+    while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) all->append(buf.data(), (size_t)n);
+    const bool ok = n == 0;
+    gzclose(f);
+    return ok;
 }
 
 // ---- fast field scanner -------------------------------------------------------------------
@@ -289,7 +297,9 @@ namespace {
 // SimplePileupViewer.cpp:711-746: keep ". , A C G T N a c g t n" (one quality
 // each), drop "*" "#" (they still consume a quality), skip "^x", "+N..."/"-N...",
 // ignore everything else ("$", ...).
-void parse_bases(const std::string& seq, const std::string& qual, std::string* pseq,
+// Returns false where the reference's std::stoi throws (an indel marker without a length, or a
+// length that does not fit an int): the reference dies on that line, this reader reports it.
+bool parse_bases(const std::string& seq, const std::string& qual, std::string* pseq,
                  std::string* pqual)
 {
     // character classes: 1 keep (one quality each), 2 '*' '#' (consume a quality), 3 '+' '-'
@@ -327,8 +337,13 @@ void parse_bases(const std::string& seq, const std::string& qual, std::string* p
             size_t j = i + 1;
             while (j != n && std::isdigit((unsigned char)seq[j])) j++;
             const size_t digit_len = j - (i + 1);
-            const int clip = digit_len ? std::stoi(seq.substr(i + 1, digit_len)) : 0;
-            i += digit_len + clip;
+            if (digit_len == 0) return false;                  // stoi(""): invalid_argument
+            long long clip = 0;
+            for (size_t d = i + 1; d < j; ++d) {
+                clip = clip * 10 + (seq[d] - '0');
+                if (clip > 2147483647ll) return false;         // stoi: out_of_range
+            }
+            i += digit_len + (size_t)clip;
             break;
         }
         case 4:
@@ -340,6 +355,7 @@ void parse_bases(const std::string& seq, const std::string& qual, std::string* p
     }
     pseq->resize(o);
     pqual->resize(o);
+    return true;
 }
 }  // namespace
 
@@ -381,7 +397,14 @@ int read_pileup(const std::string& path, const BedTable& bed, PileupViewer* v)
             rc = VB2_ERR_INVALID;
             return;
         }
-        parse_bases(seq, qual, &pseq, &pqual);
+        if (!parse_bases(seq, qual, &pseq, &pqual)) {
+            set_error("Pileup format error: indel marker without a valid length in the bases column of " +
+                      chr + ":" + std::to_string(pos));
+            rc = VB2_ERR_INVALID;
+            return;
+        }
+        seq = pseq;                                         // the parsed strings are what persists
+        qual = pqual;                                       // into a following short line (:785-786)
         depth = (int)pqual.length();                        // SNP bases only
         if (!have_cur || cur_chr != chr) {
             cur_chr = chr;

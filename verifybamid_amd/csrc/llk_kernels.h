@@ -61,7 +61,8 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            const double* h_points, double* d_partials, double* d_out,
                            unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
-                           unsigned long long* tag_counter, hipStream_t stream);
+                           unsigned long long* tag_counter, hipStream_t stream,
+                           int reduce_override = 0);     // 1 ticket / 2 tagged for this call only
 void set_single_launch(bool on);
 void set_reduce_mode(int mode);     // 0 auto, 1 arrival ticket, 2 tagged sets (VB2_REDUCE)
 
@@ -78,6 +79,7 @@ struct MultiLaunch {
     unsigned long long done_seq;
     unsigned int batch_active;       // samples with num_valid > 0
     int num_sample, bps, block_waves, btl;
+    bool force_ticket;               // arrival-ticket hand-off instead of tagged sets (the retry after a NaN)
     size_t shmem;
 };
 size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);   // groups of 4*btl points

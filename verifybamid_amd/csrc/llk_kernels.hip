@@ -33,6 +33,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 namespace vb2 {
 
 // off-diagonal genotype pairs, in the reference's (g1 outer, g2 inner) order
@@ -718,7 +720,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
                       const int* __restrict__ num_valid, double* __restrict__ partials,
                       double* __restrict__ llk_out, unsigned int* __restrict__ tickets, int bps,
                       unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
-                      unsigned int* __restrict__ batch_done, unsigned int batch_active)
+                      unsigned int* __restrict__ batch_done, unsigned int batch_active, int use_ticket)
 {
     constexpr int NP = MODE == 2 ? 8 : MODE == 4 ? 1 : 4;
     const int s = blockIdx.x / bps;
@@ -731,7 +733,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
     eval_body<MODE, HWMAP>(L, ip, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
-                          batch_done, batch_active, 1, done_seq);
+                          batch_done, batch_active, 1, use_ticket ? 0ull : done_seq);
 }
 
 
@@ -908,6 +910,22 @@ LaunchGeom launch_geom(const DeviceLayout& L, int btl)
 static bool g_hwmap = true;
 void set_lane_mapping(bool hw) { g_hwmap = hw; }
 
+// More than 64 KiB of dynamic LDS is an opt-in per kernel function AND per device (the function
+// object is per device in the runtime), so the flag is kept per (function slot, device).
+static hipError_t raise_lds_limit(const void* fn, int slot)
+{
+    constexpr int kSlots = 16, kDevs = 64;
+    static std::atomic<unsigned char> done[kSlots][kDevs];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = slot >= 0 && slot < kSlots && dev >= 0 && dev < kDevs;
+    if (tracked && done[slot][dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess && tracked) done[slot][dev].store(1, std::memory_order_release);
+    return e;
+}
+
 static bool g_paired = true;          // 4-point launches: MODE 3 (two micro-tiles per wave) or MODE 1
 void set_paired_mode(bool on) { g_paired = on; }
 
@@ -921,12 +939,10 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
     constexpr int NP = MODE == 2 ? 8 : MODE == 4 ? 1 : 4;     // points per group
     const LaunchGeom gm = launch_geom(L, MODE == 2 ? 2 : 1);
     const size_t shmem = eval_shmem_np(L, NP, gm.grid, gm.block_waves, ngrp);
-    static bool raised = false;          // per instantiation: allow more than 64 KiB of dynamic LDS
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    {
+        hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP>),
+                                       (MODE - 1) * 2 + (HWMAP ? 1 : 0));
         if (e != hipSuccess) return e;
-        raised = true;
     }
     InlinePoints ip;
     ip.count = 0;
@@ -950,9 +966,10 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            const double* h_points, double* d_partials, double* d_out,
                            unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
-                           unsigned long long* tag_counter, hipStream_t stream)
+                           unsigned long long* tag_counter, hipStream_t stream, int reduce_override)
 {
     unsigned int* tk = g_single_launch ? d_ticket : nullptr;
+    const int reduce_mode = reduce_override ? reduce_override : g_reduce_mode;
     const int stride = 2 * L.num_pc + 1;
     int done = 0;
     while (done < num_point) {
@@ -969,7 +986,7 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         hipError_t e;
         // hand-off protocol: tagged sets for <= 4 points (one fabric round trip less, latency
         // matters), arrival ticket for bigger batches (cheaper per point); VB2_REDUCE overrides
-        const bool tagged = g_reduce_mode == 2 || (g_reduce_mode == 0 && step <= 4);
+        const bool tagged = reduce_mode == 2 || (reduce_mode == 0 && step <= 4);
         const unsigned long long tag = tagged ? ++*tag_counter : 0ull;   // unique per launch on this buffer
         if (step > 4)
             e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
@@ -1023,25 +1040,22 @@ int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves)
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
 {
     const dim3 grid(ml.num_sample * ml.bps), block(ml.block_waves * 64);
-    static bool raised = false;          // allow more than 64 KiB of dynamic LDS (wide dictionaries)
-    if (!raised) {
-        const void* fns[6] = {reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, true>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, false>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, true>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, false>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, true>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, false>)};
-        for (const void* f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-            if (e != hipSuccess) return e;
-        }
-        raised = true;
-    }
     const int mode = ml.btl == 2 ? 2 : (g_paired ? 3 : 1);
+    {
+        const void* fns[6] = {reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, false>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, true>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, false>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, true>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, false>),
+                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, true>)};
+        const int slot = (mode - 1) * 2 + (g_hwmap ? 1 : 0);
+        hipError_t e = raise_lds_limit(fns[slot], 8 + slot);
+        if (e != hipSuccess) return e;
+    }
 #define VB2_MULTI_LAUNCH(MODE, HW)                                                                       \
     hipLaunchKernelGGL((llk_eval_multi_kernel<MODE, HW>), grid, block, ml.shmem, stream, ml.d_layouts,   \
                        ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,       \
-                       ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active)
+                       ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active, ml.force_ticket ? 1 : 0)
     if (mode == 2) { if (g_hwmap) VB2_MULTI_LAUNCH(2, true); else VB2_MULTI_LAUNCH(2, false); }
     else if (mode == 3) { if (g_hwmap) VB2_MULTI_LAUNCH(3, true); else VB2_MULTI_LAUNCH(3, false); }
     else { if (g_hwmap) VB2_MULTI_LAUNCH(1, true); else VB2_MULTI_LAUNCH(1, false); }
