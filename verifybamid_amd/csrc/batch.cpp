@@ -30,6 +30,7 @@ Batch::~Batch()
 {
     if (device >= 0) (void)hipSetDevice(device);
     if (d_layouts_) (void)hipFree(d_layouts_);
+    if (d_sched_) (void)hipFree(d_sched_);
     if (d_partials_) (void)hipFree(d_partials_);
     if (d_tickets_) (void)hipFree(d_tickets_);
     if (d_batch_done_) (void)hipFree(d_batch_done_);
@@ -68,6 +69,7 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
         b->ctx_.push_back(c);
         layouts[s] = c->L;
         layouts[s].stamps = nullptr;
+        if (c->L.row_bytes != kRowBytesWide) b->wide_rows_ = false;
         max_mt = std::max(max_mt, c->L.num_mt);
     }
     VB2_HIP(hipSetDevice(b->device));
@@ -94,6 +96,49 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
     const size_t S = (size_t)num_sample, stride = 2 * (size_t)k + 1;
     VB2_HIP(hipMalloc((void**)&b->d_layouts_, sizeof(DeviceLayout) * S));
     VB2_HIP(hipMemcpy(b->d_layouts_, layouts.data(), sizeof(DeviceLayout) * S, hipMemcpyHostToDevice));
+    // static schedules (llk_kernels.h) of every sample for the two wave shapes of a step:
+    // btl 1 = <= 4 points per sample (two tiles per wave when paired), btl 2 = 8 points
+    if (b->ctx_[0]->sched_enabled) {
+        std::vector<char> blob;
+        std::vector<size_t> where[2];
+        bool ok = true;
+        for (int btl = 1; btl <= 2 && ok; ++btl)
+            for (int s = 0; s < num_sample && ok; ++s) {
+                std::vector<uint32_t> off;
+                std::vector<uint16_t> item;
+                Context* c = b->ctx_[s];
+                if (c->L.num_mt == 0) { where[btl - 1].push_back((size_t)-1); continue; }
+                ok = build_schedule(c->h_mt_rows.data(), c->L.num_mt, bps, b->block_waves_,
+                                    btl == 1 && paired_mode() ? 2 : 1, 1, &off, &item);
+                if (!ok) break;
+                blob.resize((blob.size() + 15) / 16 * 16);
+                where[btl - 1].push_back(blob.size());
+                const size_t ob = (off.size() * sizeof(uint32_t) + 15) / 16 * 16;
+                blob.resize(blob.size() + ob + item.size() * sizeof(uint16_t));
+                std::memcpy(blob.data() + where[btl - 1].back(), off.data(), off.size() * sizeof(uint32_t));
+                std::memcpy(blob.data() + where[btl - 1].back() + ob, item.data(), item.size() * sizeof(uint16_t));
+            }
+        if (ok) {
+            blob.resize((blob.size() + 15) / 16 * 16);
+            const size_t arr0 = blob.size();
+            VB2_HIP(hipMalloc((void**)&b->d_sched_, arr0 + 2 * S * sizeof(Schedule)));
+            std::vector<Schedule> arr(2 * S, Schedule{nullptr, nullptr});
+            for (int btl = 1; btl <= 2; ++btl)
+                for (size_t s = 0; s < S; ++s) {
+                    const size_t w = where[btl - 1][s];
+                    if (w == (size_t)-1) continue;
+                    const Context* c = b->ctx_[s];
+                    (void)c;
+                    const uint32_t* o = reinterpret_cast<const uint32_t*>(b->d_sched_ + w);
+                    const size_t ob = (((size_t)bps * b->block_waves_ + 1) * sizeof(uint32_t) + 15) / 16 * 16;
+                    arr[(btl - 1) * S + s] = Schedule{o, reinterpret_cast<const uint16_t*>(b->d_sched_ + w + ob)};
+                }
+            VB2_HIP(hipMemcpy(b->d_sched_, blob.data(), arr0, hipMemcpyHostToDevice));
+            VB2_HIP(hipMemcpy(b->d_sched_ + arr0, arr.data(), 2 * S * sizeof(Schedule), hipMemcpyHostToDevice));
+            b->d_scheds_[0] = reinterpret_cast<const Schedule*>(b->d_sched_ + arr0);
+            b->d_scheds_[1] = b->d_scheds_[0] + S;
+        }
+    }
     VB2_HIP(hipMalloc((void**)&b->d_partials_, sizeof(double) * S * (kSlot + 1) * bps));
     VB2_HIP(hipMemset(b->d_partials_, 0, sizeof(double) * S * (kSlot + 1) * bps));
     VB2_HIP(hipMalloc((void**)&b->d_tickets_, sizeof(unsigned int) * S));
@@ -130,6 +175,27 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
         max_n = std::max(max_n, (int)num_point[s]);
     }
     if (max_n == 0) return VB2_OK;
+    if (max_n > 4 && !wide_rows_) {
+        // a sample with a very wide dictionary has narrow table rows: 4 points per launch at most
+        const size_t S = (size_t)num_sample;
+        std::vector<int32_t> np(S);
+        std::vector<double> p1(S * kSlot * k), p2(S * kSlot * k), al(S * kSlot), lo(S * kSlot);
+        for (int half = 0; half < 2; ++half) {
+            for (size_t s = 0; s < S; ++s) {
+                np[s] = std::max(0, std::min(4, (int)num_point[s] - 4 * half));
+                for (int j = 0; j < np[s]; ++j) {
+                    const size_t src = s * kSlot + 4 * half + j, dst = s * kSlot + j;
+                    std::memcpy(&p1[dst * k], pc1 + src * k, sizeof(double) * k);
+                    std::memcpy(&p2[dst * k], pc2 + src * k, sizeof(double) * k);
+                    al[dst] = alpha[src];
+                }
+            }
+            if (int rc = eval(np.data(), p1.data(), p2.data(), al.data(), lo.data())) return rc;
+            for (size_t s = 0; s < S; ++s)
+                for (int j = 0; j < np[s]; ++j) llk_out[s * kSlot + 4 * half + j] = lo[s * kSlot + j];
+        }
+        return VB2_OK;
+    }
     const int btl = max_n > 4 ? 2 : 1, NP = 4 * btl;
     for (int s = 0; s < num_sample; ++s) {
         int n = num_point[s];
@@ -150,6 +216,7 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
     if (active == 0) return VB2_OK;
     MultiLaunch ml{};
     ml.d_layouts = d_layouts_;
+    ml.d_scheds = d_scheds_[btl - 1];
     ml.d_points = d_points_;
     ml.d_num_valid = d_nv_;
     ml.d_partials = d_partials_;

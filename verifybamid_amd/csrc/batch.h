@@ -28,6 +28,8 @@ private:
     std::vector<Context*> ctx_;
     hipStream_t stream_ = nullptr;
     DeviceLayout* d_layouts_ = nullptr;
+    char* d_sched_ = nullptr;               // the samples' static schedules + the two Schedule[num_sample] arrays
+    const Schedule* d_scheds_[2] = {nullptr, nullptr};    // [btl - 1]
     double* d_partials_ = nullptr;
     unsigned int* d_tickets_ = nullptr;
     unsigned int* d_batch_done_ = nullptr;
@@ -37,6 +39,7 @@ private:
     unsigned long long *h_done_ = nullptr, *d_done_ = nullptr;
     unsigned long long seq_ = 0;
     int bps_ = 1, block_waves_ = 16;
+    bool wide_rows_ = true;                 // every sample has kRowBytesWide table rows (8-point launches allowed)
     size_t shmem_[2] = {0, 0};
 };
 

@@ -262,7 +262,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
                 if (depth == 0) continue;
                 if (!in->sanity_disabled && ((double)depth < lo || (double)depth > hi)) continue;
                 // steps of this marker in the kernel = runs of equal (class, quality): one
-                // (code, count) pair per distinct code, counts above 255 split
+                // (code, count) pair per distinct code, counts above kMaxRunCount split
                 const char alt = in->alt_base[i];
                 touched.clear();
                 for (int64_t j = 0; j < depth; ++j) {
@@ -275,7 +275,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
                 }
                 int32_t eff = 0;
                 for (int c2 : touched) {
-                    eff += (local_hist[c2] + 254) / 255;
+                    eff += (local_hist[c2] + kMaxRunCount - 1) / kMaxRunCount;
                     local_hist[c2] = 0;
                 }
                 n_read += depth;
@@ -345,10 +345,21 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     std::vector<uint2> mt_rec(num_mt);
     for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rows[t]);
 
-    // a dword holds two runs: code0 | count0<<8 | code1<<16 | count1<<24; unused slots hold
-    // the padding code = num_code (a zero row of the LDS table) with count 0
-    const uint32_t pad4 = 0x00010001u * (uint32_t)num_code;
-    std::vector<uint32_t> codes((size_t)total_rows * kMtMarkers, pad4);
+    // A run is one dword: low half = byte offset of the code's row in the LDS table (pre-multiplied:
+    // the kernel adds it to the table's address), high half = the top 16 bits of the IEEE double
+    // `count` (sign, exponent, 4 mantissa bits: exact for 1..31; the kernel masks it into the high
+    // word of a double whose low word is 0).  Unused slots: the padding row (zeros) with count +0.0.
+    // Two runs per (row, marker) entry.  16-bit offsets reach 163 wide rows; a bigger dictionary
+    // gets the narrow rows (and 4-point launches only).
+    const int row_bytes = num_code <= kMaxWideCodes ? kRowBytesWide : kRowBytesNarrow;
+    auto run_word = [&](int d, uint32_t n) {
+        const double nd = (double)n;
+        unsigned long long bits;
+        std::memcpy(&bits, &nd, sizeof(bits));
+        return (uint32_t)(d * row_bytes) | ((uint32_t)(bits >> 48) << 16);
+    };
+    const uint32_t pad4 = run_word(num_code, 0);
+    std::vector<uint32_t> codes((size_t)(total_rows + kCodeSlackRows) * kMtMarkers * 2, pad4);   // + prefetch slack
     std::vector<double> ud_s((size_t)k * m_pad, 0.0), mu_s(m_pad, 0.0), cdiag((size_t)4 * m_pad, 0.0);
     std::vector<double> kaf_s;
     if (in->known_af) kaf_s.assign(m_pad, 0.0);
@@ -376,14 +387,12 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         // runs in dictionary order: lanes of a wave then tend to hit the same or
         // neighbouring LDS table rows at the same step (bank-friendly)
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
-        uint8_t* row0 = reinterpret_cast<uint8_t*>(&codes[(size_t)mt_row_off[t] * kMtMarkers]);
+        uint32_t* row0 = &codes[(size_t)mt_row_off[t] * kMtMarkers * 2];
         size_t j = 0;
         for (int d : touched) {
             for (uint32_t left = run_of[d]; left > 0;) {
-                const uint32_t n = left > 255 ? 255 : left;
-                uint8_t* slot = row0 + ((j >> 1) * kMtMarkers + lane) * 4 + (j & 1) * 2;
-                slot[0] = (uint8_t)d;
-                slot[1] = (uint8_t)n;
+                const uint32_t n = left > (uint32_t)kMaxRunCount ? (uint32_t)kMaxRunCount : left;
+                row0[((j >> 1) * kMtMarkers + lane) * 2 + (j & 1)] = run_word(d, n);
                 left -= n;
                 ++j;
             }
@@ -449,6 +458,14 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     const size_t o_ticket = carve(sizeof(unsigned int));
     const size_t o_relay = carve(sizeof(unsigned long long) * relay_words);
     const size_t o_stamps = carve(want_stamps ? sizeof(unsigned long long) * 8 * nb : 0);
+    // room for the static schedules of the nine launch shapes (filled on first use)
+    size_t o_sched[9], sched_bytes[9];
+    for (int slot = 0; slot < 9; ++slot) {
+        const int tpu = slot == 7 ? 2 : slot == 8 ? 4 : 1, ngrp = slot < 6 ? slot + 1 : 1;
+        const size_t items = (size_t)((num_mt + tpu - 1) / tpu + nb) * ngrp;     // (+ per-workgroup round-up)
+        sched_bytes[slot] = (((size_t)nb * kMaxBlockWaves + 1) * sizeof(uint32_t) + 15) / 16 * 16 + items * sizeof(uint16_t);
+        o_sched[slot] = carve(sched_bytes[slot]);
+    }
     dev_total = (dev_total + 255) & ~(size_t)255;
     c->d_slab = slab_cache().take(slab_cache().dev, dev_total, dev, &c->d_slab_bytes);
     if (!c->d_slab) {
@@ -475,7 +492,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     VB2_HIP(put(o_cd, cdiag.data(), cdiag.size() * sizeof(double)));
     VB2_HIP(put(o_dpe, dict_perr.data(), dict_perr.size() * sizeof(double)));
     VB2_HIP(put(o_prim, prim.data(), prim.size() * sizeof(double2)));
-    L.codes = reinterpret_cast<const uint32_t*>(dbase + o_codes);
+    L.codes = reinterpret_cast<const uint2*>(dbase + o_codes);
     L.mt_rec = reinterpret_cast<const uint2*>(dbase + o_rec);
     L.ediag = reinterpret_cast<const double*>(dbase + o_cd);
     L.dict_perr = reinterpret_cast<const double*>(dbase + o_dpe);
@@ -487,12 +504,20 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         c->d_stamps = reinterpret_cast<unsigned long long*>(dbase + o_stamps);
         L.stamps = c->d_stamps;
     }
+    for (int slot = 0; slot < 9; ++slot) {
+        c->sched_[slot].d_base = dbase + o_sched[slot];
+        c->sched_[slot].bytes = sched_bytes[slot];
+    }
+    c->h_mt_rows.assign(mt_rows.begin(), mt_rows.end());
+    if (const char* sc = std::getenv("VB2_SCHED")) c->sched_enabled = std::atoi(sc) != 0;
     c->device_bytes = (int64_t)dev_total;
     L.num_prim = (int32_t)prim.size();
     L.num_code = num_code;
+    L.row_bytes = row_bytes;
     L.num_mt = num_mt;
     L.num_cu = num_cu;
-    L.ablate = std::getenv("VB2_ABLATE") ? std::atoi(std::getenv("VB2_ABLATE")) : 0;
+    L.dyn_limit = std::getenv("VB2_DYN_TILES") ? std::atoi(std::getenv("VB2_DYN_TILES")) : 10;
+    L.stagger = std::getenv("VB2_STAGGER") ? std::atoi(std::getenv("VB2_STAGGER")) : 0;
     L.num_pc = k;
     L.num_active = m_active;
     L.m_pad = m_pad;
@@ -569,8 +594,31 @@ int Context::eval_device(int num_point, const double* d_pts, double* d_llk, hipS
         return VB2_OK;
     }
     VB2_HIP(launch_llk_eval(L, num_point, d_pts, h_pts, d_partials, d_llk, d_ticket, done_flag, done_seq,
-                            &done_seq_, s, reduce_override));
+                            &done_seq_, s, reduce_override, this));
     return VB2_OK;
+}
+
+Schedule Context::get(int mode, int ngrp, int grid, int block_waves)
+{
+    SchedSlot& sl = sched_[sched_slot(mode, ngrp)];
+    if (sl.tried || !sched_enabled) return sl.s;
+    sl.tried = true;                                     // a failure below leaves the snake deal in place
+    std::vector<uint32_t> off;
+    std::vector<uint16_t> item;
+    const int tpu = mode == 3 ? 2 : mode == 4 ? 4 : 1;
+    if (!build_schedule(h_mt_rows.data(), L.num_mt, grid, block_waves, tpu, ngrp, &off, &item)) return sl.s;
+    const size_t off_bytes = (off.size() * sizeof(uint32_t) + 15) / 16 * 16;
+    if (off_bytes + item.size() * sizeof(uint16_t) > sl.bytes) return sl.s;
+    if (hipMemcpyAsync(sl.d_base, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(sl.d_base + off_bytes, item.data(), item.size() * sizeof(uint16_t), hipMemcpyHostToDevice,
+                       stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {   // (pageable sources: the copies are staged before this returns)
+        (void)hipGetLastError();
+        return sl.s;
+    }
+    sl.s.off = reinterpret_cast<const uint32_t*>(sl.d_base);
+    sl.s.item = reinterpret_cast<const uint16_t*>(sl.d_base + off_bytes);
+    return sl.s;
 }
 
 // One resident search per device at a time (all its workgroups must be on the CUs together).
@@ -598,6 +646,11 @@ bool Context::resident_begin()
         ra.h_state = d_state;
         ra.first_seq = done_seq_ + 1;
         ra.timeout_ticks = 100000000ull;                  // 1 s without a command: give up
+        {
+            const LaunchGeom gm = launch_geom(L, 1);
+            ra.sched_multi = get(paired_mode() ? 3 : 1, 1, gm.grid, gm.block_waves);
+            ra.sched_single = paired_mode() ? get(4, 1, gm.grid, gm.block_waves) : ra.sched_multi;
+        }
         ok = launch_llk_resident(L, ra, d_partials, d_ticket, stream) == hipSuccess;
         if (!ok) (void)hipGetLastError();
     }

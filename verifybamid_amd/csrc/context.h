@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "../../include/vb2_abi.h"
 #include "llk_kernels.h"
@@ -22,9 +23,21 @@ extern std::atomic<int> g_flatten_thread_cap;   // 0 = no cap on the flatten thr
 
 constexpr int kStagePoints = 256;   // points per host<->device staging round
 
-class Context {
+class Context : public ScheduleProvider {
 public:
     ~Context();
+    // static work schedule of a launch shape, built on first use (llk_kernels.h: Schedule)
+    Schedule get(int mode, int ngrp, int grid, int block_waves) override;
+    static int sched_slot(int mode, int ngrp) { return mode == 2 ? ngrp - 1 : mode == 1 ? 6 : mode == 3 ? 7 : 8; }
+    struct SchedSlot {
+        bool tried = false;
+        Schedule s{nullptr, nullptr};
+        char* d_base = nullptr;              // reserved space in the device slab
+        size_t bytes = 0;
+    };
+    SchedSlot sched_[9];
+    bool sched_enabled = true;               // VB2_SCHED=0: in-kernel snake deal
+    std::vector<uint32_t> h_mt_rows;         // rows per micro-tile (host copy: the schedules are built from it)
     static int create(const vb2_input* in, const vb2_options* opt, Context** out);
     // device pointers, asynchronous on s (nullptr = own stream)
     int eval_device(int num_point, const double* d_points, double* d_llk, hipStream_t s,

@@ -6,6 +6,8 @@
 #include <hip/hip_vector_types.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace vb2 {
 
 constexpr int kNumQual = 94;             // Phred 0..93 (ContaminationEstimator.h:65-74)
@@ -16,12 +18,16 @@ constexpr int kMaxBlockWaves = 16;       // 1024-thread blocks at most
 constexpr int kMaxGroups = 6;             // groups of 8 points per launch
 constexpr int kMaxPointsPerLaunch = 8 * kMaxGroups;
 constexpr int kLdsLimitBytes = 160 * 1024;
+constexpr int kRowBytesWide = 400;         // 8 points x 6 doubles + 2 doubles of padding (25 16-byte slots: odd)
+constexpr int kRowBytesNarrow = 208;       // 4 points x 6 doubles + 2 (13 slots)
+constexpr int kMaxWideCodes = 65535 / kRowBytesWide - 1;   // run words hold 16-bit byte offsets (pad row included)
+constexpr int kMaxRunCount = 31;           // the 16-bit prefix of a double holds integers up to 31 exactly
 constexpr int kInlinePointDoubles = 96;    // parameter rows that travel as kernel arguments (768 B)
 
 // Everything the kernels read, in HBM.  "Sorted order" = active markers sorted by
 // (non-"other") depth, descending; position = micro_tile*16 + m.
 struct DeviceLayout {
-    const uint32_t* codes;        // [sum_t mt_rows[t]][16] dwords = two (code, count) runs each
+    const uint2* codes;           // [sum_t mt_rows[t]][16] x {run, run}; run = row byte offset | hi16(double count) << 16
     const uint2* mt_rec;          // [num_mt] {first row, rows = ceil(most runs in the tile / 2)}
     const double* ud;             // [num_pc][m_pad]  (SoA)
     const double* mu;             // [m_pad]
@@ -32,21 +38,50 @@ struct DeviceLayout {
                                   // twin << 16}, twin = the alt code of the same quality (its row is the mirror
                                   // image of this one) or 0xffff
     int32_t num_code;
+    int32_t row_bytes;            // LDS table row stride: kRowBytesWide, or kRowBytesNarrow for > kMaxWideCodes codes
     int32_t num_prim;
     int32_t num_mt;
     int32_t num_pc;
     int32_t num_cu;               // compute units of the device
-    int32_t ablate;               // profiling aid (VB2_ABLATE): 1 no table math, 2 no read loop, 4 no epilogue math
+    int32_t dyn_limit;            // work items per wave up to which the waves of a workgroup pull items from an
+                                  // LDS queue (per-item result slots); above it the static snake deal.
+                                  // default 10 (the queue adapts to the waves' actual speeds: 76.5 us against
+                                  // 78.1 us for the host-built static schedule at 9 items per wave);
+                                  // VB2_DYN_TILES=n is the A/B knob, 0 = always static
+    int32_t stagger;              // the second half of a workgroup's waves starts its tiles this many x 64
+                                  // cycles late (VB2_STAGGER): de-phases the LDS-bound read loops and the
+                                  // VALU-bound epilogues of the waves that share a SIMD
+    int32_t reserved0;
     unsigned long long* stamps;   // profiling aid: [grid][8] wall-clock stamps, or nullptr
     int64_t num_active;
     int64_t m_pad;                // num_mt * 16
+};
+
+// Static work schedule of one launch shape: wave w of workgroup b evaluates the work items
+// item[off[b * waves + w] .. off[b * waves + w + 1]) (indices into the workgroup's (group, unit)
+// item list, sorted by group).  Built on the host from the tiles' row counts (longest-processing-
+// time-first over the waves of a workgroup: the balance of a dynamic queue, but a FIXED order, so a
+// lane can keep one running product in registers).  Null pointers = snake deal computed in-kernel.
+struct Schedule {
+    const uint32_t* off;
+    const uint16_t* item;
+};
+// Host side: off/item for `nblk` workgroups of `nwave` waves; tiles_per_unit = micro-tiles a wave
+// takes per item (1, 2 or 4), ngrp = point groups of the launch.  rows[t] = rows of micro-tile t.
+// Returns false (and leaves the vectors empty) when a workgroup has more than 65535 items.
+bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int tiles_per_unit, int ngrp,
+                    std::vector<uint32_t>* off, std::vector<uint16_t>* item);
+// Supplies the schedule of a launch shape (mode = wave shape 1..4 of llk_kernels.hip).
+struct ScheduleProvider {
+    virtual Schedule get(int mode, int ngrp, int grid, int block_waves) = 0;
+    virtual ~ScheduleProvider() {}
 };
 
 struct LaunchGeom { int grid, block_waves; };
 // Workgroups / waves per workgroup used for a launch of 4*btl points.
 LaunchGeom launch_geom(const DeviceLayout& L, int btl);
 constexpr int kMaxGridPerCU = 2;
-constexpr int kDynTilesPerWave = 10;      // up to this many tiles per wave: dynamic queue + per-tile slots
+constexpr int kCodeSlackRows = 16;        // padding rows after the last tile: the read loop prefetches unconditionally
 inline int max_grid(const DeviceLayout& L) { return kMaxGridPerCU * L.num_cu; }
 
 // Enqueue evaluation of num_point candidate rows (pc1 | pc2 | alpha) on stream.
@@ -62,13 +97,15 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
                            unsigned long long* tag_counter, hipStream_t stream,
-                           int reduce_override = 0);     // 1 ticket / 2 tagged for this call only
+                           int reduce_override = 0,      // 1 ticket / 2 tagged for this call only
+                           ScheduleProvider* sched = nullptr);
 void set_single_launch(bool on);
 void set_reduce_mode(int mode);     // 0 auto, 1 arrival ticket, 2 tagged sets (VB2_REDUCE)
 
 // One launch over several samples (contexts on the same device): see llk_eval_multi_kernel.
 struct MultiLaunch {
     const DeviceLayout* d_layouts;   // [num_sample] in HBM
+    const Schedule* d_scheds;        // [num_sample] in HBM (this launch's wave shape), or nullptr
     const double* d_points;          // [num_sample][4*btl][2k+1]
     const int* d_num_valid;          // [num_sample] 0 = sample sits this step out
     double* d_partials;              // [num_sample][4*btl + 1][bps]; done_seq doubles as the launch tag
@@ -99,6 +136,7 @@ struct ResidentArgs {
     unsigned int* h_state;               // 1 running, 2 exited on command, 3 gave up (idle timeout)
     unsigned long long first_seq;        // sequence number of the first command
     unsigned long long timeout_ticks;    // idle limit in 100 MHz wall-clock ticks
+    Schedule sched_multi, sched_single;  // static schedules of the 2..4-point and the 1-point wave shape
 };
 __host__ __device__ inline unsigned long long resident_mix(unsigned long long seq)
 {
@@ -115,6 +153,7 @@ __host__ __device__ inline unsigned long long word_hash(unsigned long long v, un
     return z ^ (z >> 29);
 }
 inline int resident_words(int num_pc) { return 2 + 4 * (2 * num_pc + 1) + 1; }
+bool paired_mode();
 void set_paired_mode(bool on);     // VB2_PAIRED=0: 4-point launches use MODE 1 instead of MODE 3
 void set_coop_launch(bool on);     // VB2_COOP=1: cooperative launch of the resident kernel
 hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, double* d_partials,

@@ -33,7 +33,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <vector>
 
 namespace vb2 {
 
@@ -53,36 +55,83 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// exp(x) for x <= 0 (arguments here are sums of log-probabilities), FP64, <= 1 ulp:
-// x = k*ln2 + r, |r| <= ln2/2; degree-13 Taylor polynomial in r (truncation 4e-18);
+// 2^(j/64), j = 0..63, correctly rounded (generated with 60-digit decimal arithmetic).
+__device__ const double kExp2Tab[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+
+// exp(x) for x <= 0 (arguments here are sums of log-probabilities), FP64, <= 1.1 ulp:
+// x = k*ln2/64 + r, |r| <= ln2/128; exp(x) = 2^(k>>6) * 2^((k&63)/64) * (1 + p(r)), p = the degree-6
+// Taylor polynomial of exp(r)-1 (truncation 2e-19), the 2^(j/64) factor from an LDS table.
+// 17 VALU instructions + one ds_read_b64, against 23 for the table-free form (degree 13).
+// `etab_lane` = LDS byte address of this lane's column of the bank-replicated table: entry j sits
+// 256*j bytes further, i.e. in LDS banks 2*(lane%32), 2*(lane%32)+1 whatever j is, so the
+// 64 lanes' lookups of a wave never conflict (a 512-byte table would: random j's collide).
 // 2^k applied with ldexp so results degrade gracefully into subnormals and reach 0
 // exactly where the reference's exp() underflows (the `markerLK > 0` test, h:310).
-__device__ __forceinline__ double exp_nonpos(double x)
+// v_max_f64 / v_min_f64 as single instructions: the compiler's fmax/fmin lowering first
+// canonicalises an operand it cannot prove free of signalling NaNs (one more v_max_f64 x, x);
+// the hardware instruction quiets them by itself.
+__device__ __forceinline__ double vmax_f64(double x, double c)
 {
-    const double kLog2e = 1.4426950408889634074;
-    const double kLn2Hi = 6.93147180369123816490e-01;   // ln2 split (fdlibm constants)
-    const double kLn2Lo = 1.90821492927058770002e-10;
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double vmin_f64(double x, double c)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(c));
+    return r;
+}
+
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+typedef double __attribute__((ext_vector_type(2))) vdouble2;      // (a plain vector: loadable through address_space(3))
+typedef __attribute__((address_space(3))) const vdouble2 lds_cdouble2;
+__device__ __forceinline__ uint32_t lds_byte_addr(const void* p)      // generic pointer into LDS -> LDS address
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+__device__ __forceinline__ double exp_nonpos(double x, uint32_t etab_lane)
+{
+    const double kInvStep = 0x1.71547652b82fep+6;        // 64/ln2
+    const double kStepHi = 0x1.62e42fee00000p-7;         // ln2/64, 32 significant bits: k*hi is exact
+    const double kStepLo = 0x1.a39ef35793c76p-39;
+    const double kMagic = 0x1.8p52;                      // 2^52 + 2^51: x + kMagic rounds x to an integer
     // below -800 the result is 0 anyway (2^-1154); the clamp also maps -inf to a finite
     // argument, so no special case is needed after the ldexp
-    x = fmax(x, -800.0);
-    const double kd = rint(x * kLog2e);
-    double r = fma(-kd, kLn2Hi, x);
-    r = fma(-kd, kLn2Lo, r);
-    double p = 1.0 / 6227020800.0;                      // 1/13!
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
+    x = vmax_f64(x, -800.0);
+    // k = rint(x * 64/ln2) by the magic-number addition: the low mantissa word of the sum IS the
+    // integer (two's complement), so no v_rndne / v_cvt_i32 pair
+    const double tk = fma(x, kInvStep, kMagic);
+    const int k = __double2loint(tk);
+    const double kd = tk - kMagic;
+    double r = fma(-kd, kStepHi, x);
+    r = fma(-kd, kStepLo, r);
+    // (the table sits at LDS address 0 and etab_lane < 256, so the index bits are OR-ed in:
+    // one v_lshlrev + one v_and_or)
+    const double t = *reinterpret_cast<lds_cdouble*>((((uint32_t)k << 8) & 0x3f00u) | etab_lane);
+    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
     p = fma(p, r, 1.0 / 24.0);
     p = fma(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)kd);
+    p = fma(p, r * r, r);
+    return ldexp(fma(t, p, t), k >> 6);
 }
 
 // log(x) for x >= 0, FP64 (fdlibm's e_log algorithm with explicit FMAs, ~1 ulp):
@@ -134,6 +183,14 @@ __device__ __forceinline__ void sp_renorm(ScaledProd& p)
     p.e += (double)__builtin_amdgcn_frexp_exp(p.m);
     p.m = __builtin_amdgcn_frexp_mant(p.m);
 }
+// The per-lane running product of the static deal: integer exponent (one v_add_u32 per marker)
+// and a mantissa that is only renormalised every kLazyRenorm factors -- each factor is a
+// mantissa in [0.5, 1), so 256 of them cannot underflow.
+struct LaneProd {
+    double m;
+    int e;
+};
+constexpr int kLazyRenorm = 256;
 
 // One table entry, with the reference's expression order (h:223-225).
 // perr_signed = +pErr(q) for class ref, -pErr(q) for class alt (one load per code;
@@ -157,20 +214,22 @@ __device__ __forceinline__ double table_entry(double alpha, double perr_signed, 
 
 __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
 {
-    if (af < 0.00005) af = 0.00005;
-    if (af > 0.99995) af = 0.99995;
+    // (v_max_f64 / v_min_f64 instead of compare + select; a NaN allele frequency -- NaN
+    // parameters -- becomes min_af here where the reference keeps the NaN)
+    af = vmin_f64(vmax_f64(af, 0.00005), 0.99995);
     gf[0] = (1 - af) * (1 - af);
     gf[1] = 2 * (af) * (1 - af);
     gf[2] = af * af;
 }
 
-// Row stride (in doubles) of the LDS table: 6 values per candidate point, padded so
-// that the stride in 16-byte slots is odd -> 16 consecutive codes land in 16 distinct
-// 4-dword bank slots for ds_read_b128 (bank = (addr/4) % 64).
-__host__ __device__ constexpr int row_stride(int npoint)
-{
-    return 6 * npoint + (((3 * npoint) % 2 == 0) ? 2 : 0);
-}
+// Row stride of the LDS table: L.row_bytes (llk_kernels.h: kRowBytesWide = 6 values x 8 points
+// + 2 doubles of padding, or kRowBytesNarrow = 6 x 4 + 2), the same for every wave shape of a
+// context because the run words of the pileup carry PRE-MULTIPLIED row offsets.  Either stride
+// is an odd number of 16-byte slots -> 16 consecutive codes land in 16 distinct 4-dword bank
+// slots for ds_read_b128 (bank = (addr/4) % 64).
+
+constexpr int kExpTabDoubles = 64 * 32;    // exp_nonpos's table in LDS (16 KiB)
+constexpr int kPrefetch = 8;               // rows of run dwords in flight per lane
 
 // Lane -> (marker m in the micro-tile, candidate slot g).
 // HWMAP: the 16 lanes that ds_read_b128 services in one LDS pass (lanes {0-3,12-15,
@@ -237,14 +296,14 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
           unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
           unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
           unsigned int* __restrict__ batch_done, unsigned int batch_active, const int ngrp,
-          const unsigned long long tag, const bool coherent_points = false)
+          const unsigned long long tag, const Schedule sch, const bool coherent_points = false)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int BTL = (MODE == 1 || MODE == 4) ? 1 : 2;
     constexpr int TPW = MODE == 3 ? 2 : MODE == 4 ? 4 : 1;   // micro-tiles per wave
     constexpr int SLOTS = 4 / TPW;                           // candidate slots per wave
     constexpr int NP = SLOTS * BTL;
-    constexpr int RS = row_stride(NP);
+    const int RS = L.row_bytes >> 3;            // doubles per table row (>= 6 * NP + 2)
     const int nrow = L.num_code + 1;
     const int nthread = blockDim.x;
     const int nwave = nthread >> 6;
@@ -254,21 +313,26 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // (tile, group) pairs are the work items, so a bigger batch re-reads the pileup from
     // L2 per group but pays launch, prologue and reduction once.
     const int NPT = NP * ngrp;                  // points of this launch
-    double* tab = lds;                          // [ngrp][nrow][RS]
-    double* red = lds + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
+    double* etab = lds;                         // [64][32] exp_nonpos's 2^(j/64), bank-replicated; at LDS address 0
+    double* tab = lds + kExpTabDoubles;         // [ngrp][nrow][RS]
+    double* red = tab + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
     unsigned int* queue = reinterpret_cast<unsigned int*>(red + NPT);
     double* pts = red + NPT + 2;                // [NPT][2k+1] this launch's parameter rows
-    const size_t prim_off = (size_t)(pts - lds) + (size_t)NPT * stride;
+    // the PCs again, as the epilogue reads them: [group][slot][2k][BTL] -- a lane's BTL points side by
+    // side, so one ds_read_b128 (4 LDS cycles) brings a coefficient of both points where two
+    // strided 8-byte reads (ds_read2_b64: 8 cycles) did
+    double* ptq = pts + (size_t)NPT * stride + ((NPT * stride) & 1);
+    const size_t prim_off = (size_t)(ptq - lds) + (size_t)NPT * 2 * k;
     double2* prim_lds = reinterpret_cast<double2*>(lds + prim_off + (prim_off & 1));   // [num_prim], 16-B aligned
     double* tile_llk = reinterpret_cast<double*>(prim_lds + L.num_prim);   // [work items or waves][NP] {mantissa, exponent}
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it)
     int m, g4;
     lane_map<HWMAP>(lane, m, g4);
     const int g = g4 & (SLOTS - 1);              // candidate slot
-    const int half = g4 / SLOTS;                 // which of the item's TPW micro-tiles
+    const int half = TPW == 1 ? 0 : g4 / SLOTS;  // which of the item's TPW micro-tiles
     // profiling aid: 100 MHz wall-clock stamps per workgroup (L.stamps == nullptr normally)
     unsigned long long* stamps = L.stamps ? L.stamps + (size_t)blk * 8 : nullptr;
     if (stamps && tid == 0) stamps[0] = wall_clock64();
@@ -280,10 +344,15 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         const int src = b < num_valid ? b : num_valid - 1;
         const int idx = src * stride + (e - b * stride);
         // resident mode: the rows were just written by another workgroup -> L1-bypassing loads
-        pts[e] = ip.count > 0 ? ip.v[idx]
-                 : coherent_points ? __hip_atomic_load(&points[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : points[idx];
+        const double v = ip.count > 0 ? ip.v[idx]
+                         : coherent_points ? __hip_atomic_load(&points[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : points[idx];
+        pts[e] = v;
+        const int c = e - b * stride;                       // 0..2k-1: a PC coordinate, 2k: alpha
+        if (c < 2 * k) ptq[((b / BTL) * 2 * k + c) * BTL + (b % BTL)] = v;
     }
+    // 2^(j/64) table of exp_nonpos, one copy per pair of LDS banks (see there)
+    for (int e = tid; e < kExpTabDoubles; e += nthread) etab[e] = kExp2Tab[e >> 5];
     // With several groups a thread builds several table entries: the primary-code records (a
     // few dozen) go to LDS first so that the loop below does not wait on a global load per
     // entry.  With one group each thread builds about one entry and loads its record directly.
@@ -314,8 +383,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
 #pragma unroll
         for (int grp_e = 0; grp_e < kMaxGroups; ++grp_e)
             if (grp_e < ngrp)
-                v[grp_e] = (L.ablate & 1) ? -0.01 * (dc + p)
-                                          : table_entry(pts[(grp_e * NP + bb) * stride + 2 * k], rec.x, g1, g2);
+                v[grp_e] = table_entry(pts[(grp_e * NP + bb) * stride + 2 * k], rec.x, g1, g2);
 #pragma unroll
         for (int grp_e = 0; grp_e < kMaxGroups; ++grp_e)
             if (grp_e < ngrp) {
@@ -333,24 +401,22 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
 
     // Work distribution.  Workgroup b owns micro-tiles b, b+grid, b+2*grid, ... (the tiles are
     // depth-sorted, so every workgroup -- hence every CU, and every XCD's L2 at every launch --
-    // gets the same depth mix of the same data).  Inside the workgroup the waves pull tiles
-    // from that list longest-first through an LDS counter, which evens out the 1-vs-2-tiles
-    // imbalance a static deal leaves.  Each tile's result goes to its own LDS slot and the
-    // slots are summed in index order afterwards, so the dynamic schedule does not change
-    // a single bit of the result.
+    // gets the same depth mix of the same data).  The (tile, group) work items of the workgroup
+    // are dealt to its waves in snake order (static: a lane then keeps ONE running product per
+    // group in registers and a work item costs no cross-lane traffic at all), or -- L.dyn_limit,
+    // an A/B knob -- pulled longest-first through an LDS counter, each item's product going to its
+    // own LDS slot.  Either way the multiplication order is fixed, so the schedule does not
+    // change a single bit of the result.
     const uint32_t ntile_blk = ((uint32_t)L.num_mt + nblk - 1 - blk) / nblk;
-    const uint32_t padw = 0x00010001u * (uint32_t)L.num_code;
     const size_t mp = L.m_pad;
-    // work items: (tile, group), or (pair of consecutive owned tiles, group) in PAIRED mode
+    // work items: (tile, group), or (TPW consecutive owned tiles, group)
     const uint32_t nunit = (ntile_blk + TPW - 1) / TPW;
     const uint32_t nitem = nunit * (uint32_t)ngrp;
-    // With many tiles per wave a static deal (wave w takes tiles w, w+nwave, ...) is already
-    // balanced and needs no per-tile result slots; the queue is for the few-tiles case.
     // Decided on ceil(tiles / workgroups), the same for every workgroup and exactly what
     // eval_shmem_np sized the result slots for (a workgroup with one tile fewer must not choose
     // differently: the queue needs a slot per item, the static deal only one per wave).
     const uint32_t max_tiles_blk = ((uint32_t)L.num_mt + nblk - 1) / nblk;
-    const bool dyn = max_tiles_blk * (uint32_t)ngrp <= (uint32_t)(kDynTilesPerWave * nwave);
+    const bool dyn = max_tiles_blk * (uint32_t)ngrp <= (uint32_t)(L.dyn_limit * nwave);
     // The per-marker likelihoods of a work item are MULTIPLIED (mantissa x 2^exponent): over
     // the 16 markers of the tile by a butterfly, then slot by slot in the block reduction.
     auto tile_product = [&](ScaledProd* p) {              // over the 16 lanes sharing slot g
@@ -373,46 +439,74 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             }
         }
     };
-    ScaledProd wave_prod[BTL];                            // static mode: this lane's running product
+    LaneProd wave_prod[BTL];                              // static mode: this lane's running product
 #pragma unroll
-    for (int t = 0; t < BTL; ++t) wave_prod[t] = ScaledProd{1.0, 0.0};
+    for (int t = 0; t < BTL; ++t) wave_prod[t] = LaneProd{1.0, 0};
+    int nfactor = 0;                                      // factors in wave_prod.m since its last renormalisation
+    auto renorm_wave = [&]() {
+#pragma unroll
+        for (int t = 0; t < BTL; ++t) {
+            wave_prod[t].e += __builtin_amdgcn_frexp_exp(wave_prod[t].m);
+            wave_prod[t].m = __builtin_amdgcn_frexp_mant(wave_prod[t].m);
+        }
+        nfactor = 0;
+    };
     uint32_t grp_wave = 0;                                // static mode: group wave_prod belongs to
     auto flush_wave = [&](uint32_t grp) {                 // static mode: one slot per (wave, group)
-        tile_product(wave_prod);
+        renorm_wave();
+        ScaledProd sp[BTL];
+#pragma unroll
+        for (int t = 0; t < BTL; ++t) sp[t] = ScaledProd{wave_prod[t].m, (double)wave_prod[t].e};
+        tile_product(sp);
         if (m == 0 && half == 0) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
                 const size_t o = (((size_t)grp * nwave + wave) * NP + g * BTL + t) * 2;
-                tile_llk[o] = wave_prod[t].m;
-                tile_llk[o + 1] = wave_prod[t].e;
+                tile_llk[o] = sp[t].m;
+                tile_llk[o + 1] = sp[t].e;
             }
         }
 #pragma unroll
-        for (int t = 0; t < BTL; ++t) wave_prod[t] = ScaledProd{1.0, 0.0};
+        for (int t = 0; t < BTL; ++t) wave_prod[t] = LaneProd{1.0, 0};
     };
-    uint32_t round = 0;                                   // static mode: items are dealt in snake order
-    for (uint32_t idx = (uint32_t)wave; idx < nitem;) {
+    const uint32_t etab_lane = (uint32_t)(lane & 31) * 8u;     // etab is at LDS address 0 (no static LDS in this file)
+    const uint32_t tab_addr = lds_byte_addr(tab);
+    const uint32_t ptq_addr = lds_byte_addr(ptq);
+    if (L.stagger > 0 && wave >= (nwave >> 1))
+        for (int i = 0; i < L.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    // static mode: the host-built schedule (LPT over the waves), or items dealt in snake order
+    const bool have_sched = !dyn && sch.off != nullptr;
+    uint32_t s_i = 0, s_end = 0;
+    if (have_sched) {
+        s_i = sch.off[blk * (uint32_t)nwave + (uint32_t)wave];
+        s_end = sch.off[blk * (uint32_t)nwave + (uint32_t)wave + 1];
+    }
+    uint32_t round = 0;
+    for (uint32_t idx = have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem) : (uint32_t)wave; idx < nitem;) {
         const uint32_t grp = idx / nunit;
         const uint32_t unit = idx - grp * nunit;
         const uint32_t it = TPW * unit + (uint32_t)half;     // index in this workgroup's tile list
-        const bool have_tile = it < ntile_blk;               // TPW > 1: the list's end may leave lanes idle
+        const bool have_tile = TPW == 1 || it < ntile_blk;   // TPW > 1: the list's end may leave lanes idle
         const uint32_t mt = have_tile ? blk + it * nblk : blk;
-        const double* my_tab = tab + (size_t)grp * nrow * RS + g * (6 * BTL);
-        const double* my_pts = pts + ((size_t)grp * NP + g * BTL) * stride;
+        const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)L.row_bytes + (uint32_t)g * (6 * BTL * 8));
+        const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
         while (!dyn && grp_wave < grp) {                     // wave-uniform
             flush_wave(grp_wave);
             ++grp_wave;
         }
-        ScaledProd lane_prod[BTL];                           // this marker's likelihood per point
-#pragma unroll
-        for (int t = 0; t < BTL; ++t) lane_prod[t] = ScaledProd{1.0, 0.0};
-        const uint2 rec = L.mt_rec[mt];                      // {first row, rows}
+        const uint2 rec = L.mt_rec[mt];                      // {first row, rows}; one scalar load when TPW == 1
         // per-marker constants: issued now, consumed after the read loop
         const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
         const bool live = have_tile && pos < (size_t)L.num_active;
         const size_t posc = live ? pos : 0;
         const double cst = L.ediag[posc];
         const double e0 = L.ediag[mp + posc], e1 = L.ediag[2 * mp + posc], e2 = L.ediag[3 * mp + posc];
+
+        // (the panel row of the marker too: up to four UD columns and the mean)
+        double udr[4], mur = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) udr[kk] = (!L.known_af && kk < k) ? L.ud[(size_t)kk * mp + posc] : 0.0;
+        if (!L.known_af) mur = L.mu[posc];
 
         // the six off-diagonal sums start from the marker's "other base" constant (it is part of
         // every genotype pair's sum, h:299-303), so the epilogue needs no separate addition
@@ -423,28 +517,31 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         // ---- per-read accumulate (h:288-303), one step per run ----
         // Rows are prefetched kPrefetch deep: with one sample its pileup sits in L2, but a cohort
         // launch streams every sample's rows from HBM once, and two rows ahead (~0.6 us of work)
-        // does not cover that latency.
-        const uint32_t* cp = L.codes + (size_t)rec.x * kMtMarkers + m;
-        const int rows = ((L.ablate & 2) || !have_tile) ? 0 : (int)rec.y;
-        constexpr int kPrefetch = 8;
-        uint32_t w[kPrefetch];
+        // does not cover that latency.  The loads are unconditional: a prefetch past the tile's
+        // last row reads the next tile's rows (never consumed), and the array ends in
+        // 2 * kPrefetch padding rows (context.cpp).
+        const uint2* cp = L.codes + (size_t)rec.x * kMtMarkers + m;
+        const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
+        uint2 w[kPrefetch];
 #pragma unroll
-        for (int j = 0; j < kPrefetch; ++j) w[j] = j < rows ? cp[(size_t)j * kMtMarkers] : padw;
+        for (int j = 0; j < kPrefetch; ++j) w[j] = cp[(size_t)j * kMtMarkers];
         for (int s0 = 0; s0 < rows; s0 += kPrefetch) {
 #pragma unroll
             for (int u = 0; u < kPrefetch; ++u) {
                 if (s0 + u >= rows) break;
-                const uint32_t w_cur = w[u];
-                w[u] = (s0 + u + kPrefetch < rows) ? cp[(size_t)(s0 + u + kPrefetch) * kMtMarkers] : padw;
+                const uint2 w_cur = w[u];
+                w[u] = cp[(size_t)(s0 + u + kPrefetch) * kMtMarkers];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    // one run: `n` reads of the same (class, quality) -> n * table row
-                    const uint32_t c = (w_cur >> (16 * j)) & 0xffu;
-                    const double n = (double)((w_cur >> (16 * j + 8)) & 0xffu);
-                    const double2* row = reinterpret_cast<const double2*>(my_tab + c * RS);
+                    // one run: `n` reads of the same (class, quality) -> n * table row.  The run
+                    // word is {low half: byte offset of the row, high half: the top 16 bits of the
+                    // double n} -- one add and one and, no multiply, no int -> double conversion
+                    const uint32_t rw = j ? w_cur.y : w_cur.x;
+                    const double n = __hiloint2double((int)(rw & 0xffff0000u), 0);
+                    lds_cdouble2* row = reinterpret_cast<lds_cdouble2*>(my_tab + (rw & 0xffffu));
 #pragma unroll
                     for (int i = 0; i < 3 * BTL; ++i) {
-                        const double2 t = row[i];
+                        const vdouble2 t = row[i];
                         acc[2 * i] = fma(n, t.x, acc[2 * i]);
                         acc[2 * i + 1] = fma(n, t.y, acc[2 * i + 1]);
                     }
@@ -452,31 +549,39 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             }
         }
 
-        // ---- per-marker epilogue ----
-        if (live && (L.ablate & 4)) {
+        // ---- per-marker epilogue: this marker's likelihood as (mantissa, exponent) per point ----
+        double lk_m[BTL];
+        int lk_e[BTL];
 #pragma unroll
-            for (int t = 0; t < BTL; ++t)
-                lane_prod[t].e += acc[t * 6] + acc[t * 6 + 1] + acc[t * 6 + 2] + acc[t * 6 + 3] +
-                                  acc[t * 6 + 4] + acc[t * 6 + 5] + e0 + e1 + e2;
-        } else if (live) {
+        for (int t = 0; t < BTL; ++t) { lk_m[t] = 1.0; lk_e[t] = 0; }
+        if (live) {
             double af1[BTL], af2[BTL];
             if (L.known_af) {
                 const double a = L.known_af[pos];
 #pragma unroll
                 for (int t = 0; t < BTL; ++t) af1[t] = af2[t] = a;
             } else {
-                // h:251-267: AF = (sum_k UD[i][k]*pc[k] + mean) / 2, same op order
+                // h:251-267: AF = (sum_k UD[i][k]*pc[k] + mean) / 2, same order of the k terms; each
+                // term enters with one rounding (FMA) where the reference's x86-64 build rounds the
+                // product first: AF differs by <= k/2 ulp, far inside the 1e-12 the tests hold the LLK to
 #pragma unroll
                 for (int t = 0; t < BTL; ++t) af1[t] = af2[t] = 0.;
-                for (int kk = 0; kk < k; ++kk) {
-                    const double uu = L.ud[(size_t)kk * mp + pos];
-#pragma unroll
-                    for (int t = 0; t < BTL; ++t) {
-                        af1[t] += uu * my_pts[t * stride + kk];
-                        af2[t] += uu * my_pts[t * stride + k + kk];
+                auto project = [&](int kk, double uu) {
+                    if constexpr (BTL == 2) {              // both points' coefficient in one ds_read_b128
+                        const vdouble2 c1 = *reinterpret_cast<lds_cdouble2*>(my_ptq + (uint32_t)kk * 16u);
+                        const vdouble2 c2 = *reinterpret_cast<lds_cdouble2*>(my_ptq + (uint32_t)(k + kk) * 16u);
+                        af1[0] = fma(uu, c1.x, af1[0]); af1[1] = fma(uu, c1.y, af1[1]);
+                        af2[0] = fma(uu, c2.x, af2[0]); af2[1] = fma(uu, c2.y, af2[1]);
+                    } else {
+                        af1[0] = fma(uu, *reinterpret_cast<lds_cdouble*>(my_ptq + (uint32_t)kk * 8u), af1[0]);
+                        af2[0] = fma(uu, *reinterpret_cast<lds_cdouble*>(my_ptq + (uint32_t)(k + kk) * 8u), af2[0]);
                     }
-                }
-                const double mu = L.mu[pos];
+                };
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    if (kk < k) project(kk, udr[kk]);                       // rows loaded before the read loop
+                for (int kk = 4; kk < k; ++kk) project(kk, L.ud[(size_t)kk * mp + pos]);
+                const double mu = mur;
 #pragma unroll
                 for (int t = 0; t < BTL; ++t) {
                     af1[t] += mu; af1[t] /= 2.0;
@@ -489,31 +594,36 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 initial_gf(af1[t], gf);
                 initial_gf(af2[t], gf2);
                 const double* a = acc + t * 6;
-                // h:307-311, (g1 outer, g2 inner) order; the three g1==g2 exponentials
-                // do not depend on (alpha, PC) and were taken at context creation
-                double lk = 0;
-                lk += e0 * gf[0] * gf2[0];
-                lk += exp_nonpos(a[0]) * gf[0] * gf2[1];
-                lk += exp_nonpos(a[1]) * gf[0] * gf2[2];
-                lk += exp_nonpos(a[2]) * gf[1] * gf2[0];
-                lk += e1 * gf[1] * gf2[1];
-                lk += exp_nonpos(a[3]) * gf[1] * gf2[2];
-                lk += exp_nonpos(a[4]) * gf[2] * gf2[0];
-                lk += exp_nonpos(a[5]) * gf[2] * gf2[1];
-                lk += e2 * gf[2] * gf2[2];
+                // h:307-311: lk = sum_{g1,g2} exp(A[g1][g2]) GF[g1] GF2[g2], factored as
+                // sum_g1 GF[g1] * (sum_g2 exp(A[g1][g2]) GF2[g2]) with FMAs (12 operations instead
+                // of 27; the rounding differs from the reference's term-by-term sum at the 1e-16
+                // level, like the marker summation order does).  The three g1==g2 exponentials do
+                // not depend on (alpha, PC) and were taken at context creation.
+                const double x01 = exp_nonpos(a[0], etab_lane), x02 = exp_nonpos(a[1], etab_lane);
+                const double x10 = exp_nonpos(a[2], etab_lane), x12 = exp_nonpos(a[3], etab_lane);
+                const double x20 = exp_nonpos(a[4], etab_lane), x21 = exp_nonpos(a[5], etab_lane);
+                const double s0 = fma(x02, gf2[2], fma(x01, gf2[1], e0 * gf2[0]));
+                const double s1 = fma(x12, gf2[2], fma(e1, gf2[1], x10 * gf2[0]));
+                const double s2 = fma(e2, gf2[2], fma(x21, gf2[1], x20 * gf2[0]));
+                double lk = fma(s2, gf[2], fma(s1, gf[1], s0 * gf[0]));
                 // the reference adds log(lk) only if lk > 0 (h:310-311): a dropped marker is
                 // the factor 1
-                const bool keep = lk > 0;
-                lane_prod[t].m = keep ? __builtin_amdgcn_frexp_mant(lk) : 1.0;
-                lane_prod[t].e = keep ? (double)__builtin_amdgcn_frexp_exp(lk) : 0.0;
+                lk = lk > 0 ? lk : 1.0;
+                lk_m[t] = __builtin_amdgcn_frexp_mant(lk);
+                lk_e[t] = __builtin_amdgcn_frexp_exp(lk);
             }
         }
         if (!dyn) {
 #pragma unroll
-            for (int t = 0; t < BTL; ++t) {               // running product, renormalised per tile
-                wave_prod[t].m *= lane_prod[t].m;
-                wave_prod[t].e += lane_prod[t].e;
-                sp_renorm(wave_prod[t]);
+            for (int t = 0; t < BTL; ++t) {               // running product, renormalised lazily
+                wave_prod[t].m *= lk_m[t];
+                wave_prod[t].e += lk_e[t];
+            }
+            if (++nfactor == kLazyRenorm) renorm_wave();
+            if (have_sched) {
+                ++s_i;
+                idx = s_i < s_end ? (uint32_t)sch.item[s_i] : nitem;
+                continue;
             }
             // next round, direction reversed: the items are depth-sorted, and a plain deal would
             // hand wave 0 the deepest tile of every round
@@ -521,6 +631,9 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             idx = round * (uint32_t)nwave + ((round & 1u) ? (uint32_t)(nwave - 1 - wave) : (uint32_t)wave);
             continue;
         }
+        ScaledProd lane_prod[BTL];
+#pragma unroll
+        for (int t = 0; t < BTL; ++t) lane_prod[t] = ScaledProd{lk_m[t], (double)lk_e[t]};
         tile_product(lane_prod);
         if (m == 0 && half == 0) {
 #pragma unroll
@@ -535,7 +648,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (lane == 0) nxt = atomicAdd(queue, 1u);
         idx = __builtin_amdgcn_readfirstlane(nxt);
     }
-    if (!dyn) {                                           // slots (wave, group): zeros if idle
+    if (!dyn) {                                           // slots (wave, group): factor 1 if idle
         for (uint32_t grp = grp_wave; grp < (uint32_t)ngrp; ++grp) flush_wave(grp);
     }
 
@@ -705,10 +818,10 @@ __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWaves
 llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
                 int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
-                unsigned long long done_seq, int ngrp, unsigned long long tag)
+                unsigned long long done_seq, int ngrp, unsigned long long tag, const Schedule sch)
 {
     eval_body<MODE, HWMAP>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
-                           blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag);
+                           blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
 }
 
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
@@ -716,7 +829,8 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
 template <int MODE, bool HWMAP>
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
-llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __restrict__ points,
+llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* __restrict__ scheds,
+                      const double* __restrict__ points,
                       const int* __restrict__ num_valid, double* __restrict__ partials,
                       double* __restrict__ llk_out, unsigned int* __restrict__ tickets, int bps,
                       unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
@@ -733,7 +847,8 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const double* __
     eval_body<MODE, HWMAP>(L, ip, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
-                          batch_done, batch_active, 1, use_ticket ? 0ull : done_seq);
+                          batch_done, batch_active, 1, use_ticket ? 0ull : done_seq,
+                          scheds ? scheds[s] : Schedule{nullptr, nullptr});
 }
 
 
@@ -840,10 +955,10 @@ llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restr
         if (L.stamps && blockIdx.x == 0 && tid == 0) L.stamps[7] = t_seen;     // profiling: command seen
         if (MODE == 3 && nv == 1)       // a single point: the one-point wave shape (a quarter of the work)
             eval_body<4, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
-                                ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, true);
+                                ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, ra.sched_single, true);
         else
             eval_body<MODE, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
-                                   ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, true);
+                                   ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, ra.sched_multi, true);
     }
 }
 
@@ -928,16 +1043,18 @@ static hipError_t raise_lds_limit(const void* fn, int slot)
 
 static bool g_paired = true;          // 4-point launches: MODE 3 (two micro-tiles per wave) or MODE 1
 void set_paired_mode(bool on) { g_paired = on; }
+bool paired_mode() { return g_paired; }
 
 template <int MODE, bool HWMAP>
 static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, const double* h_points,
                              int num_valid, int ngrp,
                              double* d_partials, double* d_out, unsigned int* d_ticket,
                              unsigned long long* done_flag, unsigned long long done_seq,
-                             unsigned long long tag, hipStream_t stream)
+                             unsigned long long tag, hipStream_t stream, ScheduleProvider* sp)
 {
     constexpr int NP = MODE == 2 ? 8 : MODE == 4 ? 1 : 4;     // points per group
     const LaunchGeom gm = launch_geom(L, MODE == 2 ? 2 : 1);
+    const Schedule sch = sp ? sp->get(MODE, ngrp, gm.grid, gm.block_waves) : Schedule{nullptr, nullptr};
     const size_t shmem = eval_shmem_np(L, NP, gm.grid, gm.block_waves, ngrp);
     {
         hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP>),
@@ -953,7 +1070,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
     }
     hipLaunchKernelGGL((llk_eval_kernel<MODE, HWMAP>), dim3(gm.grid), dim3(gm.block_waves * 64), shmem,
                        stream, L, ip, d_points, num_valid, d_partials, d_out, d_ticket, done_flag,
-                       done_seq, ngrp, tag);
+                       done_seq, ngrp, tag, sch);
     return hipGetLastError();
 }
 
@@ -966,7 +1083,8 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            const double* h_points, double* d_partials, double* d_out,
                            unsigned int* d_ticket,
                            unsigned long long* done_flag, unsigned long long done_seq,
-                           unsigned long long* tag_counter, hipStream_t stream, int reduce_override)
+                           unsigned long long* tag_counter, hipStream_t stream, int reduce_override,
+                           ScheduleProvider* sched)
 {
     unsigned int* tk = g_single_launch ? d_ticket : nullptr;
     const int reduce_mode = reduce_override ? reduce_override : g_reduce_mode;
@@ -978,7 +1096,9 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         const double* hp = h_points ? h_points + (size_t)done * stride : nullptr;
         // up to max_groups x 8 points per launch (more points amortise the fixed costs)
         const LaunchGeom gm2 = launch_geom(L, 2);
-        const int cap = 8 * max_groups(L, 2, gm2.grid, gm2.block_waves);
+        // (8-point groups need the wide table rows; a context whose dictionary is too big for
+        // 16-bit offsets into wide rows has narrow ones and evaluates 4 points per launch)
+        const int cap = L.row_bytes == kRowBytesWide ? 8 * max_groups(L, 2, gm2.grid, gm2.block_waves) : 4;
         const int step = left < cap ? left : cap;
         const int ngrp = step > 4 ? (step + 7) / 8 : 1;
         unsigned long long* df = (done + step >= num_point) ? done_flag : nullptr;   // last launch signals
@@ -989,17 +1109,17 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         const bool tagged = reduce_mode == 2 || (reduce_mode == 0 && step <= 4);
         const unsigned long long tag = tagged ? ++*tag_counter : 0ull;   // unique per launch on this buffer
         if (step > 4)
-            e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
-                        : launch_btl<2, false>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
+            e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched)
+                        : launch_btl<2, false>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
         else if (g_paired && step == 1)
-            e = g_hwmap ? launch_btl<4, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
-                        : launch_btl<4, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
+            e = g_hwmap ? launch_btl<4, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched)
+                        : launch_btl<4, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
         else if (g_paired)
-            e = g_hwmap ? launch_btl<3, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
-                        : launch_btl<3, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
+            e = g_hwmap ? launch_btl<3, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched)
+                        : launch_btl<3, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
         else
-            e = g_hwmap ? launch_btl<1, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream)
-                        : launch_btl<1, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream);
+            e = g_hwmap ? launch_btl<1, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched)
+                        : launch_btl<1, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
         if (e != hipSuccess) return e;
         if (!tk) {
             hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(256), 0, stream, d_partials,
@@ -1015,10 +1135,11 @@ size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, i
 {
     const size_t NP = (size_t)np, G = (size_t)ngrp;
     const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;
-    const size_t slots = items <= (size_t)kDynTilesPerWave * block_waves ? items : (size_t)block_waves * G;
-    const size_t bytes = sizeof(double) * (G * (L.num_code + 1) * row_stride((int)NP) + G * NP + 2 +
-                                           G * NP * (2 * L.num_pc + 1) + 1 + 2 * (size_t)L.num_prim +
-                                           2 * slots * NP);
+    const size_t slots = items <= (size_t)L.dyn_limit * block_waves ? items : (size_t)block_waves * G;
+    const size_t bytes = sizeof(double) * (G * (L.num_code + 1) * (size_t)(L.row_bytes / 8) + G * NP + 2 +
+                                           G * NP * (2 * L.num_pc + 1) + 1 + G * NP * 2 * L.num_pc +
+                                           1 + 2 * (size_t)L.num_prim +
+                                           kExpTabDoubles + 2 * slots * NP);
     // workgroup 0 stages every workgroup's partial sums ([points][workgroups]) over the dead table
     const size_t stage = sizeof(double) * G * NP * (size_t)nblk;
     return bytes > stage ? bytes : stage;
@@ -1054,13 +1175,59 @@ hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
     }
 #define VB2_MULTI_LAUNCH(MODE, HW)                                                                       \
     hipLaunchKernelGGL((llk_eval_multi_kernel<MODE, HW>), grid, block, ml.shmem, stream, ml.d_layouts,   \
-                       ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,       \
+                       ml.d_scheds, ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,       \
                        ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active, ml.force_ticket ? 1 : 0)
     if (mode == 2) { if (g_hwmap) VB2_MULTI_LAUNCH(2, true); else VB2_MULTI_LAUNCH(2, false); }
     else if (mode == 3) { if (g_hwmap) VB2_MULTI_LAUNCH(3, true); else VB2_MULTI_LAUNCH(3, false); }
     else { if (g_hwmap) VB2_MULTI_LAUNCH(1, true); else VB2_MULTI_LAUNCH(1, false); }
 #undef VB2_MULTI_LAUNCH
     return hipGetLastError();
+}
+
+bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int tpu, int ngrp,
+                    std::vector<uint32_t>* off, std::vector<uint16_t>* item)
+{
+    off->clear();
+    item->clear();
+    if (num_mt <= 0 || nblk <= 0 || nwave <= 0) return false;
+    const uint32_t max_tiles = ((uint32_t)num_mt + nblk - 1) / nblk;
+    if ((size_t)((max_tiles + tpu - 1) / tpu) * ngrp > 65535) return false;
+    off->reserve((size_t)nblk * nwave + 1);
+    std::vector<uint64_t> load(nwave);
+    std::vector<std::vector<uint16_t>> mine(nwave);
+    // cost model (VALU instructions per lane): 28 per row of two runs x two points, ~370 for the
+    // per-marker epilogue and the item's fixed work; only the ratio matters
+    constexpr uint64_t kRowCost = 28, kFixCost = 370;
+    for (int b = 0; b < nblk; ++b) {
+        const uint32_t ntile = ((uint32_t)num_mt + nblk - 1 - b) / nblk;
+        const uint32_t nunit = (ntile + tpu - 1) / tpu;
+        std::fill(load.begin(), load.end(), 0);
+        for (auto& v : mine) v.clear();
+        // the workgroup's tiles b, b + nblk, ... are in descending row order, so walking the units
+        // in index order IS longest-first
+        for (uint32_t u = 0; u < nunit; ++u) {
+            uint32_t r = 0;
+            for (int h = 0; h < tpu; ++h) {
+                const uint32_t it = (uint32_t)tpu * u + h;
+                if (it < ntile) r = std::max(r, rows[(size_t)b + (size_t)it * nblk]);
+            }
+            const uint64_t cost = kRowCost * r + kFixCost;
+            for (int g = 0; g < ngrp; ++g) {
+                int best = 0;
+                for (int w = 1; w < nwave; ++w)
+                    if (load[w] < load[best]) best = w;
+                load[best] += cost;
+                mine[best].push_back((uint16_t)((uint32_t)g * nunit + u));
+            }
+        }
+        for (int w = 0; w < nwave; ++w) {
+            std::sort(mine[w].begin(), mine[w].end());       // by (group, unit): few group changes per wave
+            off->push_back((uint32_t)item->size());
+            item->insert(item->end(), mine[w].begin(), mine[w].end());
+        }
+    }
+    off->push_back((uint32_t)item->size());
+    return true;
 }
 
 static bool g_coop_launch = false;
