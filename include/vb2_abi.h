@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VB2_ABI_VERSION 1
+#define VB2_ABI_VERSION 2
 
 typedef enum vb2_status {
     VB2_OK = 0,
@@ -214,6 +214,52 @@ int vb2_batch_optimize_llk(vb2_batch *b, const vb2_model *models, int32_t num_mo
                            vb2_estimate *out);
 
 /* ------------------------------------------------------------------------- *
+ * 2c. Marker shards: ONE sample's markers spread over several GPUs (BASELINE.json configs[3]).
+ *     LLK is a sum of independent per-marker terms -- the reference's OpenMP
+ *     `reduction(+:sumLLK)` over markers (ContaminationEstimator.h:232-235) -- so each device
+ *     evaluates a contiguous, read-balanced marker range and the B partial sums of a batch meet
+ *     in ONE ncclAllReduce of B doubles over RCCL/xGMI.  librccl is bound at run time when a
+ *     group spans more than one device.
+ * ------------------------------------------------------------------------- */
+typedef struct vb2_shard_group vb2_shard_group;
+
+/* One process drives every device (VerifyBamID --Devices a,b,...).  `in` is the WHOLE sample;
+ * shard d lives on devices[d].  Evaluations: one launch per device + a grouped ncclAllReduce;
+ * vb2_shard_group_optimize_llk runs the search against one resident kernel per device and adds
+ * the (<= 4) partial sums per device on the host.  A device listed twice gets two shards that
+ * are added on the host (no RCCL): that is how a single-GPU machine exercises the code. */
+int vb2_shard_group_create(const vb2_input *in, const int32_t *devices, int32_t num_device,
+                           vb2_shard_group **out);
+/* One process per GPU (python -m torch.distributed.run, mpirun): rank 0 calls vb2_rccl_unique_id,
+ * the caller broadcasts the 128 bytes by its own means, then every rank builds the group with the
+ * WHOLE sample, its device, its rank.  Every evaluation is launch + ncclAllReduce on the
+ * context's stream; all ranks receive identical sums and take identical search decisions.
+ * id128 == NULL with nranks == 1 gives a group without a communicator. */
+int vb2_rccl_unique_id(void *id128 /* 128 bytes out */);
+int vb2_shard_group_create_rank(const vb2_input *in, int32_t device, int32_t rank, int32_t nranks,
+                                const void *id128, vb2_shard_group **out);
+/* ComputeMixLLKs over all shards for B points (host pointers, synchronous). */
+int vb2_shard_group_eval(vb2_shard_group *g, int32_t num_point, const double *pc1, const double *pc2,
+                         const double *alpha, double *llk_out);
+int vb2_shard_group_optimize_llk(vb2_shard_group *g, const vb2_model *model, vb2_estimate *out,
+                                 vb2_trace *trace);
+typedef struct vb2_shard_info {
+    int32_t num_shard;         /* shards owned by THIS process                     */
+    int32_t nranks;            /* processes in the group (1 = single process)      */
+    int32_t rank;
+    int32_t uses_rccl;         /* partial sums meet in ncclAllReduce (else: host)  */
+    int64_t num_allreduce;     /* collectives issued so far                        */
+    int32_t marker_lo[64];     /* marker range of each owned shard                 */
+    int32_t marker_hi[64];
+    int64_t num_read[64];      /* reads of each owned shard                        */
+} vb2_shard_info;
+int vb2_shard_group_info(const vb2_shard_group *g, vb2_shard_info *info);
+/* The partition itself (no device needed): shard `rank` of `nranks` owns markers [*lo, *hi), cut so
+ * that every shard holds about the same number of READS (balance on R, not M). */
+int vb2_shard_range(const vb2_input *in, int32_t rank, int32_t nranks, int32_t *lo, int32_t *hi);
+void vb2_shard_group_destroy(vb2_shard_group *g);
+
+/* ------------------------------------------------------------------------- *
  * 3. File level: the --SVDPrefix/--PileupFile flow of execute()
  *    (main.cpp:283-411): panel + pileup readers, sanity check, OptimizeLLK,
  *    <out>.Ancestry and <out>.selfSM writers.
@@ -230,6 +276,12 @@ typedef struct vb2_run_args {
     int32_t output_pileup;     /* --OutputPileup                                   */
     int32_t device;            /* HIP device ordinal, -1 = current                 */
     vb2_model model;
+    /* --Devices a,b,...: more than one entry spreads the work over those GPUs -- vb2_run shards
+     * the sample's markers (2c), vb2_cohort_run deals whole groups of samples to the devices
+     * (no collective).  NULL / 0 = `device` alone. */
+    const int32_t *devices;
+    int32_t num_device;
+    int32_t reserved;
 } vb2_run_args;
 
 typedef struct vb2_run_result {
@@ -259,7 +311,8 @@ typedef struct vb2_cohort_args {
     const char *const *pileup_paths;     /* [num_sample]                                      */
     const char *const *output_prefixes;  /* [num_sample], or NULL = write nothing             */
     int32_t group_size;                  /* samples searched together; 0 = 32                 */
-    int32_t num_host_thread;             /* pileup readers/flatteners; 0 = up to 16           */
+    int32_t num_host_thread;             /* pileup readers/flatteners; 0 = half the host's cores,
+                                          * at least 4 and at most 64 per device               */
 } vb2_cohort_args;
 int vb2_cohort_run(const vb2_cohort_args *args, vb2_run_result *out /* [num_sample] */,
                    int32_t *status /* [num_sample] */);

@@ -34,7 +34,7 @@ def test_header_symbols_exported():
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vb2_abi_version() == 1
+    assert lib.vb2_abi_version() == 2
 
 
 def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
@@ -43,7 +43,7 @@ def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
     import subprocess
     src = tmp_path / "abi_check.c"
     names = ["vb2_input", "vb2_options", "vb2_info", "vb2_model", "vb2_estimate", "vb2_trace",
-             "vb2_run_args", "vb2_run_result", "vb2_cohort_args"]
+             "vb2_run_args", "vb2_run_result", "vb2_cohort_args", "vb2_shard_info"]
     src.write_text('#include <stdio.h>\n#include "vb2_abi.h"\nint main(void) {\n' +
                    "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) +
                    "  return 0;\n}\n")
@@ -54,7 +54,7 @@ def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
                                                          check=True).stdout.splitlines())
     binding = dict(vb2_input=_abi.Input, vb2_options=_abi.Options, vb2_info=_abi.Info, vb2_model=_abi.Model,
                    vb2_estimate=_abi.Estimate, vb2_trace=_abi.Trace, vb2_run_args=_abi.RunArgs,
-                   vb2_run_result=_abi.RunResult, vb2_cohort_args=_abi.CohortArgs)
+                   vb2_run_result=_abi.RunResult, vb2_cohort_args=_abi.CohortArgs, vb2_shard_info=_abi.ShardInfo)
     for n, cls in binding.items():
         assert int(sizes[n]) == C.sizeof(cls), (n, sizes[n], C.sizeof(cls))
 
@@ -294,6 +294,23 @@ def test_ud_with_too_few_columns(tmp_path):
     with pytest.raises(_abi.Vb2Error) as ei:
         vb.PileupData.from_files(pre, pre + ".pileup", 2)
     assert "NumPC" in str(ei.value)
+
+
+def test_shard_range_is_the_read_balanced_partition():
+    """vb2_shard_range: contiguous, complete, balanced on reads -- and well defined at the edges
+    (more shards than markers, markers without reads)."""
+    d = vb.synth.make_pileup(997, 17, 2, seed=8, missing_frac=0.3)
+    for world in (1, 2, 5, 8, 64):
+        cuts = [d.shard_range(r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == d.num_marker
+        assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+        reads = [int(d.read_off[hi] - d.read_off[lo]) for lo, hi in cuts]
+        assert sum(reads) == d.num_read
+        assert max(reads) - min(reads) <= 2 * 40
+    tiny = vb.synth.make_pileup(3, 10, 2, seed=9)
+    cuts = [tiny.shard_range(r, 8) for r in range(8)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == 3 and all(lo <= hi for lo, hi in cuts)
+    assert sum(hi - lo for lo, hi in cuts) == 3
 
 
 def test_shard_partition_covers_all_reads():

@@ -487,6 +487,79 @@ def test_marker_sharded_single_process(c2):
     assert abs(est["llk1"] - one["llk1"]) <= 1e-9 * abs(one["llk1"])
 
 
+def test_shard_group_virtual_shards_match_single_context(c2):
+    """vb2_shard_group over three shards that share the one device of this box (host-summed
+    partial LLKs): evaluations equal the single context's to rounding, the resident / launched
+    search gives the single-context estimate, the shards cover every read exactly once."""
+    d, od = c2
+    rng = np.random.default_rng(21)
+    B, k = 7, d.num_pc
+    pc1, pc2, al = rng.normal(0, 0.03, (B, k)), rng.normal(0, 0.03, (B, k)), rng.uniform(0, 0.5, B)
+    with vb.LikelihoodContext(d) as ctx:
+        want = ctx.llk(pc1, pc2, al)
+        one = ctx.optimize()
+    with vb.ShardGroup(d, devices=[0, 0, 0]) as g:
+        info = g.info()
+        assert info["num_shard"] == 3 and not info["uses_rccl"] and info["nranks"] == 1
+        assert info["marker_lo"][0] == 0 and info["marker_hi"][-1] == d.num_marker
+        assert info["marker_hi"][:-1] == info["marker_lo"][1:]
+        assert sum(info["num_read"]) == d.num_read
+        assert max(info["num_read"]) - min(info["num_read"]) <= 2 * 60
+        got = g.llk(pc1, pc2, al)
+        assert np.max(np.abs(got - want) / np.abs(want)) <= 1e-13
+        ref = np.array([od.llk(pc1[i], pc2[i], al[i]) for i in range(B)])
+        assert np.max(np.abs(got - ref) / np.abs(ref)) <= 1e-12
+        est = g.optimize()
+    assert abs(est["alpha"] - one["alpha"]) <= 1e-6
+    assert abs(est["llk1"] - one["llk1"]) <= 1e-9 * abs(one["llk1"])
+
+
+def test_shard_group_rank_mode_goes_through_rccl(c2):
+    """Process-per-GPU form with a ONE-rank communicator: exercises the run-time binding of
+    librccl (ncclGetUniqueId, ncclCommInitRank, ncclAllReduce on the context's stream)."""
+    d, _ = c2
+    rng = np.random.default_rng(22)
+    B, k = 9, d.num_pc
+    pc1, pc2, al = rng.normal(0, 0.03, (B, k)), rng.normal(0, 0.03, (B, k)), rng.uniform(0, 0.5, B)
+    with vb.LikelihoodContext(d) as ctx:
+        want = ctx.llk(pc1, pc2, al)
+        one = ctx.optimize()
+    uid = vb.ShardGroup.unique_id()
+    assert len(uid) == 128
+    with vb.ShardGroup(d, device=0, rank=0, nranks=1, unique_id=uid) as g:
+        info = g.info()
+        assert info["uses_rccl"] and info["num_shard"] == 1
+        got = g.llk(pc1, pc2, al)
+        assert np.array_equal(got, want)                     # one shard: the all-reduce is the identity
+        assert g.info()["num_allreduce"] >= 1
+        est = g.optimize()
+        assert est["alpha"] == one["alpha"] and est["num_eval"] == one["num_eval"]
+    # one device, single-process form: ncclCommInitAll with one device
+    with vb.ShardGroup(d, devices=[0]) as g:
+        assert g.info()["uses_rccl"]
+        assert np.array_equal(g.llk(pc1, pc2, al), want)
+        assert g.optimize()["alpha"] == one["alpha"]
+
+
+def test_shard_group_two_devices_rccl_all_reduce(c2):
+    """Two real devices: marker shards + ONE ncclAllReduce per batch (configs[3] in small)."""
+    if _abi.lib().vb2_device_count() < 2:
+        pytest.skip("needs two gfx950 devices")
+    d, _ = c2
+    rng = np.random.default_rng(23)
+    B, k = 11, d.num_pc
+    pc1, pc2, al = rng.normal(0, 0.03, (B, k)), rng.normal(0, 0.03, (B, k)), rng.uniform(0, 0.5, B)
+    with vb.LikelihoodContext(d) as ctx:
+        want = ctx.llk(pc1, pc2, al)
+        one = ctx.optimize()
+    with vb.ShardGroup(d, devices=[0, 1]) as g:
+        assert g.info()["uses_rccl"]
+        got = g.llk(pc1, pc2, al)
+        assert np.max(np.abs(got - want) / np.abs(want)) <= 1e-13
+        est = g.optimize()
+    assert abs(est["alpha"] - one["alpha"]) <= 1e-6
+
+
 def test_cohort_batch_lockstep_matches_individual_runs():
     """vb2_batch: samples of different sizes (one of them with no reads at all) evaluated and
     optimised in lock-step give each sample the result of its own single-context run."""

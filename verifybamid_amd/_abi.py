@@ -73,6 +73,7 @@ class RunArgs(C.Structure):
         ("pileup_path", C.c_char_p), ("known_af_path", C.c_char_p), ("output_prefix", C.c_char_p),
         ("num_pc", C.c_int32), ("disable_sanity", C.c_int32), ("output_pileup", C.c_int32),
         ("device", C.c_int32), ("model", Model),
+        ("devices", C.POINTER(C.c_int32)), ("num_device", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -91,6 +92,14 @@ class CohortArgs(C.Structure):
     ]
 
 
+class ShardInfo(C.Structure):
+    _fields_ = [
+        ("num_shard", C.c_int32), ("nranks", C.c_int32), ("rank", C.c_int32), ("uses_rccl", C.c_int32),
+        ("num_allreduce", C.c_int64), ("marker_lo", C.c_int32 * 64), ("marker_hi", C.c_int32 * 64),
+        ("num_read", C.c_int64 * 64),
+    ]
+
+
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                       C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -101,6 +110,8 @@ SYMBOLS = [
     "vb2_flat_load", "vb2_flat_input", "vb2_flat_stats", "vb2_flat_free", "vb2_last_error",
     "vb2_abi_version", "vb2_device_count",
     "vb2_batch_create", "vb2_batch_destroy", "vb2_batch_eval", "vb2_batch_optimize_llk",
+    "vb2_shard_group_create", "vb2_rccl_unique_id", "vb2_shard_group_create_rank", "vb2_shard_group_eval",
+    "vb2_shard_group_optimize_llk", "vb2_shard_group_info", "vb2_shard_group_destroy", "vb2_shard_range",
 ]
 
 _lib = None
@@ -157,6 +168,16 @@ def lib():
     L.vb2_batch_destroy.restype = None
     L.vb2_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.vb2_batch_optimize_llk.argtypes = [C.c_void_p, C.POINTER(Model), C.c_int32, C.POINTER(Estimate)]
+    L.vb2_shard_group_create.argtypes = [C.POINTER(Input), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
+    L.vb2_rccl_unique_id.argtypes = [C.c_void_p]
+    L.vb2_shard_group_create_rank.argtypes = [C.POINTER(Input), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                              C.POINTER(C.c_void_p)]
+    L.vb2_shard_group_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vb2_shard_group_optimize_llk.argtypes = [C.c_void_p, C.POINTER(Model), C.POINTER(Estimate), C.POINTER(Trace)]
+    L.vb2_shard_group_info.argtypes = [C.c_void_p, C.POINTER(ShardInfo)]
+    L.vb2_shard_range.argtypes = [C.POINTER(Input), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.vb2_shard_group_destroy.argtypes = [C.c_void_p]
+    L.vb2_shard_group_destroy.restype = None
     _lib = L
     return L
 

@@ -60,17 +60,20 @@ class PileupData:
                           _p(self.known_af), float(self.avg_depth), float(self.sd_depth),
                           int(bool(self.sanity_disabled)), 0)
 
+    def shard_range(self, rank, world):
+        """Markers [lo, hi) of shard `rank` of `world` -- the library's own partition (vb2_shard_range)."""
+        inp = self.as_input()
+        lo, hi = C.c_int32(), C.c_int32()
+        _abi.check(_abi.lib().vb2_shard_range(C.byref(inp), int(rank), int(world), C.byref(lo), C.byref(hi)),
+                   "vb2_shard_range")
+        return lo.value, hi.value
+
     def shard(self, rank, world):
         """Contiguous marker range holding ~1/world of the READS (balance on R, not M:
         SURVEY 8e).  The depth filter statistics stay global."""
-        M = self.num_marker
         if world <= 1:
             return self
-        total = self.read_off[-1] - self.read_off[0]
-        cuts = [int(np.searchsorted(self.read_off, self.read_off[0] + total * r / world, side="left"))
-                for r in range(world + 1)]
-        cuts[0], cuts[-1] = 0, M
-        lo, hi = min(cuts[rank], M), min(max(cuts[rank + 1], cuts[rank]), M)
+        lo, hi = self.shard_range(rank, world)
         b, e = int(self.read_off[lo]), int(self.read_off[hi])
         return PileupData(self.num_pc, self.ud[lo:hi], self.means[lo:hi],
                           self.read_off[lo:hi + 1] - b, self.bases[b:e], self.quals[b:e],
@@ -122,13 +125,17 @@ def _model(within_ancestry=False, fix_pc=None, fix_alpha=None, known_af=False, e
 
 
 def _run_args(svd_prefix, pileup_path, num_pc, disable_sanity, known_af_path, output_prefix,
-              device=-1, output_pileup=False, **model_kw):
+              device=-1, output_pileup=False, devices=None, **model_kw):
     m, keep = _model(known_af=known_af_path is not None, **model_kw)
     enc = lambda s: None if s is None else str(s).encode()
+    devs = None
+    if devices is not None and len(devices) > 0:
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
     args = _abi.RunArgs(enc(svd_prefix + ".UD"), enc(svd_prefix + ".mu"), enc(svd_prefix + ".bed"),
                         enc(pileup_path), enc(known_af_path), enc(output_prefix), int(num_pc),
-                        int(bool(disable_sanity)), int(bool(output_pileup)), int(device), m)
-    return args, keep
+                        int(bool(disable_sanity)), int(bool(output_pileup)), int(device), m,
+                        devs, 0 if devs is None else len(devices), 0)
+    return args, (keep, devs)
 
 
 def _estimate_dict(est, k):
@@ -283,6 +290,83 @@ class CohortBatch:
         return [_estimate_dict(est[s], self.num_pc) for s in range(S)]
 
 
+class ShardGroup:
+    """vb2_shard_group: ONE sample's markers sharded over several GPUs, partial LLKs met in one
+    RCCL all-reduce per batch (BASELINE.json configs[3]).
+
+    ShardGroup(data, devices=[0, 1, ...])            one process drives all devices
+    ShardGroup(data, device=d, rank=r, nranks=n, unique_id=b)   one process per GPU; rank 0 gets the
+        128-byte id from ShardGroup.unique_id() and the caller broadcasts it (torch.distributed,
+        MPI, a file ...)."""
+
+    def __init__(self, data: PileupData, devices=None, device=0, rank=0, nranks=1, unique_id=None):
+        self._lib = _abi.lib()
+        self.data = data
+        self.num_pc = data.num_pc
+        inp = data.as_input()
+        h = C.c_void_p()
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            _abi.check(self._lib.vb2_shard_group_create(C.byref(inp), arr, len(devices), C.byref(h)),
+                       "vb2_shard_group_create")
+        else:
+            idbuf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), 128)
+            _abi.check(self._lib.vb2_shard_group_create_rank(C.byref(inp), int(device), int(rank), int(nranks),
+                                                             idbuf, C.byref(h)),
+                       "vb2_shard_group_create_rank")
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _abi.check(_abi.lib().vb2_rccl_unique_id(buf), "vb2_rccl_unique_id")
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vb2_shard_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self):
+        i = _abi.ShardInfo()
+        _abi.check(self._lib.vb2_shard_group_info(self._h, C.byref(i)), "vb2_shard_group_info")
+        n = i.num_shard
+        return dict(num_shard=n, nranks=i.nranks, rank=i.rank, uses_rccl=bool(i.uses_rccl),
+                    num_allreduce=int(i.num_allreduce), marker_lo=list(i.marker_lo[:n]),
+                    marker_hi=list(i.marker_hi[:n]), num_read=[int(x) for x in i.num_read[:n]])
+
+    def llk(self, pc1, pc2, alpha):
+        pc1 = np.ascontiguousarray(np.atleast_2d(np.asarray(pc1, dtype=np.float64)))
+        pc2 = np.ascontiguousarray(np.atleast_2d(np.asarray(pc2, dtype=np.float64)))
+        alpha = np.ascontiguousarray(np.atleast_1d(np.asarray(alpha, dtype=np.float64)))
+        B = alpha.shape[0]
+        assert pc1.shape == (B, self.num_pc) and pc2.shape == (B, self.num_pc)
+        out = np.zeros(B)
+        _abi.check(self._lib.vb2_shard_group_eval(self._h, B, _p(pc1), _p(pc2), _p(alpha), _p(out)),
+                   "vb2_shard_group_eval")
+        return out
+
+    def optimize(self, trace_capacity=0, **model_kw):
+        m, keep = _model(known_af=self.data.known_af is not None, **model_kw)
+        est = _abi.Estimate()
+        tb = _TraceBuf(trace_capacity, self.num_pc) if trace_capacity else None
+        _abi.check(self._lib.vb2_shard_group_optimize_llk(self._h, C.byref(m), C.byref(est),
+                                                          C.byref(tb.c) if tb else None),
+                   "vb2_shard_group_optimize_llk")
+        out = _estimate_dict(est, self.num_pc)
+        if tb:
+            out["trace"], out["trace_count"] = tb.result()
+        return out
+
+
 def optimize_with_evaluator(evaluate, num_pc, trace_capacity=0, known_af=False, **model_kw):
     """OptimizeLLK over an arbitrary batched evaluator
         evaluate(pc1[B,k], pc2[B,k], alpha[B]) -> llk[B]
@@ -317,10 +401,11 @@ def optimize_with_evaluator(evaluate, num_pc, trace_capacity=0, known_af=False, 
 
 
 def run_files(svd_prefix, pileup_path, output_prefix=None, num_pc=2, disable_sanity=False,
-              known_af_path=None, device=-1, output_pileup=False, **model_kw):
-    """The --SVDPrefix/--PileupFile flow of execute() (vb2_run)."""
+              known_af_path=None, device=-1, output_pileup=False, devices=None, **model_kw):
+    """The --SVDPrefix/--PileupFile flow of execute() (vb2_run); devices=[a, b, ...] shards the
+    sample's markers over those GPUs."""
     args, keep = _run_args(svd_prefix, pileup_path, num_pc, disable_sanity, known_af_path,
-                           output_prefix, device, output_pileup, **model_kw)
+                           output_prefix, device, output_pileup, devices=devices, **model_kw)
     res = _abi.RunResult()
     _abi.check(_abi.lib().vb2_run(C.byref(args), C.byref(res)), "vb2_run")
     out = _estimate_dict(res.est, num_pc)
@@ -332,13 +417,13 @@ def run_files(svd_prefix, pileup_path, output_prefix=None, num_pc=2, disable_san
 
 def run_cohort_files(svd_prefix, pileup_paths, output_prefixes=None, num_pc=2, disable_sanity=False,
                      known_af_path=None, device=-1, output_pileup=False, group_size=0, num_host_thread=0,
-                     **model_kw):
+                     devices=None, **model_kw):
     """Many pileups against one panel (vb2_cohort_run): the panel is read once, the pileups are read
     and flattened by host threads while the device searches the previous group in lock-step.
     Returns one dict per sample (with its own "status" code)."""
     S = len(pileup_paths)
     args, keep = _run_args(svd_prefix, pileup_paths[0], num_pc, disable_sanity, known_af_path, None,
-                           device, output_pileup, **model_kw)
+                           device, output_pileup, devices=devices, **model_kw)
     ca = _abi.CohortArgs()
     ca.base = args
     ca.num_sample = S

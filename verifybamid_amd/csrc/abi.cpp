@@ -21,6 +21,7 @@
 #include "context.h"
 #include "estimator.h"
 #include "hostio.h"
+#include "shard.h"
 
 using vb2::set_error;
 
@@ -62,6 +63,9 @@ const char* estimation_title(const vb2_model& model)
 
 // The panel files of a run (reference order of errors: .bed, AF, .UD, .mu); .UD and .mu are parsed
 // on helper threads while this one reads the .bed.
+}  // namespace
+
+namespace vb2 {
 int load_panel(const vb2_run_args* a, vb2::Panel* panel)
 {
     int rc_ud = VB2_OK, rc_mu = VB2_OK;
@@ -89,6 +93,9 @@ int load_panel(const vb2_run_args* a, vb2::Panel* panel)
     }
     return VB2_OK;
 }
+}  // namespace vb2
+
+namespace {
 
 double now_s()
 {
@@ -282,6 +289,113 @@ int vb2_batch_optimize_llk(vb2_batch* b, const vb2_model* models, int32_t num_mo
     }
 }
 
+int vb2_shard_group_create(const vb2_input* in, const int32_t* devices, int32_t num_device, vb2_shard_group** out)
+{
+    if (!out) return VB2_ERR_INVALID;
+    *out = nullptr;
+    try {
+        vb2::ShardGroup* g = nullptr;
+        const int rc = vb2::ShardGroup::create(in, devices, num_device, &g);
+        if (rc) return rc;
+        *out = new vb2_shard_group{g};
+        return VB2_OK;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return VB2_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
+}
+
+int vb2_rccl_unique_id(void* id128)
+{
+    if (!id128) return VB2_ERR_INVALID;
+    return vb2::rccl_unique_id(id128);
+}
+
+int vb2_shard_group_create_rank(const vb2_input* in, int32_t device, int32_t rank, int32_t nranks,
+                                const void* id128, vb2_shard_group** out)
+{
+    if (!out) return VB2_ERR_INVALID;
+    *out = nullptr;
+    try {
+        vb2::ShardGroup* g = nullptr;
+        const int rc = vb2::ShardGroup::create_rank(in, device, rank, nranks, id128, &g);
+        if (rc) return rc;
+        *out = new vb2_shard_group{g};
+        return VB2_OK;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return VB2_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
+}
+
+int vb2_shard_group_eval(vb2_shard_group* g, int32_t num_point, const double* pc1, const double* pc2,
+                         const double* alpha, double* llk_out)
+{
+    if (!g || !g->impl) {
+        set_error("null vb2_shard_group");
+        return VB2_ERR_INVALID;
+    }
+    return g->impl->eval(num_point, pc1, pc2, alpha, llk_out);
+}
+
+int vb2_shard_group_optimize_llk(vb2_shard_group* g, const vb2_model* model, vb2_estimate* out, vb2_trace* trace)
+{
+    if (!g || !g->impl) {
+        set_error("null vb2_shard_group");
+        return VB2_ERR_INVALID;
+    }
+    try {
+        return g->impl->optimize(model, out, trace);
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
+}
+
+int vb2_shard_group_info(const vb2_shard_group* g, vb2_shard_info* info)
+{
+    if (!g || !g->impl || !info) return VB2_ERR_INVALID;
+    std::memset(info, 0, sizeof(*info));
+    const vb2::ShardGroup& sg = *g->impl;
+    info->num_shard = (int32_t)sg.ctx.size();
+    info->nranks = sg.nranks;
+    info->rank = sg.rank;
+    info->uses_rccl = sg.use_rccl ? 1 : 0;
+    info->num_allreduce = sg.num_allreduce;
+    for (size_t s = 0; s < sg.ctx.size() && s < 64; ++s) {
+        info->marker_lo[s] = sg.lo[s];
+        info->marker_hi[s] = sg.hi[s];
+        info->num_read[s] = sg.ctx[s]->num_read;
+    }
+    return VB2_OK;
+}
+
+int vb2_shard_range(const vb2_input* in, int32_t rank, int32_t nranks, int32_t* lo, int32_t* hi)
+{
+    if (!in || !in->read_off || !lo || !hi || nranks < 1 || rank < 0 || rank >= nranks || in->num_marker < 0) {
+        set_error("vb2_shard_range: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    int l = 0, h = 0;
+    vb2::shard_range(in, rank, nranks, &l, &h);
+    *lo = l;
+    *hi = h;
+    return VB2_OK;
+}
+
+void vb2_shard_group_destroy(vb2_shard_group* g)
+{
+    if (!g) return;
+    delete g->impl;
+    delete g;
+}
+
 int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
 {
     if (!a || !out || !a->ud_path || !a->mean_path || !a->bed_path || !a->pileup_path ||
@@ -412,25 +526,44 @@ int vb2_run(const vb2_run_args* a, vb2_run_result* out)
     if (a->output_pileup && a->output_prefix && (rc = vb2::write_pileup(a->output_prefix, *flat)))
         return rc;
 
-    vb2_options opt{};
-    opt.device = a->device;
-    vb2_ctx* ctx = nullptr;
-    const double t_flat0 = now_s();
-    if ((rc = vb2_ctx_create(&flat->input, &opt, &ctx))) return rc;
-    out->seconds_load = now_s() - t0;
-
     vb2_model model = a->model;
     if (flat->panel.isAFknown) model.is_af_known = 1;
-    if (notices)
-        std::fprintf(stderr, "NOTICE - Finished phase: Flatten + upload to %s  [%.3f seconds]\n",
-                     ctx->impl->device_name, now_s() - t_flat0);
-    const double t1 = now_s();
-    if (notices) std::fprintf(stderr, "NOTICE - Starting phase: Optimize likelihood\n");      // main.cpp:382
-    rc = vb2_ctx_optimize_llk(ctx, &model, &out->est, nullptr);
-    out->seconds_optimize = now_s() - t1;
-    if (notices) std::fprintf(stderr, "NOTICE - Finished phase: Optimize likelihood  [%.3f seconds]\n", out->seconds_optimize);
-    vb2_ctx_destroy(ctx);
-    if (rc) return rc;
+    const double t_flat0 = now_s();
+    if (a->devices && a->num_device > 1) {
+        // --Devices a,b,...: the sample's markers sharded over the devices (vb2_shard_group_*)
+        vb2_shard_group* grp = nullptr;
+        if ((rc = vb2_shard_group_create(&flat->input, a->devices, a->num_device, &grp))) return rc;
+        out->seconds_load = now_s() - t0;
+        if (notices)
+            std::fprintf(stderr, "NOTICE - Finished phase: Flatten + upload to %d devices (marker shards, %s)  "
+                                 "[%.3f seconds]\n", (int)a->num_device,
+                         grp->impl->use_rccl ? "RCCL all-reduce" : "host sum", now_s() - t_flat0);
+        const double t1 = now_s();
+        if (notices) std::fprintf(stderr, "NOTICE - Starting phase: Optimize likelihood\n");
+        rc = vb2_shard_group_optimize_llk(grp, &model, &out->est, nullptr);
+        out->seconds_optimize = now_s() - t1;
+        if (notices)
+            std::fprintf(stderr, "NOTICE - Finished phase: Optimize likelihood  [%.3f seconds]\n", out->seconds_optimize);
+        vb2_shard_group_destroy(grp);
+        if (rc) return rc;
+    } else {
+        vb2_options opt{};
+        opt.device = (a->devices && a->num_device == 1) ? a->devices[0] : a->device;
+        vb2_ctx* ctx = nullptr;
+        if ((rc = vb2_ctx_create(&flat->input, &opt, &ctx))) return rc;
+        out->seconds_load = now_s() - t0;
+        if (notices)
+            std::fprintf(stderr, "NOTICE - Finished phase: Flatten + upload to %s  [%.3f seconds]\n",
+                         ctx->impl->device_name, now_s() - t_flat0);
+        const double t1 = now_s();
+        if (notices) std::fprintf(stderr, "NOTICE - Starting phase: Optimize likelihood\n");      // main.cpp:382
+        rc = vb2_ctx_optimize_llk(ctx, &model, &out->est, nullptr);
+        out->seconds_optimize = now_s() - t1;
+        if (notices)
+            std::fprintf(stderr, "NOTICE - Finished phase: Optimize likelihood  [%.3f seconds]\n", out->seconds_optimize);
+        vb2_ctx_destroy(ctx);
+        if (rc) return rc;
+    }
 
     vb2::print_summary(estimation_title(model), a->num_pc, out->est);
     if (a->output_prefix) {
@@ -438,222 +571,6 @@ int vb2_run(const vb2_run_args* a, vb2_run_result* out)
         if ((rc = vb2::write_selfsm(a->output_prefix, *flat, out->est, true))) return rc;
     }
     return VB2_OK;
-}
-
-int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* status)
-{
-    if (!a || !out || !status || a->num_sample < 1 || !a->pileup_paths || !a->base.ud_path ||
-        !a->base.mean_path || !a->base.bed_path || a->base.num_pc < 1 || a->base.num_pc > VB2_MAX_PC) {
-        set_error("vb2_cohort_run: invalid argument");
-        return VB2_ERR_INVALID;
-    }
-    try {
-        const int S = a->num_sample;
-        const int G = std::max(1, std::min(a->group_size > 0 ? a->group_size : 32, 64));
-        const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-        const int T = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : 16, hw, S}));
-        for (int s = 0; s < S; ++s) {
-            std::memset(&out[s], 0, sizeof(out[s]));
-            status[s] = VB2_ERR_INVALID;
-        }
-        std::thread warm([dev = a->base.device] {      // HIP runtime start-up behind the panel reading
-            if (dev >= 0) (void)hipSetDevice(dev);
-            (void)hipFree(nullptr);
-            (void)hipGetLastError();
-        });
-        auto panel = std::make_shared<vb2::Panel>();
-        panel->numPC = a->base.num_pc;
-        int rc;
-        {
-            JoinGuard j_warm(warm);
-            rc = load_panel(&a->base, panel.get());
-        }
-        if (rc) return rc;
-
-        struct Slot {
-            std::unique_ptr<vb2_flat> flat;
-            vb2_ctx* ctx = nullptr;
-            int rc = VB2_OK;
-            bool ready = false;
-        };
-        std::vector<Slot> slots(S);
-        std::mutex mu;
-        std::condition_variable cv;
-        int next = 0, groups_done = 0;
-        bool stop = false;
-        vb2::g_flatten_thread_cap.store(std::max(1, 16 / T));
-        const bool sanity_off = a->base.disable_sanity != 0;
-
-        auto prepare = [&](int s) {
-            Slot& sl = slots[s];
-            const double t0 = now_s();
-            sl.flat.reset(new vb2_flat(panel));
-            vb2_flat& f = *sl.flat;
-            sl.rc = vb2::read_pileup(a->pileup_paths[s], panel->ChooseBed, &f.viewer);
-            if (sl.rc) return;
-            f.sanity_disabled = sanity_off;
-            const bool sane = sanity_off || vb2::sanity_check(*panel, &f.viewer);
-            f.resolve();
-            vb2_flat_stats(&f, &out[s]);
-            const char* prefix = a->output_prefixes ? a->output_prefixes[s] : nullptr;
-            if (a->base.output_pileup && prefix) (void)vb2::write_pileup(prefix, f);
-            if (!sane) {
-                sl.rc = VB2_ERR_SANITY;
-                return;
-            }
-            vb2_options opt{};
-            opt.device = a->base.device;
-            sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
-            out[s].seconds_load = now_s() - t0;
-        };
-        auto worker = [&] {
-            for (;;) {
-                int s;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    // stay at most two groups ahead of the device (bounds host and device memory)
-                    cv.wait(lk, [&] { return stop || next >= S || next < (groups_done + 2) * G; });
-                    if (stop || next >= S) return;
-                    s = next++;
-                }
-                try {
-                    prepare(s);
-                } catch (const std::bad_alloc&) {
-                    slots[s].rc = VB2_ERR_NOMEM;
-                } catch (const std::exception&) {
-                    slots[s].rc = VB2_ERR_INVALID;
-                }
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    slots[s].ready = true;
-                }
-                cv.notify_all();
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 0; t < T; ++t) pool.emplace_back(worker);
-
-        std::mutex rel_mu;
-        std::condition_variable rel_cv;
-        std::deque<std::pair<vb2_ctx*, std::unique_ptr<vb2_flat>>> rel_queue;
-        bool rel_stop = false;
-        std::thread releaser([&] {
-            for (;;) {
-                std::pair<vb2_ctx*, std::unique_ptr<vb2_flat>> item;
-                {
-                    std::unique_lock<std::mutex> lk(rel_mu);
-                    rel_cv.wait(lk, [&] { return rel_stop || !rel_queue.empty(); });
-                    if (rel_queue.empty()) return;
-                    item = std::move(rel_queue.front());
-                    rel_queue.pop_front();
-                }
-                if (item.first) vb2_ctx_destroy(item.first);
-            }
-        });
-
-        // Every way out of this scope (return, exception) stops and joins the reader pool and the
-        // releaser thread, and gives back the contexts that were never handed over.
-        struct Shutdown {
-            std::function<void()> fn;
-            ~Shutdown() { fn(); }
-        } shutdown{[&] {
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                stop = true;
-            }
-            cv.notify_all();
-            for (auto& th : pool)
-                if (th.joinable()) th.join();
-            {
-                std::lock_guard<std::mutex> lk(rel_mu);
-                rel_stop = true;
-            }
-            rel_cv.notify_one();
-            if (releaser.joinable()) releaser.join();
-            for (auto& sl : slots)
-                if (sl.ctx) { vb2_ctx_destroy(sl.ctx); sl.ctx = nullptr; }
-            vb2::g_flatten_thread_cap.store(0);
-        }};
-
-        vb2_model model = a->base.model;
-        if (panel->isAFknown) model.is_af_known = 1;
-        int rc_all = VB2_OK;
-        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
-        for (int g0 = 0; g0 < S && rc_all == VB2_OK; g0 += G) {
-            const int g1 = std::min(S, g0 + G);
-            const double tg0 = now_s();
-            double tg_wait = 0, tg_opt = 0, tg_out = 0;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] {
-                    for (int s = g0; s < g1; ++s)
-                        if (!slots[s].ready) return false;
-                    return true;
-                });
-            }
-            tg_wait = now_s();
-            std::vector<vb2_ctx*> ctxs;
-            std::vector<int> who;
-            for (int s = g0; s < g1; ++s) {
-                status[s] = slots[s].rc;
-                if (slots[s].rc == VB2_OK && slots[s].ctx) {
-                    ctxs.push_back(slots[s].ctx);
-                    who.push_back(s);
-                }
-            }
-            if (!ctxs.empty()) {
-                const double t1 = now_s();
-                std::vector<vb2_estimate> est(ctxs.size());
-                vb2_batch* batch = nullptr;
-                int rcb = vb2_batch_create(ctxs.data(), (int32_t)ctxs.size(), &batch);
-                if (!rcb) rcb = vb2_batch_optimize_llk(batch, &model, 1, est.data());
-                if (batch) vb2_batch_destroy(batch);
-                tg_opt = now_s();
-                const double dt = (tg_opt - t1) / (double)ctxs.size();
-                if (rcb) {
-                    rc_all = rcb;                      // device-level failure: concerns every sample
-                } else {
-                    for (size_t i = 0; i < who.size(); ++i) {
-                        const int s = who[i];
-                        out[s].est = est[i];
-                        out[s].seconds_optimize = dt;
-                        const char* prefix = a->output_prefixes ? a->output_prefixes[s] : nullptr;
-                        if (prefix) {
-                            int rw = vb2::write_ancestry(prefix, a->base.num_pc, est[i].pc, est[i].pc2);
-                            if (!rw) rw = vb2::write_selfsm(prefix, *slots[s].flat, est[i], true);
-                            if (rw) status[s] = rw;
-                        }
-                    }
-                }
-            }
-            tg_out = now_s();
-            {   // freeing device and pinned memory synchronises with the device and takes milliseconds
-                // per context: hand the group to the releaser thread and move on
-                std::lock_guard<std::mutex> lk(rel_mu);
-                for (int s = g0; s < g1; ++s) {
-                    rel_queue.emplace_back(slots[s].ctx, std::move(slots[s].flat));
-                    slots[s].ctx = nullptr;
-                }
-            }
-            rel_cv.notify_one();
-            if (timing)
-                std::fprintf(stderr, "vb2_cohort_run: group %d-%d: waited %.1f ms for the readers, search %.1f ms, "
-                             "outputs %.1f ms, release %.1f ms\n", g0, g1 - 1, 1e3 * (tg_wait - tg0),
-                             1e3 * (tg_opt - tg_wait), 1e3 * (tg_out - tg_opt), 1e3 * (now_s() - tg_out));
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                ++groups_done;
-            }
-            cv.notify_all();
-        }
-        return rc_all;
-    } catch (const std::bad_alloc&) {
-        set_error("out of host memory");
-        return VB2_ERR_NOMEM;
-    } catch (const std::exception& e) {
-        set_error(e.what());
-        return VB2_ERR_INVALID;
-    }
 }
 
 }  // extern "C"

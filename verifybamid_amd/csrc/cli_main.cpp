@@ -8,7 +8,9 @@
 //
 // --BamFile needs htslib (absent from this build: SURVEY.md section 8f rank 3); use
 // the reference's own --OutputPileup file with --PileupFile instead.
-// Extension: --Device n selects the GPU.
+// Extensions: --Device n selects the GPU; --Devices a,b,.. uses several -- one sample's markers
+// are sharded over them (partial log-likelihoods met in one RCCL all-reduce), a --PileupList
+// cohort is dealt to them group by group; --PileupList F runs many samples against one panel.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,7 +49,7 @@ int main(int argc, char** argv)
     // defaults: main.cpp:58-79
     std::string UDPath("Empty"), MeanPath("Empty"), BedPath("Empty"), BamFile("Empty"),
         RefPath("Empty"), outputPrefix("result"), PileupFile("Empty"), SVDPrefix("Empty"),
-        knownAF("Empty"), fixPC("Empty"), PileupList("Empty");
+        knownAF("Empty"), fixPC("Empty"), PileupList("Empty"), Devices("Empty");
     double fixAlpha = -1., epsilon = 1e-8;
     bool withinAncestry = false, outputPileup = false, verbose = false, disableSanityCheck = false;
     int seed = 12345, nPC = 2, nthread = 4, device = -1;
@@ -73,6 +75,7 @@ int main(int argc, char** argv)
         {"MeanPath", {Flag::kString, &MeanPath, false}},
         {"BedPath", {Flag::kString, &BedPath, false}},
         {"Device", {Flag::kInt, &device, false}},
+        {"Devices", {Flag::kString, &Devices, false}},
         // not in the reference: a cohort against one panel.  File of lines "<pileup>\t<output prefix>";
         // the panel is read once and the samples are searched in lock-step groups (vb2_cohort_run).
         {"PileupList", {Flag::kString, &PileupList, false}},
@@ -139,6 +142,20 @@ int main(int argc, char** argv)
     args.disable_sanity = disableSanityCheck;
     args.output_pileup = outputPileup;
     args.device = device;
+    std::vector<int32_t> devs;
+    if (Devices != "Empty") {
+        std::stringstream ds(Devices);
+        std::string tok;
+        while (std::getline(ds, tok, ',')) {
+            if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos)
+                fatal("--Devices takes a comma-separated list of device ordinals, e.g. 0,1,2,3");
+            devs.push_back(std::atoi(tok.c_str()));
+        }
+        if (devs.empty() || devs.size() > 64) fatal("--Devices names no device (or more than 64)");
+        args.devices = devs.data();
+        args.num_device = (int32_t)devs.size();
+        args.device = devs[0];
+    }
     args.model.is_heter = !withinAncestry;
     args.model.epsilon = epsilon;
     args.model.verbose = verbose;

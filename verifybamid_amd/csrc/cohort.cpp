@@ -1,0 +1,349 @@
+// cohort.cpp -- vb2_cohort_run: many samples against one panel (BASELINE.json configs[4]).
+//
+// The reference runs one process per sample (main.cpp:56-414).  Here the panel is read once, a
+// pool of host threads reads + flattens + uploads pileups, and every DEVICE of the run has its
+// own pipeline thread that takes the next ready group of samples and searches it in lock-step
+// (vb2_batch_*: one kernel launch per Nelder-Mead step for the whole group).  Samples are
+// independent, so several devices need no collective: groups are dealt round-robin
+// (--Devices a,b,...: group g runs on devices[g % n]), which is the sample-parallel sharding
+// of SURVEY.md 8e(2) inside one process.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "batch.h"
+#include "context.h"
+#include "estimator.h"
+#include "hostio.h"
+
+using vb2::set_error;
+
+namespace {
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Slot {
+    std::unique_ptr<vb2_flat> flat;
+    vb2_ctx* ctx = nullptr;
+    int rc = VB2_OK;
+    bool ready = false;
+};
+
+class CohortRunner {
+public:
+    CohortRunner(const vb2_cohort_args* a, vb2_run_result* out, int32_t* status)
+        : a_(a), out_(out), status_(status), S_(a->num_sample)
+    {
+        if (a->base.devices && a->base.num_device > 0) devices_.assign(a->base.devices, a->base.devices + a->base.num_device);
+        else devices_.push_back(a->base.device);
+        ndev_ = (int)devices_.size();
+        G_ = std::max(1, std::min(a->group_size > 0 ? a->group_size : 32, 64));
+        const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+        // readers: text parsing + run packing is ~0.1 s of one core per C3-sized sample, the device
+        // needs ~4 ms per sample -> a device keeps ~25 readers busy; the default takes half the
+        // host's cores (the lock-step search has one mostly sleeping host thread per sample)
+        const int dflt = std::max(4, std::min(hw / 2, 64 * ndev_));
+        T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, hw, S_}));
+        slots_.resize(S_);
+        cnt_.assign(ndev_, 0);
+        ngroup_ = (S_ + G_ - 1) / G_;
+    }
+
+    ~CohortRunner() { shutdown(); }
+
+    int run()
+    {
+        for (int s = 0; s < S_; ++s) {
+            std::memset(&out_[s], 0, sizeof(out_[s]));
+            status_[s] = VB2_ERR_INVALID;
+        }
+        // HIP runtime start-up (per device) behind the panel reading
+        std::vector<std::thread> warm;
+        for (int d : devices_)
+            warm.emplace_back([d] {
+                if (d >= 0) (void)hipSetDevice(d);
+                (void)hipFree(nullptr);
+                (void)hipGetLastError();
+            });
+        panel_ = std::make_shared<vb2::Panel>();
+        panel_->numPC = a_->base.num_pc;
+        int rc = VB2_OK;
+        try {
+            rc = vb2::load_panel(&a_->base, panel_.get());
+        } catch (...) {
+            for (auto& t : warm) t.join();
+            throw;
+        }
+        for (auto& t : warm) t.join();
+        if (rc) return rc;
+        model_ = a_->base.model;
+        if (panel_->isAFknown) model_.is_af_known = 1;
+        vb2::g_flatten_thread_cap.store(std::max(1, 16 / T_));
+
+        releaser_ = std::thread([this] { release_loop(); });
+        for (int t = 0; t < T_; ++t) pool_.emplace_back([this] { reader_loop(); });
+        for (int d = 0; d < ndev_; ++d) dev_threads_.emplace_back([this, d] { device_loop(d); });
+        for (auto& t : dev_threads_) t.join();
+        dev_threads_.clear();
+        shutdown();
+        return rc_all_;
+    }
+
+private:
+    const vb2_cohort_args* a_;
+    vb2_run_result* out_;
+    int32_t* status_;
+    int S_, G_ = 32, T_ = 1, ndev_ = 1, ngroup_ = 0;
+    std::vector<int> devices_;
+    std::shared_ptr<vb2::Panel> panel_;
+    vb2_model model_{};
+    std::vector<Slot> slots_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int next_ = 0;
+    std::vector<int> cnt_;                 // groups completed per device
+    bool stop_ = false;
+    int rc_all_ = VB2_OK;
+    std::string err_all_;
+    std::vector<std::thread> pool_, dev_threads_;
+    std::thread releaser_;
+    std::mutex rel_mu_;
+    std::condition_variable rel_cv_;
+    std::deque<std::pair<vb2_ctx*, std::unique_ptr<vb2_flat>>> rel_queue_;
+    bool rel_stop_ = false;
+    bool down_ = false;
+
+    int device_of_group(int gi) const { return gi % ndev_; }
+
+    // every way out (normal end, error, exception in run()) stops and joins all threads and
+    // gives back the contexts that were never handed to a device pipeline
+    void shutdown()
+    {
+        if (down_) return;
+        down_ = true;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : dev_threads_)
+            if (t.joinable()) t.join();
+        for (auto& t : pool_)
+            if (t.joinable()) t.join();
+        {
+            std::lock_guard<std::mutex> lk(rel_mu_);
+            rel_stop_ = true;
+        }
+        rel_cv_.notify_all();
+        if (releaser_.joinable()) releaser_.join();
+        for (auto& sl : slots_)
+            if (sl.ctx) {
+                vb2_ctx_destroy(sl.ctx);
+                sl.ctx = nullptr;
+            }
+        vb2::g_flatten_thread_cap.store(0);
+    }
+
+    void prepare(int s)
+    {
+        Slot& sl = slots_[s];
+        const double t0 = now_s();
+        sl.flat.reset(new vb2_flat(panel_));
+        vb2_flat& f = *sl.flat;
+        sl.rc = vb2::read_pileup(a_->pileup_paths[s], panel_->ChooseBed, &f.viewer);
+        if (sl.rc) return;
+        const bool sanity_off = a_->base.disable_sanity != 0;
+        f.sanity_disabled = sanity_off;
+        const bool sane = sanity_off || vb2::sanity_check(*panel_, &f.viewer);
+        f.resolve();
+        vb2_flat_stats(&f, &out_[s]);
+        const char* prefix = a_->output_prefixes ? a_->output_prefixes[s] : nullptr;
+        if (a_->base.output_pileup && prefix) (void)vb2::write_pileup(prefix, f);
+        if (!sane) {
+            sl.rc = VB2_ERR_SANITY;
+            return;
+        }
+        vb2_options opt{};
+        opt.device = devices_[device_of_group(s / G_)];
+        sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
+        out_[s].seconds_load = now_s() - t0;
+    }
+
+    void reader_loop()
+    {
+        for (;;) {
+            int s;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                // stay at most two groups ahead of the group's device (bounds host and device memory)
+                cv_.wait(lk, [&] {
+                    if (stop_ || next_ >= S_) return true;
+                    const int gi = next_ / G_;
+                    return gi / ndev_ < cnt_[device_of_group(gi)] + 2;
+                });
+                if (stop_ || next_ >= S_) return;
+                s = next_++;
+            }
+            try {
+                prepare(s);
+            } catch (const std::bad_alloc&) {
+                slots_[s].rc = VB2_ERR_NOMEM;
+            } catch (const std::exception&) {
+                slots_[s].rc = VB2_ERR_INVALID;
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                slots_[s].ready = true;
+            }
+            cv_.notify_all();
+        }
+    }
+
+    void release_loop()
+    {
+        for (;;) {
+            std::pair<vb2_ctx*, std::unique_ptr<vb2_flat>> item;
+            {
+                std::unique_lock<std::mutex> lk(rel_mu_);
+                rel_cv_.wait(lk, [&] { return rel_stop_ || !rel_queue_.empty(); });
+                if (rel_queue_.empty()) return;
+                item = std::move(rel_queue_.front());
+                rel_queue_.pop_front();
+            }
+            if (item.first) vb2_ctx_destroy(item.first);
+        }
+    }
+
+    void device_loop(int d)
+    {
+        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+        for (int gi = d; gi < ngroup_; gi += ndev_) {
+            const int g0 = gi * G_, g1 = std::min(S_, g0 + G_);
+            const double tg0 = now_s();
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] {
+                    if (stop_) return true;
+                    for (int s = g0; s < g1; ++s)
+                        if (!slots_[s].ready) return false;
+                    return true;
+                });
+                if (stop_) return;
+            }
+            const double tg_wait = now_s();
+            std::vector<vb2_ctx*> ctxs;
+            std::vector<int> who;
+            for (int s = g0; s < g1; ++s) {
+                status_[s] = slots_[s].rc;
+                if (slots_[s].rc == VB2_OK && slots_[s].ctx) {
+                    ctxs.push_back(slots_[s].ctx);
+                    who.push_back(s);
+                }
+            }
+            int rcb = VB2_OK;
+            if (!ctxs.empty()) {
+                const double t1 = now_s();
+                std::vector<vb2_estimate> est(ctxs.size());
+                vb2_batch* batch = nullptr;
+                try {
+                    rcb = vb2_batch_create(ctxs.data(), (int32_t)ctxs.size(), &batch);
+                    if (!rcb) rcb = vb2_batch_optimize_llk(batch, &model_, 1, est.data());
+                } catch (const std::exception& e) {
+                    set_error(e.what());
+                    rcb = VB2_ERR_INVALID;
+                }
+                if (batch) vb2_batch_destroy(batch);
+                const double dt = (now_s() - t1) / (double)ctxs.size();
+                if (!rcb) {
+                    for (size_t i = 0; i < who.size(); ++i) {
+                        const int s = who[i];
+                        out_[s].est = est[i];
+                        out_[s].seconds_optimize = dt;
+                        const char* prefix = a_->output_prefixes ? a_->output_prefixes[s] : nullptr;
+                        if (prefix) {
+                            int rw = vb2::write_ancestry(prefix, a_->base.num_pc, est[i].pc, est[i].pc2);
+                            if (!rw) rw = vb2::write_selfsm(prefix, *slots_[s].flat, est[i], true);
+                            if (rw) status_[s] = rw;
+                        }
+                    }
+                }
+            }
+            const double tg_opt = now_s();
+            {   // freeing device and pinned memory synchronises with the device and takes milliseconds
+                // per context: hand the group to the releaser thread and move on
+                std::lock_guard<std::mutex> lk(rel_mu_);
+                for (int s = g0; s < g1; ++s) {
+                    rel_queue_.emplace_back(slots_[s].ctx, std::move(slots_[s].flat));
+                    slots_[s].ctx = nullptr;
+                }
+            }
+            rel_cv_.notify_one();
+            if (timing)
+                std::fprintf(stderr, "vb2_cohort_run: device %d group %d (samples %d-%d): waited %.1f ms for the "
+                                     "readers, search + outputs %.1f ms\n", devices_[d], gi, g0, g1 - 1,
+                             1e3 * (tg_wait - tg0), 1e3 * (tg_opt - tg_wait));
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                ++cnt_[d];
+                if (rcb) {                       // device-level failure: concerns every sample
+                    if (!rc_all_) {
+                        rc_all_ = rcb;
+                        err_all_ = vb2::g_last_error;
+                    }
+                    stop_ = true;
+                }
+            }
+            cv_.notify_all();
+            if (rcb) return;
+        }
+    }
+
+public:
+    const std::string& error() const { return err_all_; }
+    int num_reader() const { return T_; }
+};
+
+}  // namespace
+
+extern "C" int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int32_t* status)
+{
+    if (!a || !out || !status || a->num_sample < 1 || !a->pileup_paths || !a->base.ud_path ||
+        !a->base.mean_path || !a->base.bed_path || a->base.num_pc < 1 || a->base.num_pc > VB2_MAX_PC ||
+        a->base.num_device < 0 || a->base.num_device > 64) {
+        set_error("vb2_cohort_run: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    for (int i = 0; i < a->base.num_device; ++i)
+        for (int j = 0; j < i; ++j)
+            if (a->base.devices && a->base.devices[i] == a->base.devices[j]) {
+                // (two lock-step pipelines on one device would each launch device-filling grids)
+                set_error("vb2_cohort_run: a device is listed twice");
+                return VB2_ERR_INVALID;
+            }
+    try {
+        CohortRunner runner(a, out, status);
+        const int rc = runner.run();
+        if (rc && !runner.error().empty()) set_error(runner.error());
+        return rc;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return VB2_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
+}

@@ -690,6 +690,57 @@ void Context::resident_end()
     g_resident_busy[device].store(0);
 }
 
+void Context::resident_submit(int n, const double* rows)
+{
+    resident_post(h_cmd, resident_words(num_pc), ++done_seq_, n, 2 * num_pc + 1, rows);
+    dbg_t_post = std::chrono::steady_clock::now();
+    if (dbg_timing && dbg_have_prev)
+        dbg_host_ns += std::chrono::duration<double, std::nano>(dbg_t_post - dbg_prev_seen).count();
+}
+
+bool Context::resident_collect(int n, double* out)
+{
+    const unsigned long long seq = done_seq_;
+    const int stride = 2 * num_pc + 1;
+    bool seen = false;
+    const auto t0 = dbg_t_post;
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+        if ((spins & 0x3ff) == 0x3ff) {
+            if (__atomic_load_n(h_state, __ATOMIC_ACQUIRE) == 3u) break;       // kernel gave up
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) break;
+        }
+        __builtin_ia32_pause();
+    }
+    // A NaN can only be the kernel's own "a workgroup never reported" marker (the partial-sum
+    // hand-off waited two seconds): part of the grid is not on the CUs.  Same treatment as no
+    // answer at all.
+    if (seen)
+        for (int b = 0; b < n; ++b)
+            if (std::isnan(h_out[b])) seen = false;
+    if (!seen) {
+        // Give up on the mode: tell the kernel to leave (it may already have, on its idle
+        // limit), wait for it, and let the caller redo the batch with plain launches.
+        (void)hipSetDevice(device);
+        resident_post(h_cmd, resident_words(num_pc), ++done_seq_, 0, stride, nullptr);
+        (void)hipStreamSynchronize(stream);
+        resident_active = false;
+        resident_enabled = false;
+        g_resident_busy[device].store(0);
+        (void)hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream);
+        return false;
+    }
+    std::memcpy(out, h_out, sizeof(double) * n);
+    ++resident_evals;
+    if (dbg_timing) {
+        dbg_prev_seen = std::chrono::steady_clock::now();
+        dbg_wait_ns += std::chrono::duration<double, std::nano>(dbg_prev_seen - t0).count();
+        dbg_have_prev = true;
+        ++dbg_cmds;
+    }
+    return true;
+}
+
 int Context::eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,
                        double* llk_out)
 {
@@ -710,46 +761,9 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
             std::memcpy(row + k, pc2 + (size_t)(served + b) * k, sizeof(double) * k);
             row[2 * k] = alpha[served + b];
         }
-        const unsigned long long seq = ++done_seq_;
-        resident_post(h_cmd, resident_words(k), seq, n, stride, rows);
-        bool seen = false;
-        const auto t0 = std::chrono::steady_clock::now();
-        if (dbg_timing && dbg_have_prev)
-            dbg_host_ns += std::chrono::duration<double, std::nano>(t0 - dbg_prev_seen).count();
-        for (unsigned spins = 0;; ++spins) {
-            if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
-            if ((spins & 0x3ff) == 0x3ff) {
-                if (__atomic_load_n(h_state, __ATOMIC_ACQUIRE) == 3u) break;       // kernel gave up
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) break;
-            }
-            __builtin_ia32_pause();
-        }
-        // A NaN can only be the kernel's own "a workgroup never reported" marker (the partial-sum
-        // hand-off waited two seconds): part of the grid is not on the CUs.  Same treatment as no
-        // answer at all.
-        if (seen)
-            for (int b = 0; b < n; ++b)
-                if (std::isnan(h_out[b])) seen = false;
-        if (!seen) {
-            // Give up on the mode: tell the kernel to leave (it may already have, on its idle
-            // limit), wait for it, and redo the batch with plain launches below.
-            resident_post(h_cmd, resident_words(k), ++done_seq_, 0, stride, nullptr);
-            (void)hipStreamSynchronize(stream);
-            resident_active = false;
-            resident_enabled = false;
-            g_resident_busy[device].store(0);
-            VB2_HIP(hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream));
-            break;
-        }
-        std::memcpy(llk_out + served, h_out, sizeof(double) * n);
+        resident_submit(n, rows);
+        if (!resident_collect(n, llk_out + served)) break;       // plain launches below
         served += n;
-        ++resident_evals;
-        if (dbg_timing) {
-            dbg_prev_seen = std::chrono::steady_clock::now();
-            dbg_wait_ns += std::chrono::duration<double, std::nano>(dbg_prev_seen - t0).count();
-            dbg_have_prev = true;
-            ++dbg_cmds;
-        }
     }
     pc1 += (size_t)served * k;
     pc2 += (size_t)served * k;

@@ -52,6 +52,11 @@ public:
     // later falls back to plain launches on its own.
     bool resident_begin();
     void resident_end();
+    // The two halves of a resident evaluation (eval_host = submit + collect): posts <= 4 rows of
+    // 2k+1 doubles to the mailbox; then spins for the results.  collect returns false when the
+    // kernel did not answer (the mode is then torn down: redo the rows with plain launches).
+    void resident_submit(int n, const double* rows);
+    bool resident_collect(int n, double* out);
     void fill_info(vb2_info* info) const;
     int read_stamps(unsigned long long* out, int max_blocks);
 
@@ -88,7 +93,7 @@ public:
     bool dbg_timing = false, dbg_have_prev = false;
     int64_t dbg_cmds = 0;
     double dbg_host_ns = 0, dbg_wait_ns = 0;
-    std::chrono::steady_clock::time_point dbg_prev_seen;
+    std::chrono::steady_clock::time_point dbg_prev_seen, dbg_t_post;
     int64_t num_read = 0, num_read_other = 0, device_bytes = 0, algorithmic_bytes = 0;
     char device_name[64] = {0};
     char arch[32] = {0};

@@ -78,6 +78,9 @@ int write_selfsm(const std::string& prefix, const vb2_flat& f, const vb2_estimat
                  bool pileup_input);
 int write_pileup(const std::string& prefix, const vb2_flat& f);
 void print_summary(const char* title, int numPC, const vb2_estimate& est);
+// The panel files of a run (abi.cpp): .UD and .mu parsed on helper threads while the caller's
+// thread reads the .bed (and the AF file); errors in the reference's reading order.
+int load_panel(const vb2_run_args* a, Panel* panel);
 }  // namespace vb2
 
 #endif

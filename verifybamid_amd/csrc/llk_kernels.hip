@@ -352,7 +352,12 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (c < 2 * k) ptq[((b / BTL) * 2 * k + c) * BTL + (b % BTL)] = v;
     }
     // 2^(j/64) table of exp_nonpos, one copy per pair of LDS banks (see there)
-    for (int e = tid; e < kExpTabDoubles; e += nthread) etab[e] = kExp2Tab[e >> 5];
+    // (entry j = e / 32 is the same for a half-wave: two SCALAR loads per step, no vector-memory
+    // round trip before the first barrier)
+    for (int jb = 2 * wave; jb < 64; jb += 2 * nwave) {
+        const double t0 = kExp2Tab[jb], t1 = kExp2Tab[jb + 1];
+        etab[jb * 32 + lane] = lane < 32 ? t0 : t1;
+    }
     // With several groups a thread builds several table entries: the primary-code records (a
     // few dozen) go to LDS first so that the loop below does not wait on a global load per
     // entry.  With one group each thread builds about one entry and loads its record directly.
