@@ -2,28 +2,34 @@
 """bench.py -- LLK evaluations per second on the BASELINE.json workload.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 runs one process per GPU over RCCL.  Started under `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` the ranks come from the environment; started plainly
+(`python bench.py --gpus N`) the script spawns the N ranks itself on 127.0.0.1.
 
 Workload (config.workload): synthetic pileup of 100 000 markers x depth 30, --NumPC 4
 (BASELINE.json configs[2], the shape the metric is quoted on), resident in HBM before the
-timed region.  One STEP = one pass of the hot path over that pileup for a batch of
-`--batch` parameter points (default 48, the most one launch carries): one
-`vb2_llk_eval_batch_device` call = one launch of the dominant kernel
-(llk_eval_kernel<2,true>: 8 points per group, 4 groups).  One "eval" = one
-(pc1, pc2, alpha) point = one call of the reference's ComputeMixLLKs.
+timed region.  One STEP = one pass of the hot path over that pileup for a batch of `--batch`
+parameter points (default 48, the most one launch carries): one `vb2_llk_eval_batch_device`
+call = one launch of the dominant kernel (llk_eval_kernel<2,true>: 8 points per group, 6
+groups).  One "eval" = one (pc1, pc2, alpha) point = one call of the reference's
+ComputeMixLLKs.
 
-N > 1 (default `--mode sample`): every rank owns a different sample of the same shape
-(sample-parallel, BASELINE.json configs[4]); no data-path collective, weak scaling.
-`--mode marker` shards one sample's markers over the ranks and all-reduces the partial
-LLKs over RCCL each step (configs[3]; strong scaling, latency-bound -- reported in
-DESIGN.md, not the default).
+N > 1, `--mode sample` (default): every rank owns a different sample of the same shape
+(sample-parallel, BASELINE.json configs[4]); no data-path collective, weak scaling; `value` is
+the whole-job rate.  The JSON also carries `marker_sharded`: ONE sample's markers sharded over
+the N ranks by the library's own C++ group (vb2_shard_group_create_rank: launch +
+ncclAllReduce of the batch's partial LLKs per step, BASELINE.json configs[3]) -- its evals/s
+and its OptimizeLLK wall-clock.  `--mode marker` makes that the primary metric (strong scaling).
 
-Prints ONE JSON line on rank 0.  The oracle (oracle/) is used only as the checker of a
-small parity probe and as the cpu_baseline leg; it is never the thing timed as `value`.
+Prints ONE JSON line on rank 0.  The oracle (oracle/) is used only as the checker of a small
+parity probe and as the cpu_baseline leg; it is never the thing timed as `value`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,9 +37,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+FP64_VALU_NOTE = ("FP64 vector peak 78.6 TFLOP/s = 16 FMA lanes/clk/SIMD: a wave64 FP64 instruction "
+                  "occupies its SIMD for 4 cycles")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -46,9 +54,78 @@ def main():
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--num-pc", type=int, default=4)
     ap.add_argument("--mode", choices=["sample", "marker"], default="sample")
+    ap.add_argument("--cohort-samples", type=int, default=32, help="samples of the single-GPU cohort leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimize", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip search_point / cohort / marker_sharded legs (profiling runs)")
+    return ap.parse_args()
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one per GPU)."""
+    import ctypes
+    try:        # fail fast (and cheaply: no torch import) when the box has fewer GPUs than ranks
+        lib = ctypes.CDLL(os.path.join(ROOT, "verifybamid_amd", "libvb2.so"))
+        have = lib.vb2_device_count()
+    except OSError:
+        have = -1
+    if 0 <= have < n and os.environ.get("VB2_BENCH_SHARE_GPU", "") != "1":
+        raise SystemExit("bench.py --gpus %d: only %d gfx950 device(s) visible" % (n, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies must not leave the others waiting in a rendezvous
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    sys.exit(max(abs(p.returncode) for p in procs))
+
+
+def latest_profile(name):
+    pdir = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(pdir):
+        return None, None
+    for rnd in sorted(os.listdir(pdir), reverse=True):
+        f = os.path.join(pdir, rnd, name)
+        if os.path.exists(f):
+            return json.load(open(f)), os.path.relpath(f, ROOT)
+    return None, None
+
+
+def timed_launches(ctx, pts, out, B, stream, steps, torch):
+    for _ in range(100):
+        ctx.llk_device(pts.data_ptr(), out.data_ptr(), B, stream.cuda_stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(steps):
+        ctx.llk_device(pts.data_ptr(), out.data_ptr(), B, stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / steps          # us per launch
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args.gpus)
 
     import numpy as np
     import torch
@@ -58,43 +135,72 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    # VB2_BENCH_SHARE_GPU=1 (plumbing check on a one-GPU box, never a measurement): every rank uses
+    # device 0, the ranks talk over gloo, and the RCCL leg is skipped
+    share_gpu = os.environ.get("VB2_BENCH_SHARE_GPU", "") == "1"
+    if share_gpu:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU: %d visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
+    red_dev = "cpu" if share_gpu else "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        if share_gpu:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=120))
 
     k, B = args.num_pc, args.batch
     # ---- inputs (synthetic, seeded), flattened into HBM before timing ----
+    shared = vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.05, seed=2)   # the sample every rank knows
     if args.mode == "sample":
-        data = vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.05, seed=2 + rank)
-        shard = data
+        data = shared if rank == 0 else vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.05,
+                                                             seed=2 + rank)
     else:
-        data = vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.05, seed=2)
-        shard = data.shard(rank, world)
-    # an explicit (non-null) stream: the kernels, the HIP events and the RCCL collective
-    # all go on it, so the events bracket exactly the timed launches
+        data = shared
+    # an explicit (non-null) stream: the kernels and the HIP events all go on it, so the events
+    # bracket exactly the timed launches
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    ctx = vb.LikelihoodContext(shard, device=local_rank, stream=stream.cuda_stream)
-    info = ctx.info()
-
     rng = np.random.default_rng(123)
     stride = 2 * k + 1
     pts_h = np.concatenate([rng.normal(0, 0.03, size=(B, 2 * k)), rng.uniform(0.01, 0.3, size=(B, 1))], axis=1)
+    pc1_h, pc2_h, al_h = (np.ascontiguousarray(pts_h[:, :k]), np.ascontiguousarray(pts_h[:, k:2 * k]),
+                          np.ascontiguousarray(pts_h[:, 2 * k]))
     pts = torch.tensor(pts_h, dtype=torch.float64, device="cuda")
     out = torch.zeros(B, dtype=torch.float64, device="cuda")
-    assert pts.is_contiguous() and pts.shape == (B, stride)
 
-    def step():
-        ctx.llk_device(pts.data_ptr(), out.data_ptr(), B, stream.cuda_stream)
-        if dist is not None and args.mode == "marker":
-            dist.all_reduce(out)      # sum of per-shard partial LLKs over RCCL
+    group = None
+    uid = None
+    if share_gpu and args.mode == "marker":
+        raise SystemExit("VB2_BENCH_SHARE_GPU=1 cannot run --mode marker (RCCL needs one device per rank)")
+    if (world > 1 or not args.no_extras) and not share_gpu:
+        # the library's own marker-shard group (C++: contexts + ncclAllReduce bound from librccl)
+        box = [vb.ShardGroup.unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    if args.mode == "marker":
+        group = vb.ShardGroup(shared, device=local_rank, rank=rank, nranks=world, unique_id=uid)
+        ctx, info = None, None
+        llk_host = np.zeros(B)
+
+        def step():
+            llk_host[:] = group.llk(pc1_h, pc2_h, al_h)       # launch + ncclAllReduce + sync, every rank
+    else:
+        ctx = vb.LikelihoodContext(data, device=local_rank, stream=stream.cuda_stream)
+        info = ctx.info()
+
+        def step():
+            ctx.llk_device(pts.data_ptr(), out.data_ptr(), B, stream.cuda_stream)
 
     # untimed: bring the clocks up (same work as a step), then the W warmup steps
     t_pw = time.perf_counter()
@@ -121,14 +227,17 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if dist is not None:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
 
     evals_per_step = B * (world if args.mode == "sample" else 1)
     value = evals_per_step * args.steps / wall
-    llk_dev = out.cpu().numpy().copy()
+    llk_dev = llk_host.copy() if args.mode == "marker" else out.cpu().numpy().copy()
 
+    if info is None:
+        info = dict(num_read=shared.num_read, num_active_marker=shared.num_marker, num_code=-1, arch="gfx950",
+                    algorithmic_bytes_per_eval=2 * shared.num_read + shared.num_marker * (8 * k + 12))
     result = {
         "metric": "llk_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps,
@@ -141,46 +250,93 @@ def main():
             "parallelism": ("1 GPU" if world == 1 else
                             ("sample-parallel x%d (one sample per GPU, no collective)" % world
                              if args.mode == "sample" else
-                             "marker-sharded x%d + RCCL all-reduce of %d doubles per step" % (world, B))),
+                             "marker-sharded x%d + ncclAllReduce of %d doubles per step (libvb2 vb2_shard_group)"
+                             % (world, B))),
+            "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
+            "shared_gpu_plumbing_check": share_gpu,
+            "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                           ("self-spawned ranks" if world > 1 else "single process"),
             "reads": int(info["num_read"]), "active_markers": int(info["num_active_marker"]),
             "distinct_codes": int(info["num_code"]), "device": info["arch"],
         },
     }
 
-    if rank == 0:
+    # ---- the other multi-GPU mode as a sub-object: one sample's markers over all ranks ----
+    if args.mode == "sample" and not args.no_extras and not share_gpu:
+        g2 = vb.ShardGroup(shared, device=local_rank, rank=rank, nranks=world, unique_id=uid)
+        for _ in range(20):
+            g2.llk(pc1_h, pc2_h, al_h)
+        if dist is not None:
+            dist.barrier()
+        n2 = 200
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            got_sh = g2.llk(pc1_h, pc2_h, al_h)
+        dt = time.perf_counter() - t1
+        g2.optimize()
+        t_opt = []
+        for _ in range(3):
+            if dist is not None:
+                dist.barrier()
+            t1 = time.perf_counter()
+            est_sh = g2.optimize()
+            t_opt.append(time.perf_counter() - t1)
+        gi = g2.info()
+        vals = torch.tensor([dt, min(t_opt)], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        result["marker_sharded"] = {
+            "what": "ONE sample's markers sharded over the %d rank(s) by libvb2 (vb2_shard_group_create_rank): per "
+                    "step a launch per rank + one ncclAllReduce of %d doubles + host sync; strong scaling, "
+                    "latency-bound" % (world, B),
+            "evals_per_s": B * n2 / float(vals[0]), "ms_per_step": 1e3 * float(vals[0]) / n2,
+            "optimize_wall_ms": 1e3 * float(vals[1]), "alpha": est_sh["alpha"], "num_eval": est_sh["num_eval"],
+            "uses_rccl": gi["uses_rccl"], "allreduces": gi["num_allreduce"],
+            "shard_reads_rank0": gi["num_read"],
+        }
+        g2.close()
+
+    if rank == 0 and args.mode == "sample":
         # roofline of the dominant kernel: algorithmic bytes per launch / device time
         bytes_per_launch = info["algorithmic_bytes_per_eval"] * B
         step_us = 1e3 * dev_ms / args.steps
         achieved = bytes_per_launch / (step_us * 1e-6) / 1e9
-        # HBM-side bytes per launch cannot be read live (PMC needs rocprofv3): take the value
+        # HBM-side bytes and VALU counters cannot be read live (PMC needs rocprofv3): take the values
         # measured by the committed PMC passes of this same command when the shape matches
         traffic, traffic_src = None, None
-        for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) \
-                if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-            f = os.path.join(ROOT, "profiles", rnd, "traffic_b%d.json" % B)
-            if os.path.exists(f):
-                tj = json.load(open(f))
-                if tj.get("markers") == args.markers and tj.get("num_pc") == k:
-                    traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
-                    break
+        tj, tsrc = latest_profile("traffic_b%d.json" % B)
+        if tj and tj.get("markers") == args.markers and tj.get("num_pc") == k:
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], tsrc
+        vj, vsrc = latest_profile("valu_b%d.json" % B)
+        valu = None
+        if vj and vj.get("markers") == args.markers and vj.get("num_pc") == k:
+            valu = {"busy_frac": vj["valu_busy_frac"],
+                    "lane_instr_per_marker_point": vj["lane_instr_per_marker_point"],
+                    "lds_busy_frac": vj.get("lds_busy_frac"), "source": vsrc, "note": FP64_VALU_NOTE}
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+            "hbm_actual_GBps": (traffic / (step_us * 1e-6) / 1e9) if traffic else None,
+            "binding_ceiling": "FP64 VALU issue (see valu), not HBM: the 10 MB pileup is read once per launch "
+                               "and re-used from L2/LDS by every point",
+            "valu": valu, "mfma_util": 0.0,
+            "mfma_note": "no MFMA instruction on the path: FP64 MFMA and FP64 VALU share the unit on gfx950 "
+                         "(profiles/r01/ubench_mfma_overlap.txt), and the UD x PC projection is 2k FMAs per marker",
             "kernel": "llk_eval_kernel<%d,true>" % (2 if B > 4 else 3),
             "launches_per_step": (B + 47) // 48,
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "device_us_per_launch": step_us,
-            "note": "device time = HIP events on the launch stream over the timed region / steps; "
-                    "the pileup is L2/MALL resident and the kernel is latency/VALU-bound, see DESIGN.md",
+            "note": "device time = HIP events on the launch stream over the timed region / steps",
         }
-        # small parity probe against the oracle (checker only)
-        from oracle.bridge import oracle_data
-        od = oracle_data(data)
-        if args.mode == "sample" or world == 1:
-            want = np.array([od.llk(pts_h[i, :k], pts_h[i, k:2 * k], pts_h[i, 2 * k],
-                                    num_thread=os.cpu_count() or 1) for i in range(min(B, 2))])
-            rel = float(np.max(np.abs(llk_dev[:len(want)] - want) / np.abs(want)))
-            result["parity_probe_max_rel_err"] = rel
+        if world == 1 and not args.no_extras:
+            # the operating points of the actual search: a 4-point launch (one Nelder-Mead
+            # iteration: R, E, C_A, C_R) and a single point
+            sp = {}
+            for nb in (4, 1):
+                us = timed_launches(ctx, pts, out, nb, stream, 1500, torch)
+                sp["points_%d" % nb] = {"device_us_per_launch": us, "evals_per_s": nb / us * 1e6,
+                                        "frac": info["algorithmic_bytes_per_eval"] * nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+            result["search_point"] = sp
         if world == 1 and not args.no_optimize:
             # second half of the metric: wall-clock of OptimizeLLK (Initialize + Homo + Heter +
             # LLK0), best of 3; measured before the CPU leg so no OpenMP threads are around
@@ -195,6 +351,47 @@ def main():
                 "alpha": est["alpha"], "alpha_true": 0.05, "num_eval": est["num_eval"],
                 "num_launch_point": est["num_launch_point"],
             }
+        if world == 1 and not args.no_extras and args.cohort_samples > 0:
+            # BASELINE.json configs[4] per GPU: a cohort of C3-shaped samples searched in lock-step
+            S = args.cohort_samples
+            # (8 distinct synthetic samples, each uploaded several times: every context has its own
+            # copy in HBM, so the device sees S independent samples; generating S of them would
+            # take a second of numpy each)
+            distinct = [data] + [vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.02 + 0.02 * s,
+                                                      seed=1000 + s) for s in range(1, min(S, 8))]
+            datas = [distinct[s % len(distinct)] for s in range(S)]
+            cctx = [ctx] + [vb.LikelihoodContext(dd, device=local_rank) for dd in datas[1:]]
+            with vb.CohortBatch(cctx) as batch:
+                npt = np.full(S, 4, dtype=np.int32)
+                p1 = np.zeros((S, 8, k)); p2 = np.zeros((S, 8, k)); al = np.full((S, 8), 0.1)
+                p1[:, :4] = pts_h[:4, :k]; p2[:, :4] = pts_h[:4, k:2 * k]; al[:, :4] = pts_h[:4, 2 * k]
+                for _ in range(20):
+                    batch.eval(npt, p1, p2, al)
+                t1 = time.perf_counter()
+                n3 = 100
+                for _ in range(n3):
+                    batch.eval(npt, p1, p2, al)
+                dt4 = (time.perf_counter() - t1) / n3
+                batch.optimize()
+                t1 = time.perf_counter()
+                ests = batch.optimize()
+                dto = time.perf_counter() - t1
+            for c in cctx[1:]:
+                c.close()
+            result["cohort"] = {
+                "what": "%d samples of the workload's shape on ONE GPU, searched in lock-step (vb2_batch_*: one launch "
+                        "per Nelder-Mead step for all samples)" % S,
+                "samples": S, "step_us_4_points_per_sample": 1e6 * dt4, "evals_per_s": 4 * S / dt4,
+                "optimize_ms_per_sample": 1e3 * dto / S, "samples_per_s_search_only": S / dto,
+                "alpha_first": ests[0]["alpha"],
+            }
+        # small parity probe against the oracle (checker only; after the GPU legs: its OpenMP threads
+        # spin for a while after the call and would slow the launching thread down)
+        from oracle.bridge import oracle_data
+        od = oracle_data(data)
+        want = np.array([od.llk(pts_h[i, :k], pts_h[i, k:2 * k], pts_h[i, 2 * k],
+                                num_thread=os.cpu_count() or 1) for i in range(min(B, 2))])
+        result["parity_probe_max_rel_err"] = float(np.max(np.abs(llk_dev[:len(want)] - want) / np.abs(want)))
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample (~10 s wall): the C oracle on the SAME pileup, OpenMP over
             # markers like the reference; thread counts 1, 4 (the reference's default
@@ -221,10 +418,22 @@ def main():
                           "%d cores available" % (args.markers, 10.0 / len(sweep),
                                                   {t: round(r, 1) for t, r in rates.items()}, navail),
             }
-        print(json.dumps(result))
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
+    if group is not None:
+        group.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio when its first communicator comes up; push that
+    # out first, so that the JSON line is the LAST line of stdout, and leave without running
+    # anything else that might print
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    sys.stdout.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

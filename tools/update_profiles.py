@@ -1,20 +1,28 @@
 """Copies the summaries tools/collect_profiles.sh left under gpurun_out/<round>/ into
-profiles/<round>/ (tracked): bench line, kernel stats, PMC summary, batch sweep, traffic file.
-Usage: python tools/update_profiles.py r01"""
-import csv, collections, io, json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+profiles/<round>/ (tracked): bench line, kernel stats (batch launches, the other wave shapes, a
+search), PMC summary, batch sweep, and the two derived files bench.py reads back
+(traffic_b48.json: HBM-side bytes per launch; valu_b48.json: VALU / LDS pipe occupancy and lane
+instructions per marker x point).
+Usage: python tools/update_profiles.py r02"""
+import csv, json, os, shutil, subprocess, sys
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles", R)
 os.makedirs(dst, exist_ok=True)
 with open(os.path.join(src, "bench.json")) as f:
     line = [l for l in f if l.startswith("{")][-1]
-B = json.loads(line)["config"]["batch_points_per_step"]
+bench = json.loads(line)
+B = bench["config"]["batch_points_per_step"]
 open(os.path.join(dst, "bench_b%d.json" % B), "w").write(line)
 shutil.copy(os.path.join(src, "trace", "b_kernel_stats.csv"), os.path.join(dst, "bench_b%d_kernel_stats.csv" % B))
 shutil.copy(os.path.join(src, "bench_batch_sweep.jsonl"), os.path.join(dst, "bench_batch_sweep.jsonl"))
+for sub, pre, name in (("trace_modes", "m", "modes_kernel_stats.csv"), ("trace_opt", "o", "optimize_kernel_stats.csv")):
+    p = os.path.join(src, sub, pre + "_kernel_stats.csv")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, name))
+passes = [d for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_grbm") if os.path.isdir(os.path.join(src, d))]
 out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] +
-                     [os.path.join(src, d) for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2")],
-                     capture_output=True, text=True).stdout
+                     [os.path.join(src, d) for d in passes], capture_output=True, text=True).stdout
 keep, on = [], False
 for l in out.splitlines():
     if l.startswith("##"):
@@ -22,8 +30,10 @@ for l in out.splitlines():
     if on:
         keep.append(l)
 open(os.path.join(dst, "bench_b%d_pmc_summary.txt" % B), "w").write(
-    "# rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --no-cpu-baseline --no-optimize --steps 50"
-    "  (one pass per counter group; tools/collect_profiles.sh)\n" + "\n".join(keep) + "\n")
+    "# rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --no-cpu-baseline --no-optimize --no-extras "
+    "--steps 50 --warmup 20 --prewarm-ms 0  (one pass per counter group; tools/collect_profiles.sh)\n" +
+    "\n".join(keep) + "\n")
+
 
 def avg(d, name):
     vals = []
@@ -33,19 +43,37 @@ def avg(d, name):
             vals.append(float(row["Counter_Value"]))
     return sum(vals) / len(vals)
 
+
+markers, k = bench["config"]["active_markers"], 4
 fetch, write = avg("pmc_fetch", "FETCH_SIZE"), avg("pmc_write", "WRITE_SIZE")
-b = json.loads(line)
 t = {"_what": "HBM-side traffic of llk_eval_kernel<2,true> per launch (%d points = %d groups of 8): rocprofv3 --pmc " % (B, B // 8) +
               "FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `python bench.py --no-cpu-baseline "
-              "--no-optimize --steps 50` (bench_b%d_pmc_summary.txt; tools/collect_profiles.sh)" % B,
-     "markers": 100000, "batch": B, "num_pc": 4,
+              "--no-optimize --no-extras --steps 50` (bench_b%d_pmc_summary.txt; tools/collect_profiles.sh)" % B,
+     "markers": markers, "batch": B, "num_pc": k,
      "FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1),
      "correction": "gfx950: FETCH_SIZE tallies 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE uncorrected",
      "traffic_bytes_per_launch": int((2 * fetch + write) * 1024)}
 json.dump(t, open(os.path.join(dst, "traffic_b%d.json" % B), "w"), indent=1)
-print("value %.0f evals/s, %.2f us/launch, frac %.3f, optimize %.2f ms, traffic %d B/launch" % (
-    b["value"], b["roofline"]["device_us_per_launch"], b["roofline"]["frac"],
-    b["optimize"]["wall_ms_to_converged_alpha"], t["traffic_bytes_per_launch"]))
+
+insts, active = avg("pmc_sq1", "SQ_INSTS_VALU"), avg("pmc_sq1", "SQ_ACTIVE_INST_VALU")
+lds_active, lds_conf = avg("pmc_sq1", "SQ_LDS_IDX_ACTIVE"), avg("pmc_sq1", "SQ_LDS_BANK_CONFLICT")
+cycles = avg("pmc_grbm", "GRBM_GUI_ACTIVE") if "pmc_grbm" in passes else None
+v = {"_what": "VALU / LDS pipe occupancy of llk_eval_kernel<2,true> per launch of %d points, from the SQ and GRBM "
+              "passes of bench_b%d_pmc_summary.txt: lane instructions = SQ_INSTS_VALU x 64 / (markers x points); "
+              "VALU busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE cycles of the "
+              "launch); LDS busy = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles)" % (B, B),
+     "markers": markers, "batch": B, "num_pc": k,
+     "SQ_INSTS_VALU": insts, "SQ_ACTIVE_INST_VALU": active, "SQ_LDS_IDX_ACTIVE": lds_active,
+     "SQ_LDS_BANK_CONFLICT": lds_conf, "GRBM_GUI_ACTIVE": cycles,
+     "lane_instr_per_marker_point": round(insts * 64 / (markers * B), 1),
+     "valu_busy_frac": round(active * 4 / (1024 * cycles), 3) if cycles else None,
+     "lds_busy_frac": round(lds_active / (256 * cycles), 3) if cycles else None}
+json.dump(v, open(os.path.join(dst, "valu_b%d.json" % B), "w"), indent=1)
+
+print("value %.0f evals/s, %.2f us/launch, frac %.3f, optimize %.2f ms, traffic %d B/launch, %s lane instr per marker x point, "
+      "VALU busy %s, LDS busy %s" % (bench["value"], bench["roofline"]["device_us_per_launch"], bench["roofline"]["frac"],
+                                     bench["optimize"]["wall_ms_to_converged_alpha"], t["traffic_bytes_per_launch"],
+                                     v["lane_instr_per_marker_point"], v["valu_busy_frac"], v["lds_busy_frac"]))
 print(open(os.path.join(dst, "bench_b%d_kernel_stats.csv" % B)).read().splitlines()[1][:200])
 for l in open(os.path.join(dst, "bench_batch_sweep.jsonl")):
     r = json.loads(l)
