@@ -667,7 +667,9 @@ def test_resident_search_matches_plain_launches(c2):
     lib.vb2_debug_resident_evals.restype = C.c_longlong
     lib.vb2_debug_resident_evals.argtypes = [C.c_void_p]
     lib.vb2_debug_set_resident.argtypes = [C.c_void_p, C.c_int]
+    lib.vb2_debug_set_device_simplex.argtypes = [C.c_void_p, C.c_int]
     with vb.LikelihoodContext(d) as ctx:
+        lib.vb2_debug_set_device_simplex(ctx._h, 0)          # the host optimiser posts every batch
         for kw in (dict(), dict(within_ancestry=True)):
             lib.vb2_debug_set_resident(ctx._h, 0)
             plain = ctx.optimize(trace_capacity=4096, **kw)
@@ -685,6 +687,72 @@ def test_resident_search_matches_plain_launches(c2):
         pc1, pc2, al = _random_points(np.random.default_rng(3), 3, 2)
         want = np.array([od.llk(pc1[i], pc2[i], al[i]) for i in range(3)])
         assert rel_err(ctx.llk(pc1, pc2, al), want) <= LLK_RTOL
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(within_ancestry=True), dict(fix_alpha=0.07),
+                                dict(within_ancestry=True, fix_alpha=0.07), dict(fix_pc=[0.01, -0.02]),
+                                dict(within_ancestry=True, fix_pc=[0.01, -0.02])],
+                         ids=["heter", "homo", "heter-fixalpha", "homo-fixalpha", "heter-fixpc", "homo-fixpc"])
+def test_device_simplex_equals_host_optimiser(c2, kw):
+    """Each Minimize() runs entirely in workgroup 0 of the resident kernel (one mailbox round trip
+    per Minimize: resident_kernel.inc).  Same decisions, same evaluation batches, InvLogit through
+    the host libm's exp algorithm: the evaluation trace -- every (pc1, pc2, alpha, llk) the
+    reference would have evaluated, in its order -- equals the host-driven search's bit for bit,
+    for all six model variants."""
+    _needs_resident_mode()
+    import ctypes as C
+    d, od = c2
+    lib = _abi.lib()
+    lib.vb2_debug_device_minimizes.restype = C.c_longlong
+    lib.vb2_debug_device_minimizes.argtypes = [C.c_void_p]
+    lib.vb2_debug_set_device_simplex.argtypes = [C.c_void_p, C.c_int]
+    with vb.LikelihoodContext(d) as ctx:
+        lib.vb2_debug_set_device_simplex(ctx._h, 0)
+        host = ctx.optimize(trace_capacity=4096, **kw)
+        assert lib.vb2_debug_device_minimizes(ctx._h) == 0
+        lib.vb2_debug_set_device_simplex(ctx._h, 1)
+        for rep in range(3):
+            n0 = lib.vb2_debug_device_minimizes(ctx._h)
+            dev = ctx.optimize(trace_capacity=4096, **kw) if rep < 2 else ctx.optimize(**kw)
+            expect = 2 if (not kw.get("within_ancestry") and "fix_pc" not in kw) else 1     # Homo first, then Heter
+            assert lib.vb2_debug_device_minimizes(ctx._h) == n0 + expect
+            for key in ("alpha", "llk1", "llk0", "num_eval", "num_launch_point", "converged"):
+                assert dev[key] == host[key], key
+            assert np.array_equal(dev["pc"], host["pc"]) and np.array_equal(dev["pc2"], host["pc2"])
+            if rep < 2:
+                assert dev["trace_count"] == host["trace_count"]
+                for key in ("llk", "alpha", "pc1", "pc2"):
+                    assert np.array_equal(dev["trace"][key], host["trace"][key]), key
+        ref = od.optimize(**kw)
+        assert abs(dev["alpha"] - ref["alpha"]) <= 1e-9 and dev["num_eval"] == ref["num_eval"]
+
+
+def test_device_simplex_deep_convergence_and_other_dimensions():
+    """An epsilon nothing but a fully collapsed simplex meets (many contractions and shrinks, the
+    rarely taken branches of MathGenMin.cpp:395-419), and k = 1 / k = 7 panels (simplex dimensions
+    1..15): device and host searches stay identical."""
+    _needs_resident_mode()
+    import ctypes as C
+    lib = _abi.lib()
+    lib.vb2_debug_set_device_simplex.argtypes = [C.c_void_p, C.c_int]
+    lib.vb2_debug_device_minimizes.restype = C.c_longlong
+    lib.vb2_debug_device_minimizes.argtypes = [C.c_void_p]
+    for k, kws in ((1, [dict(epsilon=1e-300), dict(within_ancestry=True, epsilon=1e-300)]),
+                   (2, [dict(within_ancestry=True, fix_pc=[0.0, 0.0], epsilon=1e-300), dict(epsilon=1e-13)]),
+                   (7, [dict(epsilon=1e-7), dict(fix_alpha=0.02, epsilon=1e-7)])):
+        d = vb.synth.make_pileup(1500, 10, k, alpha_true=0.1, seed=770 + k)
+        with vb.LikelihoodContext(d) as ctx:
+            for kw in kws:
+                lib.vb2_debug_set_device_simplex(ctx._h, 0)
+                host = ctx.optimize(trace_capacity=1 << 16, **kw)
+                lib.vb2_debug_set_device_simplex(ctx._h, 1)
+                n0 = lib.vb2_debug_device_minimizes(ctx._h)
+                dev = ctx.optimize(trace_capacity=1 << 16, **kw)
+                assert lib.vb2_debug_device_minimizes(ctx._h) > n0
+                for key in ("alpha", "llk1", "llk0", "num_eval", "num_launch_point", "converged"):
+                    assert dev[key] == host[key], (k, kw, key)
+                assert np.array_equal(dev["trace"]["llk"], host["trace"]["llk"]), (k, kw)
+                assert np.array_equal(dev["trace"]["alpha"], host["trace"]["alpha"]), (k, kw)
 
 
 @pytest.mark.parametrize("k", [1, 10, 40])

@@ -196,6 +196,20 @@ void vb2_ctx_search_end(vb2_ctx* ctx)
     ctx->impl->resident_end();
 }
 
+// Test aids (not part of the public header): Minimize() calls served by the on-device simplex;
+// switch that mode off/on for one context (VB2_DEVICE_SIMPLEX does it globally).
+long long vb2_debug_device_minimizes(vb2_ctx* ctx)
+{
+    if (guard_ctx(ctx)) return -1;
+    return (long long)ctx->impl->device_minimizes;
+}
+
+void vb2_debug_set_device_simplex(vb2_ctx* ctx, int on)
+{
+    if (guard_ctx(ctx)) return;
+    ctx->impl->device_simplex_enabled = on != 0;
+}
+
 // Test aid: is the context in resident mode right now?
 int vb2_debug_resident_active(vb2_ctx* ctx)
 {
@@ -235,10 +249,30 @@ int vb2_optimize_llk(vb2_eval_fn eval, void* user, int32_t num_pc, const vb2_mod
 int vb2_ctx_optimize_llk(vb2_ctx* ctx, const vb2_model* model, vb2_estimate* out, vb2_trace* trace)
 {
     if (int rc = guard_ctx(ctx)) return rc;
-    // the whole search runs against one resident kernel when that mode is available
-    const bool resident = ctx->impl->resident_begin();
-    const int rc = vb2_optimize_llk(ctx_eval_cb, ctx->impl, ctx->impl->num_pc, model, out, trace);
-    if (resident) ctx->impl->resident_end();
+    if (!model || !out) {
+        set_error("vb2_ctx_optimize_llk: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    vb2::Context* c = ctx->impl;
+    // the whole search runs against one resident kernel when that mode is available, and each
+    // Minimize() of it on the device itself (resident_kernel.inc) when the simplex fits
+    if (trace && trace->capacity > 0 && c->device_simplex_enabled) (void)c->reserve_trace(trace->capacity);
+    const bool resident = c->resident_begin();
+    int rc;
+    try {
+        vb2::Estimator est(c->num_pc, ctx_eval_cb, c);
+        vb2::apply_model(est, *model);
+        est.trace = trace;
+        if (trace) trace->count = 0;
+        if (resident && c->device_simplex_dim() > 0 && !(trace && c->trace_stage_rows < trace->capacity))
+            est.dev_ctx = c;
+        rc = est.OptimizeLLK();
+        if (!rc) vb2::fill_estimate(est, out);
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        rc = VB2_ERR_INVALID;
+    }
+    if (resident) c->resident_end();
     return rc;
 }
 

@@ -161,6 +161,7 @@ Context::~Context()
     // every device array / every pinned, device-mapped buffer of the context: back to the cache
     if (d_slab && !slab_cache().give(slab_cache().dev, d_slab, d_slab_bytes, device)) (void)hipFree(d_slab);
     if (h_slab && !slab_cache().give(slab_cache().pin, h_slab, h_slab_bytes, device)) (void)hipHostFree(h_slab);
+    if (h_trace_stage) (void)hipHostFree(h_trace_stage);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -543,6 +544,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     const size_t p_done = pcarve(sizeof(unsigned long long) * 8);        // [0] sequence number (+ spare words)
     const size_t p_cmd = pcarve(sizeof(unsigned long long) * relay_words);
     const size_t p_state = pcarve(sizeof(unsigned int));
+    const size_t p_result = pcarve(sizeof(double) * (8 + kDeviceSimplexMaxDim + 2 * VB2_MAX_PC));
     c->h_slab = slab_cache().take(slab_cache().pin, pin_total, dev, &c->h_slab_bytes);
     if (!c->h_slab) {
         VB2_HIP(hipHostMalloc((void**)&c->h_slab, pin_total, hipHostMallocMapped));
@@ -562,6 +564,9 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     c->d_cmd = reinterpret_cast<unsigned long long*>(hdev + p_cmd);
     c->h_state = reinterpret_cast<unsigned int*>(hbase + p_state);
     c->d_state = reinterpret_cast<unsigned int*>(hdev + p_state);
+    c->h_result = reinterpret_cast<double*>(hbase + p_result);
+    c->d_result = reinterpret_cast<double*>(hdev + p_result);
+    if (const char* ds = std::getenv("VB2_DEVICE_SIMPLEX")) c->device_simplex_enabled = std::atoi(ds) != 0;
     if (const char* sw = std::getenv("VB2_SPIN_WAIT")) c->spin_wait = std::atoi(sw) != 0;
     if (const char* rs = std::getenv("VB2_RESIDENT")) c->resident_enabled = std::atoi(rs) != 0;
     c->dbg_timing = timing;
@@ -646,13 +651,19 @@ bool Context::resident_begin()
         ra.h_state = d_state;
         ra.first_seq = done_seq_ + 1;
         ra.timeout_ticks = 100000000ull;                  // 1 s without a command: give up
+        ra.h_result = d_result;
+        ra.epoch = ++resident_epoch_;
+        // room for the on-device simplex of every model of this context: dimension <= 2k + 1
+        ra.state_nmax = (device_simplex_enabled && 2 * num_pc + 1 <= kDeviceSimplexMaxDim) ? 2 * num_pc + 1 : 0;
+        ra.state_off = 0;
         {
             const LaunchGeom gm = launch_geom(L, 1);
             ra.sched_multi = get(paired_mode() ? 3 : 1, 1, gm.grid, gm.block_waves);
             ra.sched_single = paired_mode() ? get(4, 1, gm.grid, gm.block_waves) : ra.sched_multi;
         }
-        ok = launch_llk_resident(L, ra, d_partials, d_ticket, stream) == hipSuccess;
+        ok = launch_llk_resident(L, &ra, d_partials, d_ticket, stream) == hipSuccess;
         if (!ok) (void)hipGetLastError();
+        resident_nmax = ok ? ra.state_nmax : 0;
     }
     if (!ok) {
         g_resident_busy[device].store(0);
@@ -739,6 +750,114 @@ bool Context::resident_collect(int n, double* out)
         ++dbg_cmds;
     }
     return true;
+}
+
+int Context::device_minimize(MinimizeRequest* req)
+{
+    const int k = num_pc, n = req->dim;
+    if (!resident_active || n < 1 || n > resident_nmax || !req->start) return VB2_ERR_INVALID;
+    const int words = resident_words(k);
+    // trace staging: rows [alpha, llk, pc1(k), pc2(k)] in mapped host memory (reserve_trace, before
+    // the resident kernel went up: no allocation call while it runs), scattered into the caller's
+    // arrays afterwards
+    double* h_trace = h_trace_stage;
+    double* d_trace = d_trace_stage;
+    long long cap = 0;
+    if (req->trace && req->trace->capacity > req->trace->count && h_trace)
+        cap = std::min<long long>(req->trace->capacity - req->trace->count, trace_stage_rows);
+    if (req->trace && cap == 0 && req->trace->capacity > req->trace->count) return VB2_ERR_INVALID;   // no staging: host search
+    // ---- the request (resident_kernel.inc: word offsets of the MINIMIZE command) ----
+    unsigned long long* cmd = h_cmd;
+    auto put_d = [&](int w, double v) { std::memcpy(&cmd[w], &v, sizeof(v)); };
+    for (int w = 1; w < words; ++w) cmd[w] = 0;
+    cmd[1] = kResidentMinimize;
+    cmd[2] = (unsigned long long)n | ((unsigned long long)req->kind << 8) | ((unsigned long long)k << 16);
+    cmd[3] = (unsigned long long)req->cycle_max;
+    put_d(4, req->ftol);
+    put_d(5, req->llk1);
+    put_d(6, req->fix_alpha);
+    put_d(7, req->g_alpha);
+    cmd[8] = (unsigned long long)d_trace;
+    cmd[9] = (unsigned long long)cap;
+    for (int j = 0; j < n; ++j) put_d(10 + j, req->start[j]);
+    for (int j = 0; j < k; ++j) {
+        put_d(10 + n + j, req->fix_pc[j]);
+        put_d(10 + n + k + j, req->fix_pc2[j]);
+        put_d(10 + n + 2 * k + j, req->g_pc[j]);
+        put_d(10 + n + 3 * k + j, req->g_pc2[j]);
+    }
+    const unsigned long long seq = ++done_seq_;
+    unsigned long long x = 0;
+    for (int w = 1; w < words - 1; ++w) x ^= word_hash(cmd[w], (unsigned)w);
+    cmd[words - 1] = x ^ resident_mix(seq);
+    __atomic_store_n(&cmd[0], seq, __ATOMIC_RELEASE);
+    // ---- one wait for the whole search (cycleMax evaluations of ~15 us each at most) ----
+    bool seen = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+        if ((spins & 0x3ff) == 0x3ff) {
+            if (__atomic_load_n(h_state, __ATOMIC_ACQUIRE) == 3u) break;       // kernel gave up
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+        }
+        __builtin_ia32_pause();
+    }
+    int rc = VB2_OK;
+    if (!seen || std::isnan(h_result[1]) || std::isnan(h_result[5])) {
+        // no answer (or a "workgroup never reported" NaN inside): leave the mode, the caller's host
+        // optimiser redoes the search with plain launches
+        (void)hipSetDevice(device);
+        resident_post(h_cmd, words, ++done_seq_, 0, 2 * k + 1, nullptr);
+        (void)hipStreamSynchronize(stream);
+        resident_active = false;
+        resident_enabled = false;
+        g_resident_busy[device].store(0);
+        (void)hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream);
+        rc = VB2_ERR_HIP;
+    } else {
+        req->status = (int)h_result[0];
+        req->ret = h_result[1];
+        req->cycle_count = (long)h_result[2];
+        req->num_eval = (long)h_result[3];
+        req->num_point = (long)h_result[4];
+        req->out_llk1 = h_result[5];
+        req->out_g_alpha = h_result[6];
+        const long long ntrace = (long long)h_result[7];
+        std::memcpy(req->point, h_result + 8, sizeof(double) * n);
+        std::memcpy(req->out_g_pc, h_result + 8 + n, sizeof(double) * k);
+        std::memcpy(req->out_g_pc2, h_result + 8 + n + k, sizeof(double) * k);
+        if (req->status != 3) {
+            ++device_minimizes;
+            if (req->trace) {
+                vb2_trace* t = req->trace;
+                for (long long i = 0; i < ntrace; ++i) {
+                    if (i < cap && t->count < t->capacity) {
+                        const double* row = h_trace + (size_t)i * (2 * k + 2);
+                        const int64_t r = t->count;
+                        t->alpha[r] = row[0];
+                        t->llk[r] = row[1];
+                        std::memcpy(t->pc1 + r * k, row + 2, sizeof(double) * k);
+                        std::memcpy(t->pc2 + r * k, row + 2 + k, sizeof(double) * k);
+                    }
+                    t->count++;
+                }
+            }
+        }
+    }
+    return rc;
+}
+
+int Context::reserve_trace(int64_t rows)
+{
+    if (rows <= trace_stage_rows) return VB2_OK;
+    VB2_HIP(hipSetDevice(device));
+    if (h_trace_stage) (void)hipHostFree(h_trace_stage);
+    h_trace_stage = d_trace_stage = nullptr;
+    trace_stage_rows = 0;
+    VB2_HIP(hipHostMalloc((void**)&h_trace_stage, sizeof(double) * (size_t)rows * (2 * num_pc + 2), hipHostMallocMapped));
+    VB2_HIP(hipHostGetDevicePointer((void**)&d_trace_stage, h_trace_stage, 0));
+    trace_stage_rows = rows;
+    return VB2_OK;
 }
 
 int Context::eval_host(int num_point, const double* pc1, const double* pc2, const double* alpha,

@@ -57,6 +57,32 @@ public:
     // kernel did not answer (the mode is then torn down: redo the rows with plain launches).
     void resident_submit(int n, const double* rows);
     bool resident_collect(int n, double* out);
+    // One AmoebaMinimizer::Minimize() run entirely on the device (resident_kernel.inc: the simplex
+    // logic in workgroup 0 of the resident kernel; one mailbox round trip for the whole search).
+    // Available between resident_begin and resident_end when device_simplex_dim() >= the simplex
+    // dimension.  Returns VB2_OK and fills req's outputs, or a negative code / req.status == 3 when
+    // the search must be (re)done by the host optimiser -- the request's inputs are never modified.
+    struct MinimizeRequest {
+        // in
+        int dim = 0, kind = 0;                  // kind: FullLLKFunc::Evaluate's packing, 0..5 (resident_kernel.inc)
+        const double* start = nullptr;          // [dim]
+        const double *fix_pc = nullptr, *fix_pc2 = nullptr, *g_pc = nullptr, *g_pc2 = nullptr;   // [k]
+        double fix_alpha = 0, g_alpha = 0, llk1 = 0, ftol = 1e-8;
+        long cycle_max = 50000;
+        vb2_trace* trace = nullptr;             // appended to (like Estimator's record())
+        // out
+        int status = 0;                         // 1 converged, 2 cycle limit, 3 redo on the host
+        double ret = 0, out_llk1 = 0, out_g_alpha = 0;
+        long cycle_count = 0, num_eval = 0, num_point = 0;
+        double point[kDeviceSimplexMaxDim];
+        double out_g_pc[VB2_MAX_PC], out_g_pc2[VB2_MAX_PC];
+    };
+    int device_simplex_dim() const { return resident_active ? resident_nmax : 0; }
+    int device_minimize(MinimizeRequest* req);
+    // Mapped staging for the evaluation trace of on-device searches; call BEFORE resident_begin.
+    int reserve_trace(int64_t rows);
+    double *h_trace_stage = nullptr, *d_trace_stage = nullptr;
+    int64_t trace_stage_rows = 0;
     void fill_info(vb2_info* info) const;
     int read_stamps(unsigned long long* out, int max_blocks);
 
@@ -87,6 +113,12 @@ public:
     unsigned long long* d_relay = nullptr;
     unsigned int* h_state = nullptr;
     unsigned int* d_state = nullptr;
+    double* h_result = nullptr;              // result block of an on-device Minimize() (mapped host memory)
+    double* d_result = nullptr;
+    int resident_nmax = 0;                   // largest simplex dimension the running resident kernel supports
+    bool device_simplex_enabled = true;      // VB2_DEVICE_SIMPLEX=0: the host optimiser drives every search
+    unsigned long long resident_epoch_ = 0;
+    int64_t device_minimizes = 0;            // Minimize() calls served on the device
     int64_t resident_evals = 0;              // batches served by the resident kernel
     int64_t nan_retries = 0;                 // plain launches redone in ticket mode after a "never reported" NaN
     // VB2_DEBUG_TIMING: where a resident search's wall-clock goes (host logic vs device round trip)

@@ -1,6 +1,8 @@
 // estimator.cpp -- see estimator.h.
 #include "estimator.h"
 
+#include "context.h"
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -170,9 +172,60 @@ Estimator::Estimator(int nPC, vb2_eval_fn eval, void* user)
     fn.fixPC2 = fn.globalPC = fn.globalPC2 = fn.fixPC;
 }
 
+// The whole Minimize() on the device when the context offers it (resident_kernel.inc): same
+// decisions, same evaluation batches, bit-identical trajectory; one host round trip.
+static bool device_minimizer(Estimator* e, AmoebaMinimizer& m, int dim, const std::vector<double>& start,
+                             double* ret, bool* ok)
+{
+    Context* c = e->dev_ctx;
+    if (!c || dim < 1 || dim > c->device_simplex_dim() || e->verbose) return false;
+    Context::MinimizeRequest rq;
+    rq.dim = dim;
+    rq.kind = !e->isHeter ? (e->isPCFixed ? 0 : e->isAlphaFixed ? 1 : 2) : (e->isPCFixed ? 3 : e->isAlphaFixed ? 4 : 5);
+    rq.start = start.data();
+    rq.fix_pc = e->fn.fixPC.data();
+    rq.fix_pc2 = e->fn.fixPC2.data();
+    rq.g_pc = e->fn.globalPC.data();
+    rq.g_pc2 = e->fn.globalPC2.data();
+    rq.fix_alpha = e->fn.fixAlpha;
+    rq.g_alpha = e->fn.globalAlpha;
+    rq.llk1 = e->fn.llk1;
+    rq.ftol = e->epsilon;
+    rq.cycle_max = m.cycleMax;
+    rq.trace = e->trace;
+    const int64_t trace_before = e->trace ? e->trace->count : 0;
+    if (c->device_minimize(&rq) != VB2_OK || rq.status == 3) {
+        if (e->trace) e->trace->count = trace_before;
+        return false;                                     // the host optimiser takes this search
+    }
+    m.Reset(dim);
+    m.point.assign(rq.status == 1 ? rq.point : start.data(), (rq.status == 1 ? rq.point : start.data()) + dim);
+    m.cycleCount = rq.cycle_count;
+    e->fn.llk1 = rq.out_llk1;
+    e->fn.globalAlpha = rq.out_g_alpha;
+    e->fn.globalPC.assign(rq.out_g_pc, rq.out_g_pc + e->numPC);
+    e->fn.globalPC2.assign(rq.out_g_pc2, rq.out_g_pc2 + e->numPC);
+    e->num_eval += rq.num_eval;
+    e->num_launch_point += rq.num_point;
+    ++e->num_device_minimize;
+    *ok = rq.status == 1;
+    *ret = *ok ? rq.ret : std::numeric_limits<double>::max();
+    if (*ok) m.fmin = rq.ret;
+    return true;
+}
+
 static bool run_minimizer(Estimator* e, AmoebaMinimizer& m, int dim,
                           const std::vector<double>& start, double* ret)
 {
+    bool dev_ok = false;
+    if (device_minimizer(e, m, dim, start, ret, &dev_ok)) {
+        if (!dev_ok) {                                    // MathGenMin.cpp:381 (statgen warning())
+            e->hit_cycle_limit = true;
+            if (e->notices)
+                std::fprintf(stderr, "WARNING - Amoeba.Minimize - Couldn't converge in %d cycles\n", 50000);
+        }
+        return dev_ok;
+    }
     m.func = &e->fn;
     m.speculate = e->speculate;
     m.Reset(dim);

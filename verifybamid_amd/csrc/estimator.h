@@ -16,6 +16,7 @@
 namespace vb2 {
 
 class Estimator;
+class Context;
 
 class FullLLKFunc : public BatchObjective {
 public:
@@ -64,6 +65,10 @@ public:
 
     vb2_eval_fn eval_;
     void* user_;
+    // A context whose resident kernel can run a whole Minimize() on the device
+    // (Context::device_minimize); nullptr = the host optimiser drives every search.
+    Context* dev_ctx = nullptr;
+    int64_t num_device_minimize = 0;
 
 private:
     bool OptimizeHomoFixedPC(AmoebaMinimizer& m);      // cpp:315-332

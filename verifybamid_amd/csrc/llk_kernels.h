@@ -137,7 +137,14 @@ struct ResidentArgs {
     unsigned long long first_seq;        // sequence number of the first command
     unsigned long long timeout_ticks;    // idle limit in 100 MHz wall-clock ticks
     Schedule sched_multi, sched_single;  // static schedules of the 2..4-point and the 1-point wave shape
+    // on-device simplex (MINIMIZE commands; resident_kernel.inc)
+    double* h_result;                    // result block in mapped host memory: [8 + nmax + 2k] doubles
+    unsigned long long epoch;            // distinguishes this launch's hand-off tags from any earlier one's
+    int32_t state_off;                   // doubles from the start of dynamic LDS to workgroup 0's search state
+    int32_t state_nmax;                  // largest simplex dimension the state was sized for (0 = no MINIMIZE)
 };
+constexpr unsigned long long kResidentMinimize = 0xffffffffull;   // mailbox word [1]: a Minimize() request
+constexpr int kDeviceSimplexMaxDim = 63;                           // one lane per coordinate, one per vertex (n + 1 <= 64)
 __host__ __device__ inline unsigned long long resident_mix(unsigned long long seq)
 {
     return seq * 0x9E3779B97F4A7C15ull;      // spreads consecutive sequence numbers over 64 bits
@@ -152,11 +159,18 @@ __host__ __device__ inline unsigned long long word_hash(unsigned long long v, un
     z = (z ^ (z >> 32)) * 0xBF58476D1CE4E5B9ull;
     return z ^ (z >> 29);
 }
-inline int resident_words(int num_pc) { return 2 + 4 * (2 * num_pc + 1) + 1; }
+// [0] seq, [1] kind, payload (4 rows of 2k+1, or a Minimize() request of 8 + n + 4k <= 6k + 9 words), check word
+inline __host__ __device__ int resident_words(int num_pc)
+{
+    const int rows = 4 * (2 * num_pc + 1), req = 6 * num_pc + 9;
+    return 2 + (rows > req ? rows : req) + 1;
+}
+// Words of dynamic LDS the resident kernel needs beyond the evaluation body's (search state + command image).
+size_t resident_state_doubles(int nmax, int num_pc);
 bool paired_mode();
 void set_paired_mode(bool on);     // VB2_PAIRED=0: 4-point launches use MODE 1 instead of MODE 3
 void set_coop_launch(bool on);     // VB2_COOP=1: cooperative launch of the resident kernel
-hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, double* d_partials,
+hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra, double* d_partials,
                                unsigned int* d_ticket, hipStream_t stream);
 // A/B switch: lanes of one ds_read_b128 service group share a candidate slot (default) or plain
 void set_lane_mapping(bool hardware_groups);

@@ -296,7 +296,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
           unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
           unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
           unsigned int* __restrict__ batch_done, unsigned int batch_active, const int ngrp,
-          const unsigned long long tag, const Schedule sch, const bool coherent_points = false)
+          const unsigned long long tag, const Schedule sch, const bool coherent_points = false,
+          const int tid_in = -1)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int BTL = (MODE == 1 || MODE == 4) ? 1 : 2;
@@ -326,7 +327,9 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     double2* prim_lds = reinterpret_cast<double2*>(lds + prim_off + (prim_off & 1));   // [num_prim], 16-B aligned
     double* tile_llk = reinterpret_cast<double*>(prim_lds + L.num_prim);   // [work items or waves][NP] {mantissa, exponent}
 
-    const int tid = threadIdx.x;
+    // (tid_in: the resident kernel passes its thread index through an opaque register each round,
+    // so that nothing derived from it is hoisted out of the round loop and kept alive across it)
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it)
     int m, g4;
@@ -424,7 +427,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const bool dyn = max_tiles_blk * (uint32_t)ngrp <= (uint32_t)(L.dyn_limit * nwave);
     // The per-marker likelihoods of a work item are MULTIPLIED (mantissa x 2^exponent): over
     // the 16 markers of the tile by a butterfly, then slot by slot in the block reduction.
-    auto tile_product = [&](ScaledProd* p) {              // over the 16 lanes sharing slot g
+    auto tile_product = [&](ScaledProd* p, bool cross) {  // over the 16 lanes sharing slot g (+ the item's other tiles)
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) {
             const int partner = lane_of<HWMAP>(m ^ off, g4);
@@ -434,6 +437,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 p[t].e += __shfl(p[t].e, partner, 64);
             }
         }
+        if (!cross) return;
 #pragma unroll
         for (int off = SLOTS; off < 4; off <<= 1) {       // the item's other micro-tiles
             const int partner = lane_of<HWMAP>(m, g4 ^ off);
@@ -462,7 +466,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         ScaledProd sp[BTL];
 #pragma unroll
         for (int t = 0; t < BTL; ++t) sp[t] = ScaledProd{wave_prod[t].m, (double)wave_prod[t].e};
-        tile_product(sp);
+        tile_product(sp, true);
         if (m == 0 && half == 0) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
@@ -639,11 +643,14 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         ScaledProd lane_prod[BTL];
 #pragma unroll
         for (int t = 0; t < BTL; ++t) lane_prod[t] = ScaledProd{lk_m[t], (double)lk_e[t]};
-        tile_product(lane_prod);
-        if (m == 0 && half == 0) {
+        // every MICRO-TILE's product goes to its own slot (not the item's): the slots and the
+        // order they are multiplied in are then the same for every wave shape, so a point's value
+        // does not depend on whether it was evaluated alone, among four, or in a group of eight
+        tile_product(lane_prod, false);
+        if (m == 0 && have_tile) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
-                const size_t o = ((size_t)idx * NP + g * BTL + t) * 2;
+                const size_t o = (((size_t)grp * ntile_blk + it) * NP + g * BTL + t) * 2;
                 tile_llk[o] = lane_prod[t].m;
                 tile_llk[o + 1] = lane_prod[t].e;
             }
@@ -663,7 +670,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     }
     // ---- deterministic block reduction -> one partial per (point, block) ----
     __syncthreads();
-    const uint32_t nres = dyn ? nunit : (uint32_t)nwave;       // result slots per group
+    const uint32_t nres = dyn ? ntile_blk : (uint32_t)nwave;   // result slots per group
     for (int b = wave; b < NPT; b += nwave) {         // slots in index order, then a butterfly
         const int grp = b / NP, bb = b - grp * NP;
         ScaledProd p{1.0, 0.0};
@@ -858,114 +865,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
 
 
 
-// ---------------------------------------------------------------------------------------------
-// Resident search kernel.  A Nelder-Mead search is ~480 DEPENDENT launches of 4 points, and at
-// 17 us of kernel per launch the ~7 us of launch submission + dispatch per iteration is a third
-// of the wall-clock.  This kernel is launched once per search and stays on the CUs: the host
-// posts each batch of <= 4 parameter rows in a mailbox in mapped host memory, workgroup 0 polls
-// it over PCIe and relays it through device memory, every workgroup evaluates its tiles exactly
-// as llk_eval_kernel<1> does, and the last workgroup writes the results + sequence number back
-// to mapped host memory.  The host optimiser keeps every decision (bit-identical trajectory).
-//
-// Mailbox / relay layout (64-bit words): [0] sequence number, [1] rows valid (0 = exit),
-// [2 .. 2+4*(2k+1)) parameter rows, [last] check word = XOR of word_hash(word, position) ^
-// mix(sequence).  The
-// check word makes one PCIe read pass self-validating: a torn read (host mid-write) fails the
-// test and is retried, so no second round trip is needed after seeing a new sequence number.
-// Both sides give up after a bounded wait (the kernel when idle for timeout_ticks of the
-// 100 MHz wall clock, the host after a few seconds) and the host falls back to plain launches.
-__device__ __forceinline__ double* lds_base()
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    return lds;
-}
-
-template <int MODE, bool HWMAP>
-__global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
-llk_resident_kernel(const DeviceLayout L, const ResidentArgs ra, double* __restrict__ partials,
-                    unsigned int* __restrict__ ticket)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int stride = 2 * L.num_pc + 1;
-    const int nword = 2 + 4 * stride + 1;
-    InlinePoints ip;
-    ip.count = 0;
-    if (blockIdx.x == 0 && tid == 0)
-        __hip_atomic_store(ra.h_state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (unsigned long long seq = ra.first_seq;; ++seq) {
-        __syncthreads();                       // everyone is out of the previous evaluation's LDS
-        const unsigned long long t_wait = wall_clock64();
-        unsigned long long t_seen = 0;
-        bool timed_out = false;
-        if (blockIdx.x == 0 && wave == 0) {
-            // ---- host mailbox -> relay (one wave; retried until a consistent image arrives) ----
-            for (unsigned it = 0;; ++it) {
-                unsigned long long x = 0, w0 = 0;
-                for (int w = lane; w < nword; w += 64) {
-                    const unsigned long long v =
-                        __hip_atomic_load(&ra.h_cmd[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (w == 0) {
-                        w0 = v;
-                    } else {
-                        if (w < nword - 1) x ^= word_hash(v, (unsigned)w);
-                        else x ^= v;                       // the check word itself
-                        __hip_atomic_store(&ra.relay[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off, 64);
-                w0 = __shfl(w0, 0, 64);
-                if (w0 == seq && x == resident_mix(seq)) break;
-                if ((it & 15) == 15 && wall_clock64() - t_wait > ra.timeout_ticks) { timed_out = true; break; }
-            }
-            if (!timed_out) {
-                t_seen = wall_clock64();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0)
-                    __hip_atomic_store(&ra.relay[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (lane == 0) {
-                // tell the other workgroups (and the host) to give up as well
-                __hip_atomic_store(&ra.relay[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // ---- one thread per workgroup waits for the relayed command ----
-        // (relaxed L1-bypassing loads: an acquire here would invalidate caches under the
-        // workgroups that are still evaluating; the rows are read with bypassing loads too)
-        unsigned long long* lds_flag = reinterpret_cast<unsigned long long*>(lds_base());
-        if (tid == 0) {
-            unsigned long long got = 0;
-            for (unsigned it = 0;; ++it) {
-                got = __hip_atomic_load(&ra.relay[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // (a relay already past this workgroup's sequence number: it started late, after the
-                // others gave up on it -- leave at once)
-                if (got >= seq) break;
-                if ((it & 63) == 63 && wall_clock64() - t_wait > 2 * ra.timeout_ticks) { got = ~0ull; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            *lds_flag = got;
-        }
-        __syncthreads();
-        timed_out = (*lds_flag != seq);         // eval_body's first barrier orders this read before its LDS writes
-        if (timed_out) {
-            if (blockIdx.x == 0 && tid == 0)
-                __hip_atomic_store(ra.h_state, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
-        }
-        const int nv = (int)__hip_atomic_load(&ra.relay[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nv <= 0) {                          // exit command
-            if (blockIdx.x == 0 && tid == 0)
-                __hip_atomic_store(ra.h_state, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
-        }
-        if (L.stamps && blockIdx.x == 0 && tid == 0) L.stamps[7] = t_seen;     // profiling: command seen
-        if (MODE == 3 && nv == 1)       // a single point: the one-point wave shape (a quarter of the work)
-            eval_body<4, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
-                                ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, ra.sched_single, true);
-        else
-            eval_body<MODE, HWMAP>(L, ip, reinterpret_cast<const double*>(ra.relay + 2), nv, partials, ra.h_out,
-                                   ticket, ra.h_done, seq, blockIdx.x, gridDim.x, nullptr, 0u, 1, seq, ra.sched_multi, true);
-    }
-}
+#include "resident_kernel.inc"
 
 // Sums the per-block partials in a fixed order -> bitwise reproducible: wave w takes
 // points w, w+4, ...; lane l adds blocks l, l+64, ... (8 independent loads in flight),
@@ -1139,7 +1039,7 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
 size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp)
 {
     const size_t NP = (size_t)np, G = (size_t)ngrp;
-    const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;
+    const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;      // (one slot per micro-tile and group)
     const size_t slots = items <= (size_t)L.dyn_limit * block_waves ? items : (size_t)block_waves * G;
     const size_t bytes = sizeof(double) * (G * (L.num_code + 1) * (size_t)(L.row_bytes / 8) + G * NP + 2 +
                                            G * NP * (2 * L.num_pc + 1) + 1 + G * NP * 2 * L.num_pc +
@@ -1238,11 +1138,24 @@ bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int t
 static bool g_coop_launch = false;
 void set_coop_launch(bool on) { g_coop_launch = on; }
 
-hipError_t launch_llk_resident(const DeviceLayout& L, const ResidentArgs& ra, double* d_partials,
+size_t resident_state_doubles(int nmax, int num_pc)
+{
+    return 8 + DeviceSimplex::lds_doubles(nmax, num_pc) + (size_t)resident_words(num_pc) + 2;
+}
+
+hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, double* d_partials,
                                unsigned int* d_ticket, hipStream_t stream)
 {
     const LaunchGeom gm = launch_geom(L, 1);
-    const size_t shmem = eval_shmem_bytes(L, 1, gm.grid, gm.block_waves, 1);
+    // dynamic LDS: the evaluation body's, then workgroup 0's search state (16-byte aligned)
+    size_t shmem = (eval_shmem_bytes(L, 1, gm.grid, gm.block_waves, 1) + 15) / 16 * 16;
+    ResidentArgs& ra = *ra_io;           // state_off / state_nmax are filled in here
+    ra.state_off = (int32_t)(shmem / sizeof(double));
+    shmem += sizeof(double) * resident_state_doubles(ra.state_nmax, L.num_pc);
+    if (shmem > (size_t)kLdsLimitBytes && ra.state_nmax > 0) {      // no room: search on the host
+        ra.state_nmax = 0;
+        shmem = ra.state_off * sizeof(double) + sizeof(double) * resident_state_doubles(0, L.num_pc);
+    }
     if (shmem > (size_t)kLdsLimitBytes || gm.grid > L.num_cu) return hipErrorInvalidConfiguration;
     const void* fn = g_paired ? (g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true>)
                                          : reinterpret_cast<const void*>(&llk_resident_kernel<3, false>))
