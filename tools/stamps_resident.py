@@ -16,10 +16,6 @@ lib.vb2_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 nb = lib.vb2_debug_read_stamps(ctx._h, buf, 512)
 s = np.array(buf[:8 * nb], dtype=np.float64).reshape(nb, 8)
 t0 = s[0, 7]
-names7 = ["state loaded", "previous round consumed, next rows unpacked", "control function entered", "state parked",
-          "round on the relay", "workgroup 0 enters the evaluation body"]
-print("control wave, us after round begun: " + "; ".join("%s %.2f" % (n, (s[i + 1, 7] - t0) / 100.0)
-                                                          for i, n in enumerate(names7) if s[i + 1, 7] > 0))
 s = s[s[:, 0] > 0]
 us = (s - t0) / 100.0
 names = ["entry", "points in LDS", "table built", "wave0 tiles done", "last wave tiles done", "block reduced", "finalized (last block)"]
