@@ -596,6 +596,86 @@ def test_cohort_batch_lockstep_matches_individual_runs():
             c.close()
 
 
+def test_c5_sized_cohort_on_one_gpu():
+    """BASELINE.json configs[4] per GPU: 32 samples of 100 000 markers x depth 30, --NumPC 4, in ONE
+    lock-step batch (static deal, ~49 work items per wave).  batch.eval equals every context's own
+    evaluation, two samples are checked against the oracle, and batch.optimize gives every sample
+    the estimate of its single-context search.  (8 distinct synthetic samples, each uploaded four
+    times: 32 independent contexts in HBM.)"""
+    k, S = 4, 32
+    distinct = [vb.synth.make_pileup(100000, 30, k, alpha_true=0.01 + 0.02 * s, seed=1000 + s) for s in range(8)]
+    ctxs = [vb.LikelihoodContext(distinct[s % 8]) for s in range(S)]
+    try:
+        rng = np.random.default_rng(17)
+        with vb.CohortBatch(ctxs) as batch:
+            for n in (4, 8, 1):
+                npt = np.full(S, n, dtype=np.int32)
+                pc1 = rng.normal(0, 0.03, size=(S, 8, k))
+                pc2 = rng.normal(0, 0.03, size=(S, 8, k))
+                al = rng.uniform(0.0, 0.4, size=(S, 8))
+                got = batch.eval(npt, pc1, pc2, al)
+                assert np.array_equal(got, batch.eval(npt, pc1, pc2, al))
+                for s in range(S):
+                    want = ctxs[s].llk(pc1[s, :n], pc2[s, :n], al[s, :n])
+                    assert rel_err(got[s, :n], want) <= LLK_RTOL, (n, s)
+                for s in (0, 13):
+                    od = oracle_data(distinct[s % 8])
+                    ref = np.array([od.llk(pc1[s, j], pc2[s, j], al[s, j], num_thread=os.cpu_count() or 1)
+                                    for j in range(min(n, 2))])
+                    assert rel_err(got[s, :len(ref)], ref) <= LLK_RTOL, (n, s)
+            ests = batch.optimize()
+        singles = [ctxs[s].optimize() for s in range(8)]
+        for s in range(S):
+            one = singles[s % 8]
+            assert abs(ests[s]["alpha"] - one["alpha"]) <= 1e-6, s
+            assert abs(ests[s]["llk1"] - one["llk1"]) <= 1e-9 * abs(one["llk1"]), s
+            assert abs(ests[s]["alpha"] - (0.01 + 0.02 * (s % 8))) <= 5e-3, s          # and it is the planted contamination
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_wide_quality_alphabet_at_100k_markers():
+    """BAQ-adjusted real pileups carry 60-90 distinct (class, quality) codes; here qualities 2..60
+    (>= 100 codes) at 100 000 markers x depth 30: the wider per-alpha tables leave room for fewer
+    point groups per launch (vb2 splits the batch), results equal the oracle's."""
+    k = 4
+    d = vb.synth.make_pileup(100000, 30, k, alpha_true=0.04, seed=31, q_lo=2, q_hi=60)
+    od = oracle_data(d)
+    rng = np.random.default_rng(18)
+    B = 50                                                     # more than one launch carries
+    pc1, pc2, al = rng.normal(0, 0.03, (B, k)), rng.normal(0, 0.03, (B, k)), rng.uniform(0, 0.4, B)
+    with vb.LikelihoodContext(d) as ctx:
+        assert ctx.info()["num_code"] >= 100
+        got = ctx.llk(pc1, pc2, al)
+        assert np.array_equal(got, ctx.llk(pc1, pc2, al))
+        idx = [0, 7, 8, 31, 47, 48, 49]
+        ref = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=os.cpu_count() or 1) for i in idx])
+        assert rel_err(got[idx], ref) <= LLK_RTOL
+        one = ctx.llk(pc1[:1], pc2[:1], al[:1])
+        assert one[0] == got[0]
+        est = ctx.optimize()
+        assert abs(est["alpha"] - 0.04) <= 5e-3
+
+
+def test_value_of_a_point_does_not_depend_on_the_wave_shape(c2, c3):
+    """A point evaluated alone (four micro-tiles per wave), among four (two tiles x two slots) or in
+    a group of eight (one tile x four slots x two points) gets the same bits: every micro-tile's
+    product goes to its own slot and the slots are multiplied in one fixed order."""
+    rng = np.random.default_rng(19)
+    for d in (c2[0], c3):
+        k = d.num_pc
+        B = 19
+        pc1, pc2, al = rng.normal(0, 0.03, (B, k)), rng.normal(0, 0.03, (B, k)), rng.uniform(0, 0.4, B)
+        with vb.LikelihoodContext(d) as ctx:
+            full = ctx.llk(pc1, pc2, al)
+            for i in range(B):
+                assert ctx.llk(pc1[i:i + 1], pc2[i:i + 1], al[i:i + 1])[0] == full[i], i
+            for i in range(0, B - 3, 3):
+                assert np.array_equal(ctx.llk(pc1[i:i + 4], pc2[i:i + 4], al[i:i + 4]), full[i:i + 4]), i
+            assert np.array_equal(ctx.llk(pc1[:8], pc2[:8], al[:8]), full[:8])
+
+
 def test_cohort_at_the_queue_vs_static_deal_boundary():
     """32 samples -> 8 workgroups of 16 waves per sample; the work queue with per-item result
     slots is used up to 10 tiles per wave = 160 tiles per workgroup, the static deal above.  A
