@@ -179,3 +179,49 @@ def amoeba(fn, start, ftol=1e-8, which="oracle"):
     else:
         ret = ref_lib().vb2ref_amoeba_minimize(cb, None, n, point, float(ftol))
     return ret, np.array(list(point))
+
+
+class _AdapterIO(C.Structure):
+    _fields_ = [
+        ("num_pc", C.c_int32), ("is_heter", C.c_int32), ("is_pc_fixed", C.c_int32), ("is_alpha_fixed", C.c_int32),
+        ("fix_alpha", C.c_double), ("epsilon", C.c_double), ("fix_pc", C.c_void_p),
+        ("alpha", C.c_double), ("llk1", C.c_double), ("llk0", C.c_double),
+        ("pc", C.c_void_p), ("pc2", C.c_void_p), ("num_eval", C.c_int64),
+        ("trace", C.c_void_p), ("trace_capacity", C.c_int64), ("trace_count", C.c_int64),
+        ("error", C.c_int32),
+    ]
+
+
+def reference_optimiser_on_gpu(product_lib, ctx_handle, num_pc, within_ancestry=False, fix_pc=None,
+                               fix_alpha=None, epsilon=1e-8, trace_capacity=8192, bracket=True):
+    """INTEGRATION.md section A, executed (oracle/ref_adapter.cpp): the REFERENCE's compiled
+    AmoebaMinimizer drives the product's GPU likelihood through the C-ABI -- a VectorFunc subclass
+    whose ComputeMixLLKs is vb2_llk_eval_batch, inside vb2_ctx_search_begin/end.  `product_lib` is
+    the loaded libvb2.so (ctypes), `ctx_handle` a vb2_ctx*.  Returns the estimate and the trace of
+    every Evaluate the reference made."""
+    r = ref_lib()
+    if r is None:
+        raise RuntimeError("oracle/_ref/libvb2ref.so was never built (needs /root/reference once)")
+    k = int(num_pc)
+    fpc = None if fix_pc is None else np.ascontiguousarray(fix_pc, dtype=np.float64)
+    pc, pc2 = np.zeros(k), np.zeros(k)
+    trace = np.zeros((trace_capacity, 2 * k + 2))
+    io = _AdapterIO(k, int(not within_ancestry), int(fix_pc is not None),
+                    int(fix_pc is None and fix_alpha is not None),
+                    float(fix_alpha if fix_alpha is not None else 0.0), float(epsilon),
+                    None if fpc is None else fpc.ctypes.data,
+                    0.0, 0.0, 0.0, pc.ctypes.data, pc2.ctypes.data, 0,
+                    trace.ctypes.data, trace_capacity, 0, 0)
+    addr = lambda f: C.cast(f, C.c_void_p)
+    r.vb2ref_adapter_optimize.restype = C.c_int
+    r.vb2ref_adapter_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_AdapterIO)]
+    rc = r.vb2ref_adapter_optimize(addr(product_lib.vb2_llk_eval_batch),
+                                   addr(product_lib.vb2_ctx_search_begin) if bracket else None,
+                                   addr(product_lib.vb2_ctx_search_end) if bracket else None,
+                                   ctx_handle, C.byref(io))
+    if rc:
+        raise RuntimeError("evaluator failed inside the reference's optimiser: %d" % rc)
+    n = int(min(io.trace_count, trace_capacity))
+    return dict(alpha=io.alpha, llk1=io.llk1, llk0=io.llk0, pc=pc, pc2=pc2, num_eval=int(io.num_eval),
+                trace=dict(alpha=trace[:n, 0].copy(), llk=trace[:n, 1].copy(), pc1=trace[:n, 2:2 + k].copy(),
+                           pc2=trace[:n, 2 + k:].copy()), trace_count=int(io.trace_count))

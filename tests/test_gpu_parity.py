@@ -90,6 +90,52 @@ def test_golden_models(golden_dir, kat, model):
         assert est["num_eval"] == spec["num_eval"]
 
 
+@pytest.mark.parametrize("model", ["result", "longread", "within", "within_fixpc", "fixalpha",
+                                   "heter_fixpc"])
+def test_reference_optimiser_drives_the_gpu_through_the_c_abi(golden_dir, kat, model):
+    """INTEGRATION.md section A, executed: oracle/ref_adapter.cpp is the reference-side binding -- a
+    subclass of the reference's VectorFunc whose ComputeMixLLKs is vb2_llk_eval_batch, installed in
+    the reference's OWN AmoebaMinimizer (compiled in place from /root/reference into oracle/_ref),
+    the search bracketed by vb2_ctx_search_begin/end.  With the reference's optimiser driving the
+    GPU the six golden .Ancestry files come out byte for byte, and the evaluations are exactly those
+    of the library's own search (vb2_ctx_optimize_llk): same points, same values, same order."""
+    from oracle import binding
+    if binding.ref_lib() is None:
+        pytest.skip("oracle/_ref/libvb2ref.so not built (needs the reference tree once)")
+    spec = kat["models"][model]
+    d = _golden(golden_dir, spec["pileup"])
+    with vb.LikelihoodContext(d) as ctx:
+        mine = ctx.optimize(trace_capacity=8192, **spec["args"])
+        for bracket in (True, False):
+            ref = binding.reference_optimiser_on_gpu(_abi.lib(), ctx._h, 2, bracket=bracket, **spec["args"])
+            assert abs(ref["alpha"] - spec["alpha"]) <= 1e-9
+            with open(os.path.join(golden_dir, spec["ancestry"])) as fh:
+                assert ancestry_text(ref["pc"], ref["pc2"]) == fh.read()
+            if "num_eval" in spec:
+                assert ref["num_eval"] == spec["num_eval"]
+            for key in ("alpha", "llk1", "llk0", "num_eval"):
+                assert ref[key] == mine[key], (key, bracket)
+            assert np.array_equal(ref["pc"], mine["pc"]) and np.array_equal(ref["pc2"], mine["pc2"])
+            assert ref["trace_count"] == mine["trace_count"]
+            for key in ("llk", "alpha", "pc1", "pc2"):
+                assert np.array_equal(ref["trace"][key], mine["trace"][key]), (key, bracket)
+
+
+def test_reference_optimiser_on_gpu_at_c2_size(c2):
+    """Same at 10 000 markers x depth 30 (BASELINE.json configs[1]): the reference's AmoebaMinimizer
+    over the C-ABI and the library's search agree evaluation by evaluation."""
+    from oracle import binding
+    if binding.ref_lib() is None:
+        pytest.skip("oracle/_ref/libvb2ref.so not built (needs the reference tree once)")
+    d, od = c2
+    with vb.LikelihoodContext(d) as ctx:
+        mine = ctx.optimize(trace_capacity=8192)
+        ref = binding.reference_optimiser_on_gpu(_abi.lib(), ctx._h, d.num_pc)
+    assert ref["alpha"] == mine["alpha"] and ref["llk1"] == mine["llk1"] and ref["num_eval"] == mine["num_eval"]
+    assert np.array_equal(ref["trace"]["llk"], mine["trace"]["llk"])
+    assert abs(ref["alpha"] - od.optimize()["alpha"]) <= 1e-9
+
+
 @pytest.mark.parametrize("case", [
     ("result", []), ("longread", []), ("within", ["--WithinAncestry"]),
     ("within_fixpc", ["--WithinAncestry", "--FixPC", "0.034756:0.0193"]),
