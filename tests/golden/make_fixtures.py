@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Regenerates the committed golden vectors of tests/golden/ -- the recipe behind the numbers.
+
+    python tests/golden/make_fixtures.py            # rewrite kat.json's LLK values + synthetic_c2/c3.json
+    python tests/golden/make_fixtures.py --check    # recompute and compare with what is committed
+
+Run in the BUILD container (it uses the oracle and, for the search half, oracle/_ref: the
+reference's own AmoebaMinimizer compiled in place from /root/reference).  Nothing here runs on
+the GPU box; the tests read the JSON files.
+
+What pins what:
+  * tests/golden/expected/* and the two pileups are byte-identical copies of the reference's own
+    CTest fixtures (resource/test/expected/*, CMakeLists.txt:86-147).  tests/test_oracle_golden.py
+    holds the ORACLE (oracle/vb2_oracle.c) to them: six .Ancestry files byte for byte, both
+    .selfSM files, 604 evaluations -- and holds its simplex search to the reference's compiled
+    AmoebaMinimizer (oracle/_ref) bit for bit.
+  * kat.json `llk_hex`: +LLK of ComputeMixLLKs at five fixed points on the two bundled inputs.
+    The values were first captured from a build of the reference's ContaminationEstimator.h
+    (SURVEY.md 8c); this script RECOMPUTES them with the pinned oracle and refuses to write if
+    they do not reproduce bit for bit -- the committed numbers are a function of committed code
+    and committed data, not a transcription.
+  * synthetic_c2.json / synthetic_c3.json (BASELINE.json configs[1] and [2] shapes): seeded
+    synthetic pileups (verifybamid_amd/synth.py), sha256 of the generated arrays, +LLK hex-floats
+    of the oracle (1 thread: a fixed summation order) at seeded points, and the OptimizeLLK result
+    -- alpha, llk1, llk0, evaluation count, a digest of the whole evaluation trace -- computed
+    twice: with the oracle's minimiser and with the reference's own (oracle/_ref); the two must
+    agree exactly or nothing is written.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HAPMAP = os.path.join(HERE, "hapmap", "hapmap_3.3.b37.dat")
+SHAPES = {
+    "synthetic_c2.json": dict(markers=10000, depth=30, num_pc=2, alpha_true=0.05, seed=1, points=12),
+    "synthetic_c3.json": dict(markers=100000, depth=30, num_pc=4, alpha_true=0.05, seed=2, points=8),
+}
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def trace_digest(tr):
+    return sha(tr["alpha"], tr["pc1"], tr["pc2"], tr["llk"])
+
+
+def synthetic_fixture(spec):
+    import verifybamid_amd as vb
+    from oracle.bridge import oracle_data
+    from oracle import binding
+    k = spec["num_pc"]
+    d = vb.synth.make_pileup(spec["markers"], spec["depth"], k, alpha_true=spec["alpha_true"], seed=spec["seed"])
+    od = oracle_data(d)
+    rng = np.random.default_rng(1000 + spec["seed"])
+    B = spec["points"]
+    pc1 = rng.normal(0, 0.03, size=(B, k))
+    pc2 = rng.normal(0, 0.03, size=(B, k))
+    alpha = rng.uniform(0.0, 0.5, size=B)
+    alpha[0] = 0.0
+    llk = [od.llk(pc1[i], pc2[i], alpha[i], num_thread=1) for i in range(B)]
+    out = dict(
+        _what="seeded synthetic pileup (verifybamid_amd.synth.make_pileup) + oracle results; "
+              "regenerate with tests/golden/make_fixtures.py",
+        generator=dict(markers=spec["markers"], mean_depth=spec["depth"], num_pc=k,
+                       alpha_true=spec["alpha_true"], seed=spec["seed"]),
+        input_sha256=sha(d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base),
+        reads=int(d.num_read),
+        points=dict(pc1=pc1.tolist(), pc2=pc2.tolist(), alpha=alpha.tolist()),
+        llk_hex=[float(x).hex() for x in llk],
+        llk_threads=1,
+        models={},
+    )
+    models = {"heter": {}, "within": {"within_ancestry": True}} if spec["markers"] <= 20000 else {"heter": {}}
+    for name, kw in models.items():
+        a = od.optimize(num_thread=1, minimizer="oracle", trace_capacity=1 << 14, **kw)
+        have_ref = binding.ref_lib() is not None
+        if have_ref:
+            b = od.optimize(num_thread=1, minimizer="reference", trace_capacity=1 << 14, **kw)
+            same = (a["alpha"] == b["alpha"] and a["llk1"] == b["llk1"] and a["llk0"] == b["llk0"] and
+                    a["num_eval"] == b["num_eval"] and trace_digest(a["trace"]) == trace_digest(b["trace"]))
+            if not same:
+                raise SystemExit("oracle minimiser and the reference's AmoebaMinimizer disagree on %s" % name)
+        out["models"][name] = dict(
+            args=kw, alpha_hex=float(a["alpha"]).hex(), llk1_hex=float(a["llk1"]).hex(),
+            llk0_hex=float(a["llk0"]).hex(), num_eval=a["num_eval"],
+            pc_hex=[float(x).hex() for x in a["pc"]], pc2_hex=[float(x).hex() for x in a["pc2"]],
+            trace_sha256=trace_digest(a["trace"]),
+            trace_head_llk_hex=[float(x).hex() for x in a["trace"]["llk"][:6]],
+            cross_checked_with_reference_minimiser=have_ref)
+    return out
+
+
+def kat_llk():
+    """The five known-answer points on the two bundled inputs, recomputed with the oracle."""
+    from oracle import binding, refio
+    kat = json.load(open(os.path.join(HERE, "kat.json")))
+    got = {}
+    for name, spec in kat["inputs"].items():
+        flat, _, _ = refio.load_flat(HAPMAP, os.path.join(HERE, spec["pileup"]), 2)
+        od = binding.OracleData(flat)
+        got[name] = [float(od.llk(p["pc1"], p["pc2"], p["alpha"], num_thread=1)).hex() for p in kat["points"]]
+    return kat, got
+
+
+def norm_hex(h):
+    return float.fromhex(h).hex()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    bad = 0
+    kat, got = kat_llk()
+    for name, vals in got.items():
+        want = [norm_hex(h) for h in kat["inputs"][name]["llk_hex"]]
+        if vals != want:
+            print("kat.json %s: oracle gives %s, file holds %s" % (name, vals, want))
+            bad += 1
+    if bad:
+        raise SystemExit("kat.json does not reproduce from the oracle: not writing anything")
+    if not args.check:
+        kat["_source"] = ("Known-answer +LLK values of the reference's FullLLKFunc::ComputeMixLLKs "
+                          "(ContaminationEstimator.h:194-314): hapmap_3.3.b37.dat panel, --NumPC 2, sanity check "
+                          "disabled; first captured from the reference (SURVEY.md 8c), reproduced bit for bit by "
+                          "tests/golden/make_fixtures.py from the oracle that tests/test_oracle_golden.py pins to "
+                          "the reference's own fixtures. Hex-floats are the exact IEEE-754 doubles.")
+        json.dump(kat, open(os.path.join(HERE, "kat.json"), "w"), indent=1)
+    for fname, spec in SHAPES.items():
+        fx = synthetic_fixture(spec)
+        path = os.path.join(HERE, fname)
+        if args.check:
+            old = json.load(open(path))
+            if old != json.loads(json.dumps(fx)):
+                print("%s differs from what the recipe produces now" % fname)
+                bad += 1
+        else:
+            json.dump(fx, open(path, "w"), indent=1)
+            print("wrote %s (%d points, models %s)" % (fname, len(fx["llk_hex"]), sorted(fx["models"])))
+    if bad:
+        raise SystemExit(1)
+    print("fixtures %s" % ("reproduce" if args.check else "written"))
+
+
+if __name__ == "__main__":
+    main()

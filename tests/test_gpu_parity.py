@@ -219,6 +219,37 @@ def test_batch_slot_independence(c2):
         assert np.array_equal(rev[::-1], full)
 
 
+@pytest.mark.parametrize("fname", ["synthetic_c2.json", "synthetic_c3.json"])
+def test_committed_synthetic_fixtures(golden_dir, fname):
+    """The committed oracle results for BASELINE.json configs[1] / [2] shaped inputs
+    (tests/golden/synthetic_c*.json, made by tests/golden/make_fixtures.py in the build container,
+    search half cross-checked there against the reference's own AmoebaMinimizer): per-evaluation
+    +LLK within 1e-12 (north star: 1e-6), alpha within 1e-9 (north star: 1e-4), the same number of
+    evaluations, the same first evaluations of the search."""
+    import hashlib
+    fx = json.load(open(os.path.join(golden_dir, fname)))
+    g = fx["generator"]
+    d = vb.synth.make_pileup(g["markers"], g["mean_depth"], g["num_pc"], alpha_true=g["alpha_true"], seed=g["seed"])
+    h = hashlib.sha256()
+    for a in (d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base):
+        h.update(np.ascontiguousarray(a).tobytes())
+    if h.hexdigest() != fx["input_sha256"]:
+        pytest.skip("this numpy draws a different synthetic sample than the one the fixture was made from")
+    P = fx["points"]
+    want = np.array([float.fromhex(x) for x in fx["llk_hex"]])
+    with vb.LikelihoodContext(d) as ctx:
+        got = ctx.llk(P["pc1"], P["pc2"], P["alpha"])
+        assert rel_err(got, want) <= NORTH_STAR_LLK_RTOL and rel_err(got, want) <= LLK_RTOL
+        for name, m in fx["models"].items():
+            est = ctx.optimize(trace_capacity=1 << 14, **m["args"])
+            assert abs(est["alpha"] - float.fromhex(m["alpha_hex"])) <= 1e-9, name
+            assert abs(est["llk1"] - float.fromhex(m["llk1_hex"])) <= LLK_RTOL * abs(est["llk1"]), name
+            assert abs(est["llk0"] - float.fromhex(m["llk0_hex"])) <= LLK_RTOL * abs(est["llk0"]), name
+            assert est["num_eval"] == m["num_eval"], name
+            head = np.array([float.fromhex(x) for x in m["trace_head_llk_hex"]])
+            assert rel_err(est["trace"]["llk"][:len(head)], head) <= LLK_RTOL, name
+
+
 # ------------------------------------------------------------------ full size, properties
 
 @pytest.fixture(scope="module")

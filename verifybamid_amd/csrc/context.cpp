@@ -51,7 +51,7 @@ struct SlabCache {
     struct Entry { void* p; size_t bytes; int device; };
     static constexpr size_t kMaxCached = 96;
     std::mutex mu;
-    std::vector<Entry> dev, pin;
+    std::vector<Entry> dev, pin, stage;      // device slabs, small pinned slabs, big pinned upload staging
     bool enabled() { static const bool on = !(std::getenv("VB2_SLAB_CACHE") && std::getenv("VB2_SLAB_CACHE")[0] == '0'); return on; }
     void* take(std::vector<Entry>& v, size_t bytes, int device, size_t* got)
     {
@@ -200,6 +200,14 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     c->num_pc = in->num_pc;
     std::snprintf(c->device_name, sizeof(c->device_name), "%s", prop.name);
     std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
+    // the context's stream: the upload, every launch and the schedules' copies go on it (never the null stream)
+    if (opt && opt->stream) {
+        c->stream = (hipStream_t)opt->stream;
+        c->own_stream = false;
+    } else {
+        VB2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
 
     const int M = in->num_marker, k = in->num_pc;
     const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
@@ -314,6 +322,25 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         dict_perr[d] = (order[d] / kNumQual) ? -pe : pe;      // sign carries the class
     }
 
+    // ---- primary codes of the per-alpha table: all ref codes (with the alt code of the same
+    // quality as twin, if that occurs) and the alt codes without a ref partner ----
+    std::vector<double2> prim;
+    auto prim_rec = [&](int d, uint32_t twin) {
+        const unsigned long long bits = (unsigned long long)((uint32_t)d | (twin << 16));
+        double y;
+        std::memcpy(&y, &bits, sizeof(y));
+        prim.push_back(make_double2(dict_perr[d], y));
+    };
+    for (int d = 0; d < num_code; ++d) {
+        const int cls = order[d] / kNumQual, q = order[d] % kNumQual;
+        if (cls == 0) {
+            const int t = dict_of[kNumQual + q];
+            prim_rec(d, t == kPadCode ? 0xffffu : (uint32_t)t);
+        } else if (dict_of[q] == kPadCode) {
+            prim_rec(d, 0xffffu);
+        }
+    }
+
     // ---- sort markers by effective depth (descending, stable); 16-marker micro-tiles ----
     // counting sort = the stable descending sort by run count (ties keep panel order)
     std::vector<int64_t> perm(m_active);
@@ -343,8 +370,6 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
 
     const auto t_sort = tnow();
     const int num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    std::vector<uint2> mt_rec(num_mt);
-    for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rows[t]);
 
     // A run is one dword: low half = byte offset of the code's row in the LDS table (pre-multiplied:
     // the kernel adds it to the table's address), high half = the top 16 bits of the IEEE double
@@ -360,10 +385,80 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         return (uint32_t)(d * row_bytes) | ((uint32_t)(bits >> 48) << 16);
     };
     const uint32_t pad4 = run_word(num_code, 0);
-    std::vector<uint32_t> codes((size_t)(total_rows + kCodeSlackRows) * kMtMarkers * 2, pad4);   // + prefetch slack
-    std::vector<double> ud_s((size_t)k * m_pad, 0.0), mu_s(m_pad, 0.0), cdiag((size_t)4 * m_pad, 0.0);
-    std::vector<double> kaf_s;
-    if (in->known_af) kaf_s.assign(m_pad, 0.0);
+
+    // ---- device memory: ONE allocation per context, carved into 256-byte aligned pieces.
+    // (A cohort creates contexts from many host threads; allocation calls go through driver
+    // ioctls under a process-wide lock and were 12 ms per context there, against 0.6 ms alone.)
+    // The data arrays come first, in one block: they are written ONCE, straight into a pinned
+    // staging slab with the same layout, and go to HBM as a single hipMemcpyAsync on the
+    // context's stream (BASELINE.json north_star: "flatten ... into pinned SoA arrays that are
+    // hipMemcpyAsync'd to HBM").
+    DeviceLayout& L = c->L;
+    std::memset(&L, 0, sizeof(L));
+    const int nb = kMaxGridPerCU * num_cu;
+    const size_t relay_words = (size_t)resident_words(k);
+    const bool want_stamps = std::getenv("VB2_STAMPS") != nullptr;
+    size_t dev_total = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t off = (dev_total + 255) & ~(size_t)255;
+        dev_total = off + bytes;
+        return off;
+    };
+    const size_t n_codes = (size_t)(total_rows + kCodeSlackRows) * kMtMarkers * 2;   // + prefetch slack
+    const size_t o_codes = carve(n_codes * sizeof(uint32_t));
+    const size_t o_rec = carve((size_t)num_mt * sizeof(uint2));
+    const size_t o_ud = carve(in->known_af ? 0 : (size_t)k * m_pad * sizeof(double));
+    const size_t o_mu = carve(in->known_af ? 0 : (size_t)m_pad * sizeof(double));
+    const size_t o_kaf = carve(in->known_af ? (size_t)m_pad * sizeof(double) : 0);
+    const size_t o_cd = carve((size_t)4 * m_pad * sizeof(double));
+    const size_t o_dpe = carve(dict_perr.size() * sizeof(double));
+    const size_t o_prim = carve(prim.size() * sizeof(double2));
+    const size_t data_bytes = (dev_total + 255) & ~(size_t)255;
+    const size_t o_part = carve(sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb);
+    const size_t o_ticket = carve(sizeof(unsigned int));
+    const size_t o_relay = carve(sizeof(unsigned long long) * relay_words);
+    const size_t o_stamps = carve(want_stamps ? sizeof(unsigned long long) * 8 * nb : 0);
+    // room for the static schedules of the nine launch shapes (filled on first use)
+    size_t o_sched[9], sched_bytes[9];
+    for (int slot = 0; slot < 9; ++slot) {
+        const int tpu = slot == 7 ? 2 : slot == 8 ? 4 : 1, ngrp = slot < 6 ? slot + 1 : 1;
+        const size_t items = (size_t)((num_mt + tpu - 1) / tpu + nb) * ngrp;     // (+ per-workgroup round-up)
+        sched_bytes[slot] = (((size_t)nb * kMaxBlockWaves + 1) * sizeof(uint32_t) + 15) / 16 * 16 + items * sizeof(uint16_t);
+        o_sched[slot] = carve(sched_bytes[slot]);
+    }
+    dev_total = (dev_total + 255) & ~(size_t)255;
+
+    // pinned staging slab (recycled through the cache like the other slabs: hipHostMalloc /
+    // hipHostFree take milliseconds and synchronise)
+    size_t stage_bytes = 0;
+    char* stage = static_cast<char*>(slab_cache().take(slab_cache().stage, data_bytes, dev, &stage_bytes));
+    if (!stage) {
+        VB2_HIP(hipHostMalloc((void**)&stage, data_bytes, hipHostMallocDefault));
+        stage_bytes = data_bytes;
+    }
+    struct StageGuard {                       // back to the cache (or the driver) on every way out
+        char* p; size_t bytes; int dev;
+        ~StageGuard() { if (p && !slab_cache().give(slab_cache().stage, p, bytes, dev)) (void)hipHostFree(p); }
+    } stage_guard{stage, stage_bytes, dev};
+    uint32_t* const codes = reinterpret_cast<uint32_t*>(stage + o_codes);
+    uint2* const mt_rec = reinterpret_cast<uint2*>(stage + o_rec);
+    double* const ud_s = reinterpret_cast<double*>(stage + o_ud);
+    double* const mu_s = reinterpret_cast<double*>(stage + o_mu);
+    double* const kaf_s = reinterpret_cast<double*>(stage + o_kaf);
+    double* const cdiag = reinterpret_cast<double*>(stage + o_cd);
+    for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rows[t]);
+    if (!dict_perr.empty()) std::memcpy(stage + o_dpe, dict_perr.data(), dict_perr.size() * sizeof(double));
+    if (!prim.empty()) std::memcpy(stage + o_prim, prim.data(), prim.size() * sizeof(double2));
+    // padding: unused run slots, and the (< 16) marker positions past the last active one
+    parallel_for((int64_t)n_codes, [&](int, int64_t i0, int64_t i1) { std::fill(codes + i0, codes + i1, pad4); });
+    for (int64_t m = m_active; m < m_pad; ++m) {
+        if (in->known_af) kaf_s[m] = 0.0;
+        else {
+            for (int kk = 0; kk < k; ++kk) ud_s[(size_t)kk * m_pad + m] = 0.0;
+            mu_s[m] = 0.0;
+        }
+        for (int q = 0; q < 4; ++q) cdiag[(size_t)q * m_pad + m] = 0.0;
+    }
     parallel_for(m_active, [&](int, int64_t m0, int64_t m1) {
     std::vector<uint32_t> run_of(num_code + 1, 0);
     std::vector<int> touched;
@@ -378,17 +473,22 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
             if (c2 == 255) {                // class "other": same term for every genotype pair
                 c_other += logc[(2 * kNumQual + clamp_qual(in->quals[beg + j])) * 3];
             } else {
-                const double* lc = &logc[c2 * 3];
-                dg[0] += lc[0]; dg[1] += lc[1]; dg[2] += lc[2];
                 const int d = dict_of[c2];
                 if (run_of[d]++ == 0) touched.push_back(d);
             }
         }
         std::sort(touched.begin(), touched.end());
+        // the g1 == g2 sums, one multiply-add per distinct (class, quality) instead of an add per
+        // read (count * log c: the summation order over a marker's reads is free, like the kernel's)
+        for (int d : touched) {
+            const double* lc = &logc[order[d] * 3];
+            const double n = (double)run_of[d];
+            dg[0] += n * lc[0]; dg[1] += n * lc[1]; dg[2] += n * lc[2];
+        }
         // runs in dictionary order: lanes of a wave then tend to hit the same or
         // neighbouring LDS table rows at the same step (bank-friendly)
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
-        uint32_t* row0 = &codes[(size_t)mt_row_off[t] * kMtMarkers * 2];
+        uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
         size_t j = 0;
         for (int d : touched) {
             for (uint32_t left = run_of[d]; left > 0;) {
@@ -414,85 +514,21 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     });
 
     const auto t_flat = tnow();
-    // ---- primary codes of the per-alpha table: all ref codes (with the alt code of the same
-    // quality as twin, if that occurs) and the alt codes without a ref partner ----
-    std::vector<double2> prim;
-    auto prim_rec = [&](int d, uint32_t twin) {
-        const unsigned long long bits = (unsigned long long)((uint32_t)d | (twin << 16));
-        double y;
-        std::memcpy(&y, &bits, sizeof(y));
-        prim.push_back(make_double2(dict_perr[d], y));
-    };
-    for (int d = 0; d < num_code; ++d) {
-        const int cls = order[d] / kNumQual, q = order[d] % kNumQual;
-        if (cls == 0) {
-            const int t = dict_of[kNumQual + q];
-            prim_rec(d, t == kPadCode ? 0xffffu : (uint32_t)t);
-        } else if (dict_of[q] == kPadCode) {
-            prim_rec(d, 0xffffu);
-        }
-    }
-
-    // ---- device memory: ONE allocation per context, carved into 256-byte aligned pieces.
-    // (A cohort creates contexts from many host threads; allocation calls go through driver
-    // ioctls under a process-wide lock and were 12 ms per context there, against 0.6 ms alone.)
-    DeviceLayout& L = c->L;
-    std::memset(&L, 0, sizeof(L));
-    const int nb = kMaxGridPerCU * num_cu;
-    const size_t relay_words = (size_t)resident_words(k);
-    const bool want_stamps = std::getenv("VB2_STAMPS") != nullptr;
-    size_t dev_total = 0;
-    auto carve = [&](size_t bytes) {
-        const size_t off = (dev_total + 255) & ~(size_t)255;
-        dev_total = off + bytes;
-        return off;
-    };
-    const size_t o_codes = carve(codes.size() * sizeof(uint32_t));
-    const size_t o_rec = carve(mt_rec.size() * sizeof(uint2));
-    const size_t o_ud = carve(in->known_af ? 0 : ud_s.size() * sizeof(double));
-    const size_t o_mu = carve(in->known_af ? 0 : mu_s.size() * sizeof(double));
-    const size_t o_kaf = carve(kaf_s.size() * sizeof(double));
-    const size_t o_cd = carve(cdiag.size() * sizeof(double));
-    const size_t o_dpe = carve(dict_perr.size() * sizeof(double));
-    const size_t o_prim = carve(prim.size() * sizeof(double2));
-    const size_t o_part = carve(sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb);
-    const size_t o_ticket = carve(sizeof(unsigned int));
-    const size_t o_relay = carve(sizeof(unsigned long long) * relay_words);
-    const size_t o_stamps = carve(want_stamps ? sizeof(unsigned long long) * 8 * nb : 0);
-    // room for the static schedules of the nine launch shapes (filled on first use)
-    size_t o_sched[9], sched_bytes[9];
-    for (int slot = 0; slot < 9; ++slot) {
-        const int tpu = slot == 7 ? 2 : slot == 8 ? 4 : 1, ngrp = slot < 6 ? slot + 1 : 1;
-        const size_t items = (size_t)((num_mt + tpu - 1) / tpu + nb) * ngrp;     // (+ per-workgroup round-up)
-        sched_bytes[slot] = (((size_t)nb * kMaxBlockWaves + 1) * sizeof(uint32_t) + 15) / 16 * 16 + items * sizeof(uint16_t);
-        o_sched[slot] = carve(sched_bytes[slot]);
-    }
-    dev_total = (dev_total + 255) & ~(size_t)255;
     c->d_slab = slab_cache().take(slab_cache().dev, dev_total, dev, &c->d_slab_bytes);
     if (!c->d_slab) {
         VB2_HIP(hipMalloc((void**)&c->d_slab, dev_total));
         c->d_slab_bytes = dev_total;
     }
     char* const dbase = static_cast<char*>(c->d_slab);
-    // partial sums, ticket, relay and stamps start as zeros; the data arrays are copied over
-    VB2_HIP(hipMemset(dbase + o_part, 0, dev_total - o_part));
-    auto put = [&](size_t off, const void* src, size_t bytes) -> hipError_t {
-        return bytes ? hipMemcpy(dbase + off, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
-    };
-    VB2_HIP(put(o_codes, codes.data(), codes.size() * sizeof(uint32_t)));
-    VB2_HIP(put(o_rec, mt_rec.data(), mt_rec.size() * sizeof(uint2)));
+    // the data arrays in ONE asynchronous copy; partial sums, ticket, relay, stamps and schedule space start as zeros
+    VB2_HIP(hipMemcpyAsync(dbase, stage, data_bytes, hipMemcpyHostToDevice, c->stream));
+    VB2_HIP(hipMemsetAsync(dbase + o_part, 0, dev_total - o_part, c->stream));
     if (!in->known_af) {
-        VB2_HIP(put(o_ud, ud_s.data(), ud_s.size() * sizeof(double)));
-        VB2_HIP(put(o_mu, mu_s.data(), mu_s.size() * sizeof(double)));
         L.ud = reinterpret_cast<const double*>(dbase + o_ud);
         L.mu = reinterpret_cast<const double*>(dbase + o_mu);
     } else {
-        VB2_HIP(put(o_kaf, kaf_s.data(), kaf_s.size() * sizeof(double)));
         L.known_af = reinterpret_cast<const double*>(dbase + o_kaf);
     }
-    VB2_HIP(put(o_cd, cdiag.data(), cdiag.size() * sizeof(double)));
-    VB2_HIP(put(o_dpe, dict_perr.data(), dict_perr.size() * sizeof(double)));
-    VB2_HIP(put(o_prim, prim.data(), prim.size() * sizeof(double2)));
     L.codes = reinterpret_cast<const uint2*>(dbase + o_codes);
     L.mt_rec = reinterpret_cast<const uint2*>(dbase + o_rec);
     L.ediag = reinterpret_cast<const double*>(dbase + o_cd);
@@ -570,14 +606,9 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     if (const char* sw = std::getenv("VB2_SPIN_WAIT")) c->spin_wait = std::atoi(sw) != 0;
     if (const char* rs = std::getenv("VB2_RESIDENT")) c->resident_enabled = std::atoi(rs) != 0;
     c->dbg_timing = timing;
-    if (opt && opt->stream) {
-        c->stream = (hipStream_t)opt->stream;
-        c->own_stream = false;
-    } else {
-        VB2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
-    VB2_HIP(hipStreamSynchronize(nullptr));        // the memset/copies above (null stream); not a device-wide wait
+    // the upload has left the staging slab (which goes back to the cache now): wait for THIS
+    // context's stream only -- other contexts' streams and the null stream are not touched
+    VB2_HIP(hipStreamSynchronize(c->stream));
     if (timing)
         std::fprintf(stderr, "vb2_ctx_create: flatten %.1f ms (classify %.1f, dictionary+sort %.1f, pack %.1f; "
                      "%d threads), device alloc+upload %.1f ms\n",
