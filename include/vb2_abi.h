@@ -282,6 +282,10 @@ typedef struct vb2_run_args {
     const int32_t *devices;
     int32_t num_device;
     int32_t reserved;
+    /* --BamFile / --Reference: BAM or CRAM input through htslib (SimplePileupViewer.cpp:172-557);
+     * used when pileup_path is NULL.  A library built without htslib fails with VB2_ERR_IO. */
+    const char *bam_path;
+    const char *reference_path;
 } vb2_run_args;
 
 typedef struct vb2_run_result {

@@ -59,6 +59,38 @@ def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
         assert int(sizes[n]) == C.sizeof(cls), (n, sizes[n], C.sizeof(cls))
 
 
+def test_cmake_build_gives_the_same_library(tmp_path):
+    """CMakeLists.txt (HIP language, gfx950, -ffp-contract=off; htslib an optional component) builds
+    libvb2.so + VerifyBamID like the hand Makefile does: same ABI version, every declared symbol."""
+    import shutil
+    import subprocess
+    if shutil.which("cmake") is None or not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("cmake / ROCm clang not available")
+    b = str(tmp_path / "b")
+    subprocess.run(["cmake", "-S", ROOT, "-B", b, "-DCMAKE_HIP_COMPILER=/opt/rocm/lib/llvm/bin/clang++",
+                    "-DCMAKE_PREFIX_PATH=/opt/rocm"], check=True, capture_output=True, timeout=600)
+    subprocess.run(["cmake", "--build", b, "-j8"], check=True, capture_output=True, timeout=1200)
+    L = C.CDLL(os.path.join(b, "libvb2.so"))
+    assert L.vb2_abi_version() == _abi.lib().vb2_abi_version()
+    for name in _abi.SYMBOLS:
+        assert hasattr(L, name), name
+    assert os.access(os.path.join(b, "VerifyBamID"), os.X_OK)
+
+
+def test_bam_input_without_htslib_fails_loudly(tmp_path):
+    """--BamFile goes through htslib (bam_flatten.cpp, an optional CMake component).  This image has
+    no htslib: the request must fail with an explanation, not fall back to anything."""
+    pre = str(tmp_path / "q")
+    _tiny_panel(pre)
+    args, keep = vb.api._run_args(pre, None, 2, True, None, None)
+    args.bam_path = b"/nonexistent/sample.bam"
+    args.reference_path = b"/nonexistent/ref.fa"
+    h = C.c_void_p()
+    rc = _abi.lib().vb2_flat_load(C.byref(args), C.byref(h))
+    assert rc == _abi.VB2_ERR_IO
+    assert b"htslib" in _abi.lib().vb2_last_error()
+
+
 def test_no_device_fails_loudly():
     lib = _abi.lib()
     if lib.vb2_device_count() > 0:

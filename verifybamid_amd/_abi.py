@@ -74,6 +74,7 @@ class RunArgs(C.Structure):
         ("num_pc", C.c_int32), ("disable_sanity", C.c_int32), ("output_pileup", C.c_int32),
         ("device", C.c_int32), ("model", Model),
         ("devices", C.POINTER(C.c_int32)), ("num_device", C.c_int32), ("reserved", C.c_int32),
+        ("bam_path", C.c_char_p), ("reference_path", C.c_char_p),
     ]
 
 

@@ -134,7 +134,7 @@ def _run_args(svd_prefix, pileup_path, num_pc, disable_sanity, known_af_path, ou
     args = _abi.RunArgs(enc(svd_prefix + ".UD"), enc(svd_prefix + ".mu"), enc(svd_prefix + ".bed"),
                         enc(pileup_path), enc(known_af_path), enc(output_prefix), int(num_pc),
                         int(bool(disable_sanity)), int(bool(output_pileup)), int(device), m,
-                        devs, 0 if devs is None else len(devices), 0)
+                        devs, 0 if devs is None else len(devices), 0, None, None)
     return args, (keep, devs)
 
 

@@ -432,7 +432,7 @@ void vb2_shard_group_destroy(vb2_shard_group* g)
 
 int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
 {
-    if (!a || !out || !a->ud_path || !a->mean_path || !a->bed_path || !a->pileup_path ||
+    if (!a || !out || !a->ud_path || !a->mean_path || !a->bed_path || (!a->pileup_path && !a->bam_path) ||
         a->num_pc < 1 || a->num_pc > VB2_MAX_PC) {
         set_error("vb2_flat_load: invalid argument");
         return VB2_ERR_INVALID;
@@ -466,7 +466,9 @@ int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
         int rc_pile = VB2_OK;
         std::string err_main = rc ? vb2::g_last_error : std::string(), err_pile;
         if (!rc) {
-            rc_pile = vb2::read_pileup(a->pileup_path, f->panel.ChooseBed, &f->viewer);
+            rc_pile = a->pileup_path ? vb2::read_pileup(a->pileup_path, f->panel.ChooseBed, &f->viewer)
+                                     : vb2::read_bam(a->bam_path, a->reference_path ? a->reference_path : "",
+                                                     f->panel, &f->viewer);
             if (rc_pile) err_pile = vb2::g_last_error;
         }
         tl_pile = now_s();

@@ -1,0 +1,207 @@
+// bam_flatten.cpp -- BAM/CRAM -> per-marker pileup on the host, the
+// "SimplePileupViewer runs once on host" stage of BASELINE.json's north_star for --BamFile input.
+//
+// Behaviour restated from the reference (file:line relative to the reference root):
+//   read filter + BAQ + mapQ cap       SimplePileupViewer.cpp:172-237 (mplp_func)
+//   per-region pileup over the panel   SimplePileupViewer.cpp:245-557 (SimplePileup)
+//   base characters                    SimplePileupViewer.cpp:25-62   (pileup_seq)
+//   defaults                           main.cpp:81-96: min-MQ 2, min-BQ 13, adjust-MQ (capQ) 40,
+//                                      max depth 8000, REALN (BAQ) + SMART_OVERLAPS, read filter
+//                                      UNMAP | SECONDARY | QCFAIL | DUP
+// It fills the same PileupViewer the text-pileup reader fills (hostio.cpp: read_pileup), so the
+// sanity check, BuildResolvedMarkers and the flattening into pinned SoA arrays are shared.
+//
+// NEEDS htslib (>= 1.10: hts_pos_t), which this build image does not have: the file is compiled
+// only when CMake finds it (-DVB2_WITH_HTSLIB, CMakeLists.txt: find_library(hts)); otherwise
+// read_bam() reports that and --BamFile fails loudly.  STATUS: written against htslib's public
+// API, NOT compiled and NOT validated in this image (no htslib headers, and the reference's
+// resource/test/test.bam is absent): parity at this boundary is unpinned -- validate with
+// `--OutputPileup` against the reference's expected/result.Pileup where htslib and a BAM exist.
+#include "hostio.h"
+
+#include "context.h"   // set_error
+
+#ifdef VB2_WITH_HTSLIB
+#include <htslib/faidx.h>
+#include <htslib/hts.h>
+#include <htslib/sam.h>
+
+#include <cctype>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace vb2 {
+namespace {
+
+struct MplpConf {                      // main.cpp:81-96
+    int min_mq = 2, min_baseQ = 13, capQ_thres = 40, max_depth = 8000;
+    bool realn = true, smart_overlaps = true;
+    uint32_t rflag_filter = BAM_FUNMAP | BAM_FSECONDARY | BAM_FQCFAIL | BAM_FDUP;
+};
+
+struct Aux {
+    samFile* fp = nullptr;
+    sam_hdr_t* hdr = nullptr;
+    hts_itr_t* iter = nullptr;
+    faidx_t* fai = nullptr;
+    char* ref = nullptr;               // sequence of ref_tid (cached: consecutive markers share it)
+    int ref_tid = -1;
+    hts_pos_t ref_len = 0;
+    MplpConf conf;
+};
+
+bool fetch_ref(Aux* a, int tid)
+{
+    if (!a->fai) return false;
+    if (tid == a->ref_tid) return a->ref != nullptr;
+    free(a->ref);
+    a->ref = nullptr;
+    a->ref_tid = tid;
+    hts_pos_t len = 0;
+    a->ref = faidx_fetch_seq64(a->fai, sam_hdr_tid2name(a->hdr, tid), 0, HTS_POS_MAX, &len);
+    a->ref_len = a->ref ? len : 0;
+    return a->ref != nullptr;
+}
+
+// the pileup engine's read source: same order of tests as mplp_func (SimplePileupViewer.cpp:172-237)
+int next_read(void* data, bam1_t* b)
+{
+    Aux* a = static_cast<Aux*>(data);
+    int ret;
+    for (;;) {
+        ret = a->iter ? sam_itr_next(a->fp, a->iter, b) : sam_read1(a->fp, a->hdr, b);
+        if (ret < 0) break;
+        if (b->core.tid < 0 || (b->core.flag & BAM_FUNMAP)) continue;
+        if (a->conf.rflag_filter & b->core.flag) continue;
+        const bool has_ref = fetch_ref(a, b->core.tid);
+        if (has_ref && a->ref_len <= b->core.pos) continue;            // read outside the reference sequence
+        if (has_ref && a->conf.realn) sam_prob_realn(b, a->ref, a->ref_len, 3);     // BAQ
+        if (has_ref && a->conf.capQ_thres > 10) {
+            const int q = sam_cap_mapq(b, a->ref, a->ref_len, a->conf.capQ_thres);
+            if (q < 0) continue;
+            if (b->core.qual > q) b->core.qual = (uint8_t)q;
+        }
+        if (b->core.qual < a->conf.min_mq) continue;
+        break;
+    }
+    return ret;
+}
+
+std::string sample_name(sam_hdr_t* hdr)     // @RG SM: (SimplePileupViewer.cpp:296-314; several samples are an error there)
+{
+    const char* text = sam_hdr_str(hdr);
+    std::string sm;
+    for (const char* p = text ? std::strstr(text, "@RG") : nullptr; p; p = std::strstr(p + 3, "@RG")) {
+        const char* eol = std::strchr(p, '\n');
+        const char* t = std::strstr(p, "\tSM:");
+        if (!t || (eol && t > eol)) continue;
+        t += 4;
+        const char* e = t;
+        while (*e && *e != '\t' && *e != '\n') ++e;
+        const std::string one(t, e);
+        if (sm.empty()) sm = one;
+        else if (sm != one) return std::string();       // more than one sample
+    }
+    return sm.empty() ? std::string("DefaultSampleName") : sm;
+}
+
+}  // namespace
+
+int read_bam(const std::string& bam_path, const std::string& ref_path, const Panel& panel, PileupViewer* v)
+{
+    Aux a;
+    a.fp = sam_open(bam_path.c_str(), "rb");
+    if (!a.fp) { set_error("failed to open " + bam_path); return VB2_ERR_IO; }
+    if (hts_set_fai_filename(a.fp, ref_path.c_str()) != 0) { set_error("failed to process " + ref_path); return VB2_ERR_IO; }
+    a.hdr = sam_hdr_read(a.fp);
+    if (!a.hdr) { set_error("fail to read the header of " + bam_path); return VB2_ERR_IO; }
+    hts_idx_t* idx = sam_index_load(a.fp, bam_path.c_str());
+    if (!idx) { set_error("fail to load index for " + bam_path); return VB2_ERR_IO; }
+    a.fai = fai_load(ref_path.c_str());
+    v->SEQ_SM = sample_name(a.hdr);
+    if (v->SEQ_SM.empty()) {
+        set_error("This BAM or CRAM file contains more than 1 sample, please demultiplex or separate first!");
+        return VB2_ERR_INVALID;
+    }
+    int global_index = 0;
+    v->numBases = 0;
+    std::string bases, quals;
+    // one region per panel marker, in .bed order (the reference jumps region by region too)
+    for (const auto& marker : panel.PosVec) {
+        const std::string& chr = marker.first;
+        const int pos1 = marker.second;                                   // 1-based
+        const int tid = sam_hdr_name2tid(a.hdr, chr.c_str());
+        if (tid < 0) continue;
+        auto& idx_chr = v->posIndex[chr];
+        if (idx_chr.find(pos1) != idx_chr.end()) continue;                // duplicated marker: skipped (cpp:424-427)
+        idx_chr[pos1] = global_index++;
+        bases.clear();
+        quals.clear();
+        a.iter = sam_itr_queryi(idx, tid, pos1 - 1, pos1);
+        if (a.iter) {
+            bam_plp_t plp = bam_plp_init(next_read, &a);
+            bam_plp_set_maxcnt(plp, a.conf.max_depth);
+            if (a.conf.smart_overlaps) bam_plp_init_overlaps(plp);
+            int ptid, ppos, n;
+            const bam_pileup1_t* pl;
+            while ((pl = bam_plp_auto(plp, &ptid, &ppos, &n)) != nullptr) {
+                if (ptid != tid || ppos != pos1 - 1) continue;
+                const bool has_ref = fetch_ref(&a, tid);
+                for (int j = 0; j < n; ++j) {
+                    const bam_pileup1_t* p = pl + j;
+                    const int q = p->qpos < p->b->core.l_qseq ? bam_get_qual(p->b)[p->qpos] : 0;
+                    if (q < a.conf.min_baseQ || p->is_del) continue;      // (deletions / ref skips carry no base)
+                    int c = p->qpos < p->b->core.l_qseq ? seq_nt16_str[bam_seqi(bam_get_seq(p->b), p->qpos)] : 'N';
+                    const bool rev = bam_is_rev(p->b);
+                    if (has_ref) {                                        // pileup_seq, SimplePileupViewer.cpp:32-40
+                        const int rb = ppos < a.ref_len ? a.ref[ppos] : 'N';
+                        if (c == '=' || seq_nt16_table[c] == seq_nt16_table[rb]) c = rev ? ',' : '.';
+                        else c = rev ? std::tolower(c) : std::toupper(c);
+                    } else {
+                        c = c == '=' ? (rev ? ',' : '.') : (rev ? std::tolower(c) : std::toupper(c));
+                    }
+                    bases.push_back((char)c);
+                    quals.push_back((char)(q + 33 < 126 ? q + 33 : 126));
+                }
+            }
+            bam_plp_destroy(plp);
+            hts_itr_destroy(a.iter);
+            a.iter = nullptr;
+        }
+        if (!bases.empty()) {
+            v->effectiveNumSite++;
+            v->numBases += (int)bases.size();
+        }
+        v->baseInfo.push_back(bases);
+        v->qualInfo.push_back(quals);
+    }
+    v->avgDepth = v->effectiveNumSite ? (double)v->numBases / v->effectiveNumSite : 0.0;
+    free(a.ref);
+    if (a.fai) fai_destroy(a.fai);
+    hts_idx_destroy(idx);
+    sam_hdr_destroy(a.hdr);
+    sam_close(a.fp);
+    return VB2_OK;
+}
+
+bool bam_support() { return true; }
+
+}  // namespace vb2
+
+#else   // ---- built without htslib ----
+
+namespace vb2 {
+
+int read_bam(const std::string&, const std::string&, const Panel&, PileupViewer*)
+{
+    set_error("--BamFile needs htslib, which this build does not have (configure with CMake where libhts is "
+              "installed); run the reference once with --OutputPileup and pass the result with --PileupFile");
+    return VB2_ERR_IO;
+}
+
+bool bam_support() { return false; }
+
+}  // namespace vb2
+
+#endif

@@ -6,8 +6,8 @@
 //               [--Epsilon e] [--DisableSanityCheck] [--OutputPileup] [--Verbose]
 //               [--NumThread n] [--Seed s]      (+ deprecated --UDPath/--MeanPath/--BedPath)
 //
-// --BamFile needs htslib (absent from this build: SURVEY.md section 8f rank 3); use
-// the reference's own --OutputPileup file with --PileupFile instead.
+// --BamFile needs a build with htslib (CMake finds it: bam_flatten.cpp); a build without it --
+// this image's -- reports that and suggests the reference's own --OutputPileup file with --PileupFile.
 // Extensions: --Device n selects the GPU; --Devices a,b,.. uses several -- one sample's markers
 // are sharded over them (partial log-likelihoods met in one RCCL all-reduce), a --PileupList
 // cohort is dealt to them group by group; --PileupList F runs many samples against one panel.
@@ -124,10 +124,7 @@ int main(int argc, char** argv)
         BedPath = SVDPrefix + ".bed";
     }
     if (RefPath == "Empty") fatal("--Reference is required");          // main.cpp:263-266
-    if (BamFile != "Empty")
-        fatal("--BamFile needs htslib, which this build does not have; run the reference once with "
-              "--OutputPileup and pass the result with --PileupFile");
-    if (PileupFile == "Empty" && PileupList == "Empty")
+    if (PileupFile == "Empty" && PileupList == "Empty" && BamFile == "Empty")
         fatal("--BamFile or --PileupFile is required");                // main.cpp:278-281
 
     vb2_run_args args;
@@ -135,7 +132,9 @@ int main(int argc, char** argv)
     args.ud_path = UDPath.c_str();
     args.mean_path = MeanPath.c_str();
     args.bed_path = BedPath.c_str();
-    args.pileup_path = PileupFile.c_str();
+    args.pileup_path = PileupFile == "Empty" ? nullptr : PileupFile.c_str();
+    args.bam_path = BamFile == "Empty" ? nullptr : BamFile.c_str();       // needs an htslib build (bam_flatten.cpp)
+    args.reference_path = RefPath.c_str();
     args.known_af_path = knownAF == "Empty" ? nullptr : knownAF.c_str();
     args.output_prefix = outputPrefix.c_str();
     args.num_pc = nPC;

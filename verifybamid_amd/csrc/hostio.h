@@ -49,6 +49,10 @@ int read_ud(const std::string& path, Panel* p);
 int read_mean(const std::string& path, Panel* p);
 int read_known_af(const std::string& path, Panel* p);
 int read_pileup(const std::string& path, const BedTable& bed, PileupViewer* v);
+// BAM/CRAM input through htslib (bam_flatten.cpp; VB2_ERR_IO with an explanation when the library was
+// built without htslib).  SimplePileupViewer.cpp:172-557 with main.cpp:81-96's defaults.
+int read_bam(const std::string& bam_path, const std::string& ref_path, const Panel& panel, PileupViewer* v);
+bool bam_support();
 bool sanity_check(const Panel& p, PileupViewer* v);
 
 }  // namespace vb2
