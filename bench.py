@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--cohort-samples", type=int, default=32, help="samples of the single-GPU cohort leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimize", action="store_true")
+    ap.add_argument("--soft-exit", action="store_true",
+                    help="leave through the interpreter's normal exit (profilers flush their output there) instead of os._exit")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip search_point / cohort / marker_sharded legs (profiling runs)")
     return ap.parse_args()
@@ -433,7 +435,8 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     sys.stdout.flush()
-    os._exit(0)
+    if not args.soft_exit:
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ python bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | head -c 400; echo
 for b in 1 4 8 16 32 48; do python bench.py --batch $b --no-cpu-baseline --no-optimize --no-extras 2>/dev/null | tail -1 >> $O/bench_batch_sweep.jsonl; done
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-optimize --no-extras"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-optimize --no-extras --soft-exit"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- $B > $O/trace.log 2>&1
 P="--steps 50 --warmup 20 --prewarm-ms 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o b -- $B $P > /dev/null 2>&1

@@ -57,14 +57,17 @@ json.dump(t, open(os.path.join(dst, "traffic_b%d.json" % B), "w"), indent=1)
 
 insts, active = avg("pmc_sq1", "SQ_INSTS_VALU"), avg("pmc_sq1", "SQ_ACTIVE_INST_VALU")
 lds_active, lds_conf = avg("pmc_sq1", "SQ_LDS_IDX_ACTIVE"), avg("pmc_sq1", "SQ_LDS_BANK_CONFLICT")
-cycles = avg("pmc_grbm", "GRBM_GUI_ACTIVE") if "pmc_grbm" in passes else None
+# rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs of the device: cycles of one launch = value / 8
+# (197 k cycles for a ~90 us profiled launch = 2.2 GHz, a plausible shader clock; the raw sum is not)
+cycles = avg("pmc_grbm", "GRBM_GUI_ACTIVE") / 8.0 if "pmc_grbm" in passes else None
 v = {"_what": "VALU / LDS pipe occupancy of llk_eval_kernel<2,true> per launch of %d points, from the SQ and GRBM "
               "passes of bench_b%d_pmc_summary.txt: lane instructions = SQ_INSTS_VALU x 64 / (markers x points); "
               "VALU busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE cycles of the "
-              "launch); LDS busy = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles)" % (B, B),
+              "launch, GRBM_GUI_ACTIVE being summed over the 8 XCDs -> / 8); LDS busy = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles). "
+              "Profiled launches run ~15 %% slower than un-profiled ones, so both fractions read low by about that much" % (B, B),
      "markers": markers, "batch": B, "num_pc": k,
      "SQ_INSTS_VALU": insts, "SQ_ACTIVE_INST_VALU": active, "SQ_LDS_IDX_ACTIVE": lds_active,
-     "SQ_LDS_BANK_CONFLICT": lds_conf, "GRBM_GUI_ACTIVE": cycles,
+     "SQ_LDS_BANK_CONFLICT": lds_conf, "cycles_per_launch_profiled": cycles,
      "lane_instr_per_marker_point": round(insts * 64 / (markers * B), 1),
      "valu_busy_frac": round(active * 4 / (1024 * cycles), 3) if cycles else None,
      "lds_busy_frac": round(lds_active / (256 * cycles), 3) if cycles else None}
