@@ -307,12 +307,28 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         }
     const int64_t m_active = (int64_t)active.size();
 
-    // ---- dictionary: observed (class, q) pairs, most frequent first ----
+    // ---- dictionary: observed (class, q) pairs.  Order: by quality (the more frequent first), the
+    // two classes of a quality next to each other.  A marker's runs are stored in dictionary order,
+    // so at a given step the 16 markers a ds_read_b128 pass serves sit on NEIGHBOURING table rows
+    // whether they are hom-ref, hom-alt or het -- rows whose 16-byte slots differ mod 16, i.e. no
+    // bank conflict (with all ref codes before all alt codes, a het marker's step j was ~20 rows
+    // away from a hom-alt marker's).  VB2_DICT_ORDER=freq restores plain frequency order (A/B).
     std::vector<int> order;
     for (int c2 = 0; c2 < kMaxCode; ++c2)
         if (code_hist[c2] > 0) order.push_back(c2);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int a, int b) { return code_hist[a] > code_hist[b]; });
+    {
+        static const bool by_freq = std::getenv("VB2_DICT_ORDER") && !std::strcmp(std::getenv("VB2_DICT_ORDER"), "freq");
+        std::vector<int64_t> qfreq(kNumQual, 0);
+        for (int c2 : order) qfreq[c2 % kNumQual] += code_hist[c2];
+        if (by_freq)
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return code_hist[a] > code_hist[b]; });
+        else
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                const int qa = a % kNumQual, qb = b % kNumQual;
+                if (qa != qb) return qfreq[qa] != qfreq[qb] ? qfreq[qa] > qfreq[qb] : qa < qb;
+                return a < b;                                  // ref before alt
+            });
+    }
     const int num_code = (int)order.size();
     std::vector<uint8_t> dict_of(kMaxCode, (uint8_t)kPadCode);
     std::vector<double> dict_perr(num_code);
