@@ -420,6 +420,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // work items: (tile, group), or (TPW consecutive owned tiles, group)
     const uint32_t nunit = (ntile_blk + TPW - 1) / TPW;
     const uint32_t nitem = nunit * (uint32_t)ngrp;
+    const float inv_nunit = 1.0f / (float)(nunit ? nunit : 1u);
     // Decided on ceil(tiles / workgroups), the same for every workgroup and exactly what
     // eval_shmem_np sized the result slots for (a workgroup with one tile fewer must not choose
     // differently: the queue needs a slot per item, the static deal only one per wave).
@@ -492,7 +493,13 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     }
     uint32_t round = 0;
     for (uint32_t idx = have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem) : (uint32_t)wave; idx < nitem;) {
-        const uint32_t grp = idx / nunit;
+        // grp = idx / nunit without the ~25-instruction integer division: float estimate (exact for
+        // these magnitudes up to one) and a correction step
+        uint32_t grp = ngrp == 1 ? 0u : (uint32_t)(((float)idx + 0.5f) * inv_nunit);
+        if (ngrp != 1) {
+            if (grp * nunit > idx) --grp;
+            else if ((grp + 1) * nunit <= idx) ++grp;
+        }
         const uint32_t unit = idx - grp * nunit;
         const uint32_t it = TPW * unit + (uint32_t)half;     // index in this workgroup's tile list
         const bool have_tile = TPW == 1 || it < ntile_blk;   // TPW > 1: the list's end may leave lanes idle
@@ -640,19 +647,26 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             idx = round * (uint32_t)nwave + ((round & 1u) ? (uint32_t)(nwave - 1 - wave) : (uint32_t)wave);
             continue;
         }
-        ScaledProd lane_prod[BTL];
-#pragma unroll
-        for (int t = 0; t < BTL; ++t) lane_prod[t] = ScaledProd{lk_m[t], (double)lk_e[t]};
         // every MICRO-TILE's product goes to its own slot (not the item's): the slots and the
         // order they are multiplied in are then the same for every wave shape, so a point's value
-        // does not depend on whether it was evaluated alone, among four, or in a group of eight
-        tile_product(lane_prod, false);
+        // does not depend on whether it was evaluated alone, among four, or in a group of eight.
+        // Butterfly over the 16 lanes that share slot g: mantissas multiply (16 factors in
+        // [0.5, 1): no underflow), exponents add as integers (three dwords per exchange, not four)
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const int partner = lane_of<HWMAP>(m ^ off, g4);
+#pragma unroll
+            for (int t = 0; t < BTL; ++t) {
+                lk_m[t] *= __shfl(lk_m[t], partner, 64);
+                lk_e[t] += __shfl(lk_e[t], partner, 64);
+            }
+        }
         if (m == 0 && have_tile) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
                 const size_t o = (((size_t)grp * ntile_blk + it) * NP + g * BTL + t) * 2;
-                tile_llk[o] = lane_prod[t].m;
-                tile_llk[o + 1] = lane_prod[t].e;
+                tile_llk[o] = lk_m[t];
+                tile_llk[o + 1] = (double)lk_e[t];
             }
         }
         // next work item of this workgroup, whichever wave gets there first
