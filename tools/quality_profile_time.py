@@ -6,7 +6,7 @@ import numpy as np, torch
 import verifybamid_amd as vb
 rng = np.random.default_rng(1)
 B = 48
-for (lo, hi, label) in ((20, 40, "21 values (uniform 20..40, the bench workload)"), (30, 37, "8 values"),
+for (lo, hi, label) in ((2, 60, "59 values (BAQ-like wide alphabet, narrow table rows)"), (20, 40, "21 values (uniform 20..40, the bench workload)"), (30, 37, "8 values"),
                         (34, 37, "4 values (binned-quality instruments)"), (37, 37, "1 value")):
     d = vb.synth.make_pileup(100000, 30, 4, 0.05, 2, q_lo=lo, q_hi=hi)
     stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
