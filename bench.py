@@ -374,6 +374,20 @@ def main():
                 for _ in range(n3):
                     batch.eval(npt, p1, p2, al)
                 dt4 = (time.perf_counter() - t1) / n3
+                npt1 = np.full(S, 1, dtype=np.int32)
+                for _ in range(20):
+                    batch.eval(npt1, p1, p2, al)
+                t1 = time.perf_counter()
+                for _ in range(n3):
+                    batch.eval(npt1, p1, p2, al)
+                dt1 = (time.perf_counter() - t1) / n3
+                npt2 = np.full(S, 2, dtype=np.int32)
+                for _ in range(20):
+                    batch.eval(npt2, p1, p2, al)
+                t1 = time.perf_counter()
+                for _ in range(n3):
+                    batch.eval(npt2, p1, p2, al)
+                dt2 = (time.perf_counter() - t1) / n3
                 batch.optimize()
                 t1 = time.perf_counter()
                 ests = batch.optimize()
@@ -384,6 +398,8 @@ def main():
                 "what": "%d samples of the workload's shape on ONE GPU, searched in lock-step (vb2_batch_*: one launch "
                         "per Nelder-Mead step for all samples)" % S,
                 "samples": S, "step_us_4_points_per_sample": 1e6 * dt4, "evals_per_s": 4 * S / dt4,
+                "step_us_2_points_per_sample": 1e6 * dt2, "step_us_1_point_per_sample": 1e6 * dt1,
+                "num_eval_first": ests[0]["num_eval"], "points_launched_first": ests[0]["num_launch_point"],
                 "optimize_ms_per_sample": 1e3 * dto / S, "samples_per_s_search_only": S / dto,
                 "alpha_first": ests[0]["alpha"],
             }
@@ -392,7 +408,7 @@ def main():
         from oracle.bridge import oracle_data
         od = oracle_data(data)
         want = np.array([od.llk(pts_h[i, :k], pts_h[i, k:2 * k], pts_h[i, 2 * k],
-                                num_thread=os.cpu_count() or 1) for i in range(min(B, 2))])
+                                num_thread=min(os.cpu_count() or 1, 16)) for i in range(min(B, 2))])
         result["parity_probe_max_rel_err"] = float(np.max(np.abs(llk_dev[:len(want)] - want) / np.abs(want)))
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample (~10 s wall): the C oracle on the SAME pileup, OpenMP over
@@ -403,7 +419,16 @@ def main():
                 navail = len(os.sched_getaffinity(0))
             except AttributeError:
                 navail = os.cpu_count() or 1
-            sweep = sorted({1, 4} | {t for t in (8, 16, 32, 64, 128, 256) if t <= navail})
+            quota = None                 # a container's CFS quota: the host's cores are visible, the time is not
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    quota = max(1, round(int(q) / int(per)))
+            except (OSError, ValueError):
+                pass
+            # (thread counts beyond twice the quota only measure the throttling)
+            top = min(navail, 2 * quota) if quota else navail
+            sweep = sorted({1, 4} | {t for t in (8, 16, 32, 64, 128, 256) if t <= top})
             rates = {}
             for nt in sweep:
                 n_cpu, tc = 0, time.perf_counter()
@@ -417,8 +442,9 @@ def main():
                 "value": rates[best], "unit": "evals/s", "cores": best, "kind": "port",
                 "sample": "C oracle (oracle/vb2_oracle.c, OpenMP over markers like the reference) on the "
                           "same %d-marker pileup, ~%.1f s per thread count; evals/s by threads: %s; "
-                          "%d cores available" % (args.markers, 10.0 / len(sweep),
-                                                  {t: round(r, 1) for t, r in rates.items()}, navail),
+                          "%d hardware threads visible, CPU quota of the container: %s"
+                          % (args.markers, 10.0 / len(sweep), {t: round(r, 1) for t, r in rates.items()}, navail,
+                             "%d CPUs" % quota if quota else "none"),
             }
     if ctx is not None:
         ctx.close()

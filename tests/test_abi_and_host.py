@@ -125,6 +125,28 @@ def test_cpp_optimiser_trace_equals_oracle(golden_dir, pileup, kw):
     assert np.array_equal(got["pc"], want["pc"]) and np.array_equal(got["pc2"], want["pc2"])
 
 
+@pytest.mark.parametrize("level", [1, 2, 4])
+def test_speculation_level_does_not_change_the_trajectory(golden_dir, level, monkeypatch):
+    """amoeba.h: 4 = {R, E, C_A, C_R} per iteration, 2 = {R, C_R}, 1 = one point at a time.  The
+    committed evaluations (the trace) are the reference's in every case; only the number of points
+    launched differs."""
+    flat, _, _ = refio.load_flat(os.path.join(golden_dir, HAPMAP), os.path.join(golden_dir, "expected/result.Pileup"), 2)
+    od = binding.OracleData(flat)
+    want = od.optimize(trace_capacity=4096)
+    monkeypatch.setenv("VB2_SPECULATE", str(level))
+    got = vb.optimize_with_evaluator(_oracle_evaluator(od), 2, trace_capacity=4096)
+    assert got["num_eval"] == want["num_eval"]
+    for key in ("alpha", "pc1", "pc2", "llk"):
+        assert np.array_equal(got["trace"][key], want["trace"][key]), key
+    assert got["alpha"] == want["alpha"] and got["llk1"] == want["llk1"]
+    if level == 1:
+        assert got["num_launch_point"] == got["num_eval"]
+    elif level == 2:
+        assert got["num_eval"] < got["num_launch_point"] < 2 * got["num_eval"]
+    else:
+        assert got["num_launch_point"] > 2 * got["num_eval"]
+
+
 def test_cpp_optimiser_other_dimensions():
     """k = 1 (the reference's hard-coded index-1 swap must not run) and k = 4."""
     for k, seed in ((1, 11), (4, 12)):

@@ -109,7 +109,7 @@ double AmoebaMinimizer::Minimize(double ftol)
         double* CR = &cand[(size_t)3 * n];
         const double* hi = &simplex_[(size_t)ihi * n];
         TryPoint(psum_.data(), hi, -1.0, R);
-        if (speculate) {
+        if (speculate >= 4) {
             // State the simplex would be in if the reflection is accepted.
             for (int i = 0; i < n; ++i) psum_acc[i] = psum_[i] - hi[i];
             for (int i = 0; i < n; ++i) psum_acc[i] += R[i];
@@ -117,6 +117,11 @@ double AmoebaMinimizer::Minimize(double ftol)
             TryPoint(psum_acc.data(), R, 0.5, CA);       // contraction after acceptance
             TryPoint(psum_.data(), hi, 0.5, CR);         // contraction, reflection rejected
             if ((error = func->EvaluateBatch(4, cand.data(), n, ycand.data()))) return fmin;
+        } else if (speculate >= 2) {
+            TryPoint(psum_.data(), hi, 0.5, E);          // (second row of the batch: C_R)
+            if ((error = func->EvaluateBatch(2, cand.data(), n, ycand.data()))) return fmin;
+            std::memcpy(CR, E, sizeof(double) * n);
+            ycand[3] = ycand[1];
         } else {
             if ((error = func->EvaluateBatch(1, R, n, ycand.data()))) return fmin;
         }
@@ -127,7 +132,7 @@ double AmoebaMinimizer::Minimize(double ftol)
         if (ytry <= y_[ilo]) {                           // cpp:392-394
             double yexp;
             const double* pe;
-            if (speculate && accepted) {
+            if (speculate >= 4 && accepted) {
                 pe = E;
                 yexp = ycand[1];
             } else {
@@ -140,7 +145,7 @@ double AmoebaMinimizer::Minimize(double ftol)
         } else if (ytry >= y_[inhi]) {                   // cpp:395-419
             const double ysave = y_[ihi];
             const double* pc;
-            if (speculate) {
+            if (speculate >= 4 || (speculate >= 2 && !accepted)) {
                 pc = accepted ? CA : CR;
                 ytry = accepted ? ycand[2] : ycand[3];
             } else {

@@ -32,7 +32,15 @@ public:
     std::vector<double> point;          // GeneralMinimizer::point  (MathGenMin.h:18)
     double fmin = 1.0e+100;             // FPMAX                    (MathGenMin.cpp:14)
     long cycleCount = 0, cycleMax = 50000;   // MathGenMin.cpp:314
-    bool speculate = true;              // evaluate an iteration's possible points in one batch
+    // Points evaluated per iteration before its outcome is known (the decisions, hence the
+    // trajectory, are the same for every setting; Commit sees only what the reference evaluates):
+    //   4: {R, E, C_A, C_R} -- every point the iteration can need, one batch per iteration
+    //      (latency-bound callers: one sample on a whole GPU);
+    //   2: {R, C_R} -- the reflection and the contraction that follows a rejected reflection, by far
+    //      the most frequent second evaluation (on the C3-shaped searches: 45 % of the iterations
+    //      end in C_R, 33 % need no second point, 22 % need E or C_A and cost a second batch);
+    //   1: R alone, then whatever the reference evaluates next (throughput-bound callers).
+    int speculate = 4;
     int error = 0;                      // first non-zero EvaluateBatch status
 
     void Reset(int ndim, double scale = 1.0);   // MathGenMin.cpp:316-324, 17-25

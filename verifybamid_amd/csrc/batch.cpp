@@ -2,9 +2,11 @@
 #include "batch.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -24,6 +26,7 @@ namespace vb2 {
 
 namespace {
 constexpr int kSlot = 8;                     // point slots per sample and step (VB2_BATCH_SLOTS)
+constexpr int kShapes = Batch::kShapes;
 }
 
 Batch::~Batch()
@@ -82,11 +85,13 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
     const int k = b->num_pc;
     const int min_bw = std::max(4, (kSlot * (2 * k + 1) + 127) / 128);
     b->block_waves_ = std::max(min_bw, std::min(kMaxBlockWaves, tiles_per_block));
-    for (int btl = 1; btl <= 2; ++btl) {
+    // launch shapes of a step: 0 = up to 4 points per sample, 1 = 8 points, 2 = one point, 3 = two
+    static const int kShapeNp[kShapes] = {4, 8, 1, 2};
+    for (int sh = 0; sh < kShapes; ++sh) {
         size_t need = 0;
         for (int s = 0; s < num_sample; ++s)
-            need = std::max(need, eval_shmem_bytes(layouts[s], btl, bps, b->block_waves_));
-        b->shmem_[btl - 1] = need;
+            need = std::max(need, eval_shmem_np(layouts[s], kShapeNp[sh], bps, b->block_waves_, 1));
+        b->shmem_[sh] = need;
     }
     if (b->shmem_[1] > (size_t)kLdsLimitBytes) {
         set_error("vb2_batch_create: per-workgroup LDS need exceeds 160 KiB");
@@ -96,47 +101,44 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
     const size_t S = (size_t)num_sample, stride = 2 * (size_t)k + 1;
     VB2_HIP(hipMalloc((void**)&b->d_layouts_, sizeof(DeviceLayout) * S));
     VB2_HIP(hipMemcpy(b->d_layouts_, layouts.data(), sizeof(DeviceLayout) * S, hipMemcpyHostToDevice));
-    // static schedules (llk_kernels.h) of every sample for the two wave shapes of a step:
-    // btl 1 = <= 4 points per sample (two tiles per wave when paired), btl 2 = 8 points
+    // static schedules (llk_kernels.h) of every sample for the wave shapes of a step: two micro-tiles
+    // per wave for <= 4 points (when paired), one for 8 points, four for one or two points
     if (b->ctx_[0]->sched_enabled) {
+        const int tpu[kShapes] = {paired_mode() ? 2 : 1, 1, paired_mode() ? 4 : 1, paired_mode() ? 4 : 1};
         std::vector<char> blob;
-        std::vector<size_t> where[2];
+        std::vector<size_t> where[kShapes];
         bool ok = true;
-        for (int btl = 1; btl <= 2 && ok; ++btl)
+        for (int sh = 0; sh < kShapes && ok; ++sh)
             for (int s = 0; s < num_sample && ok; ++s) {
                 std::vector<uint32_t> off;
                 std::vector<uint16_t> item;
                 Context* c = b->ctx_[s];
-                if (c->L.num_mt == 0) { where[btl - 1].push_back((size_t)-1); continue; }
-                ok = build_schedule(c->h_mt_rows.data(), c->L.num_mt, bps, b->block_waves_,
-                                    btl == 1 && paired_mode() ? 2 : 1, 1, &off, &item);
+                if (c->L.num_mt == 0) { where[sh].push_back((size_t)-1); continue; }
+                ok = build_schedule(c->h_mt_rows.data(), c->L.num_mt, bps, b->block_waves_, tpu[sh], 1, &off, &item);
                 if (!ok) break;
                 blob.resize((blob.size() + 15) / 16 * 16);
-                where[btl - 1].push_back(blob.size());
+                where[sh].push_back(blob.size());
                 const size_t ob = (off.size() * sizeof(uint32_t) + 15) / 16 * 16;
                 blob.resize(blob.size() + ob + item.size() * sizeof(uint16_t));
-                std::memcpy(blob.data() + where[btl - 1].back(), off.data(), off.size() * sizeof(uint32_t));
-                std::memcpy(blob.data() + where[btl - 1].back() + ob, item.data(), item.size() * sizeof(uint16_t));
+                std::memcpy(blob.data() + where[sh].back(), off.data(), off.size() * sizeof(uint32_t));
+                std::memcpy(blob.data() + where[sh].back() + ob, item.data(), item.size() * sizeof(uint16_t));
             }
         if (ok) {
             blob.resize((blob.size() + 15) / 16 * 16);
             const size_t arr0 = blob.size();
-            VB2_HIP(hipMalloc((void**)&b->d_sched_, arr0 + 2 * S * sizeof(Schedule)));
-            std::vector<Schedule> arr(2 * S, Schedule{nullptr, nullptr});
-            for (int btl = 1; btl <= 2; ++btl)
+            VB2_HIP(hipMalloc((void**)&b->d_sched_, arr0 + kShapes * S * sizeof(Schedule)));
+            std::vector<Schedule> arr(kShapes * S, Schedule{nullptr, nullptr});
+            const size_t ob = (((size_t)bps * b->block_waves_ + 1) * sizeof(uint32_t) + 15) / 16 * 16;
+            for (int sh = 0; sh < kShapes; ++sh)
                 for (size_t s = 0; s < S; ++s) {
-                    const size_t w = where[btl - 1][s];
+                    const size_t w = where[sh][s];
                     if (w == (size_t)-1) continue;
-                    const Context* c = b->ctx_[s];
-                    (void)c;
                     const uint32_t* o = reinterpret_cast<const uint32_t*>(b->d_sched_ + w);
-                    const size_t ob = (((size_t)bps * b->block_waves_ + 1) * sizeof(uint32_t) + 15) / 16 * 16;
-                    arr[(btl - 1) * S + s] = Schedule{o, reinterpret_cast<const uint16_t*>(b->d_sched_ + w + ob)};
+                    arr[sh * S + s] = Schedule{o, reinterpret_cast<const uint16_t*>(b->d_sched_ + w + ob)};
                 }
             VB2_HIP(hipMemcpy(b->d_sched_, blob.data(), arr0, hipMemcpyHostToDevice));
-            VB2_HIP(hipMemcpy(b->d_sched_ + arr0, arr.data(), 2 * S * sizeof(Schedule), hipMemcpyHostToDevice));
-            b->d_scheds_[0] = reinterpret_cast<const Schedule*>(b->d_sched_ + arr0);
-            b->d_scheds_[1] = b->d_scheds_[0] + S;
+            VB2_HIP(hipMemcpy(b->d_sched_ + arr0, arr.data(), kShapes * S * sizeof(Schedule), hipMemcpyHostToDevice));
+            for (int sh = 0; sh < kShapes; ++sh) b->d_scheds_[sh] = reinterpret_cast<const Schedule*>(b->d_sched_ + arr0) + sh * S;
         }
     }
     VB2_HIP(hipMalloc((void**)&b->d_partials_, sizeof(double) * S * (kSlot + 1) * bps));
@@ -196,7 +198,11 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
         }
         return VB2_OK;
     }
-    const int btl = max_n > 4 ? 2 : 1, NP = 4 * btl;
+    // one or two points per sample (a search that speculates little or not at all): the wave takes
+    // four micro-tiles, and the step costs a quarter / half of a 4-point step whose other slots
+    // would replicate the last point
+    const bool small = max_n <= 2 && paired_mode();
+    const int NP = max_n > 4 ? 8 : small ? max_n : 4, shape = max_n > 4 ? 1 : small ? (max_n == 1 ? 2 : 3) : 0;
     for (int s = 0; s < num_sample; ++s) {
         int n = num_point[s];
         // a sample without active markers has LLK 0 for every point: answer it here
@@ -216,7 +222,7 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
     if (active == 0) return VB2_OK;
     MultiLaunch ml{};
     ml.d_layouts = d_layouts_;
-    ml.d_scheds = d_scheds_[btl - 1];
+    ml.d_scheds = d_scheds_[shape];
     ml.d_points = d_points_;
     ml.d_num_valid = d_nv_;
     ml.d_partials = d_partials_;
@@ -229,8 +235,8 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
     ml.num_sample = num_sample;
     ml.bps = bps_;
     ml.block_waves = block_waves_;
-    ml.btl = btl;
-    ml.shmem = shmem_[btl - 1];
+    ml.np = NP;
+    ml.shmem = shmem_[shape];
     // (a NaN is the tagged hand-off's "a workgroup never reported" marker: redo the step once with
     // the arrival-ticket hand-off, see Context::eval_host -- NaN must not reach the optimisers)
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -262,51 +268,98 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
 // ---------------------------------------------------------------------------
 namespace {
 
+// Waiting threads spin on the generation word before they sleep: a step of the cohort takes
+// 0.1-0.3 ms on the device, and futex wake-ups of ~30 sleepers cost about as much again once
+// the host is busy reading the next group's pileups.  Only where the process really has the CPUs
+// (usable_cpu_count: a cgroup quota counts): under a 16-CPU quota, 31 spinning threads get the whole
+// cgroup throttled and a group's search goes from 130 ms to 300-400 ms (measured).  There the
+// waiters sleep at once.  VB2_RV_SPIN_US overrides.
 struct Rendezvous {
     Batch* batch;
     int S, k;
-    std::mutex mu;
+    std::mutex mu;                      // arrival bookkeeping (held for a few instructions only)
+    std::mutex sleep_mu;
     std::condition_variable cv;
     int active, arrived = 0;
-    unsigned long long generation = 0;
-    int error = 0;
+    std::atomic<unsigned long long> generation{0};
+    std::atomic<int> sleepers{0};
+    std::atomic<int> error{0};
+    long spin_ns;
     std::vector<int32_t> npts;
     std::vector<double> pc1, pc2, alpha, out;
 
     Rendezvous(Batch* b, int s, int kk)
         : batch(b), S(s), k(kk), active(s), npts(s, 0), pc1((size_t)s * kSlot * kk), pc2((size_t)s * kSlot * kk),
-          alpha((size_t)s * kSlot), out((size_t)s * kSlot) {}
+          alpha((size_t)s * kSlot), out((size_t)s * kSlot)
+    {
+        spin_ns = usable_cpu_count() >= 4 * s ? 300000 : 0;
+        if (const char* e = std::getenv("VB2_RV_SPIN_US")) spin_ns = 1000L * std::atol(e);
+    }
 
-    void run_locked()
+    // every active sample has submitted (or left): nobody else touches the arrays until the
+    // generation moves on
+    void run_step()
     {
         const int rc = batch->eval(npts.data(), pc1.data(), pc2.data(), alpha.data(), out.data());
-        if (rc && !error) error = rc;
+        if (rc) {
+            int zero = 0;
+            error.compare_exchange_strong(zero, rc);
+        }
         std::fill(npts.begin(), npts.end(), 0);
-        arrived = 0;
-        ++generation;
-        cv.notify_all();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            arrived = 0;
+        }
+        generation.fetch_add(1, std::memory_order_release);
+        if (sleepers.load(std::memory_order_acquire) > 0) {
+            { std::lock_guard<std::mutex> lk(sleep_mu); }
+            cv.notify_all();
+        }
+    }
+
+    void wait_generation(unsigned long long gen)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (generation.load(std::memory_order_acquire) != gen) return;
+            __builtin_ia32_pause();
+            if ((spins & 0xff) == 0xff &&
+                std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > spin_ns)
+                break;
+        }
+        std::unique_lock<std::mutex> lk(sleep_mu);
+        sleepers.fetch_add(1, std::memory_order_acq_rel);
+        cv.wait(lk, [&] { return generation.load(std::memory_order_acquire) != gen; });
+        sleepers.fetch_sub(1, std::memory_order_acq_rel);
     }
 
     int submit(int s, int n, const double* p1, const double* p2, const double* a, double* o)
     {
-        std::unique_lock<std::mutex> lk(mu);
         std::memcpy(&pc1[(size_t)s * kSlot * k], p1, sizeof(double) * n * k);
         std::memcpy(&pc2[(size_t)s * kSlot * k], p2, sizeof(double) * n * k);
         std::memcpy(&alpha[(size_t)s * kSlot], a, sizeof(double) * n);
         npts[s] = n;
-        ++arrived;
-        const unsigned long long gen = generation;
-        if (arrived == active) run_locked();
-        else cv.wait(lk, [&] { return generation != gen; });
+        const unsigned long long gen = generation.load(std::memory_order_acquire);
+        bool run;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            run = ++arrived == active;
+        }
+        if (run) run_step();
+        else wait_generation(gen);
         std::memcpy(o, &out[(size_t)s * kSlot], sizeof(double) * n);
-        return error;
+        return error.load(std::memory_order_acquire);
     }
 
     void leave()
     {
-        std::unique_lock<std::mutex> lk(mu);
-        --active;
-        if (active > 0 && arrived == active) run_locked();
+        bool run;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            --active;
+            run = active > 0 && arrived == active;
+        }
+        if (run) run_step();
     }
 };
 
@@ -335,6 +388,16 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
         set_error("vb2_batch_optimize_llk: pass 1 model or one per sample");
         return VB2_ERR_INVALID;
     }
+    // Speculation (amoeba.h) trades device work for fewer dependent steps.  A small cohort's step is
+    // latency-bound and {R, E, C_A, C_R} per iteration pays (2.5 points evaluated per point the
+    // search needs).  A big cohort's step is throughput-bound -- its cost grows with the points in
+    // it, down to the floor of streaming every sample's pileup from HBM once per step (5.7 TB/s
+    // measured: a 1-point step of 32 C3 samples takes 131 us against 236 us with 4 points) -- and
+    // {R, C_R} is the better trade: 1.2 steps per iteration at about half the points.  Same
+    // decisions, same trajectory either way.  VB2_COHORT_SPECULATE=1|2|4 forces one.
+    constexpr int kPairFrom = 8;
+    speculate_ = num_sample < kPairFrom ? 4 : 2;
+    if (const char* e = std::getenv("VB2_COHORT_SPECULATE")) speculate_ = std::max(1, std::atoi(e));
     Rendezvous rv(this, num_sample, num_pc);
     std::vector<SampleCb> cbs(num_sample);
     std::vector<int> rcs(num_sample, 0);
@@ -346,6 +409,7 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
             const vb2_model& m = models[num_model == 1 ? 0 : s];
             Estimator est(num_pc, sample_eval, &cbs[s]);
             apply_model(est, m);
+            est.speculate = speculate_;
             if (ctx_[s]->L.known_af) {       // context built with --KnownAF data
                 est.isAFknown = true;
                 est.isPCFixed = true;
@@ -357,7 +421,7 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
         });
     }
     for (auto& t : threads) t.join();
-    if (rv.error) return rv.error;
+    if (rv.error.load()) return rv.error.load();
     for (int s = 0; s < num_sample; ++s)
         if (rcs[s]) return rcs[s];
     return VB2_OK;

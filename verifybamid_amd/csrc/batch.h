@@ -21,6 +21,7 @@ public:
     // OptimizeLLK for every sample, searches advancing in lock-step; models: 1 or S entries
     int optimize(const vb2_model* models, int num_model, vb2_estimate* out);
 
+    static constexpr int kShapes = 4;       // launch shapes of a step: <= 4, 8, 1, 2 points per sample
     int num_sample = 0, num_pc = 0, device = -1;
     int64_t num_launch = 0;
 
@@ -28,8 +29,8 @@ private:
     std::vector<Context*> ctx_;
     hipStream_t stream_ = nullptr;
     DeviceLayout* d_layouts_ = nullptr;
-    char* d_sched_ = nullptr;               // the samples' static schedules + the two Schedule[num_sample] arrays
-    const Schedule* d_scheds_[2] = {nullptr, nullptr};    // [btl - 1]
+    char* d_sched_ = nullptr;               // the samples' static schedules + the three Schedule[num_sample] arrays
+    const Schedule* d_scheds_[kShapes] = {nullptr, nullptr, nullptr, nullptr};    // [shape]
     double* d_partials_ = nullptr;
     unsigned int* d_tickets_ = nullptr;
     unsigned int* d_batch_done_ = nullptr;
@@ -40,7 +41,8 @@ private:
     unsigned long long seq_ = 0;
     int bps_ = 1, block_waves_ = 16;
     bool wide_rows_ = true;                 // every sample has kRowBytesWide table rows (8-point launches allowed)
-    size_t shmem_[2] = {0, 0};
+    size_t shmem_[kShapes] = {0, 0, 0, 0};  // [shape]
+    int speculate_ = 4;                     // points a lock-step search evaluates per iteration (amoeba.h)
 };
 
 }  // namespace vb2

@@ -52,12 +52,13 @@ public:
         else devices_.push_back(a->base.device);
         ndev_ = (int)devices_.size();
         G_ = std::max(1, std::min(a->group_size > 0 ? a->group_size : 32, 64));
-        const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+        const int hw = vb2::usable_cpu_count();
         // readers: text parsing + run packing is ~0.1 s of one core per C3-sized sample, the device
-        // needs ~4 ms per sample -> a device keeps ~25 readers busy; the default takes half the
-        // host's cores (the lock-step search has one mostly sleeping host thread per sample)
-        const int dflt = std::max(4, std::min(hw / 2, 64 * ndev_));
-        T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, hw, S_}));
+        // needs ~4 ms per sample -> a device keeps ~25 readers busy.  The default leaves two CPUs of
+        // the process's allowance (cgroup quota / affinity, not the host's core count) to the
+        // lock-step search and the releaser; more runnable threads than CPUs only get the cgroup throttled
+        const int dflt = std::max(2, std::min(hw - 2, 64 * ndev_));
+        T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, std::max(hw, 1) * 4, S_}));
         slots_.resize(S_);
         cnt_.assign(ndev_, 0);
         ngroup_ = (S_ + G_ - 1) / G_;
@@ -100,6 +101,10 @@ public:
         for (auto& t : dev_threads_) t.join();
         dev_threads_.clear();
         shutdown();
+        if (std::getenv("VB2_DEBUG_TIMING"))
+            std::fprintf(stderr, "vb2_cohort_run: %d reader threads, per sample: read_pileup %.1f ms, sanity + resolve %.1f ms, "
+                                 "vb2_ctx_create %.1f ms (wall-clock inside the reader threads)\n", T_,
+                         1e3 * phase_s_[0] / S_, 1e3 * phase_s_[1] / S_, 1e3 * phase_s_[2] / S_);
         return rc_all_;
     }
 
@@ -126,6 +131,8 @@ private:
     std::deque<std::pair<vb2_ctx*, std::unique_ptr<vb2_flat>>> rel_queue_;
     bool rel_stop_ = false;
     bool down_ = false;
+
+    double phase_s_[3] = {0, 0, 0};        // reader threads' wall-clock: read_pileup, sanity + resolve, vb2_ctx_create
 
     int device_of_group(int gi) const { return gi % ndev_; }
 
@@ -166,11 +173,13 @@ private:
         vb2_flat& f = *sl.flat;
         sl.rc = vb2::read_pileup(a_->pileup_paths[s], panel_->ChooseBed, &f.viewer);
         if (sl.rc) return;
+        const double t_read = now_s();
         const bool sanity_off = a_->base.disable_sanity != 0;
         f.sanity_disabled = sanity_off;
         const bool sane = sanity_off || vb2::sanity_check(*panel_, &f.viewer);
         f.resolve();
         vb2_flat_stats(&f, &out_[s]);
+        const double t_res = now_s();
         const char* prefix = a_->output_prefixes ? a_->output_prefixes[s] : nullptr;
         if (a_->base.output_pileup && prefix) (void)vb2::write_pileup(prefix, f);
         if (!sane) {
@@ -180,7 +189,14 @@ private:
         vb2_options opt{};
         opt.device = devices_[device_of_group(s / G_)];
         sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
-        out_[s].seconds_load = now_s() - t0;
+        const double t_end = now_s();
+        out_[s].seconds_load = t_end - t0;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            phase_s_[0] += t_read - t0;
+            phase_s_[1] += t_res - t_read;
+            phase_s_[2] += t_end - t_res;
+        }
     }
 
     void reader_loop()

@@ -10,10 +10,13 @@
 // per-evaluation path: see DESIGN.md "What is computed once".
 #include "context.h"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -107,6 +110,34 @@ static void init_process_knobs()
         }
         if (const char* lm = std::getenv("VB2_LANE_MAP")) set_lane_mapping(std::strcmp(lm, "plain") != 0);
     });
+}
+
+int usable_cpu_count()
+{
+    static const int cached = [] {
+        long n = (long)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<long>(n, std::max(1, CPU_COUNT(&set)));
+        long quota = -1, period = -1;
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                 // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            if (std::fscanf(f, "%31s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atol(q);
+            std::fclose(f);
+        } else {
+            if (FILE* fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+                if (std::fscanf(fq, "%ld", &quota) != 1) quota = -1;
+                std::fclose(fq);
+            }
+            if (FILE* fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(fp, "%ld", &period) != 1) period = -1;
+                std::fclose(fp);
+            }
+        }
+        if (quota > 0 && period > 0) n = std::min(n, std::max(1L, (quota + period / 2) / period));
+        if (const char* e = std::getenv("VB2_CPUS")) n = std::max(1, std::atoi(e));
+        return (int)n;
+    }();
+    return cached;
 }
 
 int usable_device_count()
@@ -246,7 +277,7 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         }
     // The flattening is embarrassingly parallel over markers: a few host threads for big inputs.
     const int64_t total_reads = M > 0 ? in->read_off[M] - in->read_off[0] : 0;
-    int nthr = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    int nthr = std::min(usable_cpu_count(), 16);
     nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, total_reads / 200000));
     if (const int cap = g_flatten_thread_cap.load()) nthr = std::min(nthr, cap);     // cohort runner: many creates at once
     if (const char* ft = std::getenv("VB2_FLATTEN_THREADS")) nthr = std::max(1, std::atoi(ft));

@@ -19,6 +19,10 @@ namespace vb2 {
 void set_error(const std::string& msg);
 extern thread_local std::string g_last_error;
 int usable_device_count();
+// CPUs this process may actually use: min(hardware threads, affinity mask, cgroup CPU quota).  A
+// container with a CFS quota still sees every core of the host; threads beyond the quota only
+// get the whole cgroup throttled (measured on the 256-thread GPU host with a 16-CPU quota).
+int usable_cpu_count();
 extern std::atomic<int> g_flatten_thread_cap;   // 0 = no cap on the flatten threads of vb2_ctx_create
 
 constexpr int kStagePoints = 256;   // points per host<->device staging round

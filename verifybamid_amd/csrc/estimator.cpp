@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -228,6 +229,7 @@ static bool run_minimizer(Estimator* e, AmoebaMinimizer& m, int dim,
     }
     m.func = &e->fn;
     m.speculate = e->speculate;
+    if (const char* sp = std::getenv("VB2_SPECULATE")) m.speculate = std::atoi(sp);     // A/B and test knob: 1, 2, 4
     m.Reset(dim);
     m.point = start;
     *ret = m.Minimize(e->epsilon);

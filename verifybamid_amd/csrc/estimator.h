@@ -51,7 +51,7 @@ public:
     double alpha = 0.5;                    // cpp:48
     std::vector<std::vector<double>> PC;   // PC[0] contaminating, PC[1] intended (h:453)
     FullLLKFunc fn;
-    bool speculate = true;
+    int speculate = 4;                  // AmoebaMinimizer::speculate
 
     int OptimizeLLK();                     // cpp:88-155 (without the writers)
 

@@ -106,16 +106,17 @@ void set_reduce_mode(int mode);     // 0 auto, 1 arrival ticket, 2 tagged sets (
 struct MultiLaunch {
     const DeviceLayout* d_layouts;   // [num_sample] in HBM
     const Schedule* d_scheds;        // [num_sample] in HBM (this launch's wave shape), or nullptr
-    const double* d_points;          // [num_sample][4*btl][2k+1]
+    const double* d_points;          // [num_sample][NP][2k+1], NP = np points per sample
     const int* d_num_valid;          // [num_sample] 0 = sample sits this step out
-    double* d_partials;              // [num_sample][4*btl + 1][bps]; done_seq doubles as the launch tag
-    double* d_out;                   // [num_sample][4*btl]
+    double* d_partials;              // [num_sample][NP + 1][bps]; done_seq doubles as the launch tag
+    double* d_out;                   // [num_sample][NP]
     unsigned int* d_tickets;         // [num_sample], zero-initialised
     unsigned int* d_batch_done;      // one zero-initialised counter
     unsigned long long* done_flag;   // mapped host word or nullptr
     unsigned long long done_seq;
     unsigned int batch_active;       // samples with num_valid > 0
-    int num_sample, bps, block_waves, btl;
+    int num_sample, bps, block_waves;
+    int np;                          // points per sample of this step: 1, 2, 4 or 8 (picks the wave shape)
     bool force_ticket;               // arrival-ticket hand-off instead of tagged sets (the retry after a NaN)
     size_t shmem;
 };

@@ -269,6 +269,9 @@ template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU =
 template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<3> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<4> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
+template <> struct Geom<5> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
+// points per group of a wave shape
+template <int MODE> struct ModeNp { static constexpr int value = MODE == 2 ? 8 : MODE == 4 ? 1 : MODE == 5 ? 2 : 4; };
 
 // MODE picks the wave shape.  BTL = candidate points per lane, SLOTS = candidate slots per wave:
 //   MODE 1: 16 markers x 4 slots x 1 point   (NP = 4 points per group; A/B alternative to 3)
@@ -279,6 +282,8 @@ template <> struct Geom<4> { static constexpr int kMaxWaves = 16, kBlocksPerCU =
 //   MODE 4: 4 x 16 markers x 1 slot x 1 point (NP = 1): a single-point evaluation (a caller's own
 //           optimiser, Initialize, LLK0) does a quarter of the work of a 4-point launch instead of
 //           evaluating the point four times.
+//   MODE 5: 4 x 16 markers x 1 slot x 2 points (NP = 2): cohort steps of a search that speculates on
+//           one extra point per iteration (multi-sample kernel only).
 // A launch evaluates groups of NP points (num_valid of them real; the rest replicate the last).
 // The body is shared by the single-sample kernel (blk = blk, nblk = nblk) and
 // the multi-sample kernel (blk/nblk = this workgroup's index among its sample's workgroups).
@@ -301,7 +306,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int BTL = (MODE == 1 || MODE == 4) ? 1 : 2;
-    constexpr int TPW = MODE == 3 ? 2 : MODE == 4 ? 4 : 1;   // micro-tiles per wave
+    constexpr int TPW = MODE == 3 ? 2 : (MODE == 4 || MODE == 5) ? 4 : 1;   // micro-tiles per wave
     constexpr int SLOTS = 4 / TPW;                           // candidate slots per wave
     constexpr int NP = SLOTS * BTL;
     const int RS = L.row_bytes >> 3;            // doubles per table row (>= 6 * NP + 2)
@@ -862,7 +867,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
                       unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
                       unsigned int* __restrict__ batch_done, unsigned int batch_active, int use_ticket)
 {
-    constexpr int NP = MODE == 2 ? 8 : MODE == 4 ? 1 : 4;
+    constexpr int NP = ModeNp<MODE>::value;
     const int s = blockIdx.x / bps;
     const int nv = num_valid[s];
     if (nv <= 0) return;                                   // uniform for the workgroup
@@ -948,7 +953,7 @@ void set_lane_mapping(bool hw) { g_hwmap = hw; }
 // object is per device in the runtime), so the flag is kept per (function slot, device).
 static hipError_t raise_lds_limit(const void* fn, int slot)
 {
-    constexpr int kSlots = 16, kDevs = 64;
+    constexpr int kSlots = 20, kDevs = 64;
     static std::atomic<unsigned char> done[kSlots][kDevs];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -971,7 +976,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
                              unsigned long long* done_flag, unsigned long long done_seq,
                              unsigned long long tag, hipStream_t stream, ScheduleProvider* sp)
 {
-    constexpr int NP = MODE == 2 ? 8 : MODE == 4 ? 1 : 4;     // points per group
+    constexpr int NP = ModeNp<MODE>::value;     // points per group
     const LaunchGeom gm = launch_geom(L, MODE == 2 ? 2 : 1);
     const Schedule sch = sp ? sp->get(MODE, ngrp, gm.grid, gm.block_waves) : Schedule{nullptr, nullptr};
     const size_t shmem = eval_shmem_np(L, NP, gm.grid, gm.block_waves, ngrp);
@@ -1080,14 +1085,20 @@ int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves)
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
 {
     const dim3 grid(ml.num_sample * ml.bps), block(ml.block_waves * 64);
-    const int mode = ml.btl == 2 ? 2 : (g_paired ? 3 : 1);
+    // wave shape by points per sample: 8 -> MODE 2, 4 -> 3, 2 -> 5, 1 -> 4 (MODE 1 for everything
+    // below 8 when the paired shapes are switched off: VB2_PAIRED=0)
+    const int mode = ml.np == 8 ? 2 : !g_paired ? 1 : ml.np == 1 ? 4 : ml.np == 2 ? 5 : 3;
     {
-        const void* fns[6] = {reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, false>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, true>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, false>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, true>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, false>),
-                              reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, true>)};
+        const void* fns[10] = {reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, false>),
+                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, true>),
+                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, false>),
+                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, true>),
+                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, false>),
+                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, true>),
+                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<4, false>),
+                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<4, true>),
+                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<5, false>),
+                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<5, true>)};
         const int slot = (mode - 1) * 2 + (g_hwmap ? 1 : 0);
         hipError_t e = raise_lds_limit(fns[slot], 8 + slot);
         if (e != hipSuccess) return e;
@@ -1098,6 +1109,8 @@ hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
                        ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active, ml.force_ticket ? 1 : 0)
     if (mode == 2) { if (g_hwmap) VB2_MULTI_LAUNCH(2, true); else VB2_MULTI_LAUNCH(2, false); }
     else if (mode == 3) { if (g_hwmap) VB2_MULTI_LAUNCH(3, true); else VB2_MULTI_LAUNCH(3, false); }
+    else if (mode == 4) { if (g_hwmap) VB2_MULTI_LAUNCH(4, true); else VB2_MULTI_LAUNCH(4, false); }
+    else if (mode == 5) { if (g_hwmap) VB2_MULTI_LAUNCH(5, true); else VB2_MULTI_LAUNCH(5, false); }
     else { if (g_hwmap) VB2_MULTI_LAUNCH(1, true); else VB2_MULTI_LAUNCH(1, false); }
 #undef VB2_MULTI_LAUNCH
     return hipGetLastError();
