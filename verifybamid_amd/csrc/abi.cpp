@@ -81,6 +81,7 @@ int load_panel(const vb2_run_args* a, vb2::Panel* panel)
     JoinGuard j_ud(t_ud), j_mu(t_mu);
     int rc = vb2::read_bed(a->bed_path, panel);
     if (!rc && a->known_af_path) rc = vb2::read_known_af(a->known_af_path, panel);
+    if (!rc) panel->finish();
     const std::string err_main = rc ? vb2::g_last_error : std::string();
     t_ud.join();
     t_mu.join();
@@ -462,11 +463,12 @@ int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
         JoinGuard j_ud(t_ud), j_mu(t_mu);
         rc = vb2::read_bed(a->bed_path, &f->panel);
         if (!rc && a->known_af_path) rc = vb2::read_known_af(a->known_af_path, &f->panel);
+        if (!rc) f->panel.finish();
         tl_bed = now_s();
         int rc_pile = VB2_OK;
         std::string err_main = rc ? vb2::g_last_error : std::string(), err_pile;
         if (!rc) {
-            rc_pile = a->pileup_path ? vb2::read_pileup(a->pileup_path, f->panel.ChooseBed, &f->viewer)
+            rc_pile = a->pileup_path ? vb2::read_pileup(a->pileup_path, f->panel, &f->viewer)
                                      : vb2::read_bam(a->bam_path, a->reference_path ? a->reference_path : "",
                                                      f->panel, &f->viewer);
             if (rc_pile) err_pile = vb2::g_last_error;

@@ -8,7 +8,7 @@
 //   defaults                           main.cpp:81-96: min-MQ 2, min-BQ 13, adjust-MQ (capQ) 40,
 //                                      max depth 8000, REALN (BAQ) + SMART_OVERLAPS, read filter
 //                                      UNMAP | SECONDARY | QCFAIL | DUP
-// It fills the same PileupViewer the text-pileup reader fills (hostio.cpp: read_pileup), so the
+// It fills the same PileupViewer (sites in two pools, hostio.h) the text-pileup reader fills, so the
 // sanity check, BuildResolvedMarkers and the flattening into pinned SoA arrays are shared.
 //
 // NEEDS htslib (>= 1.10: hts_pos_t), which this build image does not have: the file is compiled
@@ -124,18 +124,18 @@ int read_bam(const std::string& bam_path, const std::string& ref_path, const Pan
         set_error("This BAM or CRAM file contains more than 1 sample, please demultiplex or separate first!");
         return VB2_ERR_INVALID;
     }
-    int global_index = 0;
+    v->init(panel);
     v->numBases = 0;
     std::string bases, quals;
     // one region per panel marker, in .bed order (the reference jumps region by region too)
-    for (const auto& marker : panel.PosVec) {
+    for (size_t row = 0; row < panel.PosVec.size(); ++row) {
+        const auto& marker = panel.PosVec[row];
         const std::string& chr = marker.first;
         const int pos1 = marker.second;                                   // 1-based
         const int tid = sam_hdr_name2tid(a.hdr, chr.c_str());
         if (tid < 0) continue;
-        auto& idx_chr = v->posIndex[chr];
-        if (idx_chr.find(pos1) != idx_chr.end()) continue;                // duplicated marker: skipped (cpp:424-427)
-        idx_chr[pos1] = global_index++;
+        const int32_t slot = panel.rowSlot[row];
+        if (v->siteOfSlot[slot] >= 0) continue;                           // duplicated marker: skipped (cpp:424-427)
         bases.clear();
         quals.clear();
         a.iter = sam_itr_queryi(idx, tid, pos1 - 1, pos1);
@@ -173,8 +173,7 @@ int read_bam(const std::string& bam_path, const std::string& ref_path, const Pan
             v->effectiveNumSite++;
             v->numBases += (int)bases.size();
         }
-        v->baseInfo.push_back(bases);
-        v->qualInfo.push_back(quals);
+        v->add_site(slot, bases.data(), quals.data(), bases.size());
     }
     v->avgDepth = v->effectiveNumSite ? (double)v->numBases / v->effectiveNumSite : 0.0;
     free(a.ref);

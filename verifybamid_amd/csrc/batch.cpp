@@ -1,15 +1,15 @@
 // batch.cpp -- see batch.h.
 #include "batch.h"
 
+#include <ucontext.h>
+
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cmath>
-#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <thread>
+#include <functional>
+#include <memory>
 
 #include "estimator.h"
 
@@ -263,119 +263,63 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
 }
 
 // ---------------------------------------------------------------------------
-// lock-step search: one host thread per sample runs the ordinary Estimator; their
-// evaluation requests meet in a rendezvous and leave as one launch.
+// lock-step search: every sample runs the ordinary Estimator (OptimizeLLK with its six models,
+// the reference-exact simplex) as a FIBER of the calling thread -- its own small stack, switched
+// with swapcontext.  A fiber runs until its optimiser asks for likelihood values, parks the
+// request and yields; when every live fiber has parked, the requests leave as ONE launch, the
+// values are handed back and the fibers run on.  No threads, no locks, no wake-ups: a step costs
+// the host ~0.3 us per sample where one thread per sample cost a futex round trip each (9 ms of
+// CPU per sample and search at C3 size -- a third of what reading the sample costs, and under a
+// container's CPU quota it throttled the readers and the search alike).
 // ---------------------------------------------------------------------------
 namespace {
 
-// Waiting threads spin on the generation word before they sleep: a step of the cohort takes
-// 0.1-0.3 ms on the device, and futex wake-ups of ~30 sleepers cost about as much again once
-// the host is busy reading the next group's pileups.  Only where the process really has the CPUs
-// (usable_cpu_count: a cgroup quota counts): under a 16-CPU quota, 31 spinning threads get the whole
-// cgroup throttled and a group's search goes from 130 ms to 300-400 ms (measured).  There the
-// waiters sleep at once.  VB2_RV_SPIN_US overrides.
-struct Rendezvous {
-    Batch* batch;
-    int S, k;
-    std::mutex mu;                      // arrival bookkeeping (held for a few instructions only)
-    std::mutex sleep_mu;
-    std::condition_variable cv;
-    int active, arrived = 0;
-    std::atomic<unsigned long long> generation{0};
-    std::atomic<int> sleepers{0};
-    std::atomic<int> error{0};
-    long spin_ns;
-    std::vector<int32_t> npts;
-    std::vector<double> pc1, pc2, alpha, out;
+constexpr size_t kFiberStack = 256 * 1024;
 
-    Rendezvous(Batch* b, int s, int kk)
-        : batch(b), S(s), k(kk), active(s), npts(s, 0), pc1((size_t)s * kSlot * kk), pc2((size_t)s * kSlot * kk),
-          alpha((size_t)s * kSlot), out((size_t)s * kSlot)
-    {
-        spin_ns = usable_cpu_count() >= 4 * s ? 300000 : 0;
-        if (const char* e = std::getenv("VB2_RV_SPIN_US")) spin_ns = 1000L * std::atol(e);
-    }
+struct Fiber {
+    ucontext_t ctx;
+    std::unique_ptr<char[]> stack;
+    std::function<void()> body;
+    bool done = false;
+    // the parked request (pointers into the fiber's own frames: alive while it is parked)
+    int n = 0;
+    const double *p1 = nullptr, *p2 = nullptr, *a = nullptr;
+    double* o = nullptr;
+};
 
-    // every active sample has submitted (or left): nobody else touches the arrays until the
-    // generation moves on
-    void run_step()
-    {
-        const int rc = batch->eval(npts.data(), pc1.data(), pc2.data(), alpha.data(), out.data());
-        if (rc) {
-            int zero = 0;
-            error.compare_exchange_strong(zero, rc);
-        }
-        std::fill(npts.begin(), npts.end(), 0);
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            arrived = 0;
-        }
-        generation.fetch_add(1, std::memory_order_release);
-        if (sleepers.load(std::memory_order_acquire) > 0) {
-            { std::lock_guard<std::mutex> lk(sleep_mu); }
-            cv.notify_all();
-        }
-    }
-
-    void wait_generation(unsigned long long gen)
-    {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 0;; ++spins) {
-            if (generation.load(std::memory_order_acquire) != gen) return;
-            __builtin_ia32_pause();
-            if ((spins & 0xff) == 0xff &&
-                std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > spin_ns)
-                break;
-        }
-        std::unique_lock<std::mutex> lk(sleep_mu);
-        sleepers.fetch_add(1, std::memory_order_acq_rel);
-        cv.wait(lk, [&] { return generation.load(std::memory_order_acquire) != gen; });
-        sleepers.fetch_sub(1, std::memory_order_acq_rel);
-    }
-
-    int submit(int s, int n, const double* p1, const double* p2, const double* a, double* o)
-    {
-        std::memcpy(&pc1[(size_t)s * kSlot * k], p1, sizeof(double) * n * k);
-        std::memcpy(&pc2[(size_t)s * kSlot * k], p2, sizeof(double) * n * k);
-        std::memcpy(&alpha[(size_t)s * kSlot], a, sizeof(double) * n);
-        npts[s] = n;
-        const unsigned long long gen = generation.load(std::memory_order_acquire);
-        bool run;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            run = ++arrived == active;
-        }
-        if (run) run_step();
-        else wait_generation(gen);
-        std::memcpy(o, &out[(size_t)s * kSlot], sizeof(double) * n);
-        return error.load(std::memory_order_acquire);
-    }
-
-    void leave()
-    {
-        bool run;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            --active;
-            run = active > 0 && arrived == active;
-        }
-        if (run) run_step();
-    }
+struct FiberSched {
+    ucontext_t main;
+    Fiber* cur = nullptr;
+    int error = 0;
 };
 
 struct SampleCb {
-    Rendezvous* rv;
-    int s;
+    FiberSched* sched;
+    Fiber* fiber;
+    int k;
 };
+
+void fiber_entry(unsigned lo, unsigned hi)
+{
+    Fiber* f = reinterpret_cast<Fiber*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    f->body();                       // (never throws: the body catches)
+    f->done = true;
+    f->n = 0;
+}                                    // uc_link: back to the scheduler
 
 int sample_eval(void* user, int32_t n, const double* p1, const double* p2, const double* a, double* o)
 {
     SampleCb* cb = static_cast<SampleCb*>(user);
-    const int k = cb->rv->k;
+    const int k = cb->k;
     for (int done = 0; done < n; done += kSlot) {
-        const int m = std::min(kSlot, n - done);
-        const int rc = cb->rv->submit(cb->s, m, p1 + (size_t)done * k, p2 + (size_t)done * k, a + done, o + done);
-        if (rc) return rc;
+        Fiber* f = cb->fiber;
+        f->n = std::min(kSlot, n - done);
+        f->p1 = p1 + (size_t)done * k;
+        f->p2 = p2 + (size_t)done * k;
+        f->a = a + done;
+        f->o = o + done;
+        swapcontext(&f->ctx, &cb->sched->main);        // parked until the step has been evaluated
+        if (cb->sched->error) return cb->sched->error;
     }
     return 0;
 }
@@ -398,31 +342,80 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     constexpr int kPairFrom = 8;
     speculate_ = num_sample < kPairFrom ? 4 : 2;
     if (const char* e = std::getenv("VB2_COHORT_SPECULATE")) speculate_ = std::max(1, std::atoi(e));
-    Rendezvous rv(this, num_sample, num_pc);
-    std::vector<SampleCb> cbs(num_sample);
-    std::vector<int> rcs(num_sample, 0);
-    std::vector<std::thread> threads;
-    threads.reserve(num_sample);
-    for (int s = 0; s < num_sample; ++s) {
-        cbs[s] = SampleCb{&rv, s};
-        threads.emplace_back([&, s]() {
-            const vb2_model& m = models[num_model == 1 ? 0 : s];
-            Estimator est(num_pc, sample_eval, &cbs[s]);
-            apply_model(est, m);
-            est.speculate = speculate_;
-            if (ctx_[s]->L.known_af) {       // context built with --KnownAF data
-                est.isAFknown = true;
-                est.isPCFixed = true;
-                est.isHeter = false;
+
+    const int S = num_sample, k = num_pc;
+    FiberSched sched;
+    std::vector<Fiber> fibers(S);
+    std::vector<SampleCb> cbs(S);
+    std::vector<int> rcs(S, 0);
+    std::vector<int32_t> npts(S, 0);
+    std::vector<double> pc1((size_t)S * kSlot * k), pc2((size_t)S * kSlot * k), alpha((size_t)S * kSlot),
+        llk((size_t)S * kSlot);
+    auto resume = [&](Fiber& f) {
+        sched.cur = &f;
+        swapcontext(&sched.main, &f.ctx);
+    };
+    for (int s = 0; s < S; ++s) {
+        Fiber& f = fibers[s];
+        cbs[s] = SampleCb{&sched, &f, k};
+        f.stack.reset(new char[kFiberStack]);
+        f.body = [&, s]() {
+            try {
+                const vb2_model& m = models[num_model == 1 ? 0 : s];
+                Estimator est(num_pc, sample_eval, &cbs[s]);
+                apply_model(est, m);
+                est.speculate = speculate_;
+                if (ctx_[s]->L.known_af) {       // context built with --KnownAF data
+                    est.isAFknown = true;
+                    est.isPCFixed = true;
+                    est.isHeter = false;
+                }
+                rcs[s] = est.OptimizeLLK();
+                fill_estimate(est, &out[s]);
+            } catch (const std::bad_alloc&) {
+                rcs[s] = VB2_ERR_NOMEM;
+            } catch (const std::exception& e) {
+                set_error(e.what());
+                rcs[s] = VB2_ERR_INVALID;
             }
-            rcs[s] = est.OptimizeLLK();
-            fill_estimate(est, &out[s]);
-            rv.leave();
-        });
+        };
+        if (getcontext(&f.ctx) != 0) {
+            set_error("vb2_batch_optimize_llk: getcontext failed");
+            return VB2_ERR_INVALID;
+        }
+        f.ctx.uc_stack.ss_sp = f.stack.get();
+        f.ctx.uc_stack.ss_size = kFiberStack;
+        f.ctx.uc_link = &sched.main;
+        const uintptr_t p = reinterpret_cast<uintptr_t>(&f);
+        makecontext(&f.ctx, reinterpret_cast<void (*)()>(fiber_entry), 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
     }
-    for (auto& t : threads) t.join();
-    if (rv.error.load()) return rv.error.load();
-    for (int s = 0; s < num_sample; ++s)
+    for (int s = 0; s < S; ++s) resume(fibers[s]);               // up to everybody's first request
+    for (;;) {
+        bool any = false;
+        for (int s = 0; s < S; ++s) {
+            Fiber& f = fibers[s];
+            npts[s] = f.done ? 0 : f.n;
+            if (npts[s] <= 0) continue;
+            any = true;
+            std::memcpy(&pc1[(size_t)s * kSlot * k], f.p1, sizeof(double) * f.n * k);
+            std::memcpy(&pc2[(size_t)s * kSlot * k], f.p2, sizeof(double) * f.n * k);
+            std::memcpy(&alpha[(size_t)s * kSlot], f.a, sizeof(double) * f.n);
+        }
+        if (!any) break;
+        if (!sched.error) {
+            const int rc = eval(npts.data(), pc1.data(), pc2.data(), alpha.data(), llk.data());
+            if (rc) sched.error = rc;                              // the fibers see it and unwind
+        }
+        for (int s = 0; s < S; ++s) {
+            Fiber& f = fibers[s];
+            if (npts[s] <= 0) continue;
+            std::memcpy(f.o, &llk[(size_t)s * kSlot], sizeof(double) * npts[s]);
+            f.n = 0;
+            resume(f);                                             // up to its next request, or to the end
+        }
+    }
+    if (sched.error) return sched.error;
+    for (int s = 0; s < S; ++s)
         if (rcs[s]) return rcs[s];
     return VB2_OK;
 }

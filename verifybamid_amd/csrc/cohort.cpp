@@ -51,7 +51,7 @@ public:
         if (a->base.devices && a->base.num_device > 0) devices_.assign(a->base.devices, a->base.devices + a->base.num_device);
         else devices_.push_back(a->base.device);
         ndev_ = (int)devices_.size();
-        G_ = std::max(1, std::min(a->group_size > 0 ? a->group_size : 32, 64));
+        G_ = std::max(1, std::min(a->group_size != 0 ? std::abs(a->group_size) : 64, 64));
         const int hw = vb2::usable_cpu_count();
         // readers: text parsing + run packing is ~0.1 s of one core per C3-sized sample, the device
         // needs ~4 ms per sample -> a device keeps ~25 readers busy.  The default leaves two CPUs of
@@ -61,7 +61,23 @@ public:
         T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, std::max(hw, 1) * 4, S_}));
         slots_.resize(S_);
         cnt_.assign(ndev_, 0);
-        ngroup_ = (S_ + G_ - 1) / G_;
+        // Group boundaries, a function of (S, G, devices) only -- never of timing, so a run is
+        // reproducible.  A device's first groups are small (16, then 32 samples): it starts searching
+        // after a fraction of the reading a full group needs; the later ones have the full size (a
+        // bigger group costs less per sample: 3.6 / 3.25 / 3.0 ms at 16 / 32 / 48 C3-sized samples).
+        // A remainder of up to half a group joins the last group instead of running alone.
+        for (int begin = 0, gi = 0; begin < S_; ++gi) {
+            const int nth = gi / ndev_;                       // this group's index on its device
+            int want = std::min(G_, nth == 0 ? 16 : nth == 1 ? 32 : G_);
+            if (a->group_size < 0) want = G_;                 // (negative group_size: plain equal groups of |group_size|)
+            const int left = S_ - begin;
+            if (left <= want + want / 2) want = left;
+            group_begin_.push_back(begin);
+            for (int s = begin; s < begin + want; ++s) group_of_.push_back(gi);
+            begin += want;
+        }
+        group_begin_.push_back(S_);
+        ngroup_ = (int)group_begin_.size() - 1;
     }
 
     ~CohortRunner() { shutdown(); }
@@ -112,7 +128,8 @@ private:
     const vb2_cohort_args* a_;
     vb2_run_result* out_;
     int32_t* status_;
-    int S_, G_ = 32, T_ = 1, ndev_ = 1, ngroup_ = 0;
+    int S_, G_ = 64, T_ = 1, ndev_ = 1, ngroup_ = 0;
+    std::vector<int> group_begin_, group_of_;       // [group] first sample (+ S_ at the end); [sample] group
     std::vector<int> devices_;
     std::shared_ptr<vb2::Panel> panel_;
     vb2_model model_{};
@@ -171,7 +188,7 @@ private:
         const double t0 = now_s();
         sl.flat.reset(new vb2_flat(panel_));
         vb2_flat& f = *sl.flat;
-        sl.rc = vb2::read_pileup(a_->pileup_paths[s], panel_->ChooseBed, &f.viewer);
+        sl.rc = vb2::read_pileup(a_->pileup_paths[s], *panel_, &f.viewer);
         if (sl.rc) return;
         const double t_read = now_s();
         const bool sanity_off = a_->base.disable_sanity != 0;
@@ -187,7 +204,7 @@ private:
             return;
         }
         vb2_options opt{};
-        opt.device = devices_[device_of_group(s / G_)];
+        opt.device = devices_[device_of_group(group_of_[s])];
         sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
         const double t_end = now_s();
         out_[s].seconds_load = t_end - t0;
@@ -208,7 +225,7 @@ private:
                 // stay at most two groups ahead of the group's device (bounds host and device memory)
                 cv_.wait(lk, [&] {
                     if (stop_ || next_ >= S_) return true;
-                    const int gi = next_ / G_;
+                    const int gi = group_of_[next_];
                     return gi / ndev_ < cnt_[device_of_group(gi)] + 2;
                 });
                 if (stop_ || next_ >= S_) return;
@@ -248,7 +265,7 @@ private:
     {
         const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
         for (int gi = d; gi < ngroup_; gi += ndev_) {
-            const int g0 = gi * G_, g1 = std::min(S_, g0 + G_);
+            const int g0 = group_begin_[gi], g1 = group_begin_[gi + 1];
             const double tg0 = now_s();
             {
                 std::unique_lock<std::mutex> lk(mu_);

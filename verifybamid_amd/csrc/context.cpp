@@ -166,14 +166,8 @@ const double kCond[2][3][3] = {
 
 inline unsigned char ascii_upper(unsigned char c) { return (c >= 'a' && c <= 'z') ? (unsigned char)(c - 32) : c; }
 
-// classifyBase (h:180-184); toupper() in the "C" locale, without the libc call per read
-inline int classify_base(char base, char alt)
-{
-    if (base == '.' || base == ',') return 0;
-    if (ascii_upper((unsigned char)base) == ascii_upper((unsigned char)alt)) return 1;
-    return 2;
-}
-
+// classifyBase (h:180-184) is done through byte tables in Context::create: '.' ',' -> ref,
+// toupper(base) == toupper(alt) in the "C" locale -> alt, anything else -> other.
 inline int clamp_qual(char qc)
 {
     int q = (int)(unsigned char)qc - 33;
@@ -196,7 +190,23 @@ Context::~Context()
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
+int flatten_dry_run(const vb2_input* in, double* ms)
+{
+    Context* none = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = Context::create_impl(in, nullptr, &none, true);
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
 int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
+{
+    return create_impl(in, opt, out, false);
+}
+
+// dry: the host half only (classification, dictionary, run packing into plain memory) -- no HIP
+// call, nothing returned; tools/ubench/host_pipeline.cpp times it where there is no GPU
+int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** out, bool dry)
 {
     *out = nullptr;
     if (!in || in->num_marker < 0 || in->num_pc < 1 || in->num_pc > VB2_MAX_PC || !in->read_off ||
@@ -204,41 +214,43 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         set_error("vb2_ctx_create: invalid input");
         return VB2_ERR_INVALID;
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-        (void)hipGetLastError();
-        set_error("vb2_ctx_create: no HIP device visible (this library has no CPU fallback)");
-        return VB2_ERR_NO_DEVICE;
-    }
-    int dev = opt ? opt->device : -1;
-    if (dev < 0) VB2_HIP(hipGetDevice(&dev));
-    if (dev >= ndev) {
-        set_error("vb2_ctx_create: device ordinal out of range");
-        return VB2_ERR_INVALID;
-    }
+    int ndev = 0, dev = 0;
     hipDeviceProp_t prop;
-    VB2_HIP(hipGetDeviceProperties(&prop, dev));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        set_error(std::string("vb2_ctx_create: device is ") + prop.gcnArchName +
-                  ", kernels are built for gfx950 only");
-        return VB2_ERR_NO_DEVICE;
-    }
-    VB2_HIP(hipSetDevice(dev));
-
+    std::memset(&prop, 0, sizeof(prop));
     std::unique_ptr<Context> c(new Context());
+    if (!dry) {
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+            (void)hipGetLastError();
+            set_error("vb2_ctx_create: no HIP device visible (this library has no CPU fallback)");
+            return VB2_ERR_NO_DEVICE;
+        }
+        dev = opt ? opt->device : -1;
+        if (dev < 0) VB2_HIP(hipGetDevice(&dev));
+        if (dev >= ndev) {
+            set_error("vb2_ctx_create: device ordinal out of range");
+            return VB2_ERR_INVALID;
+        }
+        VB2_HIP(hipGetDeviceProperties(&prop, dev));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            set_error(std::string("vb2_ctx_create: device is ") + prop.gcnArchName +
+                      ", kernels are built for gfx950 only");
+            return VB2_ERR_NO_DEVICE;
+        }
+        VB2_HIP(hipSetDevice(dev));
+        std::snprintf(c->device_name, sizeof(c->device_name), "%s", prop.name);
+        std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
+        // the context's stream: the upload, every launch and the schedules' copies go on it (never the null stream)
+        if (opt && opt->stream) {
+            c->stream = (hipStream_t)opt->stream;
+            c->own_stream = false;
+        } else {
+            VB2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->own_stream = true;
+        }
+    }
     c->device = dev;
     c->num_marker = in->num_marker;
     c->num_pc = in->num_pc;
-    std::snprintf(c->device_name, sizeof(c->device_name), "%s", prop.name);
-    std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
-    // the context's stream: the upload, every launch and the schedules' copies go on it (never the null stream)
-    if (opt && opt->stream) {
-        c->stream = (hipStream_t)opt->stream;
-        c->own_stream = false;
-    } else {
-        VB2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
 
     const int M = in->num_marker, k = in->num_pc;
     const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
@@ -261,22 +273,22 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
                 logc[(bc * kNumQual + q) * 3 + g] =
                     std::log(kCond[1][g][bc] * phred[q] + kCond[0][g][bc] * (1.0 - phred[q]));
 
-    // ---- pass 1: which markers count (h:239-249), code histogram ----
+    // ---- pass A (panel order, sequential reads): which markers count (h:239-249); per marker the
+    // runs of equal (class, quality), the alpha-free sums, the code histogram ----
     std::vector<int32_t> active;
     active.reserve(M);
-    std::vector<int64_t> code_hist(kMaxCode, 0);
     const double lo = in->avg_depth - 3 * in->sd_depth, hi = in->avg_depth + 3 * in->sd_depth;
     int64_t num_read = 0, num_other = 0;
     std::vector<int32_t> eff_depth;     // runs per marker (see below)
     eff_depth.reserve(M);
-    std::vector<uint8_t> raw((size_t)(M > 0 ? in->read_off[M] : 0));   // (class, q) per read; 255 = other
     for (int i = 0; i < M; ++i)
         if (in->read_off[i + 1] < in->read_off[i]) {
             set_error("vb2_ctx_create: read_off not monotone");
             return VB2_ERR_INVALID;
         }
     // The flattening is embarrassingly parallel over markers: a few host threads for big inputs.
-    const int64_t total_reads = M > 0 ? in->read_off[M] - in->read_off[0] : 0;
+    const int64_t read_base = M > 0 ? in->read_off[0] : 0;
+    const int64_t total_reads = M > 0 ? in->read_off[M] - read_base : 0;
     int nthr = std::min(usable_cpu_count(), 16);
     nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, total_reads / 200000));
     if (const int cap = g_flatten_thread_cap.load()) nthr = std::min(nthr, cap);     // cohort runner: many creates at once
@@ -287,37 +299,127 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         for (int t = 0; t < nthr; ++t) th.emplace_back(fn, t, n * t / nthr, n * (t + 1) / nthr);
         for (auto& x : th) x.join();
     };
+
+    // Dictionary order of the (class, quality) codes: by quality, the more frequent first, the two
+    // classes of a quality next to each other (ref, alt).  A marker's runs are stored in that
+    // order, so at a given step the 16 markers a ds_read_b128 pass serves sit on NEIGHBOURING table
+    // rows whether they are hom-ref, hom-alt or het -- rows whose 16-byte slots differ mod 16, i.e.
+    // no bank conflict.  The frequency ranking comes from a strided sample of the reads (any order
+    // is correct; this one only has to be known BEFORE the reads are walked, so that pass A can
+    // emit every marker's runs already sorted).  `idx` = 2 * rank(quality) + class below.
+    // VB2_DICT_ORDER=plain ranks the qualities by ascending value instead (A/B).
+    int qrank[kNumQual], qof[kNumQual];
+    {
+        int64_t qh[kNumQual];
+        std::fill(qh, qh + kNumQual, 0);
+        static const bool plain = std::getenv("VB2_DICT_ORDER") && !std::strcmp(std::getenv("VB2_DICT_ORDER"), "plain");
+        const int64_t nsample = std::min<int64_t>(total_reads, 1 << 16);
+        const int64_t step = nsample > 0 ? total_reads / nsample : 1;
+        if (!plain && in->quals)
+            for (int64_t j = 0; j < nsample; ++j) ++qh[clamp_qual(in->quals[read_base + j * step])];
+        for (int q = 0; q < kNumQual; ++q) qof[q] = q;
+        std::stable_sort(qof, qof + kNumQual, [&](int x, int y) { return qh[x] > qh[y]; });
+        for (int r = 0; r < kNumQual; ++r) qrank[qof[r]] = r;
+    }
+    struct Luts {
+        uint8_t dot[256], up[256], qidx[256];
+        double other_lc[256];
+    };
+    std::unique_ptr<Luts> lut(new Luts);
+    for (int ch = 0; ch < 256; ++ch) {
+        lut->dot[ch] = (ch == '.' || ch == ',') ? 1 : 0;
+        lut->up[ch] = ascii_upper((unsigned char)ch);
+        const int q = clamp_qual((char)ch);
+        lut->qidx[ch] = (uint8_t)(2 * qrank[q]);
+        lut->other_lc[ch] = logc[(2 * kNumQual + q) * 3];
+    }
+    std::vector<double> lc3((size_t)kMaxCode * 3);                 // [idx][g]
+    for (int idx = 0; idx < kMaxCode; ++idx)
+        for (int g = 0; g < 3; ++g) lc3[(size_t)idx * 3 + g] = logc[((idx & 1) * kNumQual + qof[idx >> 1]) * 3 + g];
+
     std::vector<int32_t> eff_all(M, -1);                       // -1: marker does not count
+    // a marker's runs, in dictionary order, at the position of its reads (runs <= reads): low byte idx, high byte count
+    // (scratch that a thread creating one context after the other keeps: fresh pages cost more
+    // than the passes that fill them)
+    struct Scratch {
+        std::unique_ptr<uint16_t[]> runs;
+        std::unique_ptr<double[]> cd;
+        size_t runs_cap = 0, cd_cap = 0;
+    };
+    static thread_local Scratch scratch;
+    const size_t runs_need = (size_t)std::max<int64_t>(total_reads, 1), cd_need = (size_t)std::max(M, 1) * 4;
+    if (scratch.runs_cap < runs_need || scratch.runs_cap > 4 * runs_need + (1u << 20)) {
+        scratch.runs.reset(new uint16_t[runs_need]);
+        scratch.runs_cap = runs_need;
+    }
+    if (scratch.cd_cap < cd_need || scratch.cd_cap > 4 * cd_need + (1u << 20)) {
+        scratch.cd.reset(new double[cd_need]);
+        scratch.cd_cap = cd_need;
+    }
+    uint16_t* const runs = scratch.runs.get();
+    double* const cd_tmp = scratch.cd.get();                  // c_other, exp(c_other + D[g]) in panel order
+    std::vector<int64_t> code_hist(kMaxCode, 0);
     {
         std::vector<std::vector<int64_t>> hist_t(nthr, std::vector<int64_t>(kMaxCode, 0));
         std::vector<int64_t> reads_t(nthr, 0), other_t(nthr, 0);
         parallel_for(M, [&](int t, int64_t i0, int64_t i1) {
-            std::vector<int32_t> local_hist(kMaxCode, 0);
-            std::vector<int> touched;
-            touched.reserve(kMaxCode);
+            uint32_t cnt[3 * 64];
+            std::fill(cnt, cnt + 3 * 64, 0u);
             std::vector<int64_t>& hist = hist_t[t];
             int64_t n_read = 0, n_other = 0;          // thread-local: no shared cache lines in the loop
+            const Luts& T = *lut;
             for (int64_t i = i0; i < i1; ++i) {
                 const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
                 if (depth == 0) continue;
                 if (!in->sanity_disabled && ((double)depth < lo || (double)depth > hi)) continue;
-                // steps of this marker in the kernel = runs of equal (class, quality): one
-                // (code, count) pair per distinct code, counts above kMaxRunCount split
-                const char alt = in->alt_base[i];
-                touched.clear();
+                // classifyBase + quality clamp (h:180-184, 296-298) through byte tables
+                const uint8_t alt_up = T.up[(unsigned char)in->alt_base[i]];
+                const unsigned char* bs = reinterpret_cast<const unsigned char*>(in->bases + beg);
+                const unsigned char* qs = reinterpret_cast<const unsigned char*>(in->quals + beg);
+                uint64_t bm[3] = {0, 0, 0};
+                double c_other = 0.0;                 // class "other": same term for every genotype pair
                 for (int64_t j = 0; j < depth; ++j) {
-                    const int bc = classify_base(in->bases[beg + j], alt);
-                    if (bc == 2) { ++n_other; raw[beg + j] = 255; continue; }
-                    const int c2 = bc * kNumQual + clamp_qual(in->quals[beg + j]);
-                    raw[beg + j] = (uint8_t)c2;
-                    ++hist[c2];
-                    if (local_hist[c2]++ == 0) touched.push_back(c2);
+                    const unsigned char b = bs[j], qv = qs[j];
+                    int cls;
+                    if (T.dot[b]) cls = 0;
+                    else if (T.up[b] == alt_up) cls = 1;
+                    else {
+                        c_other += T.other_lc[qv];
+                        ++n_other;
+                        continue;
+                    }
+                    const unsigned idx = (unsigned)T.qidx[qv] + (unsigned)cls;
+                    ++cnt[idx];
+                    bm[idx >> 6] |= 1ull << (idx & 63);
                 }
+                // steps of this marker in the kernel = runs of equal (class, quality): one
+                // (code, count) pair per distinct code, counts above kMaxRunCount split.
+                // the g1 == g2 sums, one multiply-add per distinct (class, quality) instead of an add per
+                // read (count * log c: the summation order over a marker's reads is free, like the kernel's)
+                uint16_t* out = runs + (beg - read_base);
                 int32_t eff = 0;
-                for (int c2 : touched) {
-                    eff += (local_hist[c2] + kMaxRunCount - 1) / kMaxRunCount;
-                    local_hist[c2] = 0;
-                }
+                double dg[3] = {0.0, 0.0, 0.0};
+                for (int w = 0; w < 3; ++w)
+                    for (uint64_t bits = bm[w]; bits; bits &= bits - 1) {
+                        const unsigned idx = (unsigned)w * 64u + (unsigned)__builtin_ctzll(bits);
+                        uint32_t left = cnt[idx];
+                        cnt[idx] = 0;
+                        hist[idx] += left;
+                        const double n = (double)left;
+                        const double* lc = &lc3[(size_t)idx * 3];
+                        dg[0] += n * lc[0]; dg[1] += n * lc[1]; dg[2] += n * lc[2];
+                        while (left > 0) {
+                            const uint32_t c1 = left > (uint32_t)kMaxRunCount ? (uint32_t)kMaxRunCount : left;
+                            out[eff++] = (uint16_t)(idx | (c1 << 8));
+                            left -= c1;
+                        }
+                    }
+                // the g1 == g2 terms of h:307-311 are constants of the marker
+                double* cd = cd_tmp + (size_t)i * 4;
+                cd[0] = c_other;
+                cd[1] = std::exp(dg[0] + c_other);
+                cd[2] = std::exp(dg[1] + c_other);
+                cd[3] = std::exp(dg[2] + c_other);
                 n_read += depth;
                 eff_all[i] = eff;
             }
@@ -338,33 +440,17 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         }
     const int64_t m_active = (int64_t)active.size();
 
-    // ---- dictionary: observed (class, q) pairs.  Order: by quality (the more frequent first), the
-    // two classes of a quality next to each other.  A marker's runs are stored in dictionary order,
-    // so at a given step the 16 markers a ds_read_b128 pass serves sit on NEIGHBOURING table rows
-    // whether they are hom-ref, hom-alt or het -- rows whose 16-byte slots differ mod 16, i.e. no
-    // bank conflict (with all ref codes before all alt codes, a het marker's step j was ~20 rows
-    // away from a hom-alt marker's).  VB2_DICT_ORDER=freq restores plain frequency order (A/B).
-    std::vector<int> order;
-    for (int c2 = 0; c2 < kMaxCode; ++c2)
-        if (code_hist[c2] > 0) order.push_back(c2);
-    {
-        static const bool by_freq = std::getenv("VB2_DICT_ORDER") && !std::strcmp(std::getenv("VB2_DICT_ORDER"), "freq");
-        std::vector<int64_t> qfreq(kNumQual, 0);
-        for (int c2 : order) qfreq[c2 % kNumQual] += code_hist[c2];
-        if (by_freq)
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return code_hist[a] > code_hist[b]; });
-        else
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-                const int qa = a % kNumQual, qb = b % kNumQual;
-                if (qa != qb) return qfreq[qa] != qfreq[qb] ? qfreq[qa] > qfreq[qb] : qa < qb;
-                return a < b;                                  // ref before alt
-            });
-    }
+    // ---- dictionary: the observed codes, in idx order (see above) ----
+    std::vector<int> order;                                   // dictionary index -> class * kNumQual + quality
+    std::vector<uint8_t> dict_of(kMaxCode, (uint8_t)kPadCode); // idx -> dictionary index
+    for (int idx = 0; idx < kMaxCode; ++idx)
+        if (code_hist[idx] > 0) {
+            dict_of[idx] = (uint8_t)order.size();
+            order.push_back((idx & 1) * kNumQual + qof[idx >> 1]);
+        }
     const int num_code = (int)order.size();
-    std::vector<uint8_t> dict_of(kMaxCode, (uint8_t)kPadCode);
     std::vector<double> dict_perr(num_code);
     for (int d = 0; d < num_code; ++d) {
-        dict_of[order[d]] = (uint8_t)d;
         const double pe = phred[order[d] % kNumQual];
         dict_perr[d] = (order[d] / kNumQual) ? -pe : pe;      // sign carries the class
     }
@@ -378,12 +464,13 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         std::memcpy(&y, &bits, sizeof(y));
         prim.push_back(make_double2(dict_perr[d], y));
     };
-    for (int d = 0; d < num_code; ++d) {
-        const int cls = order[d] / kNumQual, q = order[d] % kNumQual;
-        if (cls == 0) {
-            const int t = dict_of[kNumQual + q];
+    for (int idx = 0; idx < kMaxCode; ++idx) {
+        const int d = dict_of[idx];
+        if (d == kPadCode) continue;
+        if ((idx & 1) == 0) {
+            const int t = dict_of[idx | 1];
             prim_rec(d, t == kPadCode ? 0xffffu : (uint32_t)t);
-        } else if (dict_of[q] == kPadCode) {
+        } else if (dict_of[idx & ~1] == kPadCode) {
             prim_rec(d, 0xffffu);
         }
     }
@@ -432,6 +519,9 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
         return (uint32_t)(d * row_bytes) | ((uint32_t)(bits >> 48) << 16);
     };
     const uint32_t pad4 = run_word(num_code, 0);
+    uint32_t row_of_idx[kMaxCode], hi_of_count[kMaxRunCount + 1];     // the two halves of a run word, by table
+    for (int idx = 0; idx < kMaxCode; ++idx) row_of_idx[idx] = dict_of[idx] == kPadCode ? 0u : (uint32_t)(dict_of[idx] * row_bytes);
+    for (int n = 0; n <= kMaxRunCount; ++n) hi_of_count[n] = run_word(0, (uint32_t)n);
 
     // ---- device memory: ONE allocation per context, carved into 256-byte aligned pieces.
     // (A cohort creates contexts from many host threads; allocation calls go through driver
@@ -478,15 +568,21 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     // pinned staging slab (recycled through the cache like the other slabs: hipHostMalloc /
     // hipHostFree take milliseconds and synchronise)
     size_t stage_bytes = 0;
-    char* stage = static_cast<char*>(slab_cache().take(slab_cache().stage, data_bytes, dev, &stage_bytes));
+    char* stage = dry ? static_cast<char*>(std::malloc(data_bytes))
+                      : static_cast<char*>(slab_cache().take(slab_cache().stage, data_bytes, dev, &stage_bytes));
     if (!stage) {
+        if (dry) { set_error("out of host memory"); return VB2_ERR_NOMEM; }
         VB2_HIP(hipHostMalloc((void**)&stage, data_bytes, hipHostMallocDefault));
         stage_bytes = data_bytes;
     }
     struct StageGuard {                       // back to the cache (or the driver) on every way out
-        char* p; size_t bytes; int dev;
-        ~StageGuard() { if (p && !slab_cache().give(slab_cache().stage, p, bytes, dev)) (void)hipHostFree(p); }
-    } stage_guard{stage, stage_bytes, dev};
+        char* p; size_t bytes; int dev; bool dry;
+        ~StageGuard()
+        {
+            if (dry) std::free(p);
+            else if (p && !slab_cache().give(slab_cache().stage, p, bytes, dev)) (void)hipHostFree(p);
+        }
+    } stage_guard{stage, stage_bytes, dev, dry};
     uint32_t* const codes = reinterpret_cast<uint32_t*>(stage + o_codes);
     uint2* const mt_rec = reinterpret_cast<uint2*>(stage + o_rec);
     double* const ud_s = reinterpret_cast<double*>(stage + o_ud);
@@ -496,8 +592,8 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
     for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rows[t]);
     if (!dict_perr.empty()) std::memcpy(stage + o_dpe, dict_perr.data(), dict_perr.size() * sizeof(double));
     if (!prim.empty()) std::memcpy(stage + o_prim, prim.data(), prim.size() * sizeof(double2));
-    // padding: unused run slots, and the (< 16) marker positions past the last active one
-    parallel_for((int64_t)n_codes, [&](int, int64_t i0, int64_t i1) { std::fill(codes + i0, codes + i1, pad4); });
+    // padding: the slack rows behind the last tile, and the (< 16) marker positions past the last active one
+    std::fill(codes + (size_t)total_rows * kMtMarkers * 2, codes + n_codes, pad4);
     for (int64_t m = m_active; m < m_pad; ++m) {
         if (in->known_af) kaf_s[m] = 0.0;
         else {
@@ -505,62 +601,64 @@ int Context::create(const vb2_input* in, const vb2_options* opt, Context** out)
             mu_s[m] = 0.0;
         }
         for (int q = 0; q < 4; ++q) cdiag[(size_t)q * m_pad + m] = 0.0;
+        const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
+        uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
+        for (size_t j = 0; j < (size_t)mt_rows[t] * 2; ++j) row0[((j >> 1) * kMtMarkers + lane) * 2 + (j & 1)] = pad4;
     }
+    // ---- pass B (kernel order: markers sorted by run count, i.e. scattered reads of the panel
+    // order arrays -- prefetched): run words, panel rows, diagonal terms into the staging slab ----
     parallel_for(m_active, [&](int, int64_t m0, int64_t m1) {
-    std::vector<uint32_t> run_of(num_code + 1, 0);
-    std::vector<int> touched;
-    touched.reserve(kMaxCode);
+    constexpr int64_t kAhead = 12;
     for (int64_t m = m0; m < m1; ++m) {
-        const int i = active[perm[m]];
-        const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
-        double c_other = 0.0, dg[3] = {0.0, 0.0, 0.0};
-        touched.clear();
-        for (int64_t j = 0; j < depth; ++j) {
-            const int c2 = raw[beg + j];
-            if (c2 == 255) {                // class "other": same term for every genotype pair
-                c_other += logc[(2 * kNumQual + clamp_qual(in->quals[beg + j])) * 3];
-            } else {
-                const int d = dict_of[c2];
-                if (run_of[d]++ == 0) touched.push_back(d);
+        if (m + 2 * kAhead < m1) {                    // (its read_off entry first: the run list is found through it)
+            const int i2 = active[perm[m + 2 * kAhead]];
+            __builtin_prefetch(&in->read_off[i2]);
+            __builtin_prefetch(cd_tmp + (size_t)i2 * 4);
+            if (in->known_af) __builtin_prefetch(&in->known_af[i2]);
+            else {
+                __builtin_prefetch(&in->ud[(size_t)i2 * k]);
+                __builtin_prefetch(&in->means[i2]);
             }
         }
-        std::sort(touched.begin(), touched.end());
-        // the g1 == g2 sums, one multiply-add per distinct (class, quality) instead of an add per
-        // read (count * log c: the summation order over a marker's reads is free, like the kernel's)
-        for (int d : touched) {
-            const double* lc = &logc[order[d] * 3];
-            const double n = (double)run_of[d];
-            dg[0] += n * lc[0]; dg[1] += n * lc[1]; dg[2] += n * lc[2];
+        if (m + kAhead < m1) {
+            const int i1 = active[perm[m + kAhead]];
+            __builtin_prefetch(runs + (in->read_off[i1] - read_base));
         }
+        const int i = active[perm[m]];
+        const uint16_t* src = runs + (in->read_off[i] - read_base);
+        const size_t eff = (size_t)eff_all[i];
         // runs in dictionary order: lanes of a wave then tend to hit the same or
         // neighbouring LDS table rows at the same step (bank-friendly)
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
         uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
+        const size_t slots = (size_t)mt_rows[t] * 2;
         size_t j = 0;
-        for (int d : touched) {
-            for (uint32_t left = run_of[d]; left > 0;) {
-                const uint32_t n = left > (uint32_t)kMaxRunCount ? (uint32_t)kMaxRunCount : left;
-                row0[((j >> 1) * kMtMarkers + lane) * 2 + (j & 1)] = run_word(d, n);
-                left -= n;
-                ++j;
-            }
-            run_of[d] = 0;
+        for (; j < eff; ++j) {
+            const uint32_t rw = src[j];
+            row0[((j >> 1) * kMtMarkers + lane) * 2 + (j & 1)] = row_of_idx[rw & 0xffu] | hi_of_count[rw >> 8];
         }
+        for (; j < slots; ++j) row0[((j >> 1) * kMtMarkers + lane) * 2 + (j & 1)] = pad4;
         if (in->known_af) {
             kaf_s[m] = in->known_af[i];
         } else {
             for (int kk = 0; kk < k; ++kk) ud_s[(size_t)kk * m_pad + m] = in->ud[(size_t)i * k + kk];
             mu_s[m] = in->means[i];
         }
-        // the g1 == g2 terms of h:307-311 are constants of the marker
-        cdiag[m] = c_other;
-        cdiag[m_pad + m] = std::exp(dg[0] + c_other);
-        cdiag[2 * m_pad + m] = std::exp(dg[1] + c_other);
-        cdiag[3 * m_pad + m] = std::exp(dg[2] + c_other);
+        const double* cd = cd_tmp + (size_t)i * 4;
+        cdiag[m] = cd[0];
+        cdiag[m_pad + m] = cd[1];
+        cdiag[2 * m_pad + m] = cd[2];
+        cdiag[3 * m_pad + m] = cd[3];
     }
     });
 
     const auto t_flat = tnow();
+    if (dry) {
+        if (timing)
+            std::fprintf(stderr, "flatten (dry): %.1f ms (classify %.1f, dictionary+sort %.1f, pack %.1f; %d threads)\n",
+                         tms(t_start, t_flat), tms(t_start, t_pass1), tms(t_pass1, t_sort), tms(t_sort, t_flat), nthr);
+        return VB2_OK;
+    }
     c->d_slab = slab_cache().take(slab_cache().dev, dev_total, dev, &c->d_slab_bytes);
     if (!c->d_slab) {
         VB2_HIP(hipMalloc((void**)&c->d_slab, dev_total));

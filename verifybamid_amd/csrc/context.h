@@ -23,6 +23,8 @@ int usable_device_count();
 // container with a CFS quota still sees every core of the host; threads beyond the quota only
 // get the whole cgroup throttled (measured on the 256-thread GPU host with a 16-CPU quota).
 int usable_cpu_count();
+// The host half of vb2_ctx_create (flatten) without a device: timing aid for tools/ubench/host_pipeline.cpp.
+int flatten_dry_run(const vb2_input* in, double* ms);
 extern std::atomic<int> g_flatten_thread_cap;   // 0 = no cap on the flatten threads of vb2_ctx_create
 
 constexpr int kStagePoints = 256;   // points per host<->device staging round
@@ -43,6 +45,7 @@ public:
     bool sched_enabled = true;               // VB2_SCHED=0: in-kernel snake deal
     std::vector<uint32_t> h_mt_rows;         // rows per micro-tile (host copy: the schedules are built from it)
     static int create(const vb2_input* in, const vb2_options* opt, Context** out);
+    static int create_impl(const vb2_input* in, const vb2_options* opt, Context** out, bool dry);
     // device pointers, asynchronous on s (nullptr = own stream)
     int eval_device(int num_point, const double* d_points, double* d_llk, hipStream_t s,
                     unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0,

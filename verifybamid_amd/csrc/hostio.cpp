@@ -1,6 +1,10 @@
 // hostio.cpp -- see hostio.h.
 #include "hostio.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -30,6 +34,30 @@ int io_error(const std::string& what)
 // read as it is -- zlib's gzread does both.
 bool slurp(const std::string& path, std::string* all)
 {
+    // plain files (everything but the gzip'd panels the reference's InputFile also accepts) are
+    // read in one go; zlib's transparent mode would copy them through its own buffers
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        unsigned char magic[2] = {0, 0};
+        struct stat st;
+        const bool regular = ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+        const ssize_t got = regular ? ::pread(fd, magic, 2, 0) : 0;
+        if (regular && !(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+            all->resize((size_t)st.st_size);
+            size_t done = 0;
+            while (done < all->size()) {
+                const ssize_t n = ::read(fd, &(*all)[done], all->size() - done);
+                if (n < 0) { ::close(fd); return false; }
+                if (n == 0) break;                       // (shrank meanwhile)
+                done += (size_t)n;
+            }
+            all->resize(done);
+            ::close(fd);
+            return true;
+        }
+        ::close(fd);
+    }
     gzFile f = gzopen(path.c_str(), "rb");
     if (!f) return false;
     gzbuffer(f, 1 << 20);
@@ -52,7 +80,16 @@ bool slurp(const std::string& path, std::string* all)
 // differential tests compare the two paths on deliberately odd files.
 inline bool slow_parse() { const char* e = std::getenv("VB2_SLOW_PARSE"); return e && e[0] == '1'; }
 
-inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
+struct WsTable {
+    unsigned char ws[256];
+    WsTable()
+    {
+        std::memset(ws, 0, sizeof(ws));
+        for (const char* k = " \t\r\v\f\n"; *k; ++k) ws[(unsigned char)*k] = 1;
+    }
+};
+static const WsTable kWs;
+inline bool is_ws(char c) { return kWs.ws[(unsigned char)c] != 0; }
 
 struct Scan {
     const char* p;
@@ -180,8 +217,9 @@ int read_bed(const std::string& path, Panel* p)
     std::string chr;
     int pos = 0;
     char ref = 0, alt = 0;
-    std::unordered_map<int, std::pair<char, char>>* inner = nullptr;    // ChooseBed[chr] of the last line
+    std::unordered_map<int, int32_t>* inner = nullptr;    // slotOf[chr] of the last line
     std::string inner_chr;
+    int32_t inner_id = -1;
     const bool slow = slow_parse();
     for_each_line(all, false, [&](const char* b, const char* e) {
         Scan sc{b, e};
@@ -201,12 +239,45 @@ int read_bed(const std::string& path, Panel* p)
         }
         p->PosVec.push_back(std::make_pair(chr, pos));
         if (!inner || inner_chr != chr) {
-            inner = &p->ChooseBed[chr];
+            const bool fresh = p->slotOf.find(chr) == p->slotOf.end();
+            inner = &p->slotOf[chr];
             inner_chr = chr;
+            if (fresh) {
+                inner_id = (int32_t)p->chrNames.size();
+                p->chrNames.push_back(chr);
+            } else {
+                inner_id = 0;
+                while (p->chrNames[inner_id] != chr) ++inner_id;
+            }
         }
-        (*inner)[pos] = std::make_pair(ref, alt);
+        // ChooseBed[chr][pos] = (ref, alt): a repeated position keeps its slot, the later alleles win
+        auto ins = inner->emplace(pos, (int32_t)p->slotPos.size());
+        const int32_t slot = ins.first->second;
+        if (ins.second) {
+            p->slotPos.push_back(pos);
+            p->slotChr.push_back(inner_id);
+            p->slotRef.push_back(ref);
+            p->slotAlt.push_back(alt);
+        } else {
+            p->slotRef[slot] = ref;
+            p->slotAlt[slot] = alt;
+        }
+        p->rowSlot.push_back(slot);
     });
     return VB2_OK;
+}
+
+void Panel::finish()
+{
+    slotAF.assign(num_slot(), 0.0);
+    if (!isAFknown) return;
+    // the reference's knownAF[chr][pos] yields 0 for a site the AF file does not list
+    for (size_t s = 0; s < num_slot(); ++s) {
+        auto ac = knownAF.find(chrNames[slotChr[s]]);
+        if (ac == knownAF.end()) continue;
+        auto ap = ac->second.find((uint32_t)slotPos[s]);
+        if (ap != ac->second.end()) slotAF[s] = ap->second;
+    }
 }
 
 // ContaminationEstimator.cpp:342-373: first numPC columns; fewer is fatal.
@@ -299,8 +370,8 @@ namespace {
 // ignore everything else ("$", ...).
 // Returns false where the reference's std::stoi throws (an indel marker without a length, or a
 // length that does not fit an int): the reference dies on that line, this reader reports it.
-bool parse_bases(const std::string& seq, const std::string& qual, std::string* pseq,
-                 std::string* pqual)
+// Core on character ranges: ps / pq must have room for n characters; *out = pairs kept.
+bool parse_bases_raw(const char* seq, size_t n, const char* qual, size_t nq, char* ps, char* pq, size_t* out)
 {
     // character classes: 1 keep (one quality each), 2 '*' '#' (consume a quality), 3 '+' '-'
     // (indel: skip the length and that many characters), 4 '^' (skip the next character)
@@ -315,11 +386,6 @@ bool parse_bases(const std::string& seq, const std::string& qual, std::string* p
             cls[(unsigned char)'^'] = 4;
         }
     } table;
-    const size_t n = seq.size(), nq = qual.size();
-    pseq->resize(n);
-    pqual->resize(n);
-    char* ps = &(*pseq)[0];
-    char* pq = &(*pqual)[0];
     size_t iq = 0, o = 0;
     for (size_t i = 0; i < n; ++i) {
         const char c = seq[i];
@@ -353,6 +419,19 @@ bool parse_bases(const std::string& seq, const std::string& qual, std::string* p
             break;
         }
     }
+    *out = o;
+    return true;
+}
+
+bool parse_bases(const std::string& seq, const std::string& qual, std::string* pseq,
+                 std::string* pqual)
+{
+    const size_t n = seq.size();
+    pseq->resize(n);
+    pqual->resize(n);
+    size_t o = 0;
+    if (!parse_bases_raw(seq.data(), n, qual.data(), qual.size(), n ? &(*pseq)[0] : nullptr, n ? &(*pqual)[0] : nullptr, &o))
+        return false;
     pseq->resize(o);
     pqual->resize(o);
     return true;
@@ -360,21 +439,86 @@ bool parse_bases(const std::string& seq, const std::string& qual, std::string* p
 }  // namespace
 
 // SimplePileupViewer.cpp:748-833.
-int read_pileup(const std::string& path, const BedTable& bed, PileupViewer* v)
+//
+// The reference reads every line with `ss >> chr >> pos >> ref >> depth >> seq >> qual` into
+// variables that live across lines, so a short or malformed line inherits the fields of the line
+// before it (after that line's own processing: parsed strings for a line outside the .bed, empty
+// strings and depth 0 for a line inside it).  Plainly formatted lines -- all of them, normally --
+// take the scanner below and never touch those variables; the state a following malformed line
+// would inherit is rebuilt from the remembered line only when such a line turns up.
+int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v)
 {
     std::string all;
     if (!slurp(path, &all)) return io_error("open file " + path + " failed!");
-    int global_index = 0;
-    std::string chr, ref, seq, qual, pseq, pqual;
+    v->init(panel);
+    v->basePool.reserve(all.size() / 3);
+    v->qualPool.reserve(all.size() / 3);
+    v->siteOff.reserve(panel.num_slot() + 1);
+    std::string chr, ref, seq, qual, pseq, pqual;          // the reference's persistent variables
     int pos = 0, depth = 0;
     v->numBases = 0;
     int rc = VB2_OK;
-    // per-chromosome tables of the last line (consecutive lines share the chromosome)
-    std::string cur_chr;
-    const std::unordered_map<int, std::pair<char, char>>* bed_chr = nullptr;
-    std::unordered_map<int32_t, int32_t>* idx_chr = nullptr;
-    bool have_cur = false;
+    // the last plainly formatted line, not yet folded into the variables above
+    struct Last {
+        bool pending = false, in_bed = false;
+        const char *c0, *c1, *r0, *r1, *s0, *s1, *q0, *q1;
+        int pos;
+    } last;
+    auto materialise = [&]() {
+        if (!last.pending) return;
+        last.pending = false;
+        chr.assign(last.c0, last.c1);
+        pos = last.pos;
+        ref.assign(last.r0, last.r1);
+        if (last.in_bed) {                                  // cpp:825-827
+            depth = 0;
+            seq.clear();
+            qual.clear();
+        } else {                                            // the parsed strings persist (:785-786)
+            seq.assign(last.s0, last.s1);
+            qual.assign(last.q0, last.q1);
+            parse_bases(seq, qual, &pseq, &pqual);
+            seq = pseq;
+            qual = pqual;
+            depth = (int)pqual.length();
+        }
+    };
+    // per-chromosome table of the last line (consecutive lines share the chromosome); the next
+    // line usually is the next slot of the .bed, which needs no table at all
+    const std::unordered_map<int, int32_t>* tab = nullptr;
+    const char* tab_c0 = nullptr;
+    size_t tab_len = 0;
+    int32_t next_slot = 0;
+    const int32_t nslot = (int32_t)panel.num_slot();
+    auto slot_of = [&](const char* c0, const char* c1, int p) -> int32_t {
+        const size_t len = (size_t)(c1 - c0);
+        if (next_slot < nslot && panel.slotPos[next_slot] == p) {
+            const std::string& name = panel.chrNames[panel.slotChr[next_slot]];
+            if (name.size() == len && std::memcmp(name.data(), c0, len) == 0) return next_slot;
+        }
+        if (!tab_c0 || tab_len != len || std::memcmp(tab_c0, c0, len) != 0) {
+            auto it = panel.slotOf.find(std::string(c0, c1));
+            tab = it == panel.slotOf.end() ? nullptr : &it->second;
+            tab_c0 = c0;
+            tab_len = len;
+        }
+        if (!tab) return -1;
+        auto s = tab->find(p);
+        return s == tab->end() ? -1 : s->second;
+    };
+    auto record = [&](int32_t slot, const char* b, const char* q, size_t n) {
+        if (v->siteOfSlot[slot] >= 0) {
+            std::cerr << "[WARNING] The pileup file has duplicated lines! Merged here" << std::endl;
+            // the reference builds a merged copy and then drops it (quirk vii)
+        } else {
+            v->add_site(slot, b, q, n);
+        }
+        v->numBases += (int)n;
+        v->effectiveNumSite++;
+        next_slot = slot + 1;
+    };
     const bool slow = slow_parse();
+    std::string scratch_b, scratch_q;
     for_each_line(all, true, [&](const char* b, const char* e) {
         if (rc) return;
         Scan sc{b, e};
@@ -382,13 +526,33 @@ int read_pileup(const std::string& path, const BedTable& bed, PileupViewer* v)
         int ppos = 0, pdepth = 0;
         if (!slow && sc.token(&c0, &c1) && sc.token(&p0, &p1) && plain_int(p0, p1, &ppos) && sc.token(&r0, &r1) &&
             sc.token(&d0, &d1) && plain_int(d0, d1, &pdepth) && sc.token(&s0, &s1) && sc.token(&q0, &q1)) {
-            chr.assign(c0, c1);
-            pos = ppos;
-            ref.assign(r0, r1);
-            depth = pdepth;
-            seq.assign(s0, s1);
-            qual.assign(q0, q1);
-        } else {                                    // fields persist across malformed lines
+            const size_t n = (size_t)(s1 - s0);
+            if (r1 - r0 == 1 && *r0 == '.' && (std::memchr(s0, '.', n) || std::memchr(s0, ',', n))) {
+                set_error("Pileup format error: cannot find ref allele, exit!");
+                rc = VB2_ERR_INVALID;
+                return;
+            }
+            // parse straight into the pools' spare room; kept only if the line is a new site
+            scratch_b.resize(n);
+            scratch_q.resize(n);
+            size_t kept = 0;
+            if (!parse_bases_raw(s0, n, q0, (size_t)(q1 - q0), n ? &scratch_b[0] : nullptr, n ? &scratch_q[0] : nullptr, &kept)) {
+                set_error("Pileup format error: indel marker without a valid length in the bases column of " +
+                          std::string(c0, c1) + ":" + std::to_string(ppos));
+                rc = VB2_ERR_INVALID;
+                return;
+            }
+            const int32_t slot = slot_of(c0, c1, ppos);
+            last.pending = true;
+            last.in_bed = slot >= 0;
+            last.c0 = c0; last.c1 = c1; last.r0 = r0; last.r1 = r1; last.s0 = s0; last.s1 = s1; last.q0 = q0; last.q1 = q1;
+            last.pos = ppos;
+            if (slot >= 0) record(slot, scratch_b.data(), scratch_q.data(), kept);
+            return;
+        }
+        // any other line: the original statements, on the variables as the previous lines left them
+        materialise();
+        {
             std::stringstream ss(std::string(b, e));
             ss >> chr >> pos >> ref >> depth >> seq >> qual;
         }
@@ -406,34 +570,13 @@ int read_pileup(const std::string& path, const BedTable& bed, PileupViewer* v)
         seq = pseq;                                         // the parsed strings are what persists
         qual = pqual;                                       // into a following short line (:785-786)
         depth = (int)pqual.length();                        // SNP bases only
-        if (!have_cur || cur_chr != chr) {
-            cur_chr = chr;
-            have_cur = true;
-            auto bc = bed.find(chr);
-            bed_chr = bc == bed.end() ? nullptr : &bc->second;
-            auto pc = v->posIndex.find(chr);
-            idx_chr = pc == v->posIndex.end() ? nullptr : &pc->second;
-        }
-        if (!bed_chr || bed_chr->find(pos) == bed_chr->end()) return;
-
-        bool existed = false;
-        if (idx_chr && idx_chr->find(pos) != idx_chr->end()) existed = true;
-        else {
-            if (!idx_chr) idx_chr = &v->posIndex[chr];
-            (*idx_chr)[pos] = global_index++;
-        }
-        if (existed) {
-            std::cerr << "[WARNING] The pileup file has duplicated lines! Merged here" << std::endl;
-            // the reference builds a merged copy and then drops it (quirk vii)
-        } else {
-            v->baseInfo.push_back(pseq);
-            v->qualInfo.push_back(pqual);
-        }
-        v->numBases += depth;
+        const int32_t slot = slot_of(chr.data(), chr.data() + chr.size(), pos);
+        tab_c0 = nullptr;                                   // (chr's buffer is not part of `all`)
+        if (slot < 0) return;
+        record(slot, pseq.data(), pqual.data(), pqual.size());
         depth = 0;
         seq = "";
         qual = "";
-        v->effectiveNumSite++;
     });
     if (rc) return rc;
     v->avgDepth = (double)v->numBases / v->effectiveNumSite;
@@ -446,12 +589,10 @@ bool sanity_check(const Panel& p, PileupViewer* v)
     std::fprintf(stderr, "NOTICE - Number of marker in Reference Matrix:%d\n", (int)p.NumMarker);
     std::fprintf(stderr, "NOTICE - Number of marker shared with input file:%d\n", v->effectiveNumSite);
     auto depth_at = [&](size_t i, int* d) {
-        if (i >= p.PosVec.size()) return false;
-        auto c = v->posIndex.find(p.PosVec[i].first);
-        if (c == v->posIndex.end()) return false;
-        auto s = c->second.find(p.PosVec[i].second);
-        if (s == c->second.end()) return false;
-        *d = (int)v->baseInfo[s->second].size();
+        if (i >= p.rowSlot.size()) return false;
+        const int32_t site = v->site_of(p.rowSlot[i]);
+        if (site < 0) return false;
+        *d = (int)v->depth(site);
         return true;
     };
     int d = 0;
@@ -510,16 +651,17 @@ int write_pileup(const std::string& prefix, const vb2_flat& f)
     const std::string name(prefix + ".Pileup");
     std::ofstream fout(name);
     if (!fout.is_open()) return io_error("Open file " + name + " failed!");
-    for (const auto& item : f.panel.PosVec) {
-        auto c = f.viewer.posIndex.find(item.first);
-        if (c == f.viewer.posIndex.end()) continue;
-        auto s = c->second.find(item.second);
-        if (s == c->second.end()) continue;
-        const std::string& b = f.viewer.baseInfo[s->second];
-        if (b.empty()) continue;
-        fout << item.first << "\t" << item.second << "\t"
-             << f.panel.ChooseBed.at(item.first).at(item.second).first << "\t" << b.size() << "\t"
-             << b << "\t" << f.viewer.qualInfo[s->second] << std::endl;
+    for (size_t i = 0; i < f.panel.PosVec.size(); ++i) {
+        const auto& item = f.panel.PosVec[i];
+        const int32_t slot = f.panel.rowSlot[i], site = f.viewer.site_of(slot);
+        if (site < 0) continue;
+        const uint32_t n = f.viewer.depth(site);
+        if (n == 0) continue;
+        fout << item.first << "\t" << item.second << "\t" << f.panel.slotRef[slot] << "\t" << n << "\t";
+        fout.write(f.viewer.bases(site), n);
+        fout << "\t";
+        fout.write(f.viewer.quals(site), n);
+        fout << std::endl;
     }
     fout.close();
     if (!fout) return io_error("Errors detected when writing to file " + name + " !");
@@ -552,28 +694,18 @@ void vb2_flat::resolve()
     bases.clear();
     quals.clear();
     num_site = 0;
+    bases.reserve(viewer.basePool.size());
+    quals.reserve(viewer.qualPool.size());
     for (uint32_t i = 0; i < M; ++i) {
         read_off[i] = (int64_t)bases.size();
-        if (i >= panel.PosVec.size()) continue;
-        const std::string& chr = panel.PosVec[i].first;
-        const int pos = panel.PosVec[i].second;
-        auto c = viewer.posIndex.find(chr);
-        if (c == viewer.posIndex.end()) continue;
-        auto s = c->second.find(pos);
-        if (s == c->second.end()) continue;
+        if (i >= panel.rowSlot.size()) continue;
+        const int32_t slot = panel.rowSlot[i], site = viewer.site_of(slot);
+        if (site < 0) continue;
         ++num_site;
-        bases += viewer.baseInfo[s->second];
-        quals += viewer.qualInfo[s->second];
-        // lookups only: the panel may be shared by several samples being resolved at once
-        alt_base[i] = panel.ChooseBed.at(chr).at(pos).second;
-        if (panel.isAFknown) {
-            // the reference's knownAF[chr][pos] yields 0 for a site the AF file does not list
-            auto ac = panel.knownAF.find(chr);
-            if (ac != panel.knownAF.end()) {
-                auto ap = ac->second.find((uint32_t)pos);
-                if (ap != ac->second.end()) known_af[i] = ap->second;
-            }
-        }
+        bases.append(viewer.bases(site), viewer.depth(site));
+        quals.append(viewer.quals(site), viewer.depth(site));
+        alt_base[i] = panel.slotAlt[slot];
+        if (panel.isAFknown && (size_t)slot < panel.slotAF.size()) known_af[i] = panel.slotAF[slot];
     }
     read_off[M] = (int64_t)bases.size();
     input = vb2_input{};

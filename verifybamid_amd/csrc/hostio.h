@@ -21,34 +21,75 @@
 
 namespace vb2 {
 
-typedef std::unordered_map<std::string, std::unordered_map<int, std::pair<char, char>>> BedTable;
-
+// The .bed rows name positions; a position listed twice is ONE entry of the reference's
+// ChooseBed[chr][pos] map (the later row's alleles win, cpp:433).  Here every distinct (chr, pos)
+// gets a dense id in order of first appearance -- a "slot" -- so that everything per position is a
+// flat array: one hash lookup per pileup line, none per marker afterwards.
 struct Panel {
     int numPC = 0;
     uint32_t NumMarker = 0;                               // rows of .UD (cpp:366)
     std::vector<double> UD;                               // NumMarker x numPC
     std::vector<double> means;
-    std::vector<std::pair<std::string, int>> PosVec;      // cpp:432
-    BedTable ChooseBed;                                   // cpp:433 (pos is 1-based)
+    std::vector<std::pair<std::string, int>> PosVec;      // cpp:432 (pos is 1-based)
+    // ChooseBed (cpp:433) as slots
+    std::unordered_map<std::string, std::unordered_map<int, int32_t>> slotOf;   // (chr, pos) -> slot
+    std::vector<int32_t> rowSlot;                         // PosVec row -> slot
+    std::vector<char> slotRef, slotAlt;                   // ChooseBed[chr][pos].first / .second
+    std::vector<int32_t> slotPos, slotChr;                // the slot's position; index into chrNames
+    std::vector<std::string> chrNames;
     bool isAFknown = false;
     std::unordered_map<std::string, std::unordered_map<uint32_t, double>> knownAF;
+    std::vector<double> slotAF;                           // knownAF[chr][pos] per slot (0 where the AF file has no row)
+    size_t num_slot() const { return slotPos.size(); }
+    int32_t find_slot(const std::string& chr, int pos) const
+    {
+        auto c = slotOf.find(chr);
+        if (c == slotOf.end()) return -1;
+        auto s = c->second.find(pos);
+        return s == c->second.end() ? -1 : s->second;
+    }
+    void finish();                                        // after read_bed (+ read_known_af): slotAF
 };
 
-struct PileupViewer {                                     // SimplePileupViewer.h:84-147
-    std::vector<std::string> baseInfo, qualInfo;
-    std::unordered_map<std::string, std::unordered_map<int32_t, int32_t>> posIndex;
+// SimplePileupViewer.h:84-147: baseInfo / qualInfo / posIndex.  A "site" is a pileup line whose
+// position is in the .bed, numbered in order of appearance (the reference's global index); its
+// parsed bases and qualities sit back to back in two pools instead of one std::string each.
+struct PileupViewer {
+    std::string basePool, qualPool;
+    std::vector<uint32_t> siteOff{0};                     // site s owns [siteOff[s], siteOff[s + 1])
+    std::vector<int32_t> siteOfSlot;                      // panel slot -> site, -1 = not in the pileup (posIndex)
     std::string SEQ_SM = "DefaultSampleName";
     int numBases = 0;
     int effectiveNumSite = 0;
     double avgDepth = 0;
     double sdDepth = 0;
+    void init(const Panel& p)
+    {
+        siteOfSlot.assign(p.num_slot(), -1);
+        siteOff.assign(1, 0u);
+        basePool.clear();
+        qualPool.clear();
+    }
+    int num_site() const { return (int)siteOff.size() - 1; }
+    int32_t site_of(int32_t slot) const { return slot >= 0 && (size_t)slot < siteOfSlot.size() ? siteOfSlot[slot] : -1; }
+    uint32_t depth(int32_t site) const { return siteOff[site + 1] - siteOff[site]; }
+    const char* bases(int32_t site) const { return basePool.data() + siteOff[site]; }
+    const char* quals(int32_t site) const { return qualPool.data() + siteOff[site]; }
+    // a new site for `slot` with n parsed (base, quality) pairs
+    void add_site(int32_t slot, const char* b, const char* q, size_t n)
+    {
+        siteOfSlot[slot] = num_site();
+        basePool.append(b, n);
+        qualPool.append(q, n);
+        siteOff.push_back((uint32_t)basePool.size());
+    }
 };
 
 int read_bed(const std::string& path, Panel* p);
 int read_ud(const std::string& path, Panel* p);
 int read_mean(const std::string& path, Panel* p);
 int read_known_af(const std::string& path, Panel* p);
-int read_pileup(const std::string& path, const BedTable& bed, PileupViewer* v);
+int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v);
 // BAM/CRAM input through htslib (bam_flatten.cpp; VB2_ERR_IO with an explanation when the library was
 // built without htslib).  SimplePileupViewer.cpp:172-557 with main.cpp:81-96's defaults.
 int read_bam(const std::string& bam_path, const std::string& ref_path, const Panel& panel, PileupViewer* v);
