@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--num-pc", type=int, default=4)
     ap.add_argument("--mode", choices=["sample", "marker"], default="sample")
     ap.add_argument("--cohort-samples", type=int, default=32, help="samples of the single-GPU cohort leg (0 = skip)")
+    ap.add_argument("--cohort-files", type=int, default=256,
+                    help="samples of the cohort-from-text-files leg (BASELINE configs[4] per GPU; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimize", action="store_true")
     ap.add_argument("--soft-exit", action="store_true",
@@ -403,6 +405,44 @@ def main():
                 "optimize_ms_per_sample": 1e3 * dto / S, "samples_per_s_search_only": S / dto,
                 "alpha_first": ests[0]["alpha"],
             }
+        if world == 1 and not args.no_extras and args.cohort_samples > 0 and args.cohort_files > 0:
+            # the same cohort from TEXT files (vb2_cohort_run: the panel read once, pileups parsed and
+            # flattened by host threads while the device searches the previous group) -- BASELINE.json
+            # configs[4] per GPU, end to end.  8 distinct pileups, read cyclically.
+            import shutil
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="vb2_bench_")
+            try:
+                base = vb.synth.with_sanity_stats(data)
+                pre = vb.synth.write_files(base, os.path.join(tmp, "panel"))
+                piles = []
+                for s_ in range(8):
+                    dd = vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.01 * (1 + s_), seed=2000 + s_)
+                    dd = vb.PileupData(k, base.ud, base.means, dd.read_off, dd.bases, dd.quals, base.alt_base, None,
+                                       dd.avg_depth, dd.sd_depth, True, dict(base.meta))
+                    piles.append(vb.synth.write_files(dd, os.path.join(tmp, "s%d" % s_)) + ".pileup")
+                nf = args.cohort_files
+                paths = [piles[i % len(piles)] for i in range(nf)]
+                outs = [os.path.join(tmp, "out%d" % i) for i in range(nf)]
+                with open(os.devnull, "w") as devnull:          # (the reference's NOTICE lines: 3 per sample)
+                    saved = os.dup(2)
+                    os.dup2(devnull.fileno(), 2)
+                    try:
+                        t1 = time.perf_counter()
+                        res = vb.run_cohort_files(pre, paths, outs, num_pc=k)
+                        dtf = time.perf_counter() - t1
+                    finally:
+                        os.dup2(saved, 2)
+                        os.close(saved)
+                ok = sum(1 for r in res if r["status"] == 0)
+                result["cohort"]["from_text"] = {
+                    "what": "vb2_cohort_run on %d C3-shaped text pileups (7.6 MB each) + one panel, outputs written; "
+                            "wall-clock of the call" % nf,
+                    "samples": nf, "samples_ok": ok, "seconds": dtf, "samples_per_s": nf / dtf,
+                    "alpha_first": res[0]["alpha"],
+                }
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
         # small parity probe against the oracle (checker only; after the GPU legs: its OpenMP threads
         # spin for a while after the call and would slow the launching thread down)
         from oracle.bridge import oracle_data

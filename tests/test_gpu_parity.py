@@ -539,6 +539,35 @@ def test_cohort_run_equals_per_sample_runs(tmp_path):
     assert not os.path.exists(outs[7] + ".Ancestry")
 
 
+def test_cohort_run_group_schedule_does_not_change_results(tmp_path):
+    """vb2_cohort_run's groups (a device's first groups are small, the later ones full size; a
+    function of the sample count only) against plain equal groups: 40 samples, the same estimates
+    (the likelihood sums differ in the last bits with the workgroups a sample gets), every output
+    file equal.  Groups of 8 and more search with {R, C_R} speculation on fibers of one thread."""
+    k, M = 2, 1800
+    base = vb.synth.with_sanity_stats(vb.synth.make_pileup(M, 12, k, alpha_true=0.03, seed=70))
+    pre = vb.synth.write_files(base, str(tmp_path / "panel"))
+    piles = []
+    for s in range(5):
+        d = vb.synth.make_pileup(M, 9 + 2 * s, k, alpha_true=0.03 * (s + 1), seed=80 + s)
+        d = vb.PileupData(k, base.ud, base.means, d.read_off, d.bases, d.quals, base.alt_base, None,
+                          d.avg_depth, d.sd_depth, True, dict(base.meta))
+        piles.append(vb.synth.write_files(d, str(tmp_path / ("s%d" % s))) + ".pileup")
+    S = 40
+    paths = [piles[s % 5] for s in range(S)]
+    out_a = [str(tmp_path / ("a%d" % s)) for s in range(S)]
+    out_b = [str(tmp_path / ("b%d" % s)) for s in range(S)]
+    ramp = vb.run_cohort_files(pre, paths, out_a, num_pc=k)                       # groups of 16 and 24
+    flat = vb.run_cohort_files(pre, paths, out_b, num_pc=k, group_size=-5)        # eight groups of 5
+    assert all(r["status"] == 0 for r in ramp) and all(r["status"] == 0 for r in flat)
+    for s in range(S):
+        assert abs(ramp[s]["alpha"] - flat[s]["alpha"]) <= 1e-9, s
+        assert abs(ramp[s]["alpha"] - ramp[s % 5]["alpha"]) <= 1e-9, s            # same file, same answer
+        assert rel_err([ramp[s]["llk1"], ramp[s]["llk0"]], [flat[s]["llk1"], flat[s]["llk0"]]) <= LLK_RTOL
+        for ext in (".Ancestry", ".selfSM"):
+            assert open(out_a[s] + ext).read() == open(out_b[s] + ext).read(), (s, ext)
+
+
 def test_insufficient_markers_fails_sanity(golden_dir, tmp_path):
     with pytest.raises(_abi.Vb2Error) as ei:
         vb.run_files(os.path.join(golden_dir, HAPMAP), os.path.join(golden_dir, "test.LongRead.pileup"),
