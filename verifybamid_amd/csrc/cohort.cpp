@@ -88,6 +88,8 @@ public:
             std::memset(&out_[s], 0, sizeof(out_[s]));
             status_[s] = VB2_ERR_INVALID;
         }
+        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+        const double t_run0 = now_s();
         // HIP runtime start-up (per device) behind the panel reading
         std::vector<std::thread> warm;
         for (int d : devices_)
@@ -105,8 +107,10 @@ public:
             for (auto& t : warm) t.join();
             throw;
         }
+        const double t_panel = now_s();
         for (auto& t : warm) t.join();
         if (rc) return rc;
+        const double t_warm = now_s();
         model_ = a_->base.model;
         if (panel_->isAFknown) model_.is_af_known = 1;
         vb2::g_flatten_thread_cap.store(std::max(1, 16 / T_));
@@ -116,8 +120,14 @@ public:
         for (int d = 0; d < ndev_; ++d) dev_threads_.emplace_back([this, d] { device_loop(d); });
         for (auto& t : dev_threads_) t.join();
         dev_threads_.clear();
+        const double t_dev = now_s();
         shutdown();
-        if (std::getenv("VB2_DEBUG_TIMING"))
+        if (timing)
+            std::fprintf(stderr, "vb2_cohort_run: panel %.1f ms, HIP start-up beyond that %.1f ms, pipelines %.1f ms, "
+                                 "shutdown (release contexts, join) %.1f ms; releaser: %.2f ms per context, %.2f ms per sample's host arrays\n",
+                         1e3 * (t_panel - t_run0), 1e3 * (t_warm - t_panel), 1e3 * (t_dev - t_warm), 1e3 * (now_s() - t_dev),
+                         1e3 * rel_s_[0] / S_, 1e3 * rel_s_[1] / S_);
+        if (timing)
             std::fprintf(stderr, "vb2_cohort_run: %d reader threads, per sample: read_pileup %.1f ms, sanity + resolve %.1f ms, "
                                  "vb2_ctx_create %.1f ms (wall-clock inside the reader threads)\n", T_,
                          1e3 * phase_s_[0] / S_, 1e3 * phase_s_[1] / S_, 1e3 * phase_s_[2] / S_);
@@ -149,6 +159,7 @@ private:
     bool rel_stop_ = false;
     bool down_ = false;
 
+    double rel_s_[2] = {0, 0};             // releaser thread: vb2_ctx_destroy, freeing the host arrays
     double phase_s_[3] = {0, 0, 0};        // reader threads' wall-clock: read_pileup, sanity + resolve, vb2_ctx_create
 
     int device_of_group(int gi) const { return gi % ndev_; }
@@ -206,6 +217,15 @@ private:
         vb2_options opt{};
         opt.device = devices_[device_of_group(group_of_[s])];
         sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
+        // the context holds its own (flattened) copy: the sample's text-sized arrays go back now, on
+        // this reader thread, instead of piling up in front of the single releaser (the writers need
+        // only the viewer's counters and the panel)
+        std::string().swap(f.bases);
+        std::string().swap(f.quals);
+        std::string().swap(f.viewer.basePool);
+        std::string().swap(f.viewer.qualPool);
+        std::vector<int64_t>().swap(f.read_off);
+        f.input = vb2_input{};
         const double t_end = now_s();
         out_[s].seconds_load = t_end - t0;
         {
@@ -257,7 +277,12 @@ private:
                 item = std::move(rel_queue_.front());
                 rel_queue_.pop_front();
             }
+            const double t0 = now_s();
             if (item.first) vb2_ctx_destroy(item.first);
+            const double t1 = now_s();
+            item.second.reset();
+            rel_s_[0] += t1 - t0;
+            rel_s_[1] += now_s() - t1;
         }
     }
 

@@ -48,11 +48,12 @@ namespace {
 // Freed device / pinned slabs are kept for the next context of the process instead of going
 // back to the driver: hipFree and hipHostFree synchronise with the device and cost milliseconds
 // each (a cohort run creates and destroys a context per sample: 5 ms per sample went there).
-// Bounded: at most kMaxCached slabs per kind, and a slab is only reused for a request of at
-// least half its size.  VB2_SLAB_CACHE=0 turns the cache off.
+// Bounded: at most kMaxCached slabs and kMaxCachedBytes per kind (a cohort run has up to three
+// groups of 64 contexts alive), and a slab is only reused for a request of at least half its
+// size.  VB2_SLAB_CACHE=0 turns the cache off.
 struct SlabCache {
     struct Entry { void* p; size_t bytes; int device; };
-    static constexpr size_t kMaxCached = 96;
+    static constexpr size_t kMaxCached = 256, kMaxCachedBytes = (size_t)8 << 30;
     std::mutex mu;
     std::vector<Entry> dev, pin, stage;      // device slabs, small pinned slabs, big pinned upload staging
     bool enabled() { static const bool on = !(std::getenv("VB2_SLAB_CACHE") && std::getenv("VB2_SLAB_CACHE")[0] == '0'); return on; }
@@ -76,7 +77,32 @@ struct SlabCache {
         if (!enabled()) return false;
         std::lock_guard<std::mutex> lk(mu);
         if (v.size() >= kMaxCached) return false;
+        size_t held = bytes;
+        for (const Entry& e : v) held += e.bytes;
+        if (held > kMaxCachedBytes) return false;
         v.push_back(Entry{p, bytes, device});
+        return true;
+    }
+    // streams of destroyed contexts (idle: the context synchronised before giving it back), per device
+    std::vector<std::pair<hipStream_t, int>> streams;
+    hipStream_t take_stream(int device)
+    {
+        if (!enabled()) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < streams.size(); ++i)
+            if (streams[i].second == device) {
+                hipStream_t st = streams[i].first;
+                streams.erase(streams.begin() + (long)i);
+                return st;
+            }
+        return nullptr;
+    }
+    bool give_stream(hipStream_t st, int device)
+    {
+        if (!enabled()) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (streams.size() >= kMaxCached) return false;
+        streams.emplace_back(st, device);
         return true;
     }
     ~SlabCache()
@@ -187,7 +213,7 @@ Context::~Context()
     if (d_slab && !slab_cache().give(slab_cache().dev, d_slab, d_slab_bytes, device)) (void)hipFree(d_slab);
     if (h_slab && !slab_cache().give(slab_cache().pin, h_slab, h_slab_bytes, device)) (void)hipHostFree(h_slab);
     if (h_trace_stage) (void)hipHostFree(h_trace_stage);
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    if (own_stream && stream && !slab_cache().give_stream(stream, device)) (void)hipStreamDestroy(stream);
 }
 
 int flatten_dry_run(const vb2_input* in, double* ms)
@@ -244,7 +270,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             c->stream = (hipStream_t)opt->stream;
             c->own_stream = false;
         } else {
-            VB2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->stream = slab_cache().take_stream(dev);
+            if (!c->stream) VB2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
             c->own_stream = true;
         }
     }
