@@ -377,6 +377,9 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
             } catch (const std::exception& e) {
                 set_error(e.what());
                 rcs[s] = VB2_ERR_INVALID;
+            } catch (...) {                      // nothing may unwind past the fiber's entry frame
+                set_error("vb2_batch_optimize_llk: unknown exception in a sample's search");
+                rcs[s] = VB2_ERR_INVALID;
             }
         };
         if (getcontext(&f.ctx) != 0) {
