@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VB2_ABI_VERSION 2
+#define VB2_ABI_VERSION 3
 
 typedef enum vb2_status {
     VB2_OK = 0,
@@ -165,7 +165,7 @@ typedef struct vb2_estimate {
     int64_t num_eval;          /* likelihood evaluations the reference would make  */
     int64_t num_launch_point;  /* points actually evaluated (speculation included) */
     int32_t converged;         /* 0 if a Minimize() ran out of cycles              */
-    int32_t reserved;
+    int32_t reserved;          /* vb2_ctx_optimize_llk_ex: index of the winning start, else 0 */
 } vb2_estimate;
 
 /* The objective seam, batched: the analogue of VectorFunc::Evaluate
@@ -194,6 +194,27 @@ int vb2_optimize_llk(vb2_eval_fn eval, void *user, int32_t num_pc, const vb2_mod
  * when the mode is unavailable (VB2_RESIDENT=0 forces that).  Same results either way. */
 int vb2_ctx_optimize_llk(vb2_ctx *ctx, const vb2_model *model, vb2_estimate *out,
                          vb2_trace *trace);
+
+/* Optimiser variants beyond the reference's single Nelder-Mead run; with
+ * num_start <= 1 and line_search == 0 this IS vb2_ctx_optimize_llk.
+ *  - Multi-start: num_start searches from different starting points advance in lock-step on the
+ *    context, the evaluations of one step leaving as ONE launch (north_star: "objective
+ *    evaluations batch across restarts").  Start 0 is the reference's (h:321-331: PCs 0.01, alpha
+ *    0.03); starts 1.. add seeded Gaussian noise to the free parameters -- what the reference's
+ *    commented-out rand() starts (h:322, 326) and its otherwise unused --Seed were for.  *best is
+ *    the run with the smallest llk1; all (optional) receives every run, all[0] = the reference's.
+ *  - Line search: a model with ONE free parameter (--FixPC / --KnownAF: alpha alone) is minimised
+ *    by golden-ratio bracketing + Brent's method (ScalarMinimizer, MathGold.cpp:27-195, which the
+ *    reference links but never calls) instead of the two-vertex simplex. */
+typedef struct vb2_search_opts {
+    int32_t num_start;         /* >= 1 (0 counts as 1); at most 64                 */
+    uint32_t seed;             /* --Seed                                           */
+    double start_sd;           /* noise on the PC starts; logit(alpha) gets 50 x; 0 = 0.02 */
+    int32_t line_search;       /* Brent for one-parameter models                   */
+    int32_t reserved;
+} vb2_search_opts;
+int vb2_ctx_optimize_llk_ex(vb2_ctx *ctx, const vb2_model *model, const vb2_search_opts *opts,
+                            vb2_estimate *best, vb2_estimate *all /* [num_start] or NULL */);
 
 /* ------------------------------------------------------------------------- *
  * 2b. Cohorts: several samples (contexts on one device, same --NumPC) advancing in
@@ -286,6 +307,9 @@ typedef struct vb2_run_args {
      * used when pileup_path is NULL.  A library built without htslib fails with VB2_ERR_IO. */
     const char *bam_path;
     const char *reference_path;
+    /* --NumStart / --Seed / --LineSearch: optimiser variants (vb2_search_opts); all zero = the
+     * reference's single Nelder-Mead run.  One sample on one device only. */
+    vb2_search_opts search;
 } vb2_run_args;
 
 typedef struct vb2_run_result {

@@ -181,6 +181,21 @@ def amoeba(fn, start, ftol=1e-8, which="oracle"):
     return ret, np.array(list(point))
 
 
+_SCALAR = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_double)
+
+
+def reference_scalar_minimize(fn, lo, hi, tol=1e-6):
+    """The reference's own ScalarMinimizer (MathGold.cpp: Bracket + Brent, compiled in place in
+    oracle/_ref) on a Python callable.  Returns dict(min, fmin, a, b, c)."""
+    r = ref_lib()
+    r.vb2ref_scalar_minimize.restype = None
+    r.vb2ref_scalar_minimize.argtypes = [_SCALAR, C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    out = (C.c_double * 5)()
+    cb = _SCALAR(lambda _u, x: float(fn(x)))
+    r.vb2ref_scalar_minimize(cb, None, float(lo), float(hi), float(tol), out)
+    return dict(zip(("min", "fmin", "a", "b", "c"), list(out)))
+
+
 class _AdapterIO(C.Structure):
     _fields_ = [
         ("num_pc", C.c_int32), ("is_heter", C.c_int32), ("is_pc_fixed", C.c_int32), ("is_alpha_fixed", C.c_int32),

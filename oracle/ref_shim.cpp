@@ -11,6 +11,7 @@
 //
 // The signature matches vb2o_minimizer in vb2_oracle.h.
 #include "MathGenMin.h"   // reference header, found through -I$(REF)
+#include "MathGold.h"     // ScalarMinimizer (Bracket + Brent), linked into the reference but never called there
 
 #include <limits>
 
@@ -41,6 +42,28 @@ extern "C" double vb2ref_amoeba_minimize(objective_fn f, void *user, int n,
     double ret = mini.Minimize(ftol);
     for (int i = 0; i < n; ++i) point[i] = mini.point[i];
     return ret;
+}
+
+namespace {
+typedef double (*scalar_fn)(void *user, double x);
+// ScalarMinimizer::f is virtual (MathGold.h:21): route it to the callback
+class CallbackScalar : public ScalarMinimizer {
+public:
+    scalar_fn fn;
+    void *user;
+    virtual double f(double x) { return fn(user, x); }
+};
+}  // namespace
+
+// The reference's own bracket + Brent on a caller's function: out = {min, fmin, a, b, c}.
+extern "C" void vb2ref_scalar_minimize(scalar_fn f, void *user, double lo, double hi, double tol, double *out)
+{
+    CallbackScalar m;
+    m.fn = f;
+    m.user = user;
+    m.Bracket(lo, hi);
+    m.Brent(tol);
+    out[0] = m.min; out[1] = m.fmin; out[2] = m.a; out[3] = m.b; out[4] = m.c;
 }
 
 extern "C" const char *vb2ref_describe(void)

@@ -34,7 +34,7 @@ def test_header_symbols_exported():
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vb2_abi_version() == 2
+    assert lib.vb2_abi_version() == 3
 
 
 def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
@@ -43,7 +43,7 @@ def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
     import subprocess
     src = tmp_path / "abi_check.c"
     names = ["vb2_input", "vb2_options", "vb2_info", "vb2_model", "vb2_estimate", "vb2_trace",
-             "vb2_run_args", "vb2_run_result", "vb2_cohort_args", "vb2_shard_info"]
+             "vb2_run_args", "vb2_run_result", "vb2_cohort_args", "vb2_shard_info", "vb2_search_opts"]
     src.write_text('#include <stdio.h>\n#include "vb2_abi.h"\nint main(void) {\n' +
                    "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) +
                    "  return 0;\n}\n")
@@ -54,7 +54,8 @@ def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
                                                          check=True).stdout.splitlines())
     binding = dict(vb2_input=_abi.Input, vb2_options=_abi.Options, vb2_info=_abi.Info, vb2_model=_abi.Model,
                    vb2_estimate=_abi.Estimate, vb2_trace=_abi.Trace, vb2_run_args=_abi.RunArgs,
-                   vb2_run_result=_abi.RunResult, vb2_cohort_args=_abi.CohortArgs, vb2_shard_info=_abi.ShardInfo)
+                   vb2_run_result=_abi.RunResult, vb2_cohort_args=_abi.CohortArgs, vb2_shard_info=_abi.ShardInfo,
+                   vb2_search_opts=_abi.SearchOpts)
     for n, cls in binding.items():
         assert int(sizes[n]) == C.sizeof(cls), (n, sizes[n], C.sizeof(cls))
 
@@ -145,6 +146,52 @@ def test_speculation_level_does_not_change_the_trajectory(golden_dir, level, mon
         assert got["num_eval"] < got["num_launch_point"] < 2 * got["num_eval"]
     else:
         assert got["num_launch_point"] > 2 * got["num_eval"]
+
+
+def test_line_search_equals_the_references_scalar_minimizer(golden_dir):
+    """csrc/line_search.cpp (bracket + Brent; the optimiser of the one-parameter models, SURVEY.md
+    8f row 4) against the reference's own compiled ScalarMinimizer (MathGold.cpp:27-195 in
+    oracle/_ref): the same abscissae evaluated in the same order, the same result, bit for bit --
+    on plain test functions that take every branch of the bracket, and on the real objective
+    (the LLK of the bundled input as a function of logit(alpha))."""
+    import ctypes as C
+    if binding.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    L = _abi.lib()
+    FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_double)
+    CM = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.c_double)
+    L.vb2_debug_line_search.restype = C.c_int
+    L.vb2_debug_line_search.argtypes = [FN, CM, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int,
+                                        C.POINTER(C.c_double)]
+    flat, _, _ = refio.load_flat(os.path.join(golden_dir, HAPMAP), os.path.join(golden_dir, "expected/result.Pileup"), 2)
+    od = binding.OracleData(flat)
+    pc = [0.01, 0.01]
+
+    def neg_llk(x):
+        return -od.llk(pc, pc, 1.0 / (1.0 + np.exp(-x)), num_thread=1)
+
+    cases = [
+        (lambda x: (x - 2.0) ** 2 + 1.0, 0.0, 1.0, 1e-8),                  # downhill to the right
+        (lambda x: (x + 30.0) ** 2, 0.0, 1.0, 1e-10),                      # far: magnification limit
+        (lambda x: abs(x - 0.3) ** 1.5 + 0.1 * x, 5.0, 4.0, 1e-9),         # swapped ends, non-smooth
+        (lambda x: np.cosh(0.7 * x) + 0.05 * x ** 4 - x, -3.0, -2.9, 1e-12),
+        (lambda x: -np.exp(-(x - 1.0) ** 2 / 50.0), -40.0, -39.0, 1e-8),   # nearly flat start
+        (lambda x: float(np.floor(abs(x) * 3)), 2.2, 2.9, 1e-8),           # plateaus: the tie rules
+        (neg_llk, float(np.log(0.03 / 0.97)), float(np.log(0.03 / 0.97)) + 1.0, 1e-8),
+    ]
+    for fn, lo, hi, tol in cases:
+        ref_x = []
+        want = binding.reference_scalar_minimize(lambda x: (ref_x.append(x), fn(x))[1], lo, hi, tol)
+        for speculate in (0, 1):
+            got_x, launched = [], []
+            out = (C.c_double * 5)()
+            f_cb = FN(lambda _u, x: (launched.append(x), float(fn(x)))[1])
+            c_cb = CM(lambda _u, x, y: got_x.append(x))
+            rc = L.vb2_debug_line_search(f_cb, c_cb, None, lo, hi, tol, speculate, out)
+            assert rc == 0
+            assert got_x == ref_x, (speculate, len(got_x), len(ref_x))
+            assert dict(zip(("min", "fmin", "a", "b", "c"), list(out))) == want
+            assert len(launched) == len(ref_x) + (1 if speculate else 0)   # the unused candidate for c
 
 
 def test_cpp_optimiser_other_dimensions():

@@ -941,6 +941,70 @@ def test_device_simplex_deep_convergence_and_other_dimensions():
                 assert np.array_equal(dev["trace"]["alpha"], host["trace"]["alpha"]), (k, kw)
 
 
+def test_multi_start_search_batches_restarts_and_keeps_the_reference_run(c2):
+    """vb2_ctx_optimize_llk_ex, num_start > 1 (north_star: "objective evaluations
+    batch across restarts"): start 0 IS the reference's run -- evaluated in mixed launches of up to
+    48 points instead of the resident kernel's 4, and bit-identical all the same (a point's value
+    does not depend on the launch it rides in) -- the winner is never worse than it, the runs are a
+    function of the seed, and one start is plain vb2_ctx_optimize_llk."""
+    d, od = c2
+    with vb.LikelihoodContext(d) as ctx:
+        plain = ctx.optimize()
+        one, every1 = ctx.optimize_ex(num_start=1)
+        assert one["alpha"] == plain["alpha"] and one["llk1"] == plain["llk1"] and one["num_eval"] == plain["num_eval"]
+        best, every = ctx.optimize_ex(num_start=6, seed=7)
+        again, every_again = ctx.optimize_ex(num_start=6, seed=7)
+        other, every_other = ctx.optimize_ex(num_start=6, seed=8)
+        many, every_many = ctx.optimize_ex(num_start=20, seed=7)          # > 12 runs: {R, C_R} speculation
+    assert len(every) == 6 and len(every_many) == 20
+    ref = every[0]
+    for key in ("alpha", "llk1", "llk0", "num_eval"):
+        assert ref[key] == plain[key], key                              # start 0 = the reference's search
+        assert every_many[0][key] == plain[key], key
+    assert np.array_equal(ref["pc"], plain["pc"]) and np.array_equal(ref["pc2"], plain["pc2"])
+    assert best["llk1"] == min(e["llk1"] for e in every) <= plain["llk1"]
+    assert every[best["start"]]["llk1"] == best["llk1"]
+    assert [e["alpha"] for e in every] == [e["alpha"] for e in every_again] and again["start"] == best["start"]
+    assert [e["alpha"] for e in every[1:]] != [e["alpha"] for e in every_other[1:]]
+    # every start lands in the same basin on this well-conditioned sample
+    for e in every:
+        assert abs(e["alpha"] - plain["alpha"]) < 2e-3
+        assert abs(e["llk1"] - plain["llk1"]) <= 1e-6 * abs(plain["llk1"])
+    # the oracle agrees with the reported optimum
+    want = od.llk(best["pc"], best["pc2"], best["alpha"], num_thread=8)
+    assert abs(-best["llk1"] - want) <= LLK_RTOL * abs(want)
+
+
+def test_line_search_for_the_one_parameter_models(c2):
+    """--FixPC leaves alpha alone free: Brent's method (line_search.cpp, pinned to the reference's
+    compiled ScalarMinimizer on the CPU) finds the simplex's optimum with fewer evaluations; models
+    with more free parameters ignore the switch."""
+    d, od = c2
+    k = d.num_pc
+    fix = [0.012, -0.004][:k]
+    with vb.LikelihoodContext(d) as ctx:
+        kw = dict(fix_pc=fix, within_ancestry=True)             # OptimizeHomoFixedPC: logit(alpha) alone
+        simplex = ctx.optimize(**kw)
+        brent, _ = ctx.optimize_ex(line_search=True, **kw)
+        # (the simplex stops when its two values agree to --Epsilon, which pins alpha to ~2e-5 on this
+        # flat-bottomed objective; Brent's tolerance is on the abscissa and lands closer)
+        assert abs(brent["alpha"] - simplex["alpha"]) <= 1e-4          # north star: 1e-4
+        assert brent["llk1"] <= simplex["llk1"] + 1e-10 * abs(simplex["llk1"])
+        assert 0 < brent["num_eval"] < simplex["num_eval"]
+        want = od.llk(fix, fix, brent["alpha"], num_thread=8)
+        assert abs(-brent["llk1"] - want) <= LLK_RTOL * abs(want)
+        # (the reference's OptimizeHeterFixedPC runs OptimizeHomo -- numPC + 1 free parameters,
+        # cpp:261-263 -- so --FixPC without --WithinAncestry is not a one-parameter model)
+        heter = ctx.optimize(fix_pc=fix)
+        heter_ls, _ = ctx.optimize_ex(line_search=True, fix_pc=fix)
+        assert heter_ls["alpha"] == heter["alpha"] and heter_ls["num_eval"] == heter["num_eval"]
+        free = ctx.optimize()
+        same, _ = ctx.optimize_ex(line_search=True)
+        assert same["alpha"] == free["alpha"] and same["num_eval"] == free["num_eval"]
+        both, every = ctx.optimize_ex(num_start=4, seed=3, line_search=True, **kw)
+        assert abs(both["alpha"] - brent["alpha"]) <= 1e-6 and len(every) == 4
+
+
 @pytest.mark.parametrize("k", [1, 10, 40])
 def test_resident_search_with_wide_parameter_rows(k):
     """The mailbox image is 4*(2k+1)+3 words; beyond 64 words wave 0 reads it in several passes

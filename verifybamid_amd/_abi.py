@@ -51,6 +51,13 @@ class Model(C.Structure):
     ]
 
 
+class SearchOpts(C.Structure):
+    _fields_ = [
+        ("num_start", C.c_int32), ("seed", C.c_uint32), ("start_sd", C.c_double),
+        ("line_search", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 class Estimate(C.Structure):
     _fields_ = [
         ("alpha", C.c_double), ("llk1", C.c_double), ("llk0", C.c_double),
@@ -74,7 +81,7 @@ class RunArgs(C.Structure):
         ("num_pc", C.c_int32), ("disable_sanity", C.c_int32), ("output_pileup", C.c_int32),
         ("device", C.c_int32), ("model", Model),
         ("devices", C.POINTER(C.c_int32)), ("num_device", C.c_int32), ("reserved", C.c_int32),
-        ("bam_path", C.c_char_p), ("reference_path", C.c_char_p),
+        ("bam_path", C.c_char_p), ("reference_path", C.c_char_p), ("search", SearchOpts),
     ]
 
 
@@ -107,7 +114,7 @@ EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.P
 # every symbol include/vb2_abi.h declares
 SYMBOLS = [
     "vb2_ctx_create", "vb2_ctx_destroy", "vb2_ctx_info", "vb2_llk_eval_batch",
-    "vb2_llk_eval_batch_device", "vb2_ctx_search_begin", "vb2_ctx_search_end", "vb2_optimize_llk", "vb2_ctx_optimize_llk", "vb2_run", "vb2_cohort_run",
+    "vb2_llk_eval_batch_device", "vb2_ctx_search_begin", "vb2_ctx_search_end", "vb2_optimize_llk", "vb2_ctx_optimize_llk", "vb2_ctx_optimize_llk_ex", "vb2_run", "vb2_cohort_run",
     "vb2_flat_load", "vb2_flat_input", "vb2_flat_stats", "vb2_flat_free", "vb2_last_error",
     "vb2_abi_version", "vb2_device_count",
     "vb2_batch_create", "vb2_batch_destroy", "vb2_batch_eval", "vb2_batch_optimize_llk",
@@ -155,6 +162,8 @@ def lib():
     L.vb2_ctx_search_end.restype = None
     L.vb2_optimize_llk.argtypes = [EVAL_FN, C.c_void_p, C.c_int32, C.POINTER(Model),
                                    C.POINTER(Estimate), C.POINTER(Trace)]
+    L.vb2_ctx_optimize_llk_ex.argtypes = [C.c_void_p, C.POINTER(Model), C.POINTER(SearchOpts), C.POINTER(Estimate),
+                                          C.c_void_p]
     L.vb2_ctx_optimize_llk.argtypes = [C.c_void_p, C.POINTER(Model), C.POINTER(Estimate),
                                        C.POINTER(Trace)]
     L.vb2_run.argtypes = [C.POINTER(RunArgs), C.POINTER(RunResult)]

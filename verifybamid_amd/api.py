@@ -125,7 +125,7 @@ def _model(within_ancestry=False, fix_pc=None, fix_alpha=None, known_af=False, e
 
 
 def _run_args(svd_prefix, pileup_path, num_pc, disable_sanity, known_af_path, output_prefix,
-              device=-1, output_pileup=False, devices=None, **model_kw):
+              device=-1, output_pileup=False, devices=None, num_start=1, seed=0, line_search=False, **model_kw):
     m, keep = _model(known_af=known_af_path is not None, **model_kw)
     enc = lambda s: None if s is None else str(s).encode()
     devs = None
@@ -134,7 +134,8 @@ def _run_args(svd_prefix, pileup_path, num_pc, disable_sanity, known_af_path, ou
     args = _abi.RunArgs(enc(svd_prefix + ".UD"), enc(svd_prefix + ".mu"), enc(svd_prefix + ".bed"),
                         enc(pileup_path), enc(known_af_path), enc(output_prefix), int(num_pc),
                         int(bool(disable_sanity)), int(bool(output_pileup)), int(device), m,
-                        devs, 0 if devs is None else len(devices), 0, None, None)
+                        devs, 0 if devs is None else len(devices), 0, None, None,
+                        _abi.SearchOpts(int(num_start), int(seed), 0.0, 1 if line_search else 0, 0))
     return args, (keep, devs)
 
 
@@ -239,6 +240,23 @@ class LikelihoodContext:
         if tb:
             out["trace"], out["trace_count"] = tb.result()
         return out
+
+
+    def optimize_ex(self, num_start=1, seed=0, start_sd=0.0, line_search=False, **model_kw):
+        """Optimiser variants (vb2_ctx_optimize_llk_ex): num_start searches from seeded starting
+        points in lock-step (start 0 = the reference's), and / or Brent's line search for the
+        one-parameter models.  Returns (best, all): best has "start" = index of the winning run."""
+        m, keep = _model(known_af=self.data.known_af is not None, **model_kw)
+        n = max(1, int(num_start))
+        opts = _abi.SearchOpts(n, int(seed), float(start_sd), 1 if line_search else 0, 0)
+        best = _abi.Estimate()
+        every = (_abi.Estimate * n)()
+        _abi.check(self._lib.vb2_ctx_optimize_llk_ex(self._h, C.byref(m), C.byref(opts), C.byref(best),
+                                                     C.cast(every, C.c_void_p)),
+                   "vb2_ctx_optimize_llk_ex")
+        out = _estimate_dict(best, self.num_pc)
+        out["start"] = int(best.reserved)
+        return out, [_estimate_dict(every[i], self.num_pc) for i in range(n)]
 
 
 class CohortBatch:

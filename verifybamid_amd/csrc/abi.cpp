@@ -20,6 +20,8 @@
 #include "batch.h"
 #include "context.h"
 #include "estimator.h"
+#include "line_search.h"
+#include "lockstep.h"
 #include "hostio.h"
 #include "shard.h"
 
@@ -212,6 +214,38 @@ void vb2_debug_set_device_simplex(vb2_ctx* ctx, int on)
 }
 
 // Test aid: is the context in resident mode right now?
+// test hook (not in vb2_abi.h): the library's bracket + Brent (line_search.h) on a caller's scalar
+// function; `committed` is called for every evaluation the reference's ScalarMinimizer would make,
+// in its order (a speculative batch calls f for more points); out = {min, fmin, a, b, c}.
+int vb2_debug_line_search(double (*f)(void* user, double x), void (*committed)(void* user, double x, double y),
+                          void* user, double lo, double hi, double tol, int speculate, double* out)
+{
+    struct Obj : vb2::ScalarObjective {
+        double (*f)(void*, double);
+        void (*committed)(void*, double, double);
+        void* user;
+        int EvaluateBatch(int n, const double* x, double* y) override
+        {
+            for (int i = 0; i < n; ++i) y[i] = f(user, x[i]);
+            return 0;
+        }
+        void Commit(double x, double y) override
+        {
+            if (committed) committed(user, x, y);
+        }
+    } obj;
+    obj.f = f;
+    obj.committed = committed;
+    obj.user = user;
+    vb2::BrentMinimizer bm;
+    bm.func = &obj;
+    bm.speculate = speculate != 0;
+    bm.Bracket(lo, hi);
+    if (!bm.error) bm.Brent(tol);
+    out[0] = bm.min; out[1] = bm.fmin; out[2] = bm.a; out[3] = bm.b; out[4] = bm.c;
+    return bm.stuck ? 1 : 0;
+}
+
 int vb2_debug_resident_active(vb2_ctx* ctx)
 {
     if (guard_ctx(ctx)) return 0;
@@ -275,6 +309,119 @@ int vb2_ctx_optimize_llk(vb2_ctx* ctx, const vb2_model* model, vb2_estimate* out
     }
     if (resident) c->resident_end();
     return rc;
+}
+
+int vb2_ctx_optimize_llk_ex(vb2_ctx* ctx, const vb2_model* model, const vb2_search_opts* opts,
+                            vb2_estimate* best, vb2_estimate* all)
+{
+    if (int rc = guard_ctx(ctx)) return rc;
+    if (!model || !best) {
+        set_error("vb2_ctx_optimize_llk_ex: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    const int S = opts ? std::max(1, (int)opts->num_start) : 1;
+    const bool line = opts && opts->line_search != 0;
+    if (S > 64) {
+        set_error("vb2_ctx_optimize_llk_ex: at most 64 starts");
+        return VB2_ERR_INVALID;
+    }
+    if (S == 1 && !line) {
+        const int rc = vb2_ctx_optimize_llk(ctx, model, best, nullptr);
+        if (!rc && all) all[0] = *best;
+        return rc;
+    }
+    vb2::Context* c = ctx->impl;
+    const int k = c->num_pc;
+    auto configure = [&](vb2::Estimator& est, int index) {
+        vb2::apply_model(est, *model);
+        if (c->L.known_af) {                 // context built with --KnownAF data
+            est.isAFknown = true;
+            est.isPCFixed = true;
+            est.isHeter = false;
+        }
+        est.line_search = line;
+        est.start_index = index;
+        est.start_seed = opts ? opts->seed : 0u;
+        if (opts && opts->start_sd > 0) est.start_sd = opts->start_sd;
+        if (index > 0) est.notices = false;  // (the reference's phase lines once, for its own start)
+    };
+    try {
+        if (S == 1) {
+            // one run, Brent's single-point evaluations served by the resident kernel
+            const bool resident = c->resident_begin();
+            vb2::Estimator est(k, ctx_eval_cb, c);
+            configure(est, 0);
+            const int rc = est.OptimizeLLK();
+            if (resident) c->resident_end();
+            if (rc) return rc;
+            vb2::fill_estimate(est, best);
+            if (all) all[0] = *best;
+            return VB2_OK;
+        }
+        // S runs as fibers of this thread: a step's points (<= 4 per run) leave as ONE launch
+        vb2::FiberGang gang(S, 4);
+        std::vector<vb2_estimate> ests(S);
+        std::vector<int> rcs(S, 0);
+        std::vector<double> p1, p2, al, out;
+        auto body = [&](int i) {
+            try {
+                vb2::Estimator est(k, vb2::FiberGang::eval_cb, gang.user(i));
+                configure(est, i);
+                est.speculate = S * 4 <= vb2::kMaxPointsPerLaunch ? 4 : 2;     // the whole step in one launch
+                rcs[i] = est.OptimizeLLK();
+                vb2::fill_estimate(est, &ests[i]);
+            } catch (const std::bad_alloc&) {
+                rcs[i] = VB2_ERR_NOMEM;
+            } catch (const std::exception& e) {
+                set_error(e.what());
+                rcs[i] = VB2_ERR_INVALID;
+            } catch (...) {
+                set_error("vb2_ctx_optimize_llk_ex: unknown exception in a search");
+                rcs[i] = VB2_ERR_INVALID;
+            }
+        };
+        auto step = [&](std::vector<vb2::FiberGang::Request>& req) {
+            p1.clear(); p2.clear(); al.clear();
+            for (const auto& r : req) {
+                if (r.n <= 0) continue;
+                p1.insert(p1.end(), r.p1, r.p1 + (size_t)r.n * k);
+                p2.insert(p2.end(), r.p2, r.p2 + (size_t)r.n * k);
+                al.insert(al.end(), r.a, r.a + r.n);
+            }
+            out.resize(al.size());
+            if (const int rc = c->eval_host((int)al.size(), p1.data(), p2.data(), al.data(), out.data())) return rc;
+            size_t o = 0;
+            for (auto& r : req) {
+                if (r.n <= 0) continue;
+                std::memcpy(r.out, &out[o], sizeof(double) * r.n);
+                o += (size_t)r.n;
+            }
+            return 0;
+        };
+        const int rc = gang.run(k, body, step);
+        if (rc < 0) {
+            set_error("vb2_ctx_optimize_llk_ex: getcontext failed");
+            return VB2_ERR_INVALID;
+        }
+        if (rc) return rc;
+        int win = -1;
+        for (int i = 0; i < S; ++i) {
+            if (rcs[i]) return rcs[i];
+            // (a run that wandered into NaN territory never wins)
+            if (ests[i].llk1 == ests[i].llk1 && (win < 0 || ests[i].llk1 < ests[win].llk1)) win = i;
+        }
+        if (win < 0) win = 0;
+        *best = ests[win];
+        best->reserved = win;
+        if (all) std::memcpy(all, ests.data(), sizeof(vb2_estimate) * S);
+        return VB2_OK;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return VB2_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
 }
 
 int vb2_batch_create(vb2_ctx* const* ctxs, int32_t num_sample, vb2_batch** out)
@@ -595,7 +742,9 @@ int vb2_run(const vb2_run_args* a, vb2_run_result* out)
                          ctx->impl->device_name, now_s() - t_flat0);
         const double t1 = now_s();
         if (notices) std::fprintf(stderr, "NOTICE - Starting phase: Optimize likelihood\n");      // main.cpp:382
-        rc = vb2_ctx_optimize_llk(ctx, &model, &out->est, nullptr);
+        rc = (a->search.num_start > 1 || a->search.line_search)
+                 ? vb2_ctx_optimize_llk_ex(ctx, &model, &a->search, &out->est, nullptr)
+                 : vb2_ctx_optimize_llk(ctx, &model, &out->est, nullptr);
         out->seconds_optimize = now_s() - t1;
         if (notices)
             std::fprintf(stderr, "NOTICE - Finished phase: Optimize likelihood  [%.3f seconds]\n", out->seconds_optimize);

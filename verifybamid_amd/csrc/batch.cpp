@@ -1,8 +1,6 @@
 // batch.cpp -- see batch.h.
 #include "batch.h"
 
-#include <ucontext.h>
-
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -12,6 +10,7 @@
 #include <memory>
 
 #include "estimator.h"
+#include "lockstep.h"
 
 namespace vb2 {
 
@@ -264,68 +263,9 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
 
 // ---------------------------------------------------------------------------
 // lock-step search: every sample runs the ordinary Estimator (OptimizeLLK with its six models,
-// the reference-exact simplex) as a FIBER of the calling thread -- its own small stack, switched
-// with swapcontext.  A fiber runs until its optimiser asks for likelihood values, parks the
-// request and yields; when every live fiber has parked, the requests leave as ONE launch, the
-// values are handed back and the fibers run on.  No threads, no locks, no wake-ups: a step costs
-// the host ~0.3 us per sample where one thread per sample cost a futex round trip each (9 ms of
-// CPU per sample and search at C3 size -- a third of what reading the sample costs, and under a
-// container's CPU quota it throttled the readers and the search alike).
+// the reference-exact simplex) as a fiber of the calling thread (lockstep.h); the parked
+// requests of a step leave as ONE launch of the multi-sample kernel.
 // ---------------------------------------------------------------------------
-namespace {
-
-constexpr size_t kFiberStack = 256 * 1024;
-
-struct Fiber {
-    ucontext_t ctx;
-    std::unique_ptr<char[]> stack;
-    std::function<void()> body;
-    bool done = false;
-    // the parked request (pointers into the fiber's own frames: alive while it is parked)
-    int n = 0;
-    const double *p1 = nullptr, *p2 = nullptr, *a = nullptr;
-    double* o = nullptr;
-};
-
-struct FiberSched {
-    ucontext_t main;
-    Fiber* cur = nullptr;
-    int error = 0;
-};
-
-struct SampleCb {
-    FiberSched* sched;
-    Fiber* fiber;
-    int k;
-};
-
-void fiber_entry(unsigned lo, unsigned hi)
-{
-    Fiber* f = reinterpret_cast<Fiber*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
-    f->body();                       // (never throws: the body catches)
-    f->done = true;
-    f->n = 0;
-}                                    // uc_link: back to the scheduler
-
-int sample_eval(void* user, int32_t n, const double* p1, const double* p2, const double* a, double* o)
-{
-    SampleCb* cb = static_cast<SampleCb*>(user);
-    const int k = cb->k;
-    for (int done = 0; done < n; done += kSlot) {
-        Fiber* f = cb->fiber;
-        f->n = std::min(kSlot, n - done);
-        f->p1 = p1 + (size_t)done * k;
-        f->p2 = p2 + (size_t)done * k;
-        f->a = a + done;
-        f->o = o + done;
-        swapcontext(&f->ctx, &cb->sched->main);        // parked until the step has been evaluated
-        if (cb->sched->error) return cb->sched->error;
-    }
-    return 0;
-}
-
-}  // namespace
-
 int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
 {
     if (!models || !out || (num_model != 1 && num_model != num_sample)) {
@@ -344,80 +284,54 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     if (const char* e = std::getenv("VB2_COHORT_SPECULATE")) speculate_ = std::max(1, std::atoi(e));
 
     const int S = num_sample, k = num_pc;
-    FiberSched sched;
-    std::vector<Fiber> fibers(S);
-    std::vector<SampleCb> cbs(S);
+    FiberGang gang(S, kSlot);
     std::vector<int> rcs(S, 0);
     std::vector<int32_t> npts(S, 0);
     std::vector<double> pc1((size_t)S * kSlot * k), pc2((size_t)S * kSlot * k), alpha((size_t)S * kSlot),
         llk((size_t)S * kSlot);
-    auto resume = [&](Fiber& f) {
-        sched.cur = &f;
-        swapcontext(&sched.main, &f.ctx);
-    };
-    for (int s = 0; s < S; ++s) {
-        Fiber& f = fibers[s];
-        cbs[s] = SampleCb{&sched, &f, k};
-        f.stack.reset(new char[kFiberStack]);
-        f.body = [&, s]() {
-            try {
-                const vb2_model& m = models[num_model == 1 ? 0 : s];
-                Estimator est(num_pc, sample_eval, &cbs[s]);
-                apply_model(est, m);
-                est.speculate = speculate_;
-                if (ctx_[s]->L.known_af) {       // context built with --KnownAF data
-                    est.isAFknown = true;
-                    est.isPCFixed = true;
-                    est.isHeter = false;
-                }
-                rcs[s] = est.OptimizeLLK();
-                fill_estimate(est, &out[s]);
-            } catch (const std::bad_alloc&) {
-                rcs[s] = VB2_ERR_NOMEM;
-            } catch (const std::exception& e) {
-                set_error(e.what());
-                rcs[s] = VB2_ERR_INVALID;
-            } catch (...) {                      // nothing may unwind past the fiber's entry frame
-                set_error("vb2_batch_optimize_llk: unknown exception in a sample's search");
-                rcs[s] = VB2_ERR_INVALID;
+    auto body = [&](int s) {
+        try {
+            const vb2_model& m = models[num_model == 1 ? 0 : s];
+            Estimator est(num_pc, FiberGang::eval_cb, gang.user(s));
+            apply_model(est, m);
+            est.speculate = speculate_;
+            if (ctx_[s]->L.known_af) {       // context built with --KnownAF data
+                est.isAFknown = true;
+                est.isPCFixed = true;
+                est.isHeter = false;
             }
-        };
-        if (getcontext(&f.ctx) != 0) {
-            set_error("vb2_batch_optimize_llk: getcontext failed");
-            return VB2_ERR_INVALID;
+            rcs[s] = est.OptimizeLLK();
+            fill_estimate(est, &out[s]);
+        } catch (const std::bad_alloc&) {
+            rcs[s] = VB2_ERR_NOMEM;
+        } catch (const std::exception& e) {
+            set_error(e.what());
+            rcs[s] = VB2_ERR_INVALID;
+        } catch (...) {                      // nothing may unwind past the fiber's entry frame
+            set_error("vb2_batch_optimize_llk: unknown exception in a sample's search");
+            rcs[s] = VB2_ERR_INVALID;
         }
-        f.ctx.uc_stack.ss_sp = f.stack.get();
-        f.ctx.uc_stack.ss_size = kFiberStack;
-        f.ctx.uc_link = &sched.main;
-        const uintptr_t p = reinterpret_cast<uintptr_t>(&f);
-        makecontext(&f.ctx, reinterpret_cast<void (*)()>(fiber_entry), 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
-    }
-    for (int s = 0; s < S; ++s) resume(fibers[s]);               // up to everybody's first request
-    for (;;) {
-        bool any = false;
+    };
+    auto step = [&](std::vector<FiberGang::Request>& req) {
         for (int s = 0; s < S; ++s) {
-            Fiber& f = fibers[s];
-            npts[s] = f.done ? 0 : f.n;
-            if (npts[s] <= 0) continue;
-            any = true;
-            std::memcpy(&pc1[(size_t)s * kSlot * k], f.p1, sizeof(double) * f.n * k);
-            std::memcpy(&pc2[(size_t)s * kSlot * k], f.p2, sizeof(double) * f.n * k);
-            std::memcpy(&alpha[(size_t)s * kSlot], f.a, sizeof(double) * f.n);
+            const FiberGang::Request& r = req[s];
+            npts[s] = r.n;
+            if (r.n <= 0) continue;
+            std::memcpy(&pc1[(size_t)s * kSlot * k], r.p1, sizeof(double) * r.n * k);
+            std::memcpy(&pc2[(size_t)s * kSlot * k], r.p2, sizeof(double) * r.n * k);
+            std::memcpy(&alpha[(size_t)s * kSlot], r.a, sizeof(double) * r.n);
         }
-        if (!any) break;
-        if (!sched.error) {
-            const int rc = eval(npts.data(), pc1.data(), pc2.data(), alpha.data(), llk.data());
-            if (rc) sched.error = rc;                              // the fibers see it and unwind
-        }
-        for (int s = 0; s < S; ++s) {
-            Fiber& f = fibers[s];
-            if (npts[s] <= 0) continue;
-            std::memcpy(f.o, &llk[(size_t)s * kSlot], sizeof(double) * npts[s]);
-            f.n = 0;
-            resume(f);                                             // up to its next request, or to the end
-        }
+        if (const int rc = eval(npts.data(), pc1.data(), pc2.data(), alpha.data(), llk.data())) return rc;
+        for (int s = 0; s < S; ++s)
+            if (npts[s] > 0) std::memcpy(req[s].out, &llk[(size_t)s * kSlot], sizeof(double) * npts[s]);
+        return 0;
+    };
+    const int rc = gang.run(k, body, step);
+    if (rc < 0) {
+        set_error("vb2_batch_optimize_llk: getcontext failed");
+        return VB2_ERR_INVALID;
     }
-    if (sched.error) return sched.error;
+    if (rc) return rc;
     for (int s = 0; s < S; ++s)
         if (rcs[s]) return rcs[s];
     return VB2_OK;

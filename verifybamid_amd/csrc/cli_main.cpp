@@ -52,7 +52,8 @@ int main(int argc, char** argv)
         knownAF("Empty"), fixPC("Empty"), PileupList("Empty"), Devices("Empty");
     double fixAlpha = -1., epsilon = 1e-8;
     bool withinAncestry = false, outputPileup = false, verbose = false, disableSanityCheck = false;
-    int seed = 12345, nPC = 2, nthread = 4, device = -1;
+    int seed = 12345, nPC = 2, nthread = 4, device = -1, numStart = 1;
+    bool lineSearch = false;
 
     std::map<std::string, Flag> flags = {
         {"BamFile", {Flag::kString, &BamFile, false}},
@@ -79,6 +80,12 @@ int main(int argc, char** argv)
         // not in the reference: a cohort against one panel.  File of lines "<pileup>\t<output prefix>";
         // the panel is read once and the samples are searched in lock-step groups (vb2_cohort_run).
         {"PileupList", {Flag::kString, &PileupList, false}},
+        // not in the reference: optimiser variants (vb2_search_opts).  --NumStart n searches from n
+        // starting points in lock-step (start 0 = the reference's; the others add noise drawn from
+        // --Seed) and reports the best; --LineSearch uses Brent's method (the reference's unused
+        // MathGold) for the one-parameter models (--FixPC / --KnownAF).
+        {"NumStart", {Flag::kInt, &numStart, false}},
+        {"LineSearch", {Flag::kBool, &lineSearch, false}},
     };
     for (int i = 1; i < argc; ++i) {
         const char* a = argv[i];
@@ -110,7 +117,7 @@ int main(int argc, char** argv)
         else if (f.kind == Flag::kDouble) *static_cast<double*>(f.dst) = std::atof(v);
         else *static_cast<std::string*>(f.dst) = v;
     }
-    (void)seed;     // parsed and never used by the reference either (main.cpp:137,286)
+    // --Seed: parsed and never used by the reference (main.cpp:137,286); here it seeds --NumStart's starting points
     (void)nthread;  // the likelihood runs on the GPU; kept for command-line compatibility
 
     // main.cpp:214-232
@@ -140,6 +147,9 @@ int main(int argc, char** argv)
     args.num_pc = nPC;
     args.disable_sanity = disableSanityCheck;
     args.output_pileup = outputPileup;
+    args.search.num_start = numStart;
+    args.search.seed = (uint32_t)seed;
+    args.search.line_search = lineSearch ? 1 : 0;
     args.device = device;
     std::vector<int32_t> devs;
     if (Devices != "Empty") {

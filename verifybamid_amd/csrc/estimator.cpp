@@ -2,6 +2,7 @@
 #include "estimator.h"
 
 #include "context.h"
+#include "line_search.h"
 
 #include <chrono>
 #include <cmath>
@@ -291,8 +292,66 @@ bool Estimator::OptimizeHomoFixedAlpha(AmoebaMinimizer& m)
     return true;                                          // cpp:312
 }
 
+namespace {
+// the one-parameter objective of the --FixPC models as a function of logit(alpha)
+struct AlphaObjective : ScalarObjective {
+    FullLLKFunc* fn;
+    int EvaluateBatch(int n, const double* x, double* y) override { return fn->EvaluateBatch(n, x, 1, y); }
+    void Commit(double x, double y) override { fn->Commit(&x, 1, y); }
+};
+
+// splitmix64 -> uniform -> Box-Muller: a self-contained, reproducible N(0, 1) stream per (seed, run)
+struct Gauss {
+    uint64_t s;
+    uint64_t next()
+    {
+        uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    }
+    double uniform() { return ((double)(next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+    double normal() { return std::sqrt(-2.0 * std::log(uniform())) * std::cos(6.283185307179586 * uniform()); }
+};
+}  // namespace
+
+// Bracket from the simplex's own two starting vertices (logit(alpha) and logit(alpha) + 1,
+// MathGenMin.cpp:335-345 with scale 1), then Brent to --Epsilon (relative, on logit(alpha)).
+bool Estimator::LineSearchAlpha()
+{
+    AlphaObjective obj;
+    obj.fn = &fn;
+    BrentMinimizer bm;
+    bm.func = &obj;
+    const double x0 = FullLLKFunc::Logit(alpha);
+    bm.Bracket(x0, x0 + 1.0);
+    if (!bm.error) bm.Brent(epsilon);
+    if (bm.error) {
+        if (!error) error = bm.error;
+        return false;
+    }
+    alpha = FullLLKFunc::InvLogit(bm.min);
+    if (bm.stuck) {
+        hit_cycle_limit = true;
+        if (notices) std::fprintf(stderr, "WARNING - ScalarMinimizer::Brent got stuck\n");
+    }
+    return !bm.stuck;
+}
+
+void Estimator::JitterStart()
+{
+    if (start_index <= 0) return;
+    Gauss g{((uint64_t)start_seed << 32) ^ (0x5851f42d4c957f2dull * (uint64_t)start_index)};
+    if (!isPCFixed) {
+        for (int k = 0; k < numPC; ++k) PC[0][k] += start_sd * g.normal();
+        for (int k = 0; k < numPC; ++k) PC[1][k] += start_sd * g.normal();
+    }
+    if (!isAlphaFixed) alpha = FullLLKFunc::InvLogit(FullLLKFunc::Logit(alpha) + 50.0 * start_sd * g.normal());
+}
+
 bool Estimator::OptimizeHomoFixedPC(AmoebaMinimizer& m)
 {
+    if (line_search) return LineSearchAlpha();
     std::vector<double> start(1);
     start[0] = FullLLKFunc::Logit(alpha);
     double ret;
@@ -329,6 +388,7 @@ int Estimator::OptimizeLLK()
         rc = fn.Initialize();
     }
     if (rc) return rc;
+    JitterStart();
     bool ok = true;
     if (!isHeter) {                                       // cpp:98-110
         PhaseTimer t(isPCFixed ? "OptimizeHomoFixedPC" : isAlphaFixed ? "OptimizeHomoFixedAlpha" : "OptimizeHomo",

@@ -52,6 +52,15 @@ public:
     std::vector<std::vector<double>> PC;   // PC[0] contaminating, PC[1] intended (h:453)
     FullLLKFunc fn;
     int speculate = 4;                  // AmoebaMinimizer::speculate
+    // Optimiser variants (vb2_ctx_optimize_llk_ex), both off by default:
+    //   line_search: a model with ONE free parameter (--FixPC / --KnownAF: alpha) is minimised by
+    //     bracketing + Brent's method (line_search.h) instead of the two-vertex simplex;
+    //   start_index > 0: this run is restart `start_index` of a multi-start search -- the free
+    //     parameters start from the reference's values (h:328-331) plus seeded Gaussian noise.
+    bool line_search = false;
+    int start_index = 0;
+    uint32_t start_seed = 0;
+    double start_sd = 0.02;             // PC coordinates; logit(alpha) gets 50 x this
 
     int OptimizeLLK();                     // cpp:88-155 (without the writers)
 
@@ -72,6 +81,8 @@ public:
 
 private:
     bool OptimizeHomoFixedPC(AmoebaMinimizer& m);      // cpp:315-332
+    bool LineSearchAlpha();                            // the same model through Brent's method
+    void JitterStart();
     bool OptimizeHomoFixedAlpha(AmoebaMinimizer& m);   // cpp:291-313
     bool OptimizeHomo(AmoebaMinimizer& m);             // cpp:265-289
     bool OptimizeHeterFixedPC(AmoebaMinimizer& m);     // cpp:261-263
