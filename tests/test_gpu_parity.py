@@ -165,6 +165,32 @@ def test_cli_reproduces_reference_ctest(golden_dir, kat, tmp_path, case):
     assert "FREEMIX(Alpha):" in p.stdout
 
 
+def test_cli_optimiser_variants(golden_dir, tmp_path):
+    """--NumStart / --Seed / --LineSearch (not in the reference; vb2_search_opts): one start is the
+    plain run byte for byte; several starts report an LLK that is no worse; --LineSearch drives the --WithinAncestry --FixPC model through Brent."""
+    exe = os.path.join(ROOT, "verifybamid_amd", "bin", "VerifyBamID")
+    base = [exe, "--DisableSanityCheck", "--PileupFile", os.path.join(golden_dir, "expected/result.Pileup"),
+            "--SVDPrefix", os.path.join(golden_dir, HAPMAP), "--Reference", "resource/test/chr20.fa.gz", "--NumPC", "2"]
+
+    def run(tag, extra):
+        out = str(tmp_path / tag)
+        p = subprocess.run(base + ["--Output", out] + extra, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        row = open(out + ".selfSM").read().splitlines()[1].split("\t")
+        return open(out + ".Ancestry").read(), float(row[6]), float(row[7])
+
+    plain = run("plain", [])
+    assert run("one", ["--NumStart", "1", "--Seed", "99"]) == plain
+    many = run("many", ["--NumStart", "6", "--Seed", "3"])
+    # FREELK1 = +LLK.  On this 15-site input the restarts find a (slightly) better optimum than the
+    # reference's single run -- the reason to have them -- so only "never worse" is asserted
+    assert many[2] >= plain[2] - 1e-9 * abs(plain[2]) and 0.0 <= many[1] <= 0.5
+    fixed = ["--WithinAncestry", "--FixPC", "-0.03:0.02"]
+    simplex = run("simplex", fixed)
+    brent = run("brent", fixed + ["--LineSearch"])
+    assert abs(brent[1] - simplex[1]) <= 1e-4 and brent[2] >= simplex[2] - 1e-6 * abs(simplex[2])
+
+
 # ------------------------------------------------------------------ synthetic, oracle-sized
 
 @pytest.fixture(scope="module")
