@@ -25,22 +25,15 @@ namespace vb2 {
 
 namespace {
 constexpr int kSlot = 8;                     // point slots per sample and step (VB2_BATCH_SLOTS)
-constexpr int kShapes = Batch::kShapes;
 }
 
 Batch::~Batch()
 {
     if (device >= 0) (void)hipSetDevice(device);
-    if (d_layouts_) (void)hipFree(d_layouts_);
-    if (d_sched_) (void)hipFree(d_sched_);
-    if (d_partials_) (void)hipFree(d_partials_);
-    if (d_tickets_) (void)hipFree(d_tickets_);
-    if (d_batch_done_) (void)hipFree(d_batch_done_);
-    if (h_points_) (void)hipHostFree(h_points_);
-    if (h_out_) (void)hipHostFree(h_out_);
-    if (h_nv_) (void)hipHostFree(h_nv_);
-    if (h_done_) (void)hipHostFree(h_done_);
-    if (stream_) (void)hipStreamDestroy(stream_);
+    if (stream_) (void)hipStreamSynchronize(stream_);          // nothing of this batch is in flight any more
+    if (d_slab_ && !recycle_device_slab(d_slab_, d_slab_bytes_, device)) (void)hipFree(d_slab_);
+    if (h_slab_ && !recycle_pinned_slab(h_slab_, h_slab_bytes_, device)) (void)hipHostFree(h_slab_);
+    if (stream_ && !recycle_stream(stream_, device)) (void)hipStreamDestroy(stream_);
 }
 
 int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
@@ -50,16 +43,31 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
         set_error("vb2_batch_create: invalid argument");
         return VB2_ERR_INVALID;
     }
-    std::unique_ptr<Batch> b(new Batch());
-    b->num_sample = num_sample;
-    int max_mt = 0, num_cu = 256;
-    std::vector<DeviceLayout> layouts(num_sample);
+    std::vector<Context*> list;
     for (int s = 0; s < num_sample; ++s) {
         if (!ctxs[s] || !ctxs[s]->impl) {
             set_error("vb2_batch_create: null context");
             return VB2_ERR_INVALID;
         }
-        Context* c = ctxs[s]->impl;
+        list.push_back(ctxs[s]->impl);
+    }
+    return create(list, out);
+}
+
+int Batch::create(const std::vector<Context*>& ctxs, Batch** out)
+{
+    *out = nullptr;
+    const int num_sample = (int)ctxs.size();
+    if (num_sample < 1) {
+        set_error("vb2_batch_create: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    std::unique_ptr<Batch> b(new Batch());
+    b->num_sample = num_sample;
+    int max_mt = 0, num_cu = 256;
+    std::vector<DeviceLayout> layouts(num_sample);
+    for (int s = 0; s < num_sample; ++s) {
+        Context* c = ctxs[s];
         if (s == 0) {
             b->device = c->device;
             b->num_pc = c->num_pc;
@@ -97,24 +105,32 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
         return VB2_ERR_INVALID;
     }
 
+    b->layouts_ = std::move(layouts);
+    *out = b.release();
+    return VB2_OK;
+}
+
+int Batch::ensure_resources()
+{
+    if (ready_) return VB2_OK;
+    VB2_HIP(hipSetDevice(device));
+    const int k = num_pc, bps = bps_;
     const size_t S = (size_t)num_sample, stride = 2 * (size_t)k + 1;
-    VB2_HIP(hipMalloc((void**)&b->d_layouts_, sizeof(DeviceLayout) * S));
-    VB2_HIP(hipMemcpy(b->d_layouts_, layouts.data(), sizeof(DeviceLayout) * S, hipMemcpyHostToDevice));
     // static schedules (llk_kernels.h) of every sample for the wave shapes of a step: two micro-tiles
     // per wave for <= 4 points (when paired), one for 8 points, four for one or two points
-    if (b->ctx_[0]->sched_enabled) {
+    std::vector<char> blob;
+    std::vector<size_t> where[kShapes];
+    bool sched_ok = ctx_[0]->sched_enabled;
+    if (sched_ok) {
         const int tpu[kShapes] = {paired_mode() ? 2 : 1, 1, paired_mode() ? 4 : 1, paired_mode() ? 4 : 1};
-        std::vector<char> blob;
-        std::vector<size_t> where[kShapes];
-        bool ok = true;
-        for (int sh = 0; sh < kShapes && ok; ++sh)
-            for (int s = 0; s < num_sample && ok; ++s) {
+        for (int sh = 0; sh < kShapes && sched_ok; ++sh)
+            for (int s = 0; s < num_sample && sched_ok; ++s) {
                 std::vector<uint32_t> off;
                 std::vector<uint16_t> item;
-                Context* c = b->ctx_[s];
+                Context* c = ctx_[s];
                 if (c->L.num_mt == 0) { where[sh].push_back((size_t)-1); continue; }
-                ok = build_schedule(c->h_mt_rows.data(), c->L.num_mt, bps, b->block_waves_, tpu[sh], 1, &off, &item);
-                if (!ok) break;
+                sched_ok = build_schedule(c->h_mt_rows.data(), c->L.num_mt, bps, block_waves_, tpu[sh], 1, &off, &item);
+                if (!sched_ok) break;
                 blob.resize((blob.size() + 15) / 16 * 16);
                 where[sh].push_back(blob.size());
                 const size_t ob = (off.size() * sizeof(uint32_t) + 15) / 16 * 16;
@@ -122,48 +138,106 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
                 std::memcpy(blob.data() + where[sh].back(), off.data(), off.size() * sizeof(uint32_t));
                 std::memcpy(blob.data() + where[sh].back() + ob, item.data(), item.size() * sizeof(uint16_t));
             }
-        if (ok) {
-            blob.resize((blob.size() + 15) / 16 * 16);
-            const size_t arr0 = blob.size();
-            VB2_HIP(hipMalloc((void**)&b->d_sched_, arr0 + kShapes * S * sizeof(Schedule)));
-            std::vector<Schedule> arr(kShapes * S, Schedule{nullptr, nullptr});
-            const size_t ob = (((size_t)bps * b->block_waves_ + 1) * sizeof(uint32_t) + 15) / 16 * 16;
-            for (int sh = 0; sh < kShapes; ++sh)
-                for (size_t s = 0; s < S; ++s) {
-                    const size_t w = where[sh][s];
-                    if (w == (size_t)-1) continue;
-                    const uint32_t* o = reinterpret_cast<const uint32_t*>(b->d_sched_ + w);
-                    arr[sh * S + s] = Schedule{o, reinterpret_cast<const uint16_t*>(b->d_sched_ + w + ob)};
-                }
-            VB2_HIP(hipMemcpy(b->d_sched_, blob.data(), arr0, hipMemcpyHostToDevice));
-            VB2_HIP(hipMemcpy(b->d_sched_ + arr0, arr.data(), kShapes * S * sizeof(Schedule), hipMemcpyHostToDevice));
-            for (int sh = 0; sh < kShapes; ++sh) b->d_scheds_[sh] = reinterpret_cast<const Schedule*>(b->d_sched_ + arr0) + sh * S;
-        }
+        if (!sched_ok) blob.clear();
     }
-    VB2_HIP(hipMalloc((void**)&b->d_partials_, sizeof(double) * S * (kSlot + 1) * bps));
-    VB2_HIP(hipMemset(b->d_partials_, 0, sizeof(double) * S * (kSlot + 1) * bps));
-    VB2_HIP(hipMalloc((void**)&b->d_tickets_, sizeof(unsigned int) * S));
-    VB2_HIP(hipMemset(b->d_tickets_, 0, sizeof(unsigned int) * S));
-    VB2_HIP(hipMalloc((void**)&b->d_batch_done_, sizeof(unsigned int)));
-    VB2_HIP(hipMemset(b->d_batch_done_, 0, sizeof(unsigned int)));
-    VB2_HIP(hipHostMalloc((void**)&b->h_points_, sizeof(double) * S * kSlot * stride, hipHostMallocMapped));
-    VB2_HIP(hipHostMalloc((void**)&b->h_out_, sizeof(double) * S * kSlot, hipHostMallocMapped));
-    VB2_HIP(hipHostMalloc((void**)&b->h_nv_, sizeof(int) * S, hipHostMallocMapped));
-    VB2_HIP(hipHostMalloc((void**)&b->h_done_, sizeof(unsigned long long), hipHostMallocMapped));
-    *b->h_done_ = 0;
-    VB2_HIP(hipHostGetDevicePointer((void**)&b->d_points_, b->h_points_, 0));
-    VB2_HIP(hipHostGetDevicePointer((void**)&b->d_out_, b->h_out_, 0));
-    VB2_HIP(hipHostGetDevicePointer((void**)&b->d_nv_, b->h_nv_, 0));
-    VB2_HIP(hipHostGetDevicePointer((void**)&b->d_done_, b->h_done_, 0));
-    VB2_HIP(hipStreamCreateWithFlags(&b->stream_, hipStreamNonBlocking));
-    VB2_HIP(hipDeviceSynchronize());
-    *out = b.release();
+    blob.resize((blob.size() + 15) / 16 * 16);
+    // device slab
+    size_t dtot = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t off = (dtot + 255) & ~(size_t)255;
+        dtot = off + bytes;
+        return off;
+    };
+    const size_t o_lay = carve(sizeof(DeviceLayout) * S);
+    const size_t o_blob = carve(blob.size());
+    const size_t o_arr = carve(kShapes * S * sizeof(Schedule));
+    const size_t o_zero = carve(0);
+    const size_t o_part = carve(sizeof(double) * S * (kSlot + 1) * bps);
+    const size_t o_tick = carve(sizeof(unsigned int) * S);
+    const size_t o_done = carve(sizeof(unsigned int));
+    dtot = (dtot + 255) & ~(size_t)255;
+    d_slab_ = cached_device_slab(dtot, device, &d_slab_bytes_);
+    if (!d_slab_) {
+        VB2_HIP(hipMalloc(&d_slab_, dtot));
+        d_slab_bytes_ = dtot;
+    }
+    char* dbase = static_cast<char*>(d_slab_);
+    if (!stream_) {
+        stream_ = cached_stream(device);
+        if (!stream_) VB2_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    }
+    // host image of the read-only part, uploaded on the batch's stream (the launches follow on it)
+    std::vector<char> image(o_zero, 0);
+    std::memcpy(image.data() + o_lay, layouts_.data(), sizeof(DeviceLayout) * S);
+    if (!blob.empty()) std::memcpy(image.data() + o_blob, blob.data(), blob.size());
+    std::vector<Schedule> arr(kShapes * S, Schedule{nullptr, nullptr});
+    if (sched_ok) {
+        const size_t ob = (((size_t)bps * block_waves_ + 1) * sizeof(uint32_t) + 15) / 16 * 16;
+        for (int sh = 0; sh < kShapes; ++sh)
+            for (size_t s = 0; s < S; ++s) {
+                const size_t w = where[sh][s];
+                if (w == (size_t)-1) continue;
+                const uint32_t* o = reinterpret_cast<const uint32_t*>(dbase + o_blob + w);
+                arr[sh * S + s] = Schedule{o, reinterpret_cast<const uint16_t*>(dbase + o_blob + w + ob)};
+            }
+    }
+    std::memcpy(image.data() + o_arr, arr.data(), kShapes * S * sizeof(Schedule));
+    VB2_HIP(hipMemcpyAsync(dbase, image.data(), image.size(), hipMemcpyHostToDevice, stream_));
+    VB2_HIP(hipMemsetAsync(dbase + o_zero, 0, dtot - o_zero, stream_));
+    VB2_HIP(hipStreamSynchronize(stream_));                       // (image is a pageable temporary)
+    d_layouts_ = reinterpret_cast<DeviceLayout*>(dbase + o_lay);
+    for (int sh = 0; sh < kShapes; ++sh)
+        d_scheds_[sh] = sched_ok ? reinterpret_cast<const Schedule*>(dbase + o_arr) + sh * S : nullptr;
+    d_partials_ = reinterpret_cast<double*>(dbase + o_part);
+    d_tickets_ = reinterpret_cast<unsigned int*>(dbase + o_tick);
+    d_batch_done_ = reinterpret_cast<unsigned int*>(dbase + o_done);
+    // pinned, device-mapped slab
+    size_t htot = 0;
+    auto hcarve = [&](size_t bytes) {
+        const size_t off = (htot + 127) & ~(size_t)127;
+        htot = off + bytes;
+        return off;
+    };
+    const size_t p_pts = hcarve(sizeof(double) * S * kSlot * stride);
+    const size_t p_out = hcarve(sizeof(double) * S * kSlot);
+    const size_t p_nv = hcarve(sizeof(int) * S);
+    const size_t p_done = hcarve(sizeof(unsigned long long) * 8);
+    h_slab_ = cached_pinned_slab(htot, device, &h_slab_bytes_);
+    if (!h_slab_) {
+        VB2_HIP(hipHostMalloc(&h_slab_, htot, hipHostMallocMapped));
+        h_slab_bytes_ = htot;
+    }
+    std::memset(h_slab_, 0, htot);
+    char* hbase = static_cast<char*>(h_slab_);
+    char* hdev = nullptr;
+    VB2_HIP(hipHostGetDevicePointer((void**)&hdev, h_slab_, 0));
+    h_points_ = reinterpret_cast<double*>(hbase + p_pts);
+    d_points_ = reinterpret_cast<double*>(hdev + p_pts);
+    h_out_ = reinterpret_cast<double*>(hbase + p_out);
+    d_out_ = reinterpret_cast<double*>(hdev + p_out);
+    h_nv_ = reinterpret_cast<int*>(hbase + p_nv);
+    d_nv_ = reinterpret_cast<int*>(hdev + p_nv);
+    h_done_ = reinterpret_cast<unsigned long long*>(hbase + p_done);
+    d_done_ = reinterpret_cast<unsigned long long*>(hdev + p_done);
+    seq_ = 0;
+    ready_ = true;
     return VB2_OK;
 }
 
 int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, const double* alpha,
                 double* llk_out)
 {
+    if (const int rc = eval_begin(num_point, pc1, pc2, alpha, llk_out)) return rc;
+    return eval_end();
+}
+
+int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double* pc2, const double* alpha,
+                      double* llk_out)
+{
+    if (in_flight_) {
+        set_error("vb2_batch_eval: a step is already in flight");
+        return VB2_ERR_INVALID;
+    }
     VB2_HIP(hipSetDevice(device));
     const int k = num_pc, stride = 2 * k + 1;
     int max_n = 0;
@@ -176,6 +250,7 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
         max_n = std::max(max_n, (int)num_point[s]);
     }
     if (max_n == 0) return VB2_OK;
+    if (const int rc = ensure_resources()) return rc;
     if (max_n > 4 && !wide_rows_) {
         // a sample with a very wide dictionary has narrow table rows: 4 points per launch at most
         const size_t S = (size_t)num_sample;
@@ -219,7 +294,8 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
         }
     }
     if (active == 0) return VB2_OK;
-    MultiLaunch ml{};
+    MultiLaunch& ml = ml_;
+    ml = MultiLaunch{};
     ml.d_layouts = d_layouts_;
     ml.d_scheds = d_scheds_[shape];
     ml.d_points = d_points_;
@@ -236,13 +312,31 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
     ml.block_waves = block_waves_;
     ml.np = NP;
     ml.shmem = shmem_[shape];
+    ml.force_ticket = false;
+    VB2_HIP(launch_llk_eval_multi(ml, stream_));
+    ++num_launch;
+    in_flight_ = true;
+    flight_np_ = NP;
+    flight_out_ = llk_out;
+    return VB2_OK;
+}
+
+int Batch::eval_end()
+{
+    if (!in_flight_) return VB2_OK;                      // (nothing was launched: answered in eval_begin)
+    in_flight_ = false;
+    VB2_HIP(hipSetDevice(device));
+    MultiLaunch& ml = ml_;
+    const int NP = flight_np_;
     // (a NaN is the tagged hand-off's "a workgroup never reported" marker: redo the step once with
     // the arrival-ticket hand-off, see Context::eval_host -- NaN must not reach the optimisers)
     for (int attempt = 0; attempt < 2; ++attempt) {
-        ml.force_ticket = attempt > 0;
-        if (attempt > 0) ml.done_seq = ++seq_;
-        VB2_HIP(launch_llk_eval_multi(ml, stream_));
-        ++num_launch;
+        if (attempt > 0) {
+            ml.force_ticket = true;
+            ml.done_seq = ++seq_;
+            VB2_HIP(launch_llk_eval_multi(ml, stream_));
+            ++num_launch;
+        }
         bool seen = false;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; ++spins) {
@@ -257,7 +351,7 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
         if (!any_nan) break;
     }
     for (int s = 0; s < num_sample; ++s)
-        for (int j = 0; j < h_nv_[s]; ++j) llk_out[(size_t)s * kSlot + j] = h_out_[(size_t)s * NP + j];
+        for (int j = 0; j < h_nv_[s]; ++j) flight_out_[(size_t)s * kSlot + j] = h_out_[(size_t)s * NP + j];
     return VB2_OK;
 }
 
@@ -265,7 +359,25 @@ int Batch::eval(const int32_t* num_point, const double* pc1, const double* pc2, 
 // lock-step search: every sample runs the ordinary Estimator (OptimizeLLK with its six models,
 // the reference-exact simplex) as a fiber of the calling thread (lockstep.h); the parked
 // requests of a step leave as ONE launch of the multi-sample kernel.
+//
+// A cohort of kSplitFrom samples or more is searched as TWO half-cohorts taking turns: while one
+// half's step is on the device, the other half's fibers run on the host (64 fiber switches and
+// simplex updates are ~60 us, a quarter of the step they would otherwise be added to), and the
+// next launch is already queued behind the running one, so the device never waits for the host.
 // ---------------------------------------------------------------------------
+namespace {
+
+struct Lane {
+    Batch* batch = nullptr;
+    std::unique_ptr<FiberGang> gang;
+    int base = 0, count = 0;                // samples [base, base + count) of the whole cohort
+    std::vector<int32_t> npts;
+    std::vector<double> pc1, pc2, alpha, llk;
+    bool flying = false;
+};
+
+}  // namespace
+
 int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
 {
     if (!models || !out || (num_model != 1 && num_model != num_sample)) {
@@ -279,59 +391,121 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     // measured: a 1-point step of 32 C3 samples takes 131 us against 236 us with 4 points) -- and
     // {R, C_R} is the better trade: 1.2 steps per iteration at about half the points.  Same
     // decisions, same trajectory either way.  VB2_COHORT_SPECULATE=1|2|4 forces one.
-    constexpr int kPairFrom = 8;
+    constexpr int kPairFrom = 8, kSplitFrom = 16;
     speculate_ = num_sample < kPairFrom ? 4 : 2;
     if (const char* e = std::getenv("VB2_COHORT_SPECULATE")) speculate_ = std::max(1, std::atoi(e));
+    bool split = num_sample >= kSplitFrom;
+    if (const char* e = std::getenv("VB2_COHORT_SPLIT")) split = std::atoi(e) != 0 && num_sample >= 2;
 
     const int S = num_sample, k = num_pc;
-    FiberGang gang(S, kSlot);
-    std::vector<int> rcs(S, 0);
-    std::vector<int32_t> npts(S, 0);
-    std::vector<double> pc1((size_t)S * kSlot * k), pc2((size_t)S * kSlot * k), alpha((size_t)S * kSlot),
-        llk((size_t)S * kSlot);
-    auto body = [&](int s) {
-        try {
-            const vb2_model& m = models[num_model == 1 ? 0 : s];
-            Estimator est(num_pc, FiberGang::eval_cb, gang.user(s));
-            apply_model(est, m);
-            est.speculate = speculate_;
-            if (ctx_[s]->L.known_af) {       // context built with --KnownAF data
-                est.isAFknown = true;
-                est.isPCFixed = true;
-                est.isHeter = false;
+    Lane lanes[2];
+    int nlane = 1;
+    if (split) {
+        const int cut = S / 2;
+        for (int h = 0; h < 2; ++h)
+            if (!half_[h]) {
+                std::vector<Context*> part(ctx_.begin() + (h ? cut : 0), h ? ctx_.end() : ctx_.begin() + cut);
+                Batch* hb = nullptr;
+                if (const int rc = Batch::create(part, &hb)) return rc;
+                half_[h].reset(hb);
             }
-            rcs[s] = est.OptimizeLLK();
-            fill_estimate(est, &out[s]);
-        } catch (const std::bad_alloc&) {
-            rcs[s] = VB2_ERR_NOMEM;
-        } catch (const std::exception& e) {
-            set_error(e.what());
-            rcs[s] = VB2_ERR_INVALID;
-        } catch (...) {                      // nothing may unwind past the fiber's entry frame
-            set_error("vb2_batch_optimize_llk: unknown exception in a sample's search");
-            rcs[s] = VB2_ERR_INVALID;
-        }
-    };
-    auto step = [&](std::vector<FiberGang::Request>& req) {
-        for (int s = 0; s < S; ++s) {
-            const FiberGang::Request& r = req[s];
-            npts[s] = r.n;
-            if (r.n <= 0) continue;
-            std::memcpy(&pc1[(size_t)s * kSlot * k], r.p1, sizeof(double) * r.n * k);
-            std::memcpy(&pc2[(size_t)s * kSlot * k], r.p2, sizeof(double) * r.n * k);
-            std::memcpy(&alpha[(size_t)s * kSlot], r.a, sizeof(double) * r.n);
-        }
-        if (const int rc = eval(npts.data(), pc1.data(), pc2.data(), alpha.data(), llk.data())) return rc;
-        for (int s = 0; s < S; ++s)
-            if (npts[s] > 0) std::memcpy(req[s].out, &llk[(size_t)s * kSlot], sizeof(double) * npts[s]);
-        return 0;
-    };
-    const int rc = gang.run(k, body, step);
-    if (rc < 0) {
-        set_error("vb2_batch_optimize_llk: getcontext failed");
-        return VB2_ERR_INVALID;
+        nlane = 2;
+        lanes[0].batch = half_[0].get(); lanes[0].base = 0;   lanes[0].count = cut;
+        lanes[1].batch = half_[1].get(); lanes[1].base = cut; lanes[1].count = S - cut;
+    } else {
+        lanes[0].batch = this; lanes[0].base = 0; lanes[0].count = S;
     }
-    if (rc) return rc;
+    std::vector<int> rcs(S, 0);
+    for (int l = 0; l < nlane; ++l) {
+        Lane& L = lanes[l];
+        const size_t n = (size_t)L.count;
+        L.gang.reset(new FiberGang(L.count, kSlot));
+        L.npts.assign(n, 0);
+        L.pc1.resize(n * kSlot * k); L.pc2.resize(n * kSlot * k); L.alpha.resize(n * kSlot); L.llk.resize(n * kSlot);
+    }
+    auto body_of = [&](Lane& L) {
+        return [&, this](int i) {
+            const int s = L.base + i;
+            try {
+                const vb2_model& m = models[num_model == 1 ? 0 : s];
+                Estimator est(num_pc, FiberGang::eval_cb, L.gang->user(i));
+                apply_model(est, m);
+                est.speculate = speculate_;
+                if (ctx_[s]->L.known_af) {       // context built with --KnownAF data
+                    est.isAFknown = true;
+                    est.isPCFixed = true;
+                    est.isHeter = false;
+                }
+                rcs[s] = est.OptimizeLLK();
+                fill_estimate(est, &out[s]);
+            } catch (const std::bad_alloc&) {
+                rcs[s] = VB2_ERR_NOMEM;
+            } catch (const std::exception& e) {
+                set_error(e.what());
+                rcs[s] = VB2_ERR_INVALID;
+            } catch (...) {                      // nothing may unwind past the fiber's entry frame
+                set_error("vb2_batch_optimize_llk: unknown exception in a sample's search");
+                rcs[s] = VB2_ERR_INVALID;
+            }
+        };
+    };
+    int error = 0;
+    auto fail = [&](int rc) {
+        if (!error) error = rc;
+        for (int l = 0; l < nlane; ++l) lanes[l].gang->fail(rc);
+    };
+    // the parked requests of a lane -> one launch
+    auto launch = [&](Lane& L) {
+        if (error || !L.gang->pending()) return;
+        std::vector<FiberGang::Request>& req = L.gang->requests();
+        for (int i = 0; i < L.count; ++i) {
+            const FiberGang::Request& r = req[i];
+            L.npts[i] = r.n;
+            if (r.n <= 0) continue;
+            std::memcpy(&L.pc1[(size_t)i * kSlot * k], r.p1, sizeof(double) * r.n * k);
+            std::memcpy(&L.pc2[(size_t)i * kSlot * k], r.p2, sizeof(double) * r.n * k);
+            std::memcpy(&L.alpha[(size_t)i * kSlot], r.a, sizeof(double) * r.n);
+        }
+        if (const int rc = L.batch->eval_begin(L.npts.data(), L.pc1.data(), L.pc2.data(), L.alpha.data(), L.llk.data())) {
+            fail(rc);
+            return;
+        }
+        L.flying = true;
+    };
+    // wait for the lane's step, hand the values out, run its fibers up to their next requests
+    auto land = [&](Lane& L) {
+        if (L.flying) {
+            L.flying = false;
+            if (const int rc = L.batch->eval_end()) fail(rc);
+            if (!error) {
+                std::vector<FiberGang::Request>& req = L.gang->requests();
+                for (int i = 0; i < L.count; ++i)
+                    if (L.npts[i] > 0) std::memcpy(req[i].out, &L.llk[(size_t)i * kSlot], sizeof(double) * L.npts[i]);
+            }
+        }
+        if (L.gang->pending()) L.gang->resume_parked();       // (after an error: the fibers unwind)
+    };
+    for (int l = 0; l < nlane; ++l)
+        if (lanes[l].gang->start(k, body_of(lanes[l])) < 0) {
+            set_error("vb2_batch_optimize_llk: getcontext failed");
+            return VB2_ERR_INVALID;
+        }
+    launch(lanes[0]);
+    for (;;) {
+        bool busy = false;
+        for (int l = 0; l < nlane; ++l) {
+            Lane& next = lanes[(l + 1) % nlane];
+            if (nlane > 1 && !next.flying) launch(next);       // queued behind the step in flight
+            Lane& cur = lanes[l];
+            if (cur.flying || cur.gang->pending()) {
+                land(cur);
+                launch(cur);
+            }
+            busy |= cur.flying || cur.gang->pending();
+        }
+        if (!busy) break;
+    }
+    if (error) return error;
     for (int s = 0; s < S; ++s)
         if (rcs[s]) return rcs[s];
     return VB2_OK;

@@ -5,6 +5,7 @@
 #ifndef VB2_BATCH_H_
 #define VB2_BATCH_H_
 
+#include <memory>
 #include <vector>
 
 #include "context.h"
@@ -15,9 +16,15 @@ class Batch {
 public:
     ~Batch();
     static int create(vb2_ctx* const* ctxs, int num_sample, Batch** out);
+    static int create(const std::vector<Context*>& ctxs, Batch** out);
     // num_point[s] in [0, 8]; pc1/pc2: [S][8][k]; alpha, llk_out: [S][8]
     int eval(const int32_t* num_point, const double* pc1, const double* pc2, const double* alpha,
              double* llk_out);
+    // the same in two halves: begin launches and returns, end waits and delivers (into the llk_out
+    // given to begin).  One step may be in flight per Batch.
+    int eval_begin(const int32_t* num_point, const double* pc1, const double* pc2, const double* alpha,
+                   double* llk_out);
+    int eval_end();
     // OptimizeLLK for every sample, searches advancing in lock-step; models: 1 or S entries
     int optimize(const vb2_model* models, int num_model, vb2_estimate* out);
 
@@ -28,8 +35,19 @@ public:
 private:
     std::vector<Context*> ctx_;
     hipStream_t stream_ = nullptr;
+    // device side: ONE slab (layouts, schedules, partial sums, tickets, step counter), pinned side:
+    // ONE device-mapped slab (parameter rows, results, point counts, sequence word); both and the
+    // stream come from / go back to the process-wide caches (context.h), and none of it exists
+    // before the first step -- a Batch whose optimize() hands its samples to two halves never
+    // allocates anything itself
+    bool ready_ = false;
+    int ensure_resources();
+    std::vector<DeviceLayout> layouts_;
+    void* d_slab_ = nullptr;
+    size_t d_slab_bytes_ = 0;
+    void* h_slab_ = nullptr;
+    size_t h_slab_bytes_ = 0;
     DeviceLayout* d_layouts_ = nullptr;
-    char* d_sched_ = nullptr;               // the samples' static schedules + the three Schedule[num_sample] arrays
     const Schedule* d_scheds_[kShapes] = {nullptr, nullptr, nullptr, nullptr};    // [shape]
     double* d_partials_ = nullptr;
     unsigned int* d_tickets_ = nullptr;
@@ -43,6 +61,14 @@ private:
     bool wide_rows_ = true;                 // every sample has kRowBytesWide table rows (8-point launches allowed)
     size_t shmem_[kShapes] = {0, 0, 0, 0};  // [shape]
     int speculate_ = 4;                     // points a lock-step search evaluates per iteration (amoeba.h)
+    // the step in flight (eval_begin .. eval_end)
+    bool in_flight_ = false;
+    MultiLaunch ml_{};
+    int flight_np_ = 0;
+    double* flight_out_ = nullptr;
+    // optimize() of a big cohort: two half-cohorts taking turns on the device (see batch.cpp)
+    std::unique_ptr<Batch> half_[2];
+    int optimize_range(const vb2_model* models, int num_model, vb2_estimate* out);
 };
 
 }  // namespace vb2

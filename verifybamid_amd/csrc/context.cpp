@@ -216,6 +216,13 @@ Context::~Context()
     if (own_stream && stream && !slab_cache().give_stream(stream, device)) (void)hipStreamDestroy(stream);
 }
 
+void* cached_device_slab(size_t bytes, int device, size_t* got) { return slab_cache().take(slab_cache().dev, bytes, device, got); }
+bool recycle_device_slab(void* p, size_t bytes, int device) { return slab_cache().give(slab_cache().dev, p, bytes, device); }
+void* cached_pinned_slab(size_t bytes, int device, size_t* got) { return slab_cache().take(slab_cache().pin, bytes, device, got); }
+bool recycle_pinned_slab(void* p, size_t bytes, int device) { return slab_cache().give(slab_cache().pin, p, bytes, device); }
+hipStream_t cached_stream(int device) { return slab_cache().take_stream(device); }
+bool recycle_stream(hipStream_t stream, int device) { return slab_cache().give_stream(stream, device); }
+
 int flatten_dry_run(const vb2_input* in, double* ms)
 {
     Context* none = nullptr;

@@ -25,6 +25,15 @@ int usable_device_count();
 int usable_cpu_count();
 // The host half of vb2_ctx_create (flatten) without a device: timing aid for tools/ubench/host_pipeline.cpp.
 int flatten_dry_run(const vb2_input* in, double* ms);
+// The process-wide recycling of device slabs, pinned device-mapped slabs and streams (context.cpp):
+// allocation and release calls cost milliseconds and serialise in the driver.  take: nullptr = none
+// cached, allocate yourself; give: false = cache full, release it yourself.
+void* cached_device_slab(size_t bytes, int device, size_t* got);
+bool recycle_device_slab(void* p, size_t bytes, int device);
+void* cached_pinned_slab(size_t bytes, int device, size_t* got);
+bool recycle_pinned_slab(void* p, size_t bytes, int device);
+hipStream_t cached_stream(int device);
+bool recycle_stream(hipStream_t stream, int device);
 extern std::atomic<int> g_flatten_thread_cap;   // 0 = no cap on the flatten threads of vb2_ctx_create
 
 constexpr int kStagePoints = 256;   // points per host<->device staging round

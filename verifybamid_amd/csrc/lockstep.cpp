@@ -21,7 +21,7 @@ void FiberGang::entry(unsigned lo, unsigned hi)
 {
     FiberGang* g = reinterpret_cast<FiberGang*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
     const int i = g->cur_;
-    (*g->body_)(i);                  // (never throws: the body catches)
+    g->body_(i);                     // (never throws: the body catches)
     g->fibers_[i].done = true;
     g->req_[i].n = 0;
 }                                    // uc_link: back to run()
@@ -44,16 +44,12 @@ int FiberGang::eval_cb(void* user, int32_t n, const double* p1, const double* p2
     return 0;
 }
 
-int FiberGang::run(int num_pc, const std::function<void(int)>& body, const StepFn& step)
+int FiberGang::start(int num_pc, const std::function<void(int)>& body)
 {
     num_pc_ = num_pc;
-    body_ = &body;
+    body_ = body;
     error_ = 0;
     const int n = (int)fibers_.size();
-    auto resume = [&](int i) {
-        cur_ = i;
-        swapcontext(&main_, &fibers_[i].ctx);
-    };
     for (int i = 0; i < n; ++i) {
         Fiber& f = fibers_[i];
         f.stack.reset(new char[kFiberStack]);
@@ -66,21 +62,41 @@ int FiberGang::run(int num_pc, const std::function<void(int)>& body, const StepF
         const uintptr_t p = reinterpret_cast<uintptr_t>(this);
         makecontext(&f.ctx, reinterpret_cast<void (*)()>(entry), 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
     }
-    for (int i = 0; i < n; ++i) resume(i);                        // up to everybody's first request
-    for (;;) {
-        bool any = false;
-        for (int i = 0; i < n; ++i) any |= !fibers_[i].done && req_[i].n > 0;
-        if (!any) break;
+    for (int i = 0; i < n; ++i) {                                  // up to everybody's first request
+        cur_ = i;
+        swapcontext(&main_, &fibers_[i].ctx);
+    }
+    return 0;
+}
+
+bool FiberGang::pending() const
+{
+    for (size_t i = 0; i < fibers_.size(); ++i)
+        if (!fibers_[i].done && req_[i].n > 0) return true;
+    return false;
+}
+
+void FiberGang::resume_parked()
+{
+    const int n = (int)fibers_.size();
+    for (int i = 0; i < n; ++i) {
+        if (fibers_[i].done || req_[i].n <= 0) continue;
+        req_[i].n = 0;
+        cur_ = i;
+        swapcontext(&main_, &fibers_[i].ctx);                      // up to its next request, or to the end
+    }
+}
+
+int FiberGang::run(int num_pc, const std::function<void(int)>& body, const StepFn& step)
+{
+    if (start(num_pc, body) < 0) return -1;
+    while (pending()) {
         if (!error_) {
             ++steps;
             const int rc = step(req_);
             if (rc) error_ = rc;                                   // the fibers see it and unwind
         }
-        for (int i = 0; i < n; ++i) {
-            if (fibers_[i].done || req_[i].n <= 0) continue;
-            req_[i].n = 0;
-            resume(i);                                             // up to its next request, or to the end
-        }
+        resume_parked();
     }
     return error_;
 }

@@ -41,6 +41,15 @@ public:
     int run(int num_pc, const std::function<void(int)>& body, const StepFn& step);
     int64_t steps = 0;
 
+    // The same in pieces, for a caller that keeps several gangs going (one gang's step on the
+    // device while another gang's fibers run on the host):
+    int start(int num_pc, const std::function<void(int)>& body);   // every fiber up to its first request; < 0: no contexts
+    bool pending() const;                                           // some fiber is parked with a request
+    std::vector<Request>& requests() { return req_; }
+    void fail(int rc) { if (!error_) error_ = rc; }                 // the fibers see it at resume and unwind
+    int error() const { return error_; }
+    void resume_parked();                                           // values delivered: every parked fiber runs on
+
 private:
     struct Fiber {
         ucontext_t ctx;
@@ -56,7 +65,7 @@ private:
     std::vector<Fiber> fibers_;
     std::vector<Cb> cb_;
     std::vector<Request> req_;
-    const std::function<void(int)>* body_ = nullptr;
+    std::function<void(int)> body_;
     int cur_ = -1, num_pc_ = 0, max_points_, error_ = 0;
 };
 
