@@ -1,6 +1,8 @@
 """Launches of the other wave shapes, to be run under `rocprofv3 --kernel-trace --stats`:
 4-point and 1-point launches of one context (llk_eval_kernel<3,.>, <4,.>: the operating points of a
-Nelder-Mead search) and lock-step cohort steps of 32 samples (llk_eval_multi_kernel<3,.>)."""
+Nelder-Mead search) and lock-step cohort steps of 32 samples with 4, 8, 2 and 1 points per sample
+(llk_eval_multi_kernel<3,.>, <2,.>, <5,.>, <4,.>: the last two are the steps of a cohort search, which
+speculates on {R, C_R} only)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -31,5 +33,9 @@ with vb.CohortBatch(ctxs) as batch:
     p1[:] = pts_h[:8, :k]; p2[:] = pts_h[:8, k:2 * k]; al[:] = pts_h[:8, 2 * k]
     for _ in range(150):
         batch.eval(npt, p1, p2, al)
+    for n in (2, 1):
+        npt[:] = n
+        for _ in range(300):
+            batch.eval(npt, p1, p2, al)
 for c in ctxs:
     c.close()
