@@ -194,6 +194,48 @@ def test_line_search_equals_the_references_scalar_minimizer(golden_dir):
             assert len(launched) == len(ref_x) + (1 if speculate else 0)   # the unused candidate for c
 
 
+@pytest.mark.parametrize("speculate", [4, 2])
+def test_lockstep_fibers_give_each_run_its_own_search(golden_dir, speculate):
+    """lockstep.h -- what cohorts and multi-start searches run on: several OptimizeLLK searches as
+    fibers of one thread, every step's requests answered by ONE evaluator call.  Here without a
+    device: the oracle evaluates, run 0 must equal the plain search (evaluation count, alpha, LLKs
+    bit for bit), the jittered runs must equal themselves done alone, and the steps must indeed
+    carry several runs' points each."""
+    import ctypes as C
+    flat, _, _ = refio.load_flat(os.path.join(golden_dir, HAPMAP), os.path.join(golden_dir, "expected/result.Pileup"), 2)
+    od = binding.OracleData(flat)
+    k, runs = 2, 5
+    sizes = []
+
+    def cb(_user, n, p1, p2, a, out):
+        pc1 = np.ctypeslib.as_array(p1, (n, k)); pc2 = np.ctypeslib.as_array(p2, (n, k)); al = np.ctypeslib.as_array(a, (n,))
+        sizes.append(n)
+        for i in range(n):
+            out[i] = od.llk(pc1[i], pc2[i], al[i], num_thread=1)
+        return 0
+    fn = _abi.EVAL_FN(cb)
+    L = _abi.lib()
+    L.vb2_debug_lockstep_optimize.restype = C.c_int
+    L.vb2_debug_lockstep_optimize.argtypes = [_abi.EVAL_FN, C.c_void_p, C.c_int32, C.POINTER(_abi.Model), C.c_int32,
+                                              C.c_int32, C.POINTER(_abi.Estimate), C.POINTER(C.c_int64)]
+    m = _abi.Model(1, 0, 0, 0, 0.0, None, 1e-8, 0, 0)
+    ests = (_abi.Estimate * runs)()
+    steps = C.c_int64(0)
+    assert L.vb2_debug_lockstep_optimize(fn, None, k, C.byref(m), runs, speculate, ests, C.byref(steps)) == 0
+    together = list(sizes)
+    assert steps.value == len(together) and max(together) > speculate        # steps carry several runs
+    plain = od.optimize()
+    assert ests[0].alpha == plain["alpha"] and ests[0].llk1 == plain["llk1"] and ests[0].llk0 == plain["llk0"]
+    assert ests[0].num_eval == plain["num_eval"]
+    # each run alone (a gang of i + 1 runs whose last member is run i) gives the same answer
+    for i in (1, 4):
+        alone = (_abi.Estimate * (i + 1))()
+        assert L.vb2_debug_lockstep_optimize(fn, None, k, C.byref(m), i + 1, speculate, alone, None) == 0
+        for key in ("alpha", "llk1", "llk0", "num_eval"):
+            assert getattr(alone[i], key) == getattr(ests[i], key), (i, key)
+    assert len({e.alpha for e in ests}) > 1                                   # the starts do differ
+
+
 def test_cpp_optimiser_other_dimensions():
     """k = 1 (the reference's hard-coded index-1 swap must not run) and k = 4."""
     for k, seed in ((1, 11), (4, 12)):

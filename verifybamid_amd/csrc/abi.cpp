@@ -214,6 +214,62 @@ void vb2_debug_set_device_simplex(vb2_ctx* ctx, int on)
 }
 
 // Test aid: is the context in resident mode right now?
+// test hook (not in vb2_abi.h): `runs` OptimizeLLK searches over a caller's evaluator, advancing in
+// lock-step as fibers of this thread (lockstep.h: what cohorts and multi-start searches use), every
+// step's requests answered by ONE call of `eval` with all points concatenated.  Run i starts from
+// start index i (vb2_search_opts semantics, seed 1).  No device involved: the CPU suite drives it
+// with the oracle as evaluator and compares each run with the same search done on its own.
+int vb2_debug_lockstep_optimize(vb2_eval_fn eval, void* user, int32_t num_pc, const vb2_model* model, int32_t runs,
+                                int32_t speculate, vb2_estimate* out, int64_t* num_step)
+{
+    if (!eval || !model || !out || runs < 1 || num_pc < 1 || num_pc > VB2_MAX_PC) return VB2_ERR_INVALID;
+    try {
+        vb2::FiberGang gang(runs, 4);
+        std::vector<int> rcs(runs, 0);
+        std::vector<double> p1, p2, al, vals;
+        auto body = [&](int i) {
+            try {
+                vb2::Estimator est(num_pc, vb2::FiberGang::eval_cb, gang.user(i));
+                vb2::apply_model(est, *model);
+                est.speculate = speculate;
+                est.start_index = i;
+                est.start_seed = 1;
+                rcs[i] = est.OptimizeLLK();
+                vb2::fill_estimate(est, &out[i]);
+            } catch (...) {
+                rcs[i] = VB2_ERR_INVALID;
+            }
+        };
+        auto step = [&](std::vector<vb2::FiberGang::Request>& req) {
+            p1.clear(); p2.clear(); al.clear();
+            for (const auto& r : req) {
+                if (r.n <= 0) continue;
+                p1.insert(p1.end(), r.p1, r.p1 + (size_t)r.n * num_pc);
+                p2.insert(p2.end(), r.p2, r.p2 + (size_t)r.n * num_pc);
+                al.insert(al.end(), r.a, r.a + r.n);
+            }
+            vals.resize(al.size());
+            if (const int rc = eval(user, (int32_t)al.size(), p1.data(), p2.data(), al.data(), vals.data())) return rc;
+            size_t o = 0;
+            for (auto& r : req) {
+                if (r.n <= 0) continue;
+                std::memcpy(r.out, &vals[o], sizeof(double) * r.n);
+                o += (size_t)r.n;
+            }
+            return 0;
+        };
+        const int rc = gang.run(num_pc, body, step);
+        if (num_step) *num_step = gang.steps;
+        if (rc) return rc < 0 ? VB2_ERR_INVALID : rc;
+        for (int i = 0; i < runs; ++i)
+            if (rcs[i]) return rcs[i];
+        return VB2_OK;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
+}
+
 // test hook (not in vb2_abi.h): the library's bracket + Brent (line_search.h) on a caller's scalar
 // function; `committed` is called for every evaluation the reference's ScalarMinimizer would make,
 // in its order (a speculative batch calls f for more points); out = {min, fmin, a, b, c}.

@@ -1,12 +1,20 @@
 // lockstep.cpp -- see lockstep.h.
 #include "lockstep.h"
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
 
 namespace vb2 {
 
 namespace {
-constexpr size_t kFiberStack = 256 * 1024;
+constexpr size_t kFiberStack = 256 * 1024;      // the optimiser's frames are a few KB deep
+size_t page_size()
+{
+    static const size_t p = (size_t)std::max(4096L, sysconf(_SC_PAGESIZE));
+    return p;
+}
 }
 
 FiberGang::FiberGang(int num_fiber, int max_points_per_request)
@@ -15,7 +23,11 @@ FiberGang::FiberGang(int num_fiber, int max_points_per_request)
     for (int i = 0; i < num_fiber; ++i) cb_[i] = Cb{this, i};
 }
 
-FiberGang::~FiberGang() {}
+FiberGang::~FiberGang()
+{
+    for (Fiber& f : fibers_)
+        if (f.map) munmap(f.map, kFiberStack + page_size());
+}
 
 void FiberGang::entry(unsigned lo, unsigned hi)
 {
@@ -52,11 +64,18 @@ int FiberGang::start(int num_pc, const std::function<void(int)>& body)
     const int n = (int)fibers_.size();
     for (int i = 0; i < n; ++i) {
         Fiber& f = fibers_[i];
-        f.stack.reset(new char[kFiberStack]);
+        if (!f.map) {
+            // stacks grow downwards: an overflow hits the PROT_NONE page and faults instead of
+            // scribbling over the heap
+            void* m = mmap(nullptr, kFiberStack + page_size(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m == MAP_FAILED) return -1;
+            (void)mprotect(m, page_size(), PROT_NONE);
+            f.map = m;
+        }
         f.done = false;
         req_[i] = Request{};
         if (getcontext(&f.ctx) != 0) return -1;
-        f.ctx.uc_stack.ss_sp = f.stack.get();
+        f.ctx.uc_stack.ss_sp = static_cast<char*>(f.map) + page_size();
         f.ctx.uc_stack.ss_size = kFiberStack;
         f.ctx.uc_link = &main_;
         const uintptr_t p = reinterpret_cast<uintptr_t>(this);

@@ -53,7 +53,7 @@ public:
 private:
     struct Fiber {
         ucontext_t ctx;
-        std::unique_ptr<char[]> stack;
+        void* map = nullptr;                // mmap'ed: one inaccessible guard page below the stack
         bool done = false;
     };
     struct Cb {
