@@ -21,7 +21,7 @@ def _ensure_built():
     srcs = []
     for d in ("verifybamid_amd/csrc", "include", "oracle"):
         for f in os.listdir(os.path.join(ROOT, d)):
-            if f.endswith((".cpp", ".hip", ".h", ".c", "Makefile")):
+            if f.endswith((".cpp", ".hip", ".inc", ".h", ".c", "Makefile")):
                 srcs.append(os.path.join(ROOT, d, f))
     if all(os.path.exists(p) for p in need):
         oldest = min(os.path.getmtime(p) for p in need)

@@ -16,6 +16,11 @@ lib.vb2_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 nb = lib.vb2_debug_read_stamps(ctx._h, buf, 512)
 s = np.array(buf[:8 * nb], dtype=np.float64).reshape(nb, 8)
 t0 = s[0, 7]
+if nb > 4 and s[4, 7] > 0:
+    n = s[4, 7]
+    print("device-side search, %d rounds, per round: control step %.2f us, relay hop (control done -> workgroup 0 has the "
+          "round) %.2f us, evaluation (has the round -> next round's top) %.2f us"
+          % (n, s[1, 7] / n / 100.0, s[2, 7] / n / 100.0, s[3, 7] / n / 100.0))
 s = s[s[:, 0] > 0]
 us = (s - t0) / 100.0
 names = ["entry", "points in LDS", "table built", "wave0 tiles done", "last wave tiles done", "block reduced", "finalized (last block)"]
