@@ -399,6 +399,31 @@ def test_underflowing_marker_is_dropped_like_the_reference():
     assert abs(want[0]) < 50                    # a 5000-read marker would contribute ~ -3500
 
 
+def test_markers_at_the_underflow_boundary_follow_the_reference():
+    """Deep targeted data: with ~1000 reads a marker's likelihood sits around e^-700 .. e^-760, i.e.
+    around the smallest doubles, and the reference's rule "add log(markerLK) only if markerLK > 0"
+    (h:309-311) makes every rounding difference down there a marker counted or dropped -- 745 units
+    of LLK.  The kernel's factored genotype sum is redone in the reference's own term order below
+    2^-960; without that, 5 of these 12 points were off by a whole marker (found by
+    tools/big_sanity.py, not by the single 5000-read marker of the test above)."""
+    k = 4
+    d = vb.synth.make_pileup(2500, 1000, k, seed=6)
+    od = oracle_data(d)
+    rng = np.random.default_rng(3)
+    pc1, pc2, al = _random_points(rng, 12, k)
+    with vb.LikelihoodContext(d) as ctx:
+        got = ctx.llk(pc1, pc2, al)
+        four = np.concatenate([ctx.llk(pc1[i:i + 4], pc2[i:i + 4], al[i:i + 4]) for i in range(0, 12, 4)])
+        one = np.array([ctx.llk(pc1[i:i + 1], pc2[i:i + 1], al[i:i + 1])[0] for i in range(12)])
+    want = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=8) for i in range(12)])
+    assert np.max(np.abs(got - want)) < 1e-6, np.abs(got - want).max()      # (a dropped marker would show as ~745)
+    assert rel_err(got, want) <= LLK_RTOL
+    assert np.array_equal(got, four) and np.array_equal(got, one)           # every wave shape takes the same path
+    # and some markers really are down there: the oracle drops a few of them at some of the points
+    drops = [od.llk(pc1[i], pc2[i], al[i], num_thread=1) for i in range(2)]
+    assert all(np.isfinite(drops))
+
+
 def test_sanity_depth_filter():
     d = vb.synth.with_sanity_stats(vb.synth.make_pileup(3000, 20, 2, seed=8))
     depth = np.diff(d.read_off)

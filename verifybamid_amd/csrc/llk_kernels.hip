@@ -627,6 +627,25 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 const double s1 = fma(x12, gf2[2], fma(e1, gf2[1], x10 * gf2[0]));
                 const double s2 = fma(e2, gf2[2], fma(x21, gf2[1], x20 * gf2[0]));
                 double lk = fma(s2, gf[2], fma(s1, gf[1], s0 * gf[0]));
+                // Near the bottom of the double range the factoring is no longer harmless: products with
+                // the priors underflow at different places, and the reference's rule below (h:310-311,
+                // "add log(lk) only if lk > 0") turns that into a marker counted or dropped, 745 units
+                // of LLK apart (markers with ~1000 reads).  There the sum is redone term by term in the
+                // reference's own order (g1 outer, g2 inner, h:307-309), as round 1 did everywhere;
+                // wave-divergent, and never taken on whole-genome depths.
+                if (__builtin_expect(lk < 0x1p-960, 0)) {
+                    double r = 0;
+                    r += e0 * gf[0] * gf2[0];
+                    r += x01 * gf[0] * gf2[1];
+                    r += x02 * gf[0] * gf2[2];
+                    r += x10 * gf[1] * gf2[0];
+                    r += e1 * gf[1] * gf2[1];
+                    r += x12 * gf[1] * gf2[2];
+                    r += x20 * gf[2] * gf2[0];
+                    r += x21 * gf[2] * gf2[1];
+                    r += e2 * gf[2] * gf2[2];
+                    lk = r;
+                }
                 // the reference adds log(lk) only if lk > 0 (h:310-311): a dropped marker is
                 // the factor 1
                 lk = lk > 0 ? lk : 1.0;
