@@ -19,6 +19,21 @@ def check(d, k, B=5, tag=""):
 c = check(vb.synth.make_pileup(1000000, 30, 4, seed=5), 4, tag="1M markers x 30"); c.close()
 c = check(vb.synth.make_pileup(5000, 1000, 4, seed=6), 4, tag="5k markers x depth 1000"); c.close()
 c = check(vb.synth.make_pileup(20000, 40, 10, seed=7, q_lo=0, q_hi=93), 10, tag="20k markers, q 0..93, k=10")
+# parameter points far outside the plausible range (allele frequencies beyond [0, 1], alpha 0 / 0.5 / 1)
+for (M, depth, k, seed) in ((10000, 30, 2, 1), (3000, 200, 4, 9), (2000, 5, 3, 4)):
+    d = vb.synth.make_pileup(M, depth, k, seed=seed)
+    od = oracle_data(d)
+    for scale in (0.3, 2.0):
+        r2 = np.random.default_rng(11)
+        B = 16
+        pc1 = r2.normal(0, scale, size=(B, k)); pc2 = r2.normal(0, scale, size=(B, k)); al = r2.uniform(0, 1.0, size=B)
+        al[0] = 0.0; al[1] = 1.0; al[2] = 0.5
+        with vb.LikelihoodContext(d) as cx:
+            got = cx.llk(pc1, pc2, al)
+        want = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=8) for i in range(B)])
+        err = np.max(np.abs(got - want) / np.abs(want))
+        assert err < 1e-12, (M, depth, k, scale, err)
+print("extreme parameter points ok")
 d2 = [vb.synth.make_pileup(3000 + 500 * i, 20 + i, 10, seed=20 + i, q_lo=0, q_hi=93) for i in range(5)]
 ctxs = [vb.LikelihoodContext(d) for d in d2]
 with vb.CohortBatch(ctxs) as b:
