@@ -396,9 +396,22 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     {
         std::vector<std::vector<int64_t>> hist_t(nthr, std::vector<int64_t>(kMaxCode, 0));
         std::vector<int64_t> reads_t(nthr, 0), other_t(nthr, 0);
+        // class of a base given the marker's alt allele, one table row per (upper-cased) alt: 0 ref
+        // ('.' ','), 1 alt, 2 other
+        static const struct ClassTable {
+            uint8_t row[256][256];
+            ClassTable()
+            {
+                for (int a = 0; a < 256; ++a)
+                    for (int b = 0; b < 256; ++b)
+                        row[a][b] = (b == '.' || b == ',') ? 0 : (ascii_upper((unsigned char)b) == a ? 1 : 2);
+            }
+        } class_table;
         parallel_for(M, [&](int t, int64_t i0, int64_t i1) {
-            uint32_t cnt[3 * 64];
-            std::fill(cnt, cnt + 3 * 64, 0u);
+            // (two counter sets, for even and odd reads: consecutive reads mostly carry the same code,
+            // and one set would make every increment wait for the previous one's store)
+            uint32_t cnt[2][3 * 64];
+            std::fill(&cnt[0][0], &cnt[0][0] + 2 * 3 * 64, 0u);
             std::vector<int64_t>& hist = hist_t[t];
             int64_t n_read = 0, n_other = 0;          // thread-local: no shared cache lines in the loop
             const Luts& T = *lut;
@@ -412,18 +425,17 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 const unsigned char* qs = reinterpret_cast<const unsigned char*>(in->quals + beg);
                 uint64_t bm[3] = {0, 0, 0};
                 double c_other = 0.0;                 // class "other": same term for every genotype pair
+                const uint8_t* cls_of = class_table.row[alt_up];
                 for (int64_t j = 0; j < depth; ++j) {
-                    const unsigned char b = bs[j], qv = qs[j];
-                    int cls;
-                    if (T.dot[b]) cls = 0;
-                    else if (T.up[b] == alt_up) cls = 1;
-                    else {
+                    const unsigned char qv = qs[j];
+                    const unsigned cls = cls_of[bs[j]];
+                    if (__builtin_expect(cls == 2, 0)) {
                         c_other += T.other_lc[qv];
                         ++n_other;
                         continue;
                     }
-                    const unsigned idx = (unsigned)T.qidx[qv] + (unsigned)cls;
-                    ++cnt[idx];
+                    const unsigned idx = (unsigned)T.qidx[qv] + cls;
+                    ++cnt[j & 1][idx];
                     bm[idx >> 6] |= 1ull << (idx & 63);
                 }
                 // steps of this marker in the kernel = runs of equal (class, quality): one
@@ -436,8 +448,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 for (int w = 0; w < 3; ++w)
                     for (uint64_t bits = bm[w]; bits; bits &= bits - 1) {
                         const unsigned idx = (unsigned)w * 64u + (unsigned)__builtin_ctzll(bits);
-                        uint32_t left = cnt[idx];
-                        cnt[idx] = 0;
+                        uint32_t left = cnt[0][idx] + cnt[1][idx];
+                        cnt[0][idx] = cnt[1][idx] = 0;
                         hist[idx] += left;
                         const double n = (double)left;
                         const double* lc = &lc3[(size_t)idx * 3];

@@ -518,7 +518,6 @@ int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v)
         next_slot = slot + 1;
     };
     const bool slow = slow_parse();
-    std::string scratch_b, scratch_q;
     for_each_line(all, true, [&](const char* b, const char* e) {
         if (rc) return;
         Scan sc{b, e};
@@ -532,11 +531,12 @@ int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v)
                 rc = VB2_ERR_INVALID;
                 return;
             }
-            // parse straight into the pools' spare room; kept only if the line is a new site
-            scratch_b.resize(n);
-            scratch_q.resize(n);
+            // parse straight into the pools' tails; the bytes stay only if the line is a new site
+            const size_t tail = v->basePool.size();
+            v->basePool.resize(tail + n);
+            v->qualPool.resize(tail + n);
             size_t kept = 0;
-            if (!parse_bases_raw(s0, n, q0, (size_t)(q1 - q0), n ? &scratch_b[0] : nullptr, n ? &scratch_q[0] : nullptr, &kept)) {
+            if (!parse_bases_raw(s0, n, q0, (size_t)(q1 - q0), &v->basePool[tail], &v->qualPool[tail], &kept)) {
                 set_error("Pileup format error: indel marker without a valid length in the bases column of " +
                           std::string(c0, c1) + ":" + std::to_string(ppos));
                 rc = VB2_ERR_INVALID;
@@ -547,7 +547,20 @@ int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v)
             last.in_bed = slot >= 0;
             last.c0 = c0; last.c1 = c1; last.r0 = r0; last.r1 = r1; last.s0 = s0; last.s1 = s1; last.q0 = q0; last.q1 = q1;
             last.pos = ppos;
-            if (slot >= 0) record(slot, scratch_b.data(), scratch_q.data(), kept);
+            const bool fresh = slot >= 0 && v->siteOfSlot[slot] < 0;
+            v->basePool.resize(tail + (fresh ? kept : 0));
+            v->qualPool.resize(tail + (fresh ? kept : 0));
+            if (slot >= 0) {
+                if (fresh) {
+                    v->siteOfSlot[slot] = v->num_site();
+                    v->siteOff.push_back((uint32_t)v->basePool.size());
+                    v->numBases += (int)kept;
+                    v->effectiveNumSite++;
+                    next_slot = slot + 1;
+                } else {
+                    record(slot, nullptr, nullptr, kept);       // a duplicated line: warning, counters (quirk vii)
+                }
+            }
             return;
         }
         // any other line: the original statements, on the variables as the previous lines left them
