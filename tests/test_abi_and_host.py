@@ -430,6 +430,25 @@ def test_gzipped_panel_files_are_inflated_like_the_reference_inputfile(tmp_path,
     assert a.alt_base.tobytes() == b.alt_base.tobytes() and a.read_off.tobytes() == b.read_off.tobytes()
 
 
+def test_big_ud_file_parsed_by_several_threads_equals_numpy(tmp_path):
+    """A .UD of more than 1 MiB is cut at line ends and parsed by several threads (hostio.cpp:
+    read_ud): same values, same order as a plain parse, 17-digit (strtod path) and short values
+    mixed, and a bad row still reports the reference's message."""
+    M, k = 40000, 4
+    base = vb.synth.with_sanity_stats(vb.synth.make_pileup(M, 3, k, seed=12))
+    pre = vb.synth.write_files(base, str(tmp_path / "panel"))
+    assert os.path.getsize(pre + ".UD") > (1 << 20)
+    d = vb.PileupData.from_files(pre, pre + ".pileup", k, disable_sanity=True)
+    want = np.loadtxt(pre + ".UD")[:, :k]
+    assert np.array_equal(d.ud, want)
+    lines = open(pre + ".UD").read().splitlines()
+    lines[31234] = lines[31234].split()[0]                     # one column where four are needed
+    open(pre + ".UD", "w").write("\n".join(lines) + "\n")
+    with pytest.raises(_abi.Vb2Error) as ei:
+        vb.PileupData.from_files(pre, pre + ".pileup", k, disable_sanity=True)
+    assert "Expected:4 vs Observed:1" in str(ei.value)
+
+
 def test_ud_with_too_few_columns(tmp_path):
     pre = str(tmp_path / "q")
     open(pre + ".bed", "w").write("1\t0\t1\tA\tC\n")
