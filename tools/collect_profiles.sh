@@ -9,6 +9,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | head -c 400; echo
+rm -f $O/bench_batch_sweep.jsonl
 for b in 1 4 8 16 32 48; do python bench.py --batch $b --no-cpu-baseline --no-optimize --no-extras 2>/dev/null | tail -1 >> $O/bench_batch_sweep.jsonl; done
 cd /tmp && export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-optimize --no-extras --soft-exit"
