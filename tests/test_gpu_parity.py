@@ -619,6 +619,36 @@ def test_cohort_run_group_schedule_does_not_change_results(tmp_path):
             assert open(out_a[s] + ext).read() == open(out_b[s] + ext).read(), (s, ext)
 
 
+def test_cohort_run_over_several_device_pipelines(tmp_path, monkeypatch):
+    """vb2_cohort_run with a device list: one pipeline thread per entry, groups dealt round-robin,
+    each device with its own small first groups, the readers looking two groups ahead per device.
+    A machine with one GPU lists it three times (allowed by a test switch only): 70 samples, every
+    output equal to the one-pipeline run's; without the switch a repeated device is an error."""
+    k, M = 2, 1500
+    base = vb.synth.with_sanity_stats(vb.synth.make_pileup(M, 12, k, alpha_true=0.03, seed=170))
+    pre = vb.synth.write_files(base, str(tmp_path / "panel"))
+    piles = []
+    for s in range(4):
+        d = vb.synth.make_pileup(M, 9 + 3 * s, k, alpha_true=0.04 * (s + 1), seed=180 + s)
+        d = vb.PileupData(k, base.ud, base.means, d.read_off, d.bases, d.quals, base.alt_base, None,
+                          d.avg_depth, d.sd_depth, True, dict(base.meta))
+        piles.append(vb.synth.write_files(d, str(tmp_path / ("s%d" % s))) + ".pileup")
+    S = 70
+    paths = [piles[s % 4] for s in range(S)]
+    out_a = [str(tmp_path / ("a%d" % s)) for s in range(S)]
+    out_b = [str(tmp_path / ("b%d" % s)) for s in range(S)]
+    one = vb.run_cohort_files(pre, paths, out_a, num_pc=k, group_size=8)
+    with pytest.raises(_abi.Vb2Error):
+        vb.run_cohort_files(pre, paths, out_b, num_pc=k, group_size=8, devices=[0, 0, 0])
+    monkeypatch.setenv("VB2_COHORT_DUP_DEVICES", "1")
+    three = vb.run_cohort_files(pre, paths, out_b, num_pc=k, group_size=8, devices=[0, 0, 0])
+    assert all(r["status"] == 0 for r in one) and all(r["status"] == 0 for r in three)
+    for s in range(S):
+        assert abs(one[s]["alpha"] - three[s]["alpha"]) <= 1e-9, s
+        for ext in (".Ancestry", ".selfSM"):
+            assert open(out_a[s] + ext).read() == open(out_b[s] + ext).read(), (s, ext)
+
+
 def test_insufficient_markers_fails_sanity(golden_dir, tmp_path):
     with pytest.raises(_abi.Vb2Error) as ei:
         vb.run_files(os.path.join(golden_dir, HAPMAP), os.path.join(golden_dir, "test.LongRead.pileup"),

@@ -385,7 +385,10 @@ extern "C" int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int
         set_error("vb2_cohort_run: invalid argument");
         return VB2_ERR_INVALID;
     }
-    for (int i = 0; i < a->base.num_device; ++i)
+    // (VB2_COHORT_DUP_DEVICES=1: a test switch -- the pipelines of a several-device run, their group
+    // schedule and the readers' per-device look-ahead exercised on a machine with one GPU)
+    const bool dup_ok = std::getenv("VB2_COHORT_DUP_DEVICES") != nullptr;
+    for (int i = 0; i < a->base.num_device && !dup_ok; ++i)
         for (int j = 0; j < i; ++j)
             if (a->base.devices && a->base.devices[i] == a->base.devices[j]) {
                 // (two lock-step pipelines on one device would each launch device-filling grids)
