@@ -619,6 +619,45 @@ def test_cohort_run_group_schedule_does_not_change_results(tmp_path):
             assert open(out_a[s] + ext).read() == open(out_b[s] + ext).read(), (s, ext)
 
 
+def test_cohort_run_reports_bad_samples_and_finishes_the_rest(tmp_path):
+    """A cohort with a pileup that does not exist, one whose bases column is malformed (an indel
+    marker without a length: the reference dies on it) and one that is empty: the first two get
+    their own error status and no output, nothing hangs, and every other sample comes out as if
+    they had not been there."""
+    k, M = 2, 1400
+    base = vb.synth.with_sanity_stats(vb.synth.make_pileup(M, 12, k, alpha_true=0.03, seed=270))
+    pre = vb.synth.write_files(base, str(tmp_path / "panel"))
+    good = []
+    for s in range(3):
+        d = vb.synth.make_pileup(M, 10 + 3 * s, k, alpha_true=0.05 * (s + 1), seed=280 + s)
+        d = vb.PileupData(k, base.ud, base.means, d.read_off, d.bases, d.quals, base.alt_base, None,
+                          d.avg_depth, d.sd_depth, True, dict(base.meta))
+        good.append(vb.synth.write_files(d, str(tmp_path / ("s%d" % s))) + ".pileup")
+    broken = str(tmp_path / "broken.pileup")
+    lines = open(good[0]).read().splitlines()
+    f = lines[40].split("\t")
+    f[4] = f[4][:2] + "+A" + f[4][2:]                      # '+' with no length
+    lines[40] = "\t".join(f)
+    open(broken, "w").write("\n".join(lines) + "\n")
+    empty = str(tmp_path / "empty.pileup")
+    open(empty, "w").close()
+    paths = [good[0], str(tmp_path / "missing.pileup"), good[1], broken, good[2], empty] + [good[s % 3] for s in range(14)]
+    outs = [str(tmp_path / ("o%d" % s)) for s in range(len(paths))]
+    res = vb.run_cohort_files(pre, paths, outs, num_pc=k, group_size=6, disable_sanity=True)
+    st = [r["status"] for r in res]
+    # (the empty pileup, with the sanity check off, is a sample without markers: LLK 0 everywhere,
+    # status 0 -- what the reference's arithmetic makes of it too)
+    assert st[1] == _abi.VB2_ERR_IO and st[3] == _abi.VB2_ERR_INVALID
+    assert all(x == 0 for i, x in enumerate(st) if i not in (1, 3))
+    for i in (1, 3):
+        assert not os.path.exists(outs[i] + ".Ancestry")
+    assert res[5]["llk1"] == 0.0
+    alone = [vb.run_files(pre, g, str(tmp_path / ("alone%d" % i)), num_pc=k, disable_sanity=True) for i, g in enumerate(good)]
+    for i, p in enumerate(paths):
+        if p in good:
+            assert abs(res[i]["alpha"] - alone[good.index(p)]["alpha"]) <= 1e-9, i
+
+
 def test_cohort_run_over_several_device_pipelines(tmp_path, monkeypatch):
     """vb2_cohort_run with a device list: one pipeline thread per entry, groups dealt round-robin,
     each device with its own small first groups, the readers looking two groups ahead per device.
