@@ -186,12 +186,20 @@ def main():
     uid = None
     if share_gpu and args.mode == "marker":
         raise SystemExit("VB2_BENCH_SHARE_GPU=1 cannot run --mode marker (RCCL needs one device per rank)")
+    uid_error = None
     if (world > 1 or not args.no_extras) and not share_gpu:
         # the library's own marker-shard group (C++: contexts + ncclAllReduce bound from librccl)
-        box = [vb.ShardGroup.unique_id() if rank == 0 else None]
+        box = [None, None]
+        if rank == 0:
+            try:
+                box[0] = vb.ShardGroup.unique_id()
+            except Exception as exc:                 # noqa: BLE001 -- (e.g. librccl not loadable) reported, not fatal
+                box[1] = "%s: %s" % (type(exc).__name__, exc)
         if dist is not None:
             dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+        uid, uid_error = box[0], box[1]
+        if uid_error and args.mode == "marker":
+            raise SystemExit(uid_error)
     if args.mode == "marker":
         group = vb.ShardGroup(shared, device=local_rank, rank=rank, nranks=world, unique_id=uid)
         ctx, info = None, None
@@ -265,41 +273,6 @@ def main():
         },
     }
 
-    # ---- the other multi-GPU mode as a sub-object: one sample's markers over all ranks ----
-    if args.mode == "sample" and not args.no_extras and not share_gpu:
-        g2 = vb.ShardGroup(shared, device=local_rank, rank=rank, nranks=world, unique_id=uid)
-        for _ in range(20):
-            g2.llk(pc1_h, pc2_h, al_h)
-        if dist is not None:
-            dist.barrier()
-        n2 = 200
-        t1 = time.perf_counter()
-        for _ in range(n2):
-            got_sh = g2.llk(pc1_h, pc2_h, al_h)
-        dt = time.perf_counter() - t1
-        g2.optimize()
-        t_opt = []
-        for _ in range(3):
-            if dist is not None:
-                dist.barrier()
-            t1 = time.perf_counter()
-            est_sh = g2.optimize()
-            t_opt.append(time.perf_counter() - t1)
-        gi = g2.info()
-        vals = torch.tensor([dt, min(t_opt)], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-        result["marker_sharded"] = {
-            "what": "ONE sample's markers sharded over the %d rank(s) by libvb2 (vb2_shard_group_create_rank): per "
-                    "step a launch per rank + one ncclAllReduce of %d doubles + host sync; strong scaling, "
-                    "latency-bound" % (world, B),
-            "evals_per_s": B * n2 / float(vals[0]), "ms_per_step": 1e3 * float(vals[0]) / n2,
-            "optimize_wall_ms": 1e3 * float(vals[1]), "alpha": est_sh["alpha"], "num_eval": est_sh["num_eval"],
-            "uses_rccl": gi["uses_rccl"], "allreduces": gi["num_allreduce"],
-            "shard_reads_rank0": gi["num_read"],
-        }
-        g2.close()
-
     if rank == 0 and args.mode == "sample":
         # roofline of the dominant kernel: algorithmic bytes per launch / device time
         bytes_per_launch = info["algorithmic_bytes_per_eval"] * B
@@ -332,6 +305,63 @@ def main():
             "device_us_per_launch": step_us,
             "note": "device time = HIP events on the launch stream over the timed region / steps",
         }
+    # ---- the other multi-GPU mode as a sub-object: one sample's markers over all ranks ----
+    # Guarded: whatever happens in here (librccl missing, a communicator that does not come up, a
+    # rank that dies and leaves the others in a collective) must not cost the run its main line --
+    # an exception is recorded, and a watchdog prints what there is and ends every rank after 4 minutes.
+    if args.mode == "sample" and not args.no_extras and not share_gpu:
+        import threading
+
+        def bail():
+            result["marker_sharded"] = {"error": "the marker-sharded leg did not finish within 240 s"}
+            if rank == 0:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(240.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            if uid_error:
+                raise RuntimeError(uid_error)
+            g2 = vb.ShardGroup(shared, device=local_rank, rank=rank, nranks=world, unique_id=uid)
+            for _ in range(20):
+                g2.llk(pc1_h, pc2_h, al_h)
+            if dist is not None:
+                dist.barrier()
+            n2 = 200
+            t1 = time.perf_counter()
+            for _ in range(n2):
+                got_sh = g2.llk(pc1_h, pc2_h, al_h)
+            dt = time.perf_counter() - t1
+            g2.optimize()
+            t_opt = []
+            for _ in range(3):
+                if dist is not None:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                est_sh = g2.optimize()
+                t_opt.append(time.perf_counter() - t1)
+            gi = g2.info()
+            vals = torch.tensor([dt, min(t_opt)], dtype=torch.float64, device="cuda")
+            if dist is not None:
+                dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+            result["marker_sharded"] = {
+                "what": "ONE sample's markers sharded over the %d rank(s) by libvb2 (vb2_shard_group_create_rank): per "
+                        "step a launch per rank + one ncclAllReduce of %d doubles + host sync; strong scaling, "
+                        "latency-bound" % (world, B),
+                "evals_per_s": B * n2 / float(vals[0]), "ms_per_step": 1e3 * float(vals[0]) / n2,
+                "optimize_wall_ms": 1e3 * float(vals[1]), "alpha": est_sh["alpha"], "num_eval": est_sh["num_eval"],
+                "uses_rccl": gi["uses_rccl"], "allreduces": gi["num_allreduce"],
+                "shard_reads_rank0": gi["num_read"],
+            }
+            g2.close()
+        except Exception as exc:                     # noqa: BLE001 -- recorded, not fatal
+            result["marker_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        watchdog.cancel()
+
+    if rank == 0 and args.mode == "sample":
         if world == 1 and not args.no_extras:
             # the operating points of the actual search: a 4-point launch (one Nelder-Mead
             # iteration: R, E, C_A, C_R) and a single point
