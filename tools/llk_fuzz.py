@@ -1,0 +1,29 @@
+"""One-off hunt, not a test: random shapes (incl. deep markers at the underflow boundary, wide and
+narrow quality alphabets, many PCs), random parameter points, the HIP path against the oracle."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import verifybamid_amd as vb
+from oracle.bridge import oracle_data
+rng = np.random.default_rng(int(os.environ.get("VB2_FUZZ_SEED", 1)))
+N = int(os.environ.get("VB2_FUZZ_N", 40))
+worst, bad = 0.0, 0
+for it in range(N):
+    depth = float(rng.choice([2, 10, 30, 150, 700, 1000, 1500]))
+    M = int(rng.integers(30, 3000 if depth > 500 else 20000)); k = int(rng.integers(1, 11))
+    qlo = int(rng.integers(0, 40)); qhi = int(min(93, qlo + rng.integers(0, 50)))
+    d = vb.synth.make_pileup(M, depth, k, alpha_true=float(rng.uniform(0, 0.5)), seed=int(rng.integers(1, 10**6)), q_lo=qlo, q_hi=qhi,
+                             missing_frac=float(rng.choice([0.0, 0.0, 0.3])))
+    od = oracle_data(d)
+    B = int(rng.integers(1, 20))
+    scale = float(rng.choice([0.01, 0.05, 0.5]))
+    pc1 = rng.normal(0, scale, size=(B, k)); pc2 = rng.normal(0, scale, size=(B, k)); al = rng.uniform(0, 1, size=B)
+    with vb.LikelihoodContext(d) as ctx:
+        got = ctx.llk(pc1, pc2, al)
+    want = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=8) for i in range(B)])
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    worst = max(worst, float(err.max()))
+    if err.max() > 1e-11:
+        bad += 1
+        print("MISMATCH it=%d M=%d depth=%g k=%d q=%d..%d B=%d: max abs diff %.3g (rel %.2e)" % (it, M, depth, k, qlo, qhi, B, np.abs(got - want).max(), err.max()))
+print("llk fuzz: %d of %d cases off, worst relative error %.2e" % (bad, N, worst))
