@@ -585,6 +585,11 @@ int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v)
             }
             // parse straight into the pools' tails; the bytes stay only if the line is a new site
             const size_t tail = v->basePool.size();
+            if (tail + n > 0xffffffffull) {                 // (site offsets are 32-bit: 4 GiB of kept bases per sample)
+                set_error("pileup too large: more than 4 GiB of bases at the panel's sites");
+                rc = VB2_ERR_INVALID;
+                return;
+            }
             v->basePool.resize(tail + n);
             v->qualPool.resize(tail + n);
             size_t kept = 0;
