@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -78,6 +79,8 @@ struct PileupViewer {
     // a new site for `slot` with n parsed (base, quality) pairs
     void add_site(int32_t slot, const char* b, const char* q, size_t n)
     {
+        if (basePool.size() + n > 0xffffffffull)      // (32-bit site offsets; the callers turn this into VB2_ERR_INVALID)
+            throw std::length_error("pileup too large: more than 4 GiB of bases at the panel's sites");
         siteOfSlot[slot] = num_site();
         basePool.append(b, n);
         qualPool.append(q, n);
