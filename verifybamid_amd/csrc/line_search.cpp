@@ -1,4 +1,8 @@
 // line_search.cpp -- see line_search.h.
+//
+// Written around (abscissa, value) pairs; every floating-point expression is evaluated in the order
+// the reference's ScalarMinimizer evaluates it, which is what makes the two visit the same
+// abscissae (tests/test_abi_and_host.py compares them evaluation for evaluation).
 #include "line_search.h"
 
 #include <cmath>
@@ -7,16 +11,31 @@
 namespace vb2 {
 
 namespace {
-// statgen/MathConstant.h:31-39
-const double kTiny = 1.0e-30;
-const int kItMax = 200;
-const double kZeps = 3.0e-10;
-const double kGold = 0.61803399;
-const double kCGold = 0.38196601;
-const double kMaxMagnification = 100.0;      // MathGold.cpp:22
 
-inline double with_sign_of(double magnitude, double s) { return s >= 0 ? std::fabs(magnitude) : -std::fabs(magnitude); }
-inline double larger(double x, double y) { return x > y ? x : y; }
+// statgen/MathConstant.h:31-39, MathGold.cpp:22
+constexpr double kSmallest = 1.0e-30;
+constexpr int kMaxIterations = 200;
+constexpr double kAbsTolerance = 3.0e-10;
+constexpr double kGoldenRatio = 0.61803399;
+constexpr double kGoldenComplement = 0.38196601;
+constexpr double kGrowthLimit = 100.0;
+
+struct Sample {
+    double x, f;
+};
+
+inline double magnitude_with_sign(double m, double sign_of) { return sign_of >= 0 ? std::fabs(m) : -std::fabs(m); }
+
+// vertex of the parabola through three samples, guarded against a vanishing denominator
+inline double parabola_vertex(const Sample& p, const Sample& q, const Sample& r)
+{
+    const double t1 = (q.x - p.x) * (q.f - r.f);
+    const double t2 = (q.x - r.x) * (q.f - p.f);
+    const double den = t2 - t1;
+    const double guarded = std::fabs(den) > kSmallest ? std::fabs(den) : kSmallest;
+    return q.x - ((q.x - r.x) * t2 - (q.x - p.x) * t1) / (2.0 * magnitude_with_sign(guarded, den));
+}
+
 }  // namespace
 
 double BrentMinimizer::f(double x)
@@ -28,136 +47,151 @@ double BrentMinimizer::f(double x)
     return y;
 }
 
-// Walk downhill from (lo, hi) until three points a, b, c with f(b) below both ends are found.
+// Downhill from (lo, hi) by golden-ratio steps, helped by parabolic extrapolation, until the
+// middle one of three samples is the lowest.
 void BrentMinimizer::Bracket(double lo, double hi)
 {
-    a = lo;
-    b = hi;
-    const double step = kGold + 1.0;
+    const double grow = kGoldenRatio + 1.0;
+    Sample left{lo, 0}, mid{hi, 0}, right{0, 0};
     if (speculate && !error) {
-        // c = b' + step * (b' - a') for the ordered pair (a', b'): both orders' candidates at once
-        double x[4] = {lo, hi, hi + step * (hi - lo), lo + step * (lo - hi)}, y[4];
-        if ((error = func->EvaluateBatch(4, x, y))) return;
-        func->Commit(x[0], y[0]);
-        func->Commit(x[1], y[1]);
-        fa = y[0];
-        fb = y[1];
-        const bool swapped = fb > fa;
-        if (swapped) {
-            std::swap(a, b);
-            std::swap(fa, fb);
-        }
-        c = b + step * (b - a);
-        fc = swapped ? y[3] : y[2];
-        func->Commit(c, fc);
+        // the third sample lies beyond whichever of the first two is lower: both candidates at once
+        double xs[4] = {lo, hi, hi + grow * (hi - lo), lo + grow * (lo - hi)}, ys[4];
+        if ((error = func->EvaluateBatch(4, xs, ys))) return;
+        func->Commit(xs[0], ys[0]);
+        func->Commit(xs[1], ys[1]);
+        left.f = ys[0];
+        mid.f = ys[1];
+        const bool uphill = mid.f > left.f;
+        if (uphill) std::swap(left, mid);
+        right.x = mid.x + grow * (mid.x - left.x);
+        right.f = uphill ? ys[3] : ys[2];
+        func->Commit(right.x, right.f);
     } else {
-        fa = f(a);
-        fb = f(b);
-        if (fb > fa) {
-            std::swap(a, b);
-            std::swap(fa, fb);
-        }
-        c = b + step * (b - a);
-        fc = f(c);
+        left.f = f(left.x);
+        mid.f = f(mid.x);
+        if (mid.f > left.f) std::swap(left, mid);
+        right.x = mid.x + grow * (mid.x - left.x);
+        right.f = f(right.x);
     }
-    while (fb > fc && !error) {
-        // abscissa u of the vertex of the parabola through the three points
-        const double r = (b - a) * (fb - fc);
-        const double q = (b - c) * (fb - fa);
-        double u = b - ((b - c) * q - (b - a) * r) / (2.0 * with_sign_of(larger(std::fabs(q - r), kTiny), q - r));
-        const double ulim = b + kMaxMagnification * (c - b);
-        double fu;
-        if ((b - u) * (u - c) > 0.0) {                     // u between b and c
-            fu = f(u);
-            if (fu < fc) {                                 // minimum between b and c
-                a = b; b = u;
-                fa = fb; fb = fu;
-                return;
+    bool done = false;
+    while (!done && mid.f > right.f && !error) {
+        Sample trial{parabola_vertex(left, mid, right), 0};
+        const double farthest = mid.x + kGrowthLimit * (right.x - mid.x);
+        enum { kInside, kBeyond, kAtLimit, kDefault } where;
+        if ((mid.x - trial.x) * (trial.x - right.x) > 0.0) where = kInside;
+        else if ((right.x - trial.x) * (trial.x - farthest) > 0.0) where = kBeyond;
+        else if ((trial.x - farthest) * (farthest - right.x) >= 0.0) where = kAtLimit;
+        else where = kDefault;
+        switch (where) {
+        case kInside:
+            trial.f = f(trial.x);
+            if (trial.f < right.f) {                       // a minimum between mid and right
+                left = mid;
+                mid = trial;
+                done = true;
+            } else if (trial.f > mid.f) {                  // a minimum between left and trial
+                right = trial;
+                done = true;
+            } else {                                       // the fit was useless: a plain golden step
+                trial.x = right.x + grow * (right.x - mid.x);
+                trial.f = f(trial.x);
             }
-            if (fu > fb) {                                 // minimum between a and u
-                c = u;
-                fc = fu;
-                return;
+            break;
+        case kBeyond:
+            trial.f = f(trial.x);
+            if (trial.f < right.f) {                       // still going down: shift and step again
+                mid = right;
+                right = trial;
+                trial.x = right.x + grow * (right.x - mid.x);
+                trial.f = f(trial.x);
             }
-            u = c + step * (c - b);                        // no use: default magnification
-            fu = f(u);
-        } else if ((c - u) * (u - ulim) > 0.0) {           // u between c and the limit
-            fu = f(u);
-            if (fu < fc) {
-                b = c; c = u; u = c + step * (c - b);
-                fb = fc; fc = fu; fu = f(u);
-            }
-        } else if ((u - ulim) * (ulim - c) >= 0.0) {       // beyond the limit: clamp
-            u = ulim;
-            fu = f(u);
-        } else {                                           // reject the parabola
-            u = c + step * (c - b);
-            fu = f(u);
+            break;
+        case kAtLimit:
+            trial.x = farthest;
+            trial.f = f(trial.x);
+            break;
+        case kDefault:
+            trial.x = right.x + grow * (right.x - mid.x);
+            trial.f = f(trial.x);
+            break;
         }
-        a = b; b = c; c = u;
-        fa = fb; fb = fc; fc = fu;
+        if (!done) {
+            left = mid;
+            mid = right;
+            right = trial;
+        }
     }
+    a = left.x; fa = left.f;
+    b = mid.x; fb = mid.f;
+    c = right.x; fc = right.f;
 }
 
 double BrentMinimizer::Brent(double tol)
 {
-    if (a > c) {
-        std::swap(a, c);
+    double lower = a, upper = c;
+    if (lower > upper) {
+        std::swap(lower, upper);
         std::swap(fa, fc);
+        std::swap(a, c);
     }
-    min = b;
-    fmin = fb;
-    double w = b, v = b, fw = fb, fv = fb;     // second best, previous second best
-    double delta = 0.0;                        // step before last
-    double d = 0.0;
+    Sample best{b, fb}, second = best, third = best;
+    double last_step = 0.0;          // the step before the one just taken
+    double step = 0.0;
     stuck = false;
-    for (int iter = 1; iter <= kItMax && !error; ++iter) {
-        const double middle = 0.5 * (a + c);
-        const double tol1 = tol * std::fabs(min) + kZeps;
+    for (int round = 0; round < kMaxIterations && !error; ++round) {
+        const double centre = 0.5 * (lower + upper);
+        const double tol1 = tol * std::fabs(best.x) + kAbsTolerance;
         const double tol2 = 2.0 * tol1;
-        if (std::fabs(min - middle) <= (tol2 - 0.5 * (c - a))) return fmin;
-
-        bool golden = true;
-        if (std::fabs(delta) > tol1) {                     // try the parabola through min, w, v
-            const double r = (min - w) * (fmin - fv);
-            double q = (min - v) * (fmin - fw);
-            double p = (min - v) * q - (min - w) * r;
+        if (std::fabs(best.x - centre) <= (tol2 - 0.5 * (upper - lower))) {
+            a = lower; c = upper;
+            min = best.x;
+            return fmin = best.f;
+        }
+        bool interpolated = false;
+        if (std::fabs(last_step) > tol1) {                 // inverse parabolic interpolation through the three best
+            const double r = (best.x - second.x) * (best.f - third.f);
+            double q = (best.x - third.x) * (best.f - second.f);
+            double p = (best.x - third.x) * q - (best.x - second.x) * r;
             q = 2.0 * (q - r);
             if (q > 0.0) p = -p;
             q = std::fabs(q);
-            const double before_last = delta;
-            delta = d;
-            if (!(std::fabs(p) >= std::fabs(0.5 * q * before_last) || p <= q * (a - min) || p >= q * (c - min))) {
-                golden = false;
-                d = p / q;
-                const double u = min + d;
-                if (u - a < tol2 || c - u < tol2) d = with_sign_of(tol1, middle - min);
+            const double two_back = last_step;
+            last_step = step;
+            const bool reject = std::fabs(p) >= std::fabs(0.5 * q * two_back) || p <= q * (lower - best.x) ||
+                                p >= q * (upper - best.x);
+            if (!reject) {
+                interpolated = true;
+                step = p / q;
+                const double at = best.x + step;
+                if (at - lower < tol2 || upper - at < tol2) step = magnitude_with_sign(tol1, centre - best.x);
             }
         }
-        if (golden) {                                      // golden section into the larger part
-            delta = min >= middle ? a - min : c - min;
-            d = kCGold * delta;
+        if (!interpolated) {                               // golden section into the larger segment
+            last_step = best.x >= centre ? lower - best.x : upper - best.x;
+            step = kGoldenComplement * last_step;
         }
-        const double u = std::fabs(d) >= tol1 ? min + d : min + with_sign_of(tol1, d);   // never closer than tol1
-        const double fu = f(u);
+        Sample trial;
+        trial.x = std::fabs(step) >= tol1 ? best.x + step : best.x + magnitude_with_sign(tol1, step);   // never closer than tol1
+        trial.f = f(trial.x);
         if (error) break;
-        if (fu <= fmin) {
-            if (u >= min) a = min;
-            else c = min;
-            v = w; w = min; min = u;
-            fv = fw; fw = fmin; fmin = fu;
+        if (trial.f <= best.f) {
+            (trial.x >= best.x ? lower : upper) = best.x;
+            third = second;
+            second = best;
+            best = trial;
         } else {
-            if (u < min) a = u;
-            else c = u;
-            if (fu <= fw || w == min) {
-                v = w; w = u;
-                fv = fw; fw = fu;
-            } else if (fu <= fv || v == min || v == w) {
-                v = u;
-                fv = fu;
+            (trial.x < best.x ? lower : upper) = trial.x;
+            if (trial.f <= second.f || second.x == best.x) {
+                third = second;
+                second = trial;
+            } else if (trial.f <= third.f || third.x == best.x || third.x == second.x) {
+                third = trial;
             }
         }
     }
+    a = lower; c = upper;
+    min = best.x;
+    fmin = best.f;
     if (!error) stuck = true;
     return fmin;
 }
