@@ -541,6 +541,11 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         // does not cover that latency.  The loads are unconditional: a prefetch past the tile's
         // last row reads the next tile's rows (never consumed), and the array ends in
         // 2 * kPrefetch padding rows (context.cpp).
+        // The read loop is bound by the LDS pipe, the epilogue by the FP64 VALU, and the waves of a CU
+        // are spread over both phases at any time: waves in the read loop get issue priority, so that
+        // their ds_reads go out as soon as they can and the LDS pipe stays busy, while the epilogue
+        // waves fill the VALU slots in between (-0.8 % per launch measured; the other way round: +0.8 %)
+        __builtin_amdgcn_s_setprio(1);
         const uint2* cp = L.codes + (size_t)rec.x * kMtMarkers + m;
         const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
         uint2 w[kPrefetch];
@@ -570,6 +575,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             }
         }
 
+        __builtin_amdgcn_s_setprio(0);
         // ---- per-marker epilogue: this marker's likelihood as (mantissa, exponent) per point ----
         double lk_m[BTL];
         int lk_e[BTL];
