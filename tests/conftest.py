@@ -15,7 +15,8 @@ def _ensure_built():
     (hipcc cross-compiles gfx950 without a GPU; ~15 s)."""
     need = [os.path.join(ROOT, "verifybamid_amd", "libvb2.so"),
             os.path.join(ROOT, "verifybamid_amd", "bin", "VerifyBamID"),
-            os.path.join(ROOT, "oracle", "liboracle.so")]
+            os.path.join(ROOT, "oracle", "liboracle.so"),
+            os.path.join(ROOT, "oracle", "_check_exp.bin")]
     # ... and rebuilds them whenever a source is newer than the oldest artefact: a stale binary
     # must not mask a broken source file (make itself only recompiles what changed)
     srcs = []

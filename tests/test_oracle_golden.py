@@ -185,3 +185,42 @@ def test_synthetic_fixtures_reproduce_from_the_oracle(golden_dir, fname):
             for key in ("alpha", "pc1", "pc2", "llk"):
                 hh.update(np.ascontiguousarray(r["trace"][key]).tobytes())
             assert hh.hexdigest() == m["trace_sha256"], name
+
+
+# ---- the device's restatement of libm exp() (InvLogit, ContaminationEstimator.h:119-122) ----
+def test_device_exp_table_is_the_mathematical_one():
+    """libm_exp_table.inc (included by resident_kernel.inc and by oracle/check_exp_restatement.c):
+    entry k = {tail, bits(H) - (k << 45)}, H = 2^(k/128) rounded to double, tail = (2^(k/128) - H) / H
+    rounded -- recomputed here with 60-digit decimal arithmetic."""
+    import decimal
+    import re
+    import struct
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "verifybamid_amd", "csrc", "libm_exp_table.inc")).read()
+    words = [int(w, 16) for w in re.findall(r"0x([0-9a-f]{16})ull", text)]
+    assert len(words) == 256
+    decimal.getcontext().prec = 60
+    ln2 = decimal.Decimal(2).ln()
+    for k in range(128):
+        exact = (ln2 * k / 128).exp()
+        h = float(exact)                                   # correctly rounded (decimal -> double is exact-rounding)
+        tail = float((exact - decimal.Decimal(h)) / decimal.Decimal(h))
+        hbits = struct.unpack("<Q", struct.pack("<d", h))[0]
+        tbits = struct.unpack("<Q", struct.pack("<d", tail))[0]
+        assert words[2 * k + 1] == (hbits - (k << 45)) & 0xFFFFFFFFFFFFFFFF, k
+        assert words[2 * k] == tbits, k
+
+
+def test_device_exp_restatement_equals_libm_bit_for_bit():
+    """oracle/check_exp_restatement.c: the statement sequence of the device's libm_exp, on the host with
+    hardware FMAs, against this process's libm over 1.5e8 arguments + every edge (the evidence the
+    bit-identical device trajectory rests on; VERDICT r2 missing #5)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_check_exp.bin")
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "check_exp"], stdout=subprocess.DEVNULL)
+    p = subprocess.run([exe, "50000000", "7"], capture_output=True, text=True)
+    if p.returncode == 77:
+        pytest.skip(p.stdout.strip())
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert " 0 mismatches" in p.stdout and "checked 150" in p.stdout, p.stdout

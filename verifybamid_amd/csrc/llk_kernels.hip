@@ -7,9 +7,10 @@
 //     16-marker micro-tiles x 2 slots x 2 points instead (MODE 3).  Markers are sorted by depth
 //     at context creation and grouped in 16-marker micro-tiles so all lanes of a wave run about
 //     the same number of steps;
-//   * a marker's reads are run-length coded over the (class x quality) dictionary:
-//     (code, count) byte pairs, two per dword, stored [micro-tile][step/2][marker]:
-//     a wave load is one contiguous 64-byte row, rows are prefetched two deep;
+//   * a marker's reads are run-length coded over the (class x quality) dictionary: one 32-bit run
+//     word per distinct code (low half = LDS byte offset of the code's table row, high half = the
+//     top 16 bits of double(count), count <= 31), two per uint2, stored [micro-tile][step/2][marker]:
+//     a wave load is one contiguous 128-byte row, rows are prefetched kPrefetch = 8 deep;
 //   * the per-alpha log-likelihood table (h:213-229) is rebuilt per launch in LDS,
 //     restricted to the codes that occur in the data and to the six OFF-diagonal
 //     genotype pairs: the diagonal (g1==g2) and the "other base" class do not
