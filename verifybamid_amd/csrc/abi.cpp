@@ -352,7 +352,7 @@ int vb2_ctx_optimize_llk(vb2_ctx* ctx, const vb2_model* model, vb2_estimate* out
     int rc;
     try {
         vb2::Estimator est(c->num_pc, ctx_eval_cb, c);
-        vb2::apply_model(est, *model);
+        vb2::apply_model(est, *model, c->L.known_af != nullptr);
         est.trace = trace;
         if (trace) trace->count = 0;
         if (resident && c->device_simplex_dim() > 0 && !(trace && c->trace_stage_rows < trace->capacity))
@@ -389,12 +389,7 @@ int vb2_ctx_optimize_llk_ex(vb2_ctx* ctx, const vb2_model* model, const vb2_sear
     vb2::Context* c = ctx->impl;
     const int k = c->num_pc;
     auto configure = [&](vb2::Estimator& est, int index) {
-        vb2::apply_model(est, *model);
-        if (c->L.known_af) {                 // context built with --KnownAF data
-            est.isAFknown = true;
-            est.isPCFixed = true;
-            est.isHeter = false;
-        }
+        vb2::apply_model(est, *model, c->L.known_af != nullptr);
         est.line_search = line;
         est.start_index = index;
         est.start_seed = opts ? opts->seed : 0u;
@@ -772,6 +767,11 @@ int vb2_run(const vb2_run_args* a, vb2_run_result* out)
     const double t_flat0 = now_s();
     if (a->devices && a->num_device > 1) {
         // --Devices a,b,...: the sample's markers sharded over the devices (vb2_shard_group_*)
+        if (a->search.num_start > 1 || a->search.line_search) {      // (never silently ignored)
+            set_error("--NumStart / --LineSearch are single-device options: they cannot be combined with marker "
+                      "shards over several --Devices");
+            return VB2_ERR_INVALID;
+        }
         vb2_shard_group* grp = nullptr;
         if ((rc = vb2_shard_group_create(&flat->input, a->devices, a->num_device, &grp))) return rc;
         out->seconds_load = now_s() - t0;
@@ -811,7 +811,8 @@ int vb2_run(const vb2_run_args* a, vb2_run_result* out)
     vb2::print_summary(estimation_title(model), a->num_pc, out->est);
     if (a->output_prefix) {
         if ((rc = vb2::write_ancestry(a->output_prefix, a->num_pc, out->est.pc, out->est.pc2))) return rc;
-        if ((rc = vb2::write_selfsm(a->output_prefix, *flat, out->est, true))) return rc;
+        // main.cpp:398-400: #READS is viewer.numBases for BAM input, "NA" for pileup input
+        if ((rc = vb2::write_selfsm(a->output_prefix, *flat, out->est, a->pileup_path != nullptr))) return rc;
     }
     return VB2_OK;
 }

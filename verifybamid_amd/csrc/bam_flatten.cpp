@@ -11,12 +11,25 @@
 // It fills the same PileupViewer (sites in two pools, hostio.h) the text-pileup reader fills, so the
 // sanity check, BuildResolvedMarkers and the flattening into pinned SoA arrays are shared.
 //
-// NEEDS htslib (>= 1.10: hts_pos_t), which this build image does not have: the file is compiled
-// only when CMake finds it (-DVB2_WITH_HTSLIB, CMakeLists.txt: find_library(hts)); otherwise
-// read_bam() reports that and --BamFile fails loudly.  STATUS: written against htslib's public
-// API, NOT compiled and NOT validated in this image (no htslib headers, and the reference's
-// resource/test/test.bam is absent): parity at this boundary is unpinned -- validate with
-// `--OutputPileup` against the reference's expected/result.Pileup where htslib and a BAM exist.
+// NEEDS htslib (>= 1.10: hts_pos_t), which neither this build image nor the GPU box has (probed
+// in round 3: no htslib/sam.h, no libhts anywhere on either).  The file is compiled only on an
+// explicit opt-in, `cmake -DVB2_WITH_HTSLIB=ON` (default OFF since round 3: a machine that happens
+// to have libhts must not silently ship an unvalidated reader); otherwise read_bam() reports that
+// and --BamFile fails loudly.  STATUS: written against htslib's public API, NOT compiled and NOT
+// validated anywhere (no htslib, and the reference's resource/test/test.bam is absent): parity at
+// this boundary is UNPINNED -- validate with `--OutputPileup` against the reference's
+// expected/result.Pileup where htslib and a BAM exist before relying on it.
+//
+// Two behaviours of the reference that look like slips are kept on purpose, because the golden
+// outputs were produced with them (SimplePileupViewer.cpp:448-476, 502-511):
+//   * a read that has a DELETION at the site contributes no base (pileup_seq, :32) but its quality
+//     still goes to qualInfo (:462-470), so from that read on the site's bases and qualities are
+//     paired off by one -- ComputeMixLLKs walks baseInfo's length (ContaminationEstimator.h:285-298).
+//     Here: the qualities of deleted reads are kept in the list and the first bases.size() of them
+//     are what add_site pairs with the bases;
+//   * every position the pileup engine reports inside a region is indexed (posIndex, :427-438), even
+//     if every read failed min-BQ and the site ends up empty; a marker no read covers is never
+//     reported, hence never indexed (siteOfSlot stays -1: BuildResolvedMarkers' "absent").
 #include "hostio.h"
 
 #include "context.h"   // set_error
@@ -111,12 +124,26 @@ std::string sample_name(sam_hdr_t* hdr)     // @RG SM: (SimplePileupViewer.cpp:2
 int read_bam(const std::string& bam_path, const std::string& ref_path, const Panel& panel, PileupViewer* v)
 {
     Aux a;
+    hts_idx_t* idx = nullptr;
+    struct Cleanup {                       // every exit path releases what was opened so far
+        Aux& a;
+        hts_idx_t*& idx;
+        ~Cleanup()
+        {
+            if (a.iter) hts_itr_destroy(a.iter);
+            free(a.ref);
+            if (a.fai) fai_destroy(a.fai);
+            if (idx) hts_idx_destroy(idx);
+            if (a.hdr) sam_hdr_destroy(a.hdr);
+            if (a.fp) sam_close(a.fp);
+        }
+    } cleanup{a, idx};
     a.fp = sam_open(bam_path.c_str(), "rb");
     if (!a.fp) { set_error("failed to open " + bam_path); return VB2_ERR_IO; }
     if (hts_set_fai_filename(a.fp, ref_path.c_str()) != 0) { set_error("failed to process " + ref_path); return VB2_ERR_IO; }
     a.hdr = sam_hdr_read(a.fp);
     if (!a.hdr) { set_error("fail to read the header of " + bam_path); return VB2_ERR_IO; }
-    hts_idx_t* idx = sam_index_load(a.fp, bam_path.c_str());
+    idx = sam_index_load(a.fp, bam_path.c_str());
     if (!idx) { set_error("fail to load index for " + bam_path); return VB2_ERR_IO; }
     a.fai = fai_load(ref_path.c_str());
     v->SEQ_SM = sample_name(a.hdr);
@@ -138,6 +165,7 @@ int read_bam(const std::string& bam_path, const std::string& ref_path, const Pan
         if (v->siteOfSlot[slot] >= 0) continue;                           // duplicated marker: skipped (cpp:424-427)
         bases.clear();
         quals.clear();
+        bool reported = false;             // the pileup engine produced this position (>= 1 alignment over it)
         a.iter = sam_itr_queryi(idx, tid, pos1 - 1, pos1);
         if (a.iter) {
             bam_plp_t plp = bam_plp_init(next_read, &a);
@@ -147,11 +175,15 @@ int read_bam(const std::string& bam_path, const std::string& ref_path, const Pan
             const bam_pileup1_t* pl;
             while ((pl = bam_plp_auto(plp, &ptid, &ppos, &n)) != nullptr) {
                 if (ptid != tid || ppos != pos1 - 1) continue;
+                reported = true;
                 const bool has_ref = fetch_ref(&a, tid);
                 for (int j = 0; j < n; ++j) {
                     const bam_pileup1_t* p = pl + j;
                     const int q = p->qpos < p->b->core.l_qseq ? bam_get_qual(p->b)[p->qpos] : 0;
-                    if (q < a.conf.min_baseQ || p->is_del) continue;      // (deletions / ref skips carry no base)
+                    if (q < a.conf.min_baseQ) continue;                   // SimplePileupViewer.cpp:457, 467
+                    // the quality of EVERY read that passes min-BQ, deleted ones included (:462-470) ...
+                    quals.push_back((char)(q + 33 < 126 ? q + 33 : 126));
+                    if (p->is_del) continue;                              // ... but a base only where there is one (:32)
                     int c = p->qpos < p->b->core.l_qseq ? seq_nt16_str[bam_seqi(bam_get_seq(p->b), p->qpos)] : 'N';
                     const bool rev = bam_is_rev(p->b);
                     if (has_ref) {                                        // pileup_seq, SimplePileupViewer.cpp:32-40
@@ -162,25 +194,21 @@ int read_bam(const std::string& bam_path, const std::string& ref_path, const Pan
                         c = c == '=' ? (rev ? ',' : '.') : (rev ? std::tolower(c) : std::toupper(c));
                     }
                     bases.push_back((char)c);
-                    quals.push_back((char)(q + 33 < 126 ? q + 33 : 126));
                 }
             }
             bam_plp_destroy(plp);
             hts_itr_destroy(a.iter);
             a.iter = nullptr;
         }
+        if (!reported) continue;           // never seen by the reference's loop: not indexed (posIndex, :427-438)
         if (!bases.empty()) {
             v->effectiveNumSite++;
             v->numBases += (int)bases.size();
         }
+        // bases.size() <= quals.size(): the pairing is by index, like the reference's (header of this file)
         v->add_site(slot, bases.data(), quals.data(), bases.size());
     }
     v->avgDepth = v->effectiveNumSite ? (double)v->numBases / v->effectiveNumSite : 0.0;
-    free(a.ref);
-    if (a.fai) fai_destroy(a.fai);
-    hts_idx_destroy(idx);
-    sam_hdr_destroy(a.hdr);
-    sam_close(a.fp);
     return VB2_OK;
 }
 

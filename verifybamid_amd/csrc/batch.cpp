@@ -429,13 +429,8 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
             try {
                 const vb2_model& m = models[num_model == 1 ? 0 : s];
                 Estimator est(num_pc, FiberGang::eval_cb, L.gang->user(i));
-                apply_model(est, m);
+                apply_model(est, m, ctx_[s]->L.known_af != nullptr);
                 est.speculate = speculate_;
-                if (ctx_[s]->L.known_af) {       // context built with --KnownAF data
-                    est.isAFknown = true;
-                    est.isPCFixed = true;
-                    est.isHeter = false;
-                }
                 rcs[s] = est.OptimizeLLK();
                 fill_estimate(est, &out[s]);
             } catch (const std::bad_alloc&) {
@@ -487,7 +482,14 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     };
     for (int l = 0; l < nlane; ++l)
         if (lanes[l].gang->start(k, body_of(lanes[l])) < 0) {
-            set_error("vb2_batch_optimize_llk: getcontext failed");
+            // the lanes started so far have fibers parked in the middle of OptimizeLLK: tell them, and
+            // run them until they have unwound (their Estimators and vectors live on the fiber stacks,
+            // which the gang unmaps) before giving up
+            for (int m = 0; m < l; ++m) {
+                lanes[m].gang->fail(VB2_ERR_INVALID);
+                while (lanes[m].gang->pending()) lanes[m].gang->resume_parked();
+            }
+            set_error("vb2_batch_optimize_llk: could not start the search fibers (mmap / getcontext failed)");
             return VB2_ERR_INVALID;
         }
     launch(lanes[0]);

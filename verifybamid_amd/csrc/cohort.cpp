@@ -326,6 +326,8 @@ private:
                 }
                 if (batch) vb2_batch_destroy(batch);
                 const double dt = (now_s() - t1) / (double)ctxs.size();
+                if (rcb)                    // the group's search failed: its samples must not keep "ok" with a zeroed estimate
+                    for (const int s : who) status_[s] = rcb;
                 if (!rcb) {
                     for (size_t i = 0; i < who.size(); ++i) {
                         const int s = who[i];
@@ -334,7 +336,7 @@ private:
                         const char* prefix = a_->output_prefixes ? a_->output_prefixes[s] : nullptr;
                         if (prefix) {
                             int rw = vb2::write_ancestry(prefix, a_->base.num_pc, est[i].pc, est[i].pc2);
-                            if (!rw) rw = vb2::write_selfsm(prefix, *slots_[s].flat, est[i], true);
+                            if (!rw) rw = vb2::write_selfsm(prefix, *slots_[s].flat, est[i], true);   // (cohort input is text pileups: #READS = NA)
                             if (rw) status_[s] = rw;
                         }
                     }

@@ -224,7 +224,7 @@ static bool run_minimizer(Estimator* e, AmoebaMinimizer& m, int dim,
         if (!dev_ok) {                                    // MathGenMin.cpp:381 (statgen warning())
             e->hit_cycle_limit = true;
             if (e->notices)
-                std::fprintf(stderr, "WARNING - Amoeba.Minimize - Couldn't converge in %d cycles\n", 50000);
+                std::fprintf(stderr, "WARNING - Amoeba.Minimize - Couldn't converge in %ld cycles\n", m.cycleMax);
         }
         return dev_ok;
     }
@@ -239,7 +239,7 @@ static bool run_minimizer(Estimator* e, AmoebaMinimizer& m, int dim,
     if (!ok) {                                            // MathGenMin.cpp:381 (statgen warning())
         e->hit_cycle_limit = true;
         if (e->notices)
-            std::fprintf(stderr, "WARNING - Amoeba.Minimize - Couldn't converge in %d cycles\n", 50000);
+            std::fprintf(stderr, "WARNING - Amoeba.Minimize - Couldn't converge in %ld cycles\n", m.cycleMax);
     }
     return ok;
 }
@@ -450,6 +450,16 @@ void apply_model(Estimator& est, const vb2_model& model)
         est.isAlphaFixed = true;
     }
     if (model.is_af_known) {
+        est.isAFknown = true;
+        est.isPCFixed = true;
+        est.isHeter = false;
+    }
+}
+
+void apply_model(Estimator& est, const vb2_model& model, bool data_has_known_af)
+{
+    apply_model(est, model);
+    if (data_has_known_af) {
         est.isAFknown = true;
         est.isPCFixed = true;
         est.isHeter = false;

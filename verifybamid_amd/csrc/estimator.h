@@ -91,6 +91,10 @@ private:
 };
 
 void apply_model(Estimator& est, const vb2_model& model);
+// The same for an evaluator whose data carry per-marker allele frequencies (a context created from
+// --KnownAF input, Context::L.known_af): main.cpp:314-319 then forces isPCFixed and !isHeter whatever the
+// model says.  ONE place, used by every context-, batch- and shard-level optimise entry point.
+void apply_model(Estimator& est, const vb2_model& model, bool data_has_known_af);
 void fill_estimate(const Estimator& est, vb2_estimate* out);
 
 }  // namespace vb2

@@ -382,12 +382,7 @@ int ShardGroup::optimize(const vb2_model* model, vb2_estimate* out, vb2_trace* t
     }
     const bool res = begin_resident() != 0;
     Estimator est(num_pc, group_eval_cb, this);
-    apply_model(est, *model);
-    if (ctx[0]->L.known_af) {
-        est.isAFknown = true;
-        est.isPCFixed = true;
-        est.isHeter = false;
-    }
+    apply_model(est, *model, ctx[0]->L.known_af != nullptr);
     est.trace = trace;
     if (trace) trace->count = 0;
     const int rc = est.OptimizeLLK();
