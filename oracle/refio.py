@@ -28,6 +28,9 @@ def _newline_terminated_lines(path):
     EOF, so a final line without '\\n' is silently dropped (SURVEY quirk vi)."""
     with open(path, "rb") as fh:
         data = fh.read()
+    if data[:2] == b"\x1f\x8b":          # InputFile opens gzip'd files by their magic bytes (GzipFileType)
+        import gzip
+        data = gzip.decompress(data)
     parts = data.split(b"\n")
     return [p.decode("latin-1") for p in parts[:-1]]
 

@@ -42,3 +42,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def fixture_input_must_match(got_sha, want_sha, what):
+    """A committed fixture is only evidence if the seeded generator reproduces the input it was made from.
+    A mismatch (another numpy drawing other samples) FAILS -- a silent skip would let the at-size
+    parity evidence evaporate -- unless VB2_ALLOW_FIXTURE_DRIFT=1 says the box is known to differ."""
+    import pytest
+    if got_sha == want_sha:
+        return
+    msg = ("%s: the seeded generator produced input %s..., the committed fixture was made from %s... "
+           "(regenerate with tests/golden/make_fixtures.py, or set VB2_ALLOW_FIXTURE_DRIFT=1 to skip)"
+           % (what, got_sha[:12], want_sha[:12]))
+    if os.environ.get("VB2_ALLOW_FIXTURE_DRIFT", "") == "1":
+        pytest.skip(msg)
+    pytest.fail(msg)

@@ -102,6 +102,79 @@ def synthetic_fixture(spec):
     return out
 
 
+PANELS = os.path.join(HERE, "panels")
+REAL = {
+    # BASELINE.json configs[0] names this panel; configs[2] is the shape of its 100k sibling
+    "10k_k2": dict(panel="1000g.phase3.10k.b37.vcf.gz.dat", num_pc=2, depth=30, alpha_true=0.05, seed=11, points=8),
+    "10k_k4": dict(panel="1000g.phase3.10k.b37.vcf.gz.dat", num_pc=4, depth=30, alpha_true=0.08, seed=12, points=8),
+    "100k_k4": dict(panel="1000g.phase3.100k.b37.vcf.gz.dat", num_pc=4, depth=30, alpha_true=0.03, seed=13, points=3),
+}
+
+
+def file_sha(path):
+    """sha256 of a panel file's CONTENT (gzip'd copies are inflated first: the 100k panel is committed gzip'd)."""
+    import gzip
+    raw = open(path, "rb").read()
+    if raw[:2] == b"\x1f\x8b":
+        raw = gzip.decompress(raw)
+    return hashlib.sha256(raw).hexdigest()
+
+
+def real_panel_fixture(spec, tmpdir):
+    """Reads drawn on the REFERENCE'S OWN bundled panel (real U.D spectra, real mean genotypes, real
+    alleles incl. the multi-allelic `A,G` rows of which the reference keeps the first character,
+    ContaminationEstimator.cpp:417,428-429), written as a text pileup and read back through the file
+    readers with the sanity check ON (the +-3 sd depth filter of h:246-249 is active)."""
+    import verifybamid_amd as vb
+    from oracle import binding, refio
+    from oracle.bridge import oracle_data
+    k = spec["num_pc"]
+    prefix = os.path.join(PANELS, spec["panel"])
+    ref_prefix = os.path.join("/root/reference/resource", spec["panel"])
+    shas = {}
+    for ext in ("UD", "mu", "bed"):
+        shas[ext] = file_sha(prefix + "." + ext)
+        if os.path.exists(ref_prefix + "." + ext) and file_sha(ref_prefix + "." + ext) != shas[ext]:
+            raise SystemExit("%s.%s is not the reference's file" % (prefix, ext))
+    pile = vb.synth.real_panel_sample(prefix, os.path.join(tmpdir, "real.pileup"), spec["depth"], spec["alpha_true"],
+                                      spec["seed"])
+    flat, panel, viewer = refio.load_flat(prefix, pile, k, sanity_disabled=False)     # the reference's readers, restated
+    od = binding.OracleData(flat)
+    d = vb.PileupData.from_files(prefix, pile, k, disable_sanity=False)               # the product's readers (host only)
+    od2 = oracle_data(d)
+    rng = np.random.default_rng(2000 + spec["seed"])
+    B = spec["points"]
+    pc1 = rng.normal(0, 0.01, size=(B, k))
+    pc2 = rng.normal(0, 0.01, size=(B, k))
+    alpha = rng.uniform(0.0, 0.5, size=B)
+    alpha[0] = 0.0
+    llk = [od.llk(pc1[i], pc2[i], alpha[i], num_thread=1) for i in range(B)]
+    llk2 = [od2.llk(pc1[i], pc2[i], alpha[i], num_thread=1) for i in range(B)]
+    if llk != llk2:
+        raise SystemExit("the product's file readers and the restated reference readers disagree on %s" % spec["panel"])
+    multi = sum(1 for line in refio._newline_terminated_lines(prefix + ".bed") if "," in line.split()[4])
+    out = dict(
+        panel=spec["panel"], panel_sha256=shas, multi_allelic_alt_rows=multi,
+        generator=dict(mean_depth=spec["depth"], num_pc=k, alpha_true=spec["alpha_true"], seed=spec["seed"]),
+        input_sha256=sha(d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base),
+        reads=int(d.num_read), avg_depth_hex=float(d.avg_depth).hex(), sd_depth_hex=float(d.sd_depth).hex(),
+        points=dict(pc1=pc1.tolist(), pc2=pc2.tolist(), alpha=alpha.tolist()),
+        llk_hex=[float(x).hex() for x in llk], llk_threads=1, models={})
+    a = od.optimize(num_thread=1, minimizer="oracle", trace_capacity=1 << 14)
+    have_ref = binding.ref_lib() is not None
+    if have_ref:
+        b = od.optimize(num_thread=1, minimizer="reference", trace_capacity=1 << 14)
+        if not (a["alpha"] == b["alpha"] and a["llk1"] == b["llk1"] and a["llk0"] == b["llk0"] and
+                a["num_eval"] == b["num_eval"] and trace_digest(a["trace"]) == trace_digest(b["trace"])):
+            raise SystemExit("oracle minimiser and the reference's AmoebaMinimizer disagree on %s" % spec["panel"])
+    out["models"]["heter"] = dict(
+        args={}, alpha_hex=float(a["alpha"]).hex(), llk1_hex=float(a["llk1"]).hex(), llk0_hex=float(a["llk0"]).hex(),
+        num_eval=a["num_eval"], pc_hex=[float(x).hex() for x in a["pc"]], pc2_hex=[float(x).hex() for x in a["pc2"]],
+        trace_sha256=trace_digest(a["trace"]), trace_head_llk_hex=[float(x).hex() for x in a["trace"]["llk"][:6]],
+        cross_checked_with_reference_minimiser=have_ref)
+    return out
+
+
 def kat_llk():
     """The five known-answer points on the two bundled inputs, recomputed with the oracle."""
     from oracle import binding, refio
@@ -149,6 +222,23 @@ def main():
         else:
             json.dump(fx, open(path, "w"), indent=1)
             print("wrote %s (%d points, models %s)" % (fname, len(fx["llk_hex"]), sorted(fx["models"])))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        real = dict(_what="reads drawn (verifybamid_amd.synth.real_panel_sample) on the reference's bundled 1000g.phase3 "
+                          "panels (tests/golden/panels/: byte-identical data files, the 100k ones gzip'd), read back "
+                          "through the file readers with the sanity check on; oracle results; regenerate with "
+                          "tests/golden/make_fixtures.py",
+                    cases={name: real_panel_fixture(spec, tmp) for name, spec in REAL.items()})
+    path = os.path.join(HERE, "real_panel.json")
+    if args.check:
+        if json.load(open(path)) != json.loads(json.dumps(real)):
+            print("real_panel.json differs from what the recipe produces now")
+            bad += 1
+    else:
+        json.dump(real, open(path, "w"), indent=1)
+        print("wrote real_panel.json (%s)" % ", ".join("%s: alpha %.6f, %d evals" % (
+            n, float.fromhex(c["models"]["heter"]["alpha_hex"]), c["models"]["heter"]["num_eval"])
+            for n, c in real["cases"].items()))
     if bad:
         raise SystemExit(1)
     print("fixtures %s" % ("reproduce" if args.check else "written"))

@@ -259,8 +259,8 @@ def test_committed_synthetic_fixtures(golden_dir, fname):
     h = hashlib.sha256()
     for a in (d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base):
         h.update(np.ascontiguousarray(a).tobytes())
-    if h.hexdigest() != fx["input_sha256"]:
-        pytest.skip("this numpy draws a different synthetic sample than the one the fixture was made from")
+    from conftest import fixture_input_must_match
+    fixture_input_must_match(h.hexdigest(), fx["input_sha256"], fname)       # a mismatch FAILS (VB2_ALLOW_FIXTURE_DRIFT=1 skips)
     P = fx["points"]
     want = np.array([float.fromhex(x) for x in fx["llk_hex"]])
     with vb.LikelihoodContext(d) as ctx:
@@ -274,6 +274,47 @@ def test_committed_synthetic_fixtures(golden_dir, fname):
             assert est["num_eval"] == m["num_eval"], name
             head = np.array([float.fromhex(x) for x in m["trace_head_llk_hex"]])
             assert rel_err(est["trace"]["llk"][:len(head)], head) <= LLK_RTOL, name
+
+
+@pytest.mark.parametrize("case", ["10k_k2", "10k_k4", "100k_k4"])
+def test_real_panel_fixtures_through_the_file_flow(golden_dir, tmp_path, case):
+    """The reference's own bundled 1000g.phase3 panels (tests/golden/panels/; BASELINE.json configs[0] names
+    the 10k one, configs[2] is the 100k one's shape): real U.D spectra, AF clamping at real mean genotypes,
+    multi-allelic `A,G` alt rows kept by their first character (ContaminationEstimator.cpp:417,428-429),
+    sanity check ON (the +-3 sd depth filter, h:246-249).  tests/golden/real_panel.json holds the oracle's
+    results (made by tests/golden/make_fixtures.py, search cross-checked against the reference's own
+    AmoebaMinimizer).  The HIP path gets there from the FILES: vb2_flat_load -> vb2_ctx_create ->
+    vb2_llk_eval_batch for the points, and vb2_run (the --SVDPrefix/--PileupFile flow) for the estimate."""
+    import sys
+    from conftest import fixture_input_must_match
+    sys.path.insert(0, golden_dir)
+    from make_fixtures import sha
+    fx = json.load(open(os.path.join(golden_dir, "real_panel.json")))["cases"][case]
+    g = fx["generator"]
+    k = g["num_pc"]
+    prefix = os.path.join(golden_dir, "panels", fx["panel"])
+    pile = vb.synth.real_panel_sample(prefix, str(tmp_path / "real.pileup"), g["mean_depth"], g["alpha_true"], g["seed"])
+    d = vb.PileupData.from_files(prefix, pile, k, disable_sanity=False)
+    fixture_input_must_match(sha(d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base), fx["input_sha256"], case)
+    P = fx["points"]
+    want = np.array([float.fromhex(x) for x in fx["llk_hex"]])
+    m = fx["models"]["heter"]
+    with vb.LikelihoodContext(d) as ctx:
+        got = ctx.llk(P["pc1"], P["pc2"], P["alpha"])
+        assert rel_err(got, want) <= LLK_RTOL
+        est = ctx.optimize(trace_capacity=1 << 14)
+        head = np.array([float.fromhex(x) for x in m["trace_head_llk_hex"]])
+        assert rel_err(est["trace"]["llk"][:len(head)], head) <= LLK_RTOL
+    run = vb.run_files(prefix, pile, str(tmp_path / "out"), num_pc=k, disable_sanity=False)
+    for e in (est, run):
+        assert abs(e["alpha"] - float.fromhex(m["alpha_hex"])) <= 1e-9
+        assert abs(e["llk1"] - float.fromhex(m["llk1_hex"])) <= LLK_RTOL * abs(e["llk1"])
+        assert abs(e["llk0"] - float.fromhex(m["llk0_hex"])) <= LLK_RTOL * abs(e["llk0"])
+        assert e["num_eval"] == m["num_eval"]
+        assert rel_err(e["pc"], [float.fromhex(x) for x in m["pc_hex"]]) <= 1e-7
+    assert run["num_marker"] == (10000 if case.startswith("10k") else 100000)
+    anc = open(str(tmp_path / "out") + ".Ancestry").read()
+    assert anc == ancestry_text([float.fromhex(x) for x in m["pc_hex"]], [float.fromhex(x) for x in m["pc2_hex"]])
 
 
 # ------------------------------------------------------------------ full size, properties

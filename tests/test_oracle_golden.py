@@ -168,8 +168,8 @@ def test_synthetic_fixtures_reproduce_from_the_oracle(golden_dir, fname):
     h = hashlib.sha256()
     for a in (d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base):
         h.update(np.ascontiguousarray(a).tobytes())
-    if h.hexdigest() != fx["input_sha256"]:
-        pytest.skip("this numpy draws a different synthetic sample than the one the fixture was made from")
+    from conftest import fixture_input_must_match
+    fixture_input_must_match(h.hexdigest(), fx["input_sha256"], fname)
     od = oracle_data(d)
     P = fx["points"]
     npts = len(fx["llk_hex"]) if g["markers"] <= 20000 else 3
@@ -185,6 +185,53 @@ def test_synthetic_fixtures_reproduce_from_the_oracle(golden_dir, fname):
             for key in ("alpha", "pc1", "pc2", "llk"):
                 hh.update(np.ascontiguousarray(r["trace"][key]).tobytes())
             assert hh.hexdigest() == m["trace_sha256"], name
+
+
+@pytest.mark.parametrize("case", ["10k_k2", "10k_k4", "100k_k4"])
+def test_real_panel_fixtures_reproduce_from_the_oracle(golden_dir, tmp_path, case):
+    """tests/golden/real_panel.json: reads drawn on the reference's OWN bundled 1000g.phase3 panels
+    (tests/golden/panels/, byte-identical data; BASELINE.json configs[0] names the 10k one, configs[2] is
+    the 100k one's shape), through the file readers with the sanity check on.  Checked here: the panel
+    files are the recorded ones; the restated reference readers (oracle/refio.py) and the product's C++
+    readers (vb2_flat_load, host only) yield the same arrays -- including the 53 / 627 multi-allelic
+    `A,G` alt rows kept by their first character (ContaminationEstimator.cpp:417,428-429); the oracle gives
+    the recorded +LLK bits; at 10 k markers also the recorded OptimizeLLK, evaluation by evaluation."""
+    import hashlib
+    import sys
+    import verifybamid_amd as vb
+    from oracle import refio
+    from oracle.bridge import oracle_data
+    from conftest import fixture_input_must_match
+    sys.path.insert(0, golden_dir)
+    from make_fixtures import file_sha, sha
+    fx = json.load(open(os.path.join(golden_dir, "real_panel.json")))["cases"][case]
+    g = fx["generator"]
+    k = g["num_pc"]
+    prefix = os.path.join(golden_dir, "panels", fx["panel"])
+    for ext, want in fx["panel_sha256"].items():
+        assert file_sha(prefix + "." + ext) == want, ext
+    pile = vb.synth.real_panel_sample(prefix, str(tmp_path / "real.pileup"), g["mean_depth"], g["alpha_true"], g["seed"])
+    d = vb.PileupData.from_files(prefix, pile, k, disable_sanity=False)
+    fixture_input_must_match(sha(d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base), fx["input_sha256"], case)
+    assert fx["multi_allelic_alt_rows"] in (53, 627) and d.num_read == fx["reads"]
+    assert float(d.avg_depth).hex() == fx["avg_depth_hex"] and float(d.sd_depth).hex() == fx["sd_depth_hex"]
+    flat, panel, viewer = refio.load_flat(prefix, pile, k, sanity_disabled=False)
+    od, od_ref = oracle_data(d), binding.OracleData(flat)
+    P = fx["points"]
+    for i in range(len(fx["llk_hex"])):
+        a = od.llk(P["pc1"][i], P["pc2"][i], P["alpha"][i], num_thread=1)
+        assert float(a).hex() == fx["llk_hex"][i], i
+        if i < 2:
+            assert od_ref.llk(P["pc1"][i], P["pc2"][i], P["alpha"][i], num_thread=1) == a
+    if case.startswith("10k"):
+        m = fx["models"]["heter"]
+        r = od.optimize(num_thread=1, trace_capacity=1 << 14)
+        assert float(r["alpha"]).hex() == m["alpha_hex"] and float(r["llk1"]).hex() == m["llk1_hex"]
+        assert float(r["llk0"]).hex() == m["llk0_hex"] and r["num_eval"] == m["num_eval"]
+        hh = hashlib.sha256()
+        for key in ("alpha", "pc1", "pc2", "llk"):
+            hh.update(np.ascontiguousarray(r["trace"][key]).tobytes())
+        assert hh.hexdigest() == m["trace_sha256"]
 
 
 # ---- the device's restatement of libm exp() (InvLogit, ContaminationEstimator.h:119-122) ----

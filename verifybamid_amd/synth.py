@@ -99,3 +99,77 @@ def write_files(d: PileupData, prefix):
                 continue
             f.write("1\t%d\t%s\t%d\t%s\t%s\n" % (1000 + 10 * i, chr(ref[i]), e - b, bases[b:e], quals[b:e]))
     return prefix
+
+
+def reads_on_panel(means, ref_char, alt_char, mean_depth=30.0, alpha_true=0.05, seed=1, q_lo=20, q_hi=40):
+    """The read-drawing half of the recipe on a GIVEN panel (e.g. the reference's bundled
+    1000g.phase3 panels: real mean genotypes, real ref/alt alleles -- first character of the
+    .bed columns, like the reference reads them).  Genotypes ~ Binom(2, clamp(mu/2)) for both
+    samples.  Returns (read_off, bases, quals): one pileup entry per panel row, in row order."""
+    rng = np.random.default_rng(seed)
+    mu = np.asarray(means, dtype=np.float64)
+    M = mu.shape[0]
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3}
+    ref_i = np.array([code.get(int(c), 0) for c in np.asarray(ref_char, dtype=np.uint8)])
+    alt_i = np.array([code.get(int(c), 1) for c in np.asarray(alt_char, dtype=np.uint8)])
+    af = np.clip(mu / 2.0, 0.00005, 0.99995)
+    g2 = rng.binomial(2, af)
+    g1 = rng.binomial(2, af)
+    depth = rng.poisson(mean_depth, size=M).astype(np.int64)
+    read_off = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(depth, out=read_off[1:])
+    R = int(read_off[-1])
+    mk = np.repeat(np.arange(M), depth)
+    g = np.where(rng.random(R) < alpha_true, g1[mk], g2[mk])
+    is_alt = rng.random(R) < (g / 2.0)
+    q = rng.integers(q_lo, q_hi + 1, size=R)
+    err = rng.random(R) < np.power(10.0, -q / 10.0)
+    true_base = np.where(is_alt, alt_i[mk], ref_i[mk])
+    obs_base = np.where(err, (true_base + rng.integers(1, 4, size=R)) % 4, true_base)
+    fwd = rng.random(R) < 0.5
+    ch = np.where(fwd, _BASES[obs_base], _LOWER[obs_base])
+    ch = np.where(obs_base == ref_i[mk], np.where(fwd, ord("."), ord(",")), ch).astype(np.uint8)
+    return read_off, ch, (q + 33).astype(np.uint8)
+
+
+def read_bed_rows(bed_path):
+    """(chr, pos, first char of ref, first char of alt) per row of a .bed (plain or gzip'd)."""
+    import gzip
+    raw = open(bed_path, "rb").read()
+    if raw[:2] == b"\x1f\x8b":
+        raw = gzip.decompress(raw)
+    chrs, poss, refs, alts = [], [], [], []
+    for line in raw.decode("latin-1").split("\n"):
+        tok = line.split()
+        if len(tok) < 5:
+            continue
+        chrs.append(tok[0]); poss.append(int(tok[2])); refs.append(ord(tok[3][0])); alts.append(ord(tok[4][0]))
+    return chrs, np.array(poss), np.array(refs, dtype=np.uint8), np.array(alts, dtype=np.uint8)
+
+
+def read_mu_column(mu_path):
+    import gzip
+    raw = open(mu_path, "rb").read()
+    if raw[:2] == b"\x1f\x8b":
+        raw = gzip.decompress(raw)
+    return np.array([float(line.split()[1]) for line in raw.decode("latin-1").split("\n") if line.strip()])
+
+
+def write_pileup_text(path, chrs, poss, ref_char, read_off, bases, quals):
+    """6-column samtools pileup for the drawn reads, one line per covered panel row."""
+    b = np.asarray(bases, dtype=np.uint8).tobytes().decode("latin-1")
+    q = np.asarray(quals, dtype=np.uint8).tobytes().decode("latin-1")
+    with open(path, "w") as f:
+        for i in range(len(chrs)):
+            lo, hi = int(read_off[i]), int(read_off[i + 1])
+            if hi > lo:
+                f.write("%s\t%d\t%s\t%d\t%s\t%s\n" % (chrs[i], int(poss[i]), chr(int(ref_char[i])), hi - lo, b[lo:hi], q[lo:hi]))
+    return path
+
+
+def real_panel_sample(svd_prefix, pileup_path, mean_depth=30.0, alpha_true=0.05, seed=1):
+    """Draws reads on the panel behind `svd_prefix` (.mu/.bed) and writes them as a text pileup."""
+    chrs, poss, refs, alts = read_bed_rows(svd_prefix + ".bed")
+    mu = read_mu_column(svd_prefix + ".mu")
+    off, b, q = reads_on_panel(mu, refs, alts, mean_depth, alpha_true, seed)
+    return write_pileup_text(pileup_path, chrs, poss, refs, off, b, q)
