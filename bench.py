@@ -290,9 +290,19 @@ def main():
             valu = {"busy_frac": vj["valu_busy_frac"],
                     "lane_instr_per_marker_point": vj["lane_instr_per_marker_point"],
                     "lds_busy_frac": vj.get("lds_busy_frac"), "source": vsrc, "note": FP64_VALU_NOTE}
+        # the binding ceiling, next to the nominal one: FP64 VALU issue time / kernel time.  Issue time =
+        # lane-instructions per marker x point (SQ_INSTS_VALU of the committed PMC pass of this command) x
+        # markers x points / (256 CUs x 4 SIMDs x 16 FP64 lanes per clock x 2.4 GHz)
+        valu_frac = None
+        if valu:
+            issue_us = (valu["lane_instr_per_marker_point"] * info["num_active_marker"] * B /
+                        (1024 * 16 * 2.4e9)) * 1e6
+            valu_frac = issue_us / step_us
+            valu["issue_us_per_launch"] = issue_us
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": achieved / HBM_PEAK_GBPS, "valu_frac": valu_frac,
+            "traffic": traffic, "traffic_source": traffic_src,
             "hbm_actual_GBps": (traffic / (step_us * 1e-6) / 1e9) if traffic else None,
             "binding_ceiling": "FP64 VALU issue (see valu), not HBM: the 10 MB pileup is read once per launch "
                                "and re-used from L2/LDS by every point",
@@ -380,10 +390,20 @@ def main():
                 t1 = time.perf_counter()
                 est = ctx.optimize()
                 t_opt.append(time.perf_counter() - t1)
+            w_opt = min(t_opt)
             result["optimize"] = {
-                "wall_ms_to_converged_alpha": 1e3 * min(t_opt),
+                "wall_ms_to_converged_alpha": 1e3 * w_opt,
                 "alpha": est["alpha"], "alpha_true": 0.05, "num_eval": est["num_eval"],
                 "num_launch_point": est["num_launch_point"],
+                # the search against the same nominal roofline: the reference's evaluations (num_eval) x the
+                # algorithmic bytes of one, over the wall-clock; and the same for every point actually launched
+                # (the speculative {R, E, C_A, C_R} batches evaluate 2.5 points per committed one)
+                "useful_evals_per_s": est["num_eval"] / w_opt,
+                "algorithmic_GBps": info["algorithmic_bytes_per_eval"] * est["num_eval"] / w_opt / 1e9,
+                "frac": info["algorithmic_bytes_per_eval"] * est["num_eval"] / w_opt / 1e9 / HBM_PEAK_GBPS,
+                "frac_launched_points": info["algorithmic_bytes_per_eval"] * est["num_launch_point"] / w_opt / 1e9
+                                        / HBM_PEAK_GBPS,
+                "us_per_round": 1e6 * w_opt / max(1.0, est["num_launch_point"] / 4.0),
             }
         if world == 1 and not args.no_extras and args.cohort_samples > 0:
             # BASELINE.json configs[4] per GPU: a cohort of C3-shaped samples searched in lock-step
@@ -424,9 +444,29 @@ def main():
                 t1 = time.perf_counter()
                 ests = batch.optimize()
                 dto = time.perf_counter() - t1
+            step_bytes = sum(c.info()["cohort_step_bytes"] for c in cctx)        # HBM bytes one step streams (all samples)
+            alg_bytes = sum(c.info()["algorithmic_bytes_per_eval"] for c in cctx)   # SURVEY 8d, one point per sample
             for c in cctx[1:]:
                 c.close()
+            # per step shape: algorithmic bytes (points x SURVEY 8d's per-evaluation figure, summed over the
+            # samples), the device bytes the step streams from HBM (every sample's run lists, panel rows and
+            # constants once, whatever the points), and both against the 8 TB/s peak.  `traffic` = the same
+            # launch's PMC FETCH_SIZE (profiles/<round>/cohort_traffic.json) when a committed pass matches.
+            ctj, ctsrc = latest_profile("cohort_traffic.json")
+            shapes = {}
+            for npnt, dt_s in ((1, dt1), (2, dt2), (4, dt4)):
+                tr = None
+                if ctj and ctj.get("samples") == S and ctj.get("markers") == args.markers:
+                    tr = ctj.get("traffic_bytes_per_step", {}).get(str(npnt))
+                shapes["points_%d" % npnt] = {
+                    "step_us": 1e6 * dt_s, "algorithmic_bytes": int(alg_bytes * npnt),
+                    "frac": alg_bytes * npnt / dt_s / 1e9 / HBM_PEAK_GBPS,
+                    "streamed_bytes": int(step_bytes), "streamed_GBps": step_bytes / dt_s / 1e9,
+                    "streamed_frac": step_bytes / dt_s / 1e9 / HBM_PEAK_GBPS,
+                    "traffic": tr, "traffic_source": ctsrc if tr else None,
+                }
             result["cohort"] = {
+                "step_shapes": shapes, "streamed_bytes_per_sample": int(step_bytes / S),
                 "what": "%d samples of the workload's shape on ONE GPU, searched in lock-step (vb2_batch_*: one launch "
                         "per Nelder-Mead step for all samples)" % S,
                 "samples": S, "step_us_4_points_per_sample": 1e6 * dt4, "evals_per_s": 4 * S / dt4,
@@ -508,14 +548,37 @@ def main():
                     n_cpu += 1
                 rates[nt] = n_cpu / (time.perf_counter() - tc)
             best = max(rates, key=rates.get)
+            # second half of the metric on the CPU (SURVEY 8d "CPU baseline beside it"): the oracle's OptimizeLLK
+            # (same algorithm, same 780 evaluations) on the same pileup at --NumThread 1, 4 (the reference's
+            # default, main.cpp:79) and the best thread count of the sweep -- one run each, ~10 + 2.5 + 0.7 s
+            cpu_opt, cpu_alpha = {}, None
+            if not args.no_optimize:
+                for nt in sorted({1, 4, best}):
+                    tc = time.perf_counter()
+                    r_cpu = od.optimize(num_thread=nt)
+                    cpu_opt[str(nt)] = 1e3 * (time.perf_counter() - tc)
+                    cpu_alpha = r_cpu["alpha"]
             result["cpu_baseline"] = {
                 "value": rates[best], "unit": "evals/s", "cores": best, "kind": "port",
+                "evals_per_s_by_threads": {str(t): r for t, r in rates.items()},
+                "optimize_wall_ms_by_threads": cpu_opt, "optimize_alpha": cpu_alpha,
                 "sample": "C oracle (oracle/vb2_oracle.c, OpenMP over markers like the reference) on the "
-                          "same %d-marker pileup, ~%.1f s per thread count; evals/s by threads: %s; "
+                          "same %d-marker pileup, ~%.1f s per thread count; evals/s by threads: %s; one full "
+                          "OptimizeLLK per thread count in optimize_wall_ms_by_threads; "
                           "%d hardware threads visible, CPU quota of the container: %s"
                           % (args.markers, 10.0 / len(sweep), {t: round(r, 1) for t, r in rates.items()}, navail,
                              "%d CPUs" % quota if quota else "none"),
             }
+            # the two speed-ups the north star asks about (>= 50x), both against the best CPU figure and
+            # against the reference's default --NumThread 4
+            sp_up = {"evals_per_s_vs_best_cpu": value / rates[best], "evals_per_s_vs_numthread_4": value / rates[4]}
+            if cpu_opt and "optimize" in result:
+                g_ms = result["optimize"]["wall_ms_to_converged_alpha"]
+                sp_up["optimize_wall_vs_best_cpu"] = cpu_opt[str(best)] / g_ms
+                sp_up["optimize_wall_vs_numthread_4"] = cpu_opt["4"] / g_ms
+                sp_up["optimize_wall_vs_numthread_1"] = cpu_opt["1"] / g_ms
+                sp_up["alpha_gpu_minus_cpu"] = result["optimize"]["alpha"] - cpu_alpha
+            result["speedup_vs_cpu"] = sp_up
     if ctx is not None:
         ctx.close()
     if group is not None:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VB2_ABI_VERSION 3
+#define VB2_ABI_VERSION 4
 
 typedef enum vb2_status {
     VB2_OK = 0,
@@ -78,6 +78,9 @@ typedef struct vb2_input {
 typedef struct vb2_options {
     int32_t device;            /* HIP device ordinal, -1 = current device          */
     int32_t flags;             /* VB2_OPT_* bits                                   */
+#define VB2_OPT_COHORT_LAYOUT 1   /* also keep the 16-bit run lists that vb2_batch_* steps stream (half the bytes
+                                   * per sample and step; +28 % device memory).  Without it vb2_batch_create
+                                   * builds them on first use. */
     void *stream;              /* hipStream_t to run on; NULL = context-owned      */
 } vb2_options;
 
@@ -96,6 +99,9 @@ typedef struct vb2_info {
     int64_t algorithmic_bytes_per_eval;
     char device_name[64];
     char arch[32];
+    /* (ABI 4) HBM bytes ONE lock-step cohort step (vb2_batch_*) reads of this sample: run lists (16-bit
+     * once built, see VB2_OPT_COHORT_LAYOUT) + tile records + panel rows + per-marker constants */
+    int64_t cohort_step_bytes;
 } vb2_info;
 
 /* Builds the device-resident SoA form of the input (classification, quality
@@ -255,7 +261,10 @@ int vb2_shard_group_create(const vb2_input *in, const int32_t *devices, int32_t 
  * the caller broadcasts the 128 bytes by its own means, then every rank builds the group with the
  * WHOLE sample, its device, its rank.  Every evaluation is launch + ncclAllReduce on the
  * context's stream; all ranks receive identical sums and take identical search decisions.
- * id128 == NULL with nranks == 1 gives a group without a communicator. */
+ * id128 == NULL gives a group without a communicator: vb2_shard_group_eval then returns this rank's
+ * PARTIAL sums (the whole sums when nranks == 1) and the caller reduces them over its own transport
+ * (torch.distributed, MPI); vb2_shard_group_optimize_llk needs whole sums and refuses such a group
+ * when nranks > 1. */
 int vb2_rccl_unique_id(void *id128 /* 128 bytes out */);
 int vb2_shard_group_create_rank(const vb2_input *in, int32_t device, int32_t rank, int32_t nranks,
                                 const void *id128, vb2_shard_group **out);

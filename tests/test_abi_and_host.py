@@ -34,7 +34,7 @@ def test_header_symbols_exported():
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vb2_abi_version() == 3
+    assert lib.vb2_abi_version() == 4
 
 
 def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):

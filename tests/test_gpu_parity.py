@@ -808,6 +808,63 @@ def test_shard_group_rank_mode_goes_through_rccl(c2):
         assert g.optimize()["alpha"] == one["alpha"]
 
 
+def test_c4_marker_shards_at_full_size(golden_dir, c3):
+    """BASELINE.json configs[3] at its real size through vb2_shard_group: the 100 000-marker sample cut into
+    EIGHT read-balanced marker shards (here all on the one device of the box: host-summed partial LLKs, the
+    per-shard work of an 8-GPU run), against the committed oracle fixture (synthetic_c3.json) and the
+    single-context run; then the rank-per-process form -- every rank's own shard of 8 built separately
+    (vb2_shard_group_create_rank), partial sums added here like the all-reduce would -- and the RCCL path
+    itself with the one-rank communicator this box allows (launch -> ncclAllReduce -> publish kernel ->
+    one host wait)."""
+    fx = json.load(open(os.path.join(golden_dir, "synthetic_c3.json")))
+    P = fx["points"]
+    pc1, pc2, al = np.array(P["pc1"]), np.array(P["pc2"]), np.array(P["alpha"])
+    want = np.array([float.fromhex(x) for x in fx["llk_hex"]])
+    m = fx["models"]["heter"]
+    with vb.LikelihoodContext(c3) as ctx:
+        single = ctx.llk(pc1, pc2, al)
+        one = ctx.optimize()
+    assert rel_err(single, want) <= LLK_RTOL
+    with vb.ShardGroup(c3, devices=[0] * 8) as g:
+        info = g.info()
+        assert info["num_shard"] == 8 and not info["uses_rccl"]
+        assert info["marker_lo"][0] == 0 and info["marker_hi"][-1] == 100000
+        assert info["marker_hi"][:-1] == info["marker_lo"][1:]
+        assert sum(info["num_read"]) == c3.num_read
+        assert max(info["num_read"]) - min(info["num_read"]) <= 2 * 70          # balanced on reads, not markers
+        got = g.llk(pc1, pc2, al)
+        assert rel_err(got, want) <= LLK_RTOL and rel_err(got, single) <= 1e-13
+        big = g.llk(np.tile(pc1, (7, 1)), np.tile(pc2, (7, 1)), np.tile(al, 7))      # 56 points: more than one launch
+        assert np.array_equal(big, np.tile(got, 7))
+        est = g.optimize()
+    for e in (one, est):
+        assert abs(e["alpha"] - float.fromhex(m["alpha_hex"])) <= 1e-9
+        assert abs(e["llk1"] - float.fromhex(m["llk1_hex"])) <= LLK_RTOL * abs(e["llk1"])
+        assert e["num_eval"] == m["num_eval"]
+    # rank-per-process form, one group per rank (no communicator: each returns its shard's partial sums)
+    parts = []
+    reads = 0
+    for r in range(8):
+        with vb.ShardGroup(c3, device=0, rank=r, nranks=8, unique_id=None) as gr:
+            ir = gr.info()
+            assert ir["num_shard"] == 1 and ir["nranks"] == 8 and ir["rank"] == r
+            assert (ir["marker_lo"][0], ir["marker_hi"][0]) == (info["marker_lo"][r], info["marker_hi"][r])
+            reads += ir["num_read"][0]
+            parts.append(gr.llk(pc1, pc2, al))
+            if r == 3:
+                with pytest.raises(_abi.Vb2Error):           # partial sums only: no search on such a group
+                    gr.optimize()
+    assert reads == c3.num_read
+    assert rel_err(np.sum(parts, axis=0), want) <= LLK_RTOL
+    # the RCCL path at this size (a one-rank communicator: the all-reduce is the identity)
+    with vb.ShardGroup(c3, device=0, rank=0, nranks=1, unique_id=vb.ShardGroup.unique_id()) as g1:
+        assert g1.info()["uses_rccl"]
+        assert np.array_equal(g1.llk(pc1, pc2, al), single)
+        assert g1.info()["num_allreduce"] >= 1
+        e1 = g1.optimize()                    # (one rank: the search runs against the resident kernel, no collective)
+        assert e1["alpha"] == one["alpha"] and e1["num_eval"] == one["num_eval"] and e1["llk1"] == one["llk1"]
+
+
 def test_shard_group_two_devices_rccl_all_reduce(c2):
     """Two real devices: marker shards + ONE ncclAllReduce per batch (configs[3] in small)."""
     if _abi.lib().vb2_device_count() < 2:
@@ -863,6 +920,64 @@ def test_cohort_batch_lockstep_matches_individual_runs():
             c.close()
 
 
+def test_cohort_steps_on_16bit_run_lists_are_bit_identical():
+    """The 1- and 2-point steps of a cohort stream a 16-bit copy of every sample's run lists
+    (DeviceLayout::codes16: dictionary index | count << 8, re-coded on the device from the 32-bit run words;
+    half the HBM bytes per step).  Same runs, same order, same FMAs: a batch on the 16-bit lists returns,
+    BIT FOR BIT, what the same batch returns on the 32-bit lists -- for ragged depths (runs split at 31
+    reads), the widest alphabet (188 codes: narrow table rows), a sample without reads, a 17-marker sample
+    with 300 reads per marker, and for both ways the copy comes about (VB2_OPT_COHORT_LAYOUT at creation /
+    built by vb2_batch_create) -- and each sample's own single-context evaluation to rounding."""
+    import ctypes
+    k = 3
+    rng = np.random.default_rng(77)
+    datas = [vb.synth.make_pileup(3000, 25, k, alpha_true=0.02, seed=71),
+             vb.synth.make_pileup(1500, 90, k, alpha_true=0.2, seed=72, q_lo=0, q_hi=93),       # 188 codes, runs > 31 reads
+             vb.synth.make_pileup(40, 10, k, seed=73, missing_frac=1.0),
+             vb.synth.make_pileup(5000, 40, k, alpha_true=0.3, seed=74, q_lo=30, q_hi=33),
+             vb.synth.make_pileup(17, 300, k, alpha_true=0.1, seed=75, q_lo=35, q_hi=36)]       # 300 reads on 2 qualities
+    ctxs = [vb.LikelihoodContext(d, cohort_layout=(i % 2 == 0)) for i, d in enumerate(datas)]
+    lib = _abi.lib()
+    lib.vb2_debug_set_cohort_w16.argtypes = [ctypes.c_int]
+    lib.vb2_debug_set_cohort_w16.restype = None
+    try:
+        S = len(ctxs)
+        pc1 = rng.normal(0, 0.03, size=(S, 8, k))
+        pc2 = rng.normal(0, 0.03, size=(S, 8, k))
+        al = rng.uniform(0, 0.5, size=(S, 8))
+        shapes = ([1] * S, [2] * S, [4] * S, [1, 4, 0, 2, 3], [2, 1, 1, 0, 2])
+        results = {}
+        before = [c.info()["cohort_step_bytes"] for c in ctxs]
+        for w16 in (0, 1):
+            lib.vb2_debug_set_cohort_w16(w16)
+            with vb.CohortBatch(ctxs) as batch:
+                results[w16] = [batch.eval(np.array(npts, dtype=np.int32), pc1, pc2, al) for npts in shapes]
+            now = [c.info()["cohort_step_bytes"] for c in ctxs]
+            for i in range(S):
+                if w16 == 0 or i % 2 == 0 or datas[i].num_read == 0:
+                    assert now[i] == before[i]                # nothing built (or made at creation already)
+                else:
+                    assert now[i] < before[i]                 # made by vb2_batch_create: fewer bytes per step now
+        for sh, npts in enumerate(shapes):
+            for s in range(S):
+                n = npts[s]
+                if n == 0:
+                    continue
+                assert np.array_equal(results[0][sh][s, :n], results[1][sh][s, :n]), (npts, s)
+                want = ctxs[s].llk(pc1[s, :n], pc2[s, :n], al[s, :n])
+                if datas[s].num_read:
+                    assert rel_err(results[1][sh][s, :n], want) <= 1e-13, (npts, s)
+                else:
+                    assert np.all(results[1][sh][s, :n] == 0) and np.all(want == 0)
+        od = oracle_data(datas[1])
+        want = [od.llk(pc1[1, i], pc2[1, i], al[1, i]) for i in range(2)]
+        assert rel_err(results[1][1][1, :2], want) <= LLK_RTOL
+    finally:
+        lib.vb2_debug_set_cohort_w16(1)
+        for c in ctxs:
+            c.close()
+
+
 def test_c5_sized_cohort_on_one_gpu():
     """BASELINE.json configs[4] per GPU: 32 samples of 100 000 markers x depth 30, --NumPC 4, in ONE
     lock-step batch (static deal, ~49 work items per wave).  batch.eval equals every context's own
@@ -875,6 +990,8 @@ def test_c5_sized_cohort_on_one_gpu():
     try:
         rng = np.random.default_rng(17)
         with vb.CohortBatch(ctxs) as batch:
+            # one step streams <= 12 MB of each sample (16-bit run lists; VERDICT r2 item 4: was 16.5 MB)
+            assert all(c.info()["cohort_step_bytes"] <= 12.0e6 for c in ctxs)
             for n in (4, 8, 1):
                 npt = np.full(S, n, dtype=np.int32)
                 pc1 = rng.normal(0, 0.03, size=(S, 8, k))

@@ -21,6 +21,11 @@ if nb > 4 and s[4, 7] > 0:
     print("device-side search, %d rounds, per round: control step %.2f us, relay hop (control done -> workgroup 0 has the "
           "round) %.2f us, evaluation (has the round -> next round's top) %.2f us"
           % (n, s[1, 7] / n / 100.0, s[2, 7] / n / 100.0, s[3, 7] / n / 100.0))
+if nb > 12 and s[4, 7] > 0:
+    n = s[4, 7]
+    names2 = ["consume + commit + accept", "rank + candidates + convergence", "unpack (InvLogit) + rows to the relay",
+              "state load", "save + publish (incl. store drain)"]
+    print("control step pieces per round: " + ", ".join("%s %.2f us" % (nm, s[5 + i, 7] / n / 100.0) for i, nm in enumerate(names2)))
 s = s[s[:, 0] > 0]
 us = (s - t0) / 100.0
 names = ["entry", "points in LDS", "table built", "wave0 tiles done", "last wave tiles done", "block reduced", "finalized (last block)"]

@@ -162,12 +162,13 @@ class _TraceBuf:
 class LikelihoodContext:
     """vb2_ctx: the pileup + panel resident in HBM, ready for batched evaluation."""
 
-    def __init__(self, data: PileupData, device=-1, stream=None):
+    def __init__(self, data: PileupData, device=-1, stream=None, cohort_layout=False):
         self._lib = _abi.lib()
         self.data = data
         self.num_pc = data.num_pc
         inp = data.as_input()
-        opt = _abi.Options(int(device), 0, C.c_void_p(stream) if stream else None)
+        opt = _abi.Options(int(device), 1 if cohort_layout else 0,      # VB2_OPT_COHORT_LAYOUT
+                           C.c_void_p(stream) if stream else None)
         h = C.c_void_p()
         _abi.check(self._lib.vb2_ctx_create(C.byref(inp), C.byref(opt), C.byref(h)), "vb2_ctx_create")
         self._h = h

@@ -308,6 +308,10 @@ int vb2_debug_resident_active(vb2_ctx* ctx)
     return ctx->impl->resident_active ? 1 : 0;
 }
 
+// Test aid (not part of the public header): batches created from now on stream the 16-bit (1) or the 32-bit (0)
+// run lists in their 1- and 2-point steps.
+void vb2_debug_set_cohort_w16(int on) { vb2::set_cohort_w16(on != 0); }
+
 // Test aid: turn the resident search mode off/on for one context (VB2_RESIDENT does it globally).
 void vb2_debug_set_resident(vb2_ctx* ctx, int on)
 {

@@ -54,6 +54,19 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
     return create(list, out);
 }
 
+// VB2_COHORT_W16=0 (or vb2_debug_set_cohort_w16(0), a test aid): cohort steps stream the 32-bit run lists
+static std::atomic<int> g_cohort_w16{-1};
+bool cohort_w16_enabled()
+{
+    int v = g_cohort_w16.load();
+    if (v < 0) {
+        v = (std::getenv("VB2_COHORT_W16") && std::atoi(std::getenv("VB2_COHORT_W16")) == 0) ? 0 : 1;
+        g_cohort_w16.store(v);
+    }
+    return v != 0;
+}
+void set_cohort_w16(bool on) { g_cohort_w16.store(on ? 1 : 0); }
+
 int Batch::create(const std::vector<Context*>& ctxs, Batch** out)
 {
     *out = nullptr;
@@ -77,6 +90,12 @@ int Batch::create(const std::vector<Context*>& ctxs, Batch** out)
             return VB2_ERR_INVALID;
         }
         b->ctx_.push_back(c);
+        // cohort steps stream every sample's run lists from HBM once per step: the 16-bit copy halves
+        // those bytes (VB2_COHORT_W16=0: the 32-bit lists, A/B)
+        const bool w16_on = cohort_w16_enabled();
+        if (w16_on && c->L.num_mt > 0)
+            if (const int rc16 = c->ensure_codes16()) return rc16;
+        if (!w16_on || (c->L.num_mt > 0 && !c->L.codes16)) b->w16_ = false;
         layouts[s] = c->L;
         layouts[s].stamps = nullptr;
         if (c->L.row_bytes != kRowBytesWide) b->wide_rows_ = false;
@@ -313,6 +332,7 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     ml.np = NP;
     ml.shmem = shmem_[shape];
     ml.force_ticket = false;
+    ml.w16 = w16_;
     VB2_HIP(launch_llk_eval_multi(ml, stream_));
     ++num_launch;
     in_flight_ = true;

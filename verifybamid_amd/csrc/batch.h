@@ -12,6 +12,9 @@
 
 namespace vb2 {
 
+bool cohort_w16_enabled();            // cohort steps stream the 16-bit run lists (default; VB2_COHORT_W16=0 turns it off)
+void set_cohort_w16(bool on);
+
 class Batch {
 public:
     ~Batch();
@@ -58,6 +61,7 @@ private:
     unsigned long long *h_done_ = nullptr, *d_done_ = nullptr;
     unsigned long long seq_ = 0;
     int bps_ = 1, block_waves_ = 16;
+    bool w16_ = true;                       // every sample has the 16-bit run lists: the steps stream those
     bool wide_rows_ = true;                 // every sample has kRowBytesWide table rows (8-point launches allowed)
     size_t shmem_[kShapes] = {0, 0, 0, 0};  // [shape]
     int speculate_ = 4;                     // points a lock-step search evaluates per iteration (amoeba.h)

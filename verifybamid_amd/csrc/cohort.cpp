@@ -216,6 +216,7 @@ private:
         }
         vb2_options opt{};
         opt.device = devices_[device_of_group(group_of_[s])];
+        opt.flags = VB2_OPT_COHORT_LAYOUT;       // the lock-step search streams the 16-bit run lists
         sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
         // the context holds its own (flattened) copy: the sample's text-sized arrays go back now, on
         // this reader thread, instead of piling up in front of the single releaser (the writers need

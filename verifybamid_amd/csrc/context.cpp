@@ -213,6 +213,7 @@ Context::~Context()
     if (d_slab && !slab_cache().give(slab_cache().dev, d_slab, d_slab_bytes, device)) (void)hipFree(d_slab);
     if (h_slab && !slab_cache().give(slab_cache().pin, h_slab, h_slab_bytes, device)) (void)hipHostFree(h_slab);
     if (h_trace_stage) (void)hipHostFree(h_trace_stage);
+    if (d_codes16_own) (void)hipFree(d_codes16_own);
     if (own_stream && stream && !slab_cache().give_stream(stream, device)) (void)hipStreamDestroy(stream);
 }
 
@@ -596,7 +597,22 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     const size_t o_cd = carve((size_t)4 * m_pad * sizeof(double));
     const size_t o_dpe = carve(dict_perr.size() * sizeof(double));
     const size_t o_prim = carve(prim.size() * sizeof(double2));
+    // cohort-step run lists (VB2_OPT_COHORT_LAYOUT): the tile records travel with the data block, the
+    // 16-bit words themselves are made on the device from `codes` (pack_codes16_kernel)
+    const bool want16 = opt && (opt->flags & VB2_OPT_COHORT_LAYOUT) && num_mt > 0;
+    std::vector<uint2> rec16;
+    uint64_t total_rows16 = 0;
+    if (want16) {
+        rec16.resize(num_mt);
+        for (int t = 0; t < num_mt; ++t) {
+            const uint32_t r16 = (mt_rows[t] + 1) / 2;                  // four runs per row
+            rec16[t] = make_uint2((uint32_t)total_rows16, r16);
+            total_rows16 += r16;
+        }
+    }
+    const size_t o_rec16 = carve(want16 ? (size_t)num_mt * sizeof(uint2) : 0);
     const size_t data_bytes = (dev_total + 255) & ~(size_t)255;
+    const size_t o_codes16 = carve(want16 ? (size_t)(total_rows16 + kCodeSlackRows) * kMtMarkers * sizeof(uint2) : 0);
     const size_t o_part = carve(sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb);
     const size_t o_ticket = carve(sizeof(unsigned int));
     const size_t o_relay = carve(sizeof(unsigned long long) * relay_words);
@@ -638,6 +654,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rows[t]);
     if (!dict_perr.empty()) std::memcpy(stage + o_dpe, dict_perr.data(), dict_perr.size() * sizeof(double));
     if (!prim.empty()) std::memcpy(stage + o_prim, prim.data(), prim.size() * sizeof(double2));
+    if (want16) std::memcpy(stage + o_rec16, rec16.data(), rec16.size() * sizeof(uint2));
     // padding: the slack rows behind the last tile, and the (< 16) marker positions past the last active one
     std::fill(codes + (size_t)total_rows * kMtMarkers * 2, codes + n_codes, pad4);
     for (int64_t m = m_active; m < m_pad; ++m) {
@@ -749,6 +766,16 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     L.num_pc = k;
     L.num_active = m_active;
     L.m_pad = m_pad;
+    // bytes one cohort step reads of this sample: run lists + tile records + panel rows + diagonal terms
+    const int64_t panel_bytes = (int64_t)(in->known_af ? 1 : k + 1) * m_pad * 8 + 4 * m_pad * 8 + (int64_t)num_mt * 8;
+    c->cohort_bytes = (int64_t)total_rows * kMtMarkers * 8 + panel_bytes;
+    if (want16) {
+        L.mt_rec16 = reinterpret_cast<const uint2*>(dbase + o_rec16);
+        uint2* d16 = reinterpret_cast<uint2*>(dbase + o_codes16);
+        VB2_HIP(launch_pack_codes16(L, d16, L.mt_rec16, (uint32_t)total_rows16, c->stream));
+        L.codes16 = d16;
+        c->cohort_bytes = (int64_t)total_rows16 * kMtMarkers * 8 + panel_bytes;
+    }
 
     c->num_read = num_read;
     c->num_read_other = num_other;
@@ -1153,6 +1180,35 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
     return VB2_OK;
 }
 
+int Context::ensure_codes16()
+{
+    if (L.codes16 || L.num_mt == 0) return VB2_OK;
+    VB2_HIP(hipSetDevice(device));
+    std::vector<uint2> rec16(L.num_mt);
+    uint64_t total16 = 0;
+    for (int t = 0; t < L.num_mt; ++t) {
+        const uint32_t r16 = (h_mt_rows[t] + 1) / 2;
+        rec16[t] = make_uint2((uint32_t)total16, r16);
+        total16 += r16;
+    }
+    const size_t rec_bytes = ((size_t)L.num_mt * sizeof(uint2) + 255) & ~(size_t)255;
+    const size_t bytes = rec_bytes + (size_t)(total16 + kCodeSlackRows) * kMtMarkers * sizeof(uint2);
+    VB2_HIP(hipMalloc(&d_codes16_own, bytes));
+    char* base = static_cast<char*>(d_codes16_own);
+    VB2_HIP(hipMemcpyAsync(base, rec16.data(), rec16.size() * sizeof(uint2), hipMemcpyHostToDevice, stream));
+    const uint2* d_rec = reinterpret_cast<const uint2*>(base);
+    uint2* d16 = reinterpret_cast<uint2*>(base + rec_bytes);
+    VB2_HIP(launch_pack_codes16(L, d16, d_rec, (uint32_t)total16, stream));
+    VB2_HIP(hipStreamSynchronize(stream));                 // (rec16 is a pageable source; and the lists must be complete)
+    L.mt_rec16 = d_rec;
+    L.codes16 = d16;
+    int64_t rows32 = 0;
+    for (int t = 0; t < L.num_mt; ++t) rows32 += h_mt_rows[t];
+    cohort_bytes += ((int64_t)total16 - rows32) * kMtMarkers * 8;
+    device_bytes += (int64_t)bytes;
+    return VB2_OK;
+}
+
 int Context::read_stamps(unsigned long long* out, int max_blocks)
 {
     if (!d_stamps) return 0;
@@ -1176,6 +1232,7 @@ void Context::fill_info(vb2_info* info) const
     info->num_tile = L.num_mt;
     info->device_bytes = device_bytes;
     info->algorithmic_bytes_per_eval = algorithmic_bytes;
+    info->cohort_step_bytes = cohort_bytes;
     std::snprintf(info->device_name, sizeof(info->device_name), "%s", device_name);
     std::snprintf(info->arch, sizeof(info->arch), "%s", arch);
 }

@@ -101,6 +101,11 @@ public:
     int64_t trace_stage_rows = 0;
     void fill_info(vb2_info* info) const;
     int read_stamps(unsigned long long* out, int max_blocks);
+    // The cohort-step copy of the run lists (DeviceLayout::codes16): built on the device from `codes`, in the
+    // slab when the context was created with VB2_OPT_COHORT_LAYOUT, else in an allocation of its own here.
+    int ensure_codes16();
+    void* d_codes16_own = nullptr;
+    int64_t cohort_bytes = 0;                 // device bytes one cohort step streams for this sample
 
     int device = -1;
     int num_marker = 0;

@@ -37,6 +37,13 @@ struct DeviceLayout {
     const double2* prim;          // [num_prim] codes whose table rows are computed: {signed pErr, bits: code |
                                   // twin << 16}, twin = the alt code of the same quality (its row is the mirror
                                   // image of this one) or 0xffff
+    // The cohort-step copy of the run lists (nullptr unless built: Context::ensure_codes16): the same runs in
+    // the same order as 16-bit words -- dictionary index | count << 8 -- four per uint2, stored
+    // [micro-tile][step/4][marker].  Half the bytes of `codes`; the kernel pays one multiply and one
+    // conversion per run to expand them, which a cohort step (every sample's lists streamed from HBM once per
+    // step, 1-2 points each) can afford and a single-sample launch (lists in L2, VALU-bound) cannot.
+    const uint2* codes16;
+    const uint2* mt_rec16;        // [num_mt] {first row, rows = ceil(most runs in the tile / 4)} of codes16
     int32_t num_code;
     int32_t row_bytes;            // LDS table row stride: kRowBytesWide, or kRowBytesNarrow for > kMaxWideCodes codes
     int32_t num_prim;
@@ -118,6 +125,7 @@ struct MultiLaunch {
     int num_sample, bps, block_waves;
     int np;                          // points per sample of this step: 1, 2, 4 or 8 (picks the wave shape)
     bool force_ticket;               // arrival-ticket hand-off instead of tagged sets (the retry after a NaN)
+    bool w16;                        // every sample has codes16: stream the 16-bit run lists
     size_t shmem;
 };
 size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);   // groups of 4*btl points
@@ -125,6 +133,14 @@ size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, i
 int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves);
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
+// codes / mt_rec -> codes16 / mt_rec16 on the device (rec16 already holds the tiles' {first row, rows};
+// rows16_total + kCodeSlackRows rows are written, the slack as padding words)
+hipError_t launch_pack_codes16(const DeviceLayout& L, uint2* codes16, const uint2* mt_rec16, uint32_t rows16_total,
+                               hipStream_t stream);
+// n doubles from device memory to mapped host memory, then done_seq to the mapped flag (stream-ordered
+// hand-off to a spinning host: see publish_kernel)
+hipError_t launch_publish(const double* d_src, double* d_dst_mapped, int n, unsigned long long* done_flag,
+                          unsigned long long done_seq, hipStream_t stream);
 
 // Resident search kernel (llk_resident_kernel): launched once per search, fed through a mailbox.
 // Word layout of h_cmd / relay: [0] seq, [1] rows valid (0 = exit), [2..2+4*(2k+1)) rows

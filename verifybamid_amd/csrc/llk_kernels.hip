@@ -295,7 +295,7 @@ struct InlinePoints {
     double v[kInlinePointDoubles];
 };
 
-template <int MODE, bool HWMAP>
+template <int MODE, bool HWMAP, bool W16 = false>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -516,7 +516,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             flush_wave(grp_wave);
             ++grp_wave;
         }
-        const uint2 rec = L.mt_rec[mt];                      // {first row, rows}; one scalar load when TPW == 1
+        const uint2 rec = W16 ? L.mt_rec16[mt] : L.mt_rec[mt];   // {first row, rows}; one scalar load when TPW == 1
         // per-marker constants: issued now, consumed after the read loop
         const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
         const bool live = have_tile && pos < (size_t)L.num_active;
@@ -547,7 +547,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         // their ds_reads go out as soon as they can and the LDS pipe stays busy, while the epilogue
         // waves fill the VALU slots in between (-0.8 % per launch measured; the other way round: +0.8 %)
         __builtin_amdgcn_s_setprio(1);
-        const uint2* cp = L.codes + (size_t)rec.x * kMtMarkers + m;
+        const uint2* cp = (W16 ? L.codes16 : L.codes) + (size_t)rec.x * kMtMarkers + m;
         const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
         uint2 w[kPrefetch];
 #pragma unroll
@@ -559,13 +559,26 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 const uint2 w_cur = w[u];
                 w[u] = cp[(size_t)(s0 + u + kPrefetch) * kMtMarkers];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < (W16 ? 4 : 2); ++j) {
                     // one run: `n` reads of the same (class, quality) -> n * table row.  The run
                     // word is {low half: byte offset of the row, high half: the top 16 bits of the
-                    // double n} -- one add and one and, no multiply, no int -> double conversion
-                    const uint32_t rw = j ? w_cur.y : w_cur.x;
-                    const double n = __hiloint2double((int)(rw & 0xffff0000u), 0);
-                    lds_cdouble2* row = reinterpret_cast<lds_cdouble2*>(my_tab + (rw & 0xffffu));
+                    // double n} -- one add and one and, no multiply, no int -> double conversion.
+                    // W16 (cohort steps): {low byte: dictionary index, next byte: n} -- two field
+                    // extractions, a multiply-add and a conversion, for half the bytes from HBM
+                    double n;
+                    uint32_t row_addr;
+                    if constexpr (W16) {
+                        const uint32_t w2 = (j & 2) ? w_cur.y : w_cur.x;
+                        const uint32_t idx = (j & 1) ? ((w2 >> 16) & 0xffu) : (w2 & 0xffu);
+                        const uint32_t cnt = (j & 1) ? (w2 >> 24) : ((w2 >> 8) & 0xffu);
+                        n = (double)cnt;
+                        row_addr = my_tab + idx * (uint32_t)L.row_bytes;
+                    } else {
+                        const uint32_t rw = j ? w_cur.y : w_cur.x;
+                        n = __hiloint2double((int)(rw & 0xffff0000u), 0);
+                        row_addr = my_tab + (rw & 0xffffu);
+                    }
+                    lds_cdouble2* row = reinterpret_cast<lds_cdouble2*>(row_addr);
 #pragma unroll
                     for (int i = 0; i < 3 * BTL; ++i) {
                         const vdouble2 t = row[i];
@@ -884,7 +897,7 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
 // w / bps as that sample's workgroup w % bps.  Every sample has its own layout, parameter rows,
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
-template <int MODE, bool HWMAP>
+template <int MODE, bool HWMAP, bool W16>
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* __restrict__ scheds,
                       const double* __restrict__ points,
@@ -901,7 +914,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
     const int stride = 2 * L.num_pc + 1;
     InlinePoints ip;
     ip.count = 0;
-    eval_body<MODE, HWMAP>(L, ip, points + (size_t)s * NP * stride, nv,
+    eval_body<MODE, HWMAP, W16>(L, ip, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1, use_ticket ? 0ull : done_seq,
@@ -979,7 +992,7 @@ void set_lane_mapping(bool hw) { g_hwmap = hw; }
 // object is per device in the runtime), so the flag is kept per (function slot, device).
 static hipError_t raise_lds_limit(const void* fn, int slot)
 {
-    constexpr int kSlots = 20, kDevs = 64;
+    constexpr int kSlots = 28, kDevs = 64;
     static std::atomic<unsigned char> done[kSlots][kDevs];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1108,37 +1121,87 @@ int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves)
     return g;
 }
 
-hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
+// The cohort kernels of one wave shape: [plain lane map, hardware lane map, hardware lane map + 16-bit run lists]
+template <int MODE>
+static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream, int slot_base)
 {
     const dim3 grid(ml.num_sample * ml.bps), block(ml.block_waves * 64);
+    // The 16-bit run lists pay where a step is bound by the bytes it streams -- 1 and 2 points per sample
+    // (32 C3 samples: 130.6 -> 117.5 us and 139.2 -> 127.9 us) -- and cost where it is VALU-bound: 4 points per
+    // sample 230.8 -> 306.6 us with them (two more instructions per run).  So: MODE 4 and 5 only.
+    constexpr bool kHas16 = MODE == 4 || MODE == 5;
+    const int variant = !g_hwmap ? 0 : (kHas16 && ml.w16) ? 2 : 1;
+    const int use_ticket = ml.force_ticket ? 1 : 0;
+    auto go = [&](auto kernel) -> hipError_t {
+        hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kernel), slot_base + variant);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, grid, block, ml.shmem, stream, ml.d_layouts, ml.d_scheds, ml.d_points,
+                           ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps, ml.done_flag, ml.done_seq,
+                           ml.d_batch_done, ml.batch_active, use_ticket);
+        return hipGetLastError();
+    };
+    if (variant == 0) return go(&llk_eval_multi_kernel<MODE, false, false>);
+    if constexpr (kHas16)
+        if (variant == 2) return go(&llk_eval_multi_kernel<MODE, true, true>);
+    return go(&llk_eval_multi_kernel<MODE, true, false>);
+}
+
+hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
+{
     // wave shape by points per sample: 8 -> MODE 2, 4 -> 3, 2 -> 5, 1 -> 4 (MODE 1 for everything
     // below 8 when the paired shapes are switched off: VB2_PAIRED=0)
     const int mode = ml.np == 8 ? 2 : !g_paired ? 1 : ml.np == 1 ? 4 : ml.np == 2 ? 5 : 3;
-    {
-        const void* fns[10] = {reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, false>),
-                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<1, true>),
-                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, false>),
-                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<2, true>),
-                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, false>),
-                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<3, true>),
-                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<4, false>),
-                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<4, true>),
-                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<5, false>),
-                               reinterpret_cast<const void*>(&llk_eval_multi_kernel<5, true>)};
-        const int slot = (mode - 1) * 2 + (g_hwmap ? 1 : 0);
-        hipError_t e = raise_lds_limit(fns[slot], 8 + slot);
-        if (e != hipSuccess) return e;
+    const int slot_base = 10 + (mode - 1) * 3;
+    switch (mode) {
+    case 2: return launch_multi_mode<2>(ml, stream, slot_base);
+    case 3: return launch_multi_mode<3>(ml, stream, slot_base);
+    case 4: return launch_multi_mode<4>(ml, stream, slot_base);
+    case 5: return launch_multi_mode<5>(ml, stream, slot_base);
+    default: return launch_multi_mode<1>(ml, stream, slot_base);
     }
-#define VB2_MULTI_LAUNCH(MODE, HW)                                                                       \
-    hipLaunchKernelGGL((llk_eval_multi_kernel<MODE, HW>), grid, block, ml.shmem, stream, ml.d_layouts,   \
-                       ml.d_scheds, ml.d_points, ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps,       \
-                       ml.done_flag, ml.done_seq, ml.d_batch_done, ml.batch_active, ml.force_ticket ? 1 : 0)
-    if (mode == 2) { if (g_hwmap) VB2_MULTI_LAUNCH(2, true); else VB2_MULTI_LAUNCH(2, false); }
-    else if (mode == 3) { if (g_hwmap) VB2_MULTI_LAUNCH(3, true); else VB2_MULTI_LAUNCH(3, false); }
-    else if (mode == 4) { if (g_hwmap) VB2_MULTI_LAUNCH(4, true); else VB2_MULTI_LAUNCH(4, false); }
-    else if (mode == 5) { if (g_hwmap) VB2_MULTI_LAUNCH(5, true); else VB2_MULTI_LAUNCH(5, false); }
-    else { if (g_hwmap) VB2_MULTI_LAUNCH(1, true); else VB2_MULTI_LAUNCH(1, false); }
-#undef VB2_MULTI_LAUNCH
+}
+
+// One thread per (micro-tile, row of four runs, marker): the 32-bit run words of `codes` re-coded as
+// dictionary index | count << 8.  Rows past a tile's own (and the slack rows at the end) hold padding
+// words: the zero table row with count 0.
+__global__ void __launch_bounds__(256)
+pack_codes16_kernel(const DeviceLayout L, uint2* __restrict__ codes16, const uint2* __restrict__ mt_rec16,
+                    uint32_t rows16_total)
+{
+    const uint32_t pad = (uint32_t)L.num_code;                       // count 0
+    const uint32_t pad2 = pad | (pad << 16);
+    const int mt = blockIdx.x;
+    if (mt >= L.num_mt) {                                            // the last block writes the slack rows
+        for (uint32_t e = threadIdx.x; e < (uint32_t)kCodeSlackRows * kMtMarkers; e += blockDim.x)
+            codes16[(size_t)rows16_total * kMtMarkers + e] = make_uint2(pad2, pad2);
+        return;
+    }
+    const uint2 r32 = L.mt_rec[mt], r16 = mt_rec16[mt];
+    for (uint32_t e = threadIdx.x; e < r16.y * kMtMarkers; e += blockDim.x) {
+        const uint32_t row = e / kMtMarkers, m = e % kMtMarkers;
+        uint32_t w[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t row32 = 2 * row + h;
+            uint2 v = make_uint2(0u, 0u);
+            const bool have = row32 < r32.y;
+            if (have) v = L.codes[((size_t)r32.x + row32) * kMtMarkers + m];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t rw = j ? v.y : v.x;
+                const uint32_t idx = (rw & 0xffffu) / (uint32_t)L.row_bytes;
+                const uint32_t cnt = (uint32_t)__hiloint2double((int)(rw & 0xffff0000u), 0);
+                w[2 * h + j] = have ? (idx | (cnt << 8)) : pad;
+            }
+        }
+        codes16[((size_t)r16.x + row) * kMtMarkers + m] = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+    }
+}
+
+hipError_t launch_pack_codes16(const DeviceLayout& L, uint2* codes16, const uint2* mt_rec16, uint32_t rows16_total,
+                               hipStream_t stream)
+{
+    hipLaunchKernelGGL(pack_codes16_kernel, dim3(L.num_mt + 1), dim3(256), 0, stream, L, codes16, mt_rec16, rows16_total);
     return hipGetLastError();
 }
 
@@ -1233,6 +1296,27 @@ hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, doubl
         void* args[] = {&Lc, &rc, &d_partials, &d_ticket};
         return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
     }
+}
+
+// After a collective on the same stream: the reduced values go to mapped host memory, then the sequence
+// number the host spins on -- the marker-shard step needs no device-to-host copy call and no stream
+// synchronisation (shard.cpp).  One wave; every lane fences its own stores before the flag is written.
+__global__ void __launch_bounds__(64)
+publish_kernel(const double* __restrict__ src, double* __restrict__ dst_mapped, int n,
+               unsigned long long* __restrict__ done_flag, unsigned long long done_seq)
+{
+    for (int j = threadIdx.x; j < n; j += 64) dst_mapped[j] = src[j];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_publish(const double* d_src, double* d_dst_mapped, int n, unsigned long long* done_flag,
+                          unsigned long long done_seq, hipStream_t stream)
+{
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, stream, d_src, d_dst_mapped, n, done_flag, done_seq);
+    return hipGetLastError();
 }
 
 // Zero-marker case: LLK of an empty sum.
