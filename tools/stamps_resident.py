@@ -21,11 +21,15 @@ if nb > 4 and s[4, 7] > 0:
     print("device-side search, %d rounds, per round: control step %.2f us, relay hop (control done -> workgroup 0 has the "
           "round) %.2f us, evaluation (has the round -> next round's top) %.2f us"
           % (n, s[1, 7] / n / 100.0, s[2, 7] / n / 100.0, s[3, 7] / n / 100.0))
-if nb > 12 and s[4, 7] > 0:
+if nb > 16 and s[4, 7] > 0:
     n = s[4, 7]
     names2 = ["consume + commit + accept", "rank + candidates + convergence", "unpack (InvLogit) + rows to the relay",
               "state load", "save + publish (incl. store drain)"]
-    print("control step pieces per round: " + ", ".join("%s %.2f us" % (nm, s[5 + i, 7] / n / 100.0) for i, nm in enumerate(names2)))
+    print("control wave, per round (long way + replay): " + ", ".join("%s %.2f us" % (nm, s[5 + i, 7] / n / 100.0) for i, nm in enumerate(names2)))
+    print("rounds that took the short way (post_decide + one relay word): %d of %d; control wave's tile-phase work "
+          "(replay + speculate) %.2f us per round" % (s[10, 7], n, s[11, 7] / n / 100.0))
+    print("  of which: " + ", ".join("%s %.2f" % (nm, s[12 + i, 7] / n / 100.0) for i, nm in enumerate(
+        ["state load", "replay (step)", "rows check", "speculate", "save + drain"])) + " us (each incl. one clock read, ~0.4 us)")
 s = s[s[:, 0] > 0]
 us = (s - t0) / 100.0
 names = ["entry", "points in LDS", "table built", "wave0 tiles done", "last wave tiles done", "block reduced", "finalized (last block)"]

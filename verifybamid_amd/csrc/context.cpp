@@ -580,7 +580,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     DeviceLayout& L = c->L;
     std::memset(&L, 0, sizeof(L));
     const int nb = kMaxGridPerCU * num_cu;
-    const size_t relay_words = (size_t)resident_words(k);
+    const size_t relay_words = (size_t)resident_relay_words(k);
     const bool want_stamps = std::getenv("VB2_STAMPS") != nullptr;
     size_t dev_total = 0;
     auto carve = [&](size_t bytes) {
@@ -889,12 +889,13 @@ bool Context::resident_begin()
     if (ok) {
         std::memset(h_cmd, 0, sizeof(unsigned long long) * words);
         __atomic_store_n(h_state, 0u, __ATOMIC_RELEASE);
-        ok = hipMemsetAsync(d_relay, 0, sizeof(unsigned long long) * words, stream) == hipSuccess;
+        ok = hipMemsetAsync(d_relay, 0, sizeof(unsigned long long) * (size_t)resident_relay_words(num_pc), stream) == hipSuccess;
     }
     if (ok) {
         ResidentArgs ra;
         ra.h_cmd = d_cmd;
         ra.relay = d_relay;
+        ra.spec = d_relay + resident_words(num_pc);
         ra.h_out = d_out;
         ra.h_done = d_done;
         ra.h_state = d_state;

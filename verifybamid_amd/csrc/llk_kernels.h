@@ -143,11 +143,22 @@ hipError_t launch_publish(const double* d_src, double* d_dst_mapped, int n, unsi
                           unsigned long long done_seq, hipStream_t stream);
 
 // Resident search kernel (llk_resident_kernel): launched once per search, fed through a mailbox.
-// Word layout of h_cmd / relay: [0] seq, [1] rows valid (0 = exit), [2..2+4*(2k+1)) rows
+// Word layout of h_cmd: [0] seq, [1] rows valid (0 = exit), [2..2+4*(2k+1)) rows
 // (pc1 | pc2 | alpha), [2+4*(2k+1)] check word: XOR of word_hash(word w, w) over [1, last) ^ resident_mix(seq).
+// Relay (device memory, control wave -> every workgroup): [0] = round << 16 | slot << 8 | code, code = rows valid
+// 1..4, 0 = exit, kRelayEmptyRound = nothing to evaluate; slot = 0: the rows are relay[2..), slot = 1..8: they
+// are rows set slot-1 of the SPECULATION buffer of this round (below); ~0 = the control wave gave up.
+// Speculation buffers (two, used alternately by round parity, behind the relay words): [0] the round the
+// buffer is for, [1] spare, then 8 sets of 4 rows: the next iteration's {R, E, C_A, C_R} for each of the 8
+// ways the iteration in flight can end (resident_kernel.inc: DeviceSimplex::speculate).
+constexpr unsigned kRelayEmptyRound = 0xfe;
+constexpr int kSpecSets = 8;
+inline __host__ __device__ int resident_spec_words(int num_pc) { return 2 + kSpecSets * 4 * (2 * num_pc + 1); }
 struct ResidentArgs {
     const unsigned long long* h_cmd;     // mailbox in mapped host memory (device view)
-    unsigned long long* relay;           // same layout in device memory, zero-initialised
+    unsigned long long* relay;           // device memory, zero-initialised: resident_words(k) relay words, then the
+                                         // two speculation buffers (resident_relay_words(k) in all)
+    unsigned long long* spec;            // = relay + resident_words(k)
     double* h_out;                       // [4] results, mapped host memory (device view)
     unsigned long long* h_done;          // completion sequence number, mapped host memory
     unsigned int* h_state;               // 1 running, 2 exited on command, 3 gave up (idle timeout)
@@ -182,7 +193,9 @@ inline __host__ __device__ int resident_words(int num_pc)
     const int rows = 4 * (2 * num_pc + 1), req = 6 * num_pc + 9;
     return 2 + (rows > req ? rows : req) + 1;
 }
-// Words of dynamic LDS the resident kernel needs beyond the evaluation body's (search state + command image).
+inline __host__ __device__ int resident_relay_words(int num_pc) { return resident_words(num_pc) + 2 * resident_spec_words(num_pc); }
+// Words of dynamic LDS the resident kernel needs beyond the evaluation body's (search state + command image +
+// every workgroup's staging of the round's rows).
 size_t resident_state_doubles(int nmax, int num_pc);
 bool paired_mode();
 void set_paired_mode(bool on);     // VB2_PAIRED=0: 4-point launches use MODE 1 instead of MODE 3

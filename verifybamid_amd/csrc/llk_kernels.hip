@@ -295,7 +295,23 @@ struct InlinePoints {
     double v[kInlinePointDoubles];
 };
 
-template <int MODE, bool HWMAP, bool W16 = false>
+// A wave of the workgroup that spends the tile phase on something else (the resident kernel's control wave:
+// resident_kernel.inc).  on_block: this workgroup has such a wave (wave 0); mine: this wave is it.  Only with
+// the dynamic work queue (eval_is_dynamic): the other waves then start on items 0..nwave-2 and pull the rest.
+struct NoHook {
+    __device__ bool on_block() const { return false; }
+    __device__ bool mine() const { return false; }
+    __device__ void run() {}
+};
+// The waves of a workgroup pull (tile, group) items through the LDS queue (per-item result slots) when there
+// are at most dyn_limit of them per wave; else the static deal (cohort launches).
+__device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, uint32_t nblk, int nwave, int ngrp)
+{
+    const uint32_t max_tiles_blk = ((uint32_t)L.num_mt + nblk - 1) / nblk;
+    return max_tiles_blk * (uint32_t)ngrp <= (uint32_t)(L.dyn_limit * nwave);
+}
+
+template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -303,7 +319,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
           unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
           unsigned int* __restrict__ batch_done, unsigned int batch_active, const int ngrp,
           const unsigned long long tag, const Schedule sch, const bool coherent_points = false,
-          const int tid_in = -1)
+          const int tid_in = -1, const double* lds_rows = nullptr /* the parameter rows, already in LDS */,
+          Hook hook = Hook())
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int BTL = (MODE == 1 || MODE == 4) ? 1 : 2;
@@ -346,14 +363,16 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     unsigned long long* stamps = L.stamps ? L.stamps + (size_t)blk * 8 : nullptr;
     if (stamps && tid == 0) stamps[0] = wall_clock64();
 
-    if (tid == 0) *queue = (unsigned int)nwave;      // waves start on tiles 0..nwave-1
+    const bool hook_blk = hook.on_block(), hook_mine = hook.mine();
+    if (tid == 0) *queue = (unsigned int)(nwave - (hook_blk ? 1 : 0));      // waves start on tiles 0..nwave-1
     // parameter rows -> LDS with one coalesced load (they may live in mapped host memory)
     for (int e = tid; e < NPT * stride; e += nthread) {
         const int b = e / stride;
         const int src = b < num_valid ? b : num_valid - 1;
         const int idx = src * stride + (e - b * stride);
         // resident mode: the rows were just written by another workgroup -> L1-bypassing loads
-        const double v = ip.count > 0 ? ip.v[idx]
+        const double v = lds_rows ? lds_rows[idx]
+                         : ip.count > 0 ? ip.v[idx]
                          : coherent_points ? __hip_atomic_load(&points[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                            : points[idx];
         pts[e] = v;
@@ -430,8 +449,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // Decided on ceil(tiles / workgroups), the same for every workgroup and exactly what
     // eval_shmem_np sized the result slots for (a workgroup with one tile fewer must not choose
     // differently: the queue needs a slot per item, the static deal only one per wave).
-    const uint32_t max_tiles_blk = ((uint32_t)L.num_mt + nblk - 1) / nblk;
-    const bool dyn = max_tiles_blk * (uint32_t)ngrp <= (uint32_t)(L.dyn_limit * nwave);
+    const bool dyn = eval_is_dynamic(L, nblk, nwave, ngrp);
     // The per-marker likelihoods of a work item are MULTIPLIED (mantissa x 2^exponent): over
     // the 16 markers of the tile by a butterfly, then slot by slot in the block reduction.
     auto tile_product = [&](ScaledProd* p, bool cross) {  // over the 16 lanes sharing slot g (+ the item's other tiles)
@@ -498,7 +516,11 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         s_end = sch.off[blk * (uint32_t)nwave + (uint32_t)wave + 1];
     }
     uint32_t round = 0;
-    for (uint32_t idx = have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem) : (uint32_t)wave; idx < nitem;) {
+    if (hook_mine) hook.run();                            // (this wave takes no work items; the others cover for it)
+    for (uint32_t idx = hook_mine ? nitem
+                        : have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem)
+                                     : (uint32_t)(wave - (hook_blk ? 1 : 0));
+         idx < nitem;) {
         // grp = idx / nunit without the ~25-instruction integer division: float estimate (exact for
         // these magnitudes up to one) and a correction step
         uint32_t grp = ngrp == 1 ? 0u : (uint32_t)(((float)idx + 0.5f) * inv_nunit);
@@ -1256,7 +1278,8 @@ void set_coop_launch(bool on) { g_coop_launch = on; }
 
 size_t resident_state_doubles(int nmax, int num_pc)
 {
-    return 8 + DeviceSimplex::lds_doubles(nmax, num_pc) + (size_t)resident_words(num_pc) + 2;
+    return 8 + DeviceSimplex::lds_doubles(nmax, num_pc) + (size_t)resident_words(num_pc) + 2 +
+           (size_t)resident_stage_doubles(nmax, num_pc);
 }
 
 hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, double* d_partials,
