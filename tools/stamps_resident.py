@@ -29,7 +29,7 @@ if nb > 16 and s[4, 7] > 0:
     print("rounds that took the short way (post_decide + one relay word): %d of %d; control wave's tile-phase work "
           "(replay + speculate) %.2f us per round" % (s[10, 7], n, s[11, 7] / n / 100.0))
     print("  of which: " + ", ".join("%s %.2f" % (nm, s[12 + i, 7] / n / 100.0) for i, nm in enumerate(
-        ["state load", "replay (step)", "rows check", "speculate", "save + drain"])) + " us (each incl. one clock read, ~0.4 us)")
+        ["state load", "apply_outcome", "-", "speculate", "save + drain"])) + " us (each incl. one clock read, ~0.4 us)")
 s = s[s[:, 0] > 0]
 us = (s - t0) / 100.0
 names = ["entry", "points in LDS", "table built", "wave0 tiles done", "last wave tiles done", "block reduced", "finalized (last block)"]
@@ -37,4 +37,23 @@ print("blocks:", len(s), " t=0: round begun (loop top of the resident kernel)")
 for i, n in enumerate(names):
     col = us[:, i][s[:, i] > 0]
     if len(col): print("%-24s min %6.2f  median %6.2f  max %6.2f us" % (n, col.min(), np.median(col), col.max()))
+w = np.array(buf[:8 * nb], dtype=np.float64).reshape(nb, 8)[300:316]
+if nb >= 316 and w[:, 0].max() > 0:
+    t0w = w[w[:, 0] > 0][:, 0].min()
+    print("workgroup 1, first work item per wave, shader-clock cycles after the earliest wave entered its item:")
+    print("wave  item-start  loads-issued  8-rows-done  loop-done  item-done  rows")
+    for i in range(16):
+        if w[i, 0] > 0:
+            print("%4d  %10d  %12d  %11d  %9d  %9d  %4d" % (i, w[i, 0] - t0w, w[i, 1] - t0w, (w[i, 2] - t0w) if w[i, 2] else -1,
+                                                        w[i, 3] - t0w, w[i, 4] - t0w, w[i, 5]))
+
+if os.environ.get("VB2_STAMPS_DETAIL"):
+    br = us[:, 5]
+    order = np.argsort(-br)
+    print("slowest workgroups by 'block reduced' (us): " + ", ".join("%d: %.2f" % (i, br[i]) for i in order[:12]))
+    print("fastest: " + ", ".join("%d: %.2f" % (i, br[i]) for i in order[-8:]))
+    by_xcd = [np.median(br[x::8]) for x in range(8)]
+    print("median by workgroup index mod 8 (XCD): " + " ".join("%.2f" % v for v in by_xcd))
+    t2 = us[:, 2]
+    print("table built, by index mod 8: " + " ".join("%.2f" % np.median(t2[x::8]) for x in range(8)))
 ctx.close()

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libvb2.so")
+LIB_PATH = os.environ.get("VB2_LIB_PATH") or os.path.join(_PKG, "libvb2.so")      # (VB2_LIB_PATH: A/B builds)
 
 VB2_MAX_PC = 64
 VB2_OK = 0

@@ -450,6 +450,19 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // eval_shmem_np sized the result slots for (a workgroup with one tile fewer must not choose
     // differently: the queue needs a slot per item, the static deal only one per wave).
     const bool dyn = eval_is_dynamic(L, nblk, nwave, ngrp);
+    // The pileup arrays through GLOBAL-address-space pointers: the resident kernel passes its layout through
+    // opaque registers every round, after which the compiler no longer knows where the pointers came from
+    // and would use flat loads -- whose waits also cover the LDS counter, i.e. every per-marker load would
+    // be waited for together with the table reads.
+    typedef unsigned int __attribute__((ext_vector_type(2))) vuint2;          // (a plain vector: loadable through address_space(1))
+    typedef __attribute__((address_space(1))) const vuint2 g_cuint2;
+    typedef __attribute__((address_space(1))) const double g_cdouble;
+    g_cuint2* const g_rec = (g_cuint2*)(W16 ? L.mt_rec16 : L.mt_rec);
+    g_cuint2* const g_codes = (g_cuint2*)(W16 ? L.codes16 : L.codes);
+    g_cdouble* const g_ediag = (g_cdouble*)L.ediag;
+    g_cdouble* const g_ud = (g_cdouble*)L.ud;
+    g_cdouble* const g_mu = (g_cdouble*)L.mu;
+    g_cdouble* const g_kaf = (g_cdouble*)L.known_af;
     // The per-marker likelihoods of a work item are MULTIPLIED (mantissa x 2^exponent): over
     // the 16 markers of the tile by a butterfly, then slot by slot in the block reduction.
     auto tile_product = [&](ScaledProd* p, bool cross) {  // over the 16 lanes sharing slot g (+ the item's other tiles)
@@ -516,6 +529,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         s_end = sch.off[blk * (uint32_t)nwave + (uint32_t)wave + 1];
     }
     uint32_t round = 0;
+    int wstamp_n = 0;
     if (hook_mine) hook.run();                            // (this wave takes no work items; the others cover for it)
     for (uint32_t idx = hook_mine ? nitem
                         : have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem)
@@ -538,19 +552,23 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             flush_wave(grp_wave);
             ++grp_wave;
         }
-        const uint2 rec = W16 ? L.mt_rec16[mt] : L.mt_rec[mt];   // {first row, rows}; one scalar load when TPW == 1
+        // profiling aid: the first work item of every wave of workgroup 1, in shader-clock cycles (blocks 300.. of the stamps)
+        const bool wprof = stamps && blk == 1 && wstamp_n == 0;
+        unsigned long long wt[6] = {0, 0, 0, 0, 0, 0};
+        if (wprof) wt[0] = __builtin_readcyclecounter();
+        const vuint2 rec = g_rec[mt];                        // {first row, rows}; one scalar load when TPW == 1
         // per-marker constants: issued now, consumed after the read loop
         const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
         const bool live = have_tile && pos < (size_t)L.num_active;
         const size_t posc = live ? pos : 0;
-        const double cst = L.ediag[posc];
-        const double e0 = L.ediag[mp + posc], e1 = L.ediag[2 * mp + posc], e2 = L.ediag[3 * mp + posc];
+        const double cst = g_ediag[posc];
+        const double e0 = g_ediag[mp + posc], e1 = g_ediag[2 * mp + posc], e2 = g_ediag[3 * mp + posc];
 
         // (the panel row of the marker too: up to four UD columns and the mean)
         double udr[4], mur = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) udr[kk] = (!L.known_af && kk < k) ? L.ud[(size_t)kk * mp + posc] : 0.0;
-        if (!L.known_af) mur = L.mu[posc];
+        for (int kk = 0; kk < 4; ++kk) udr[kk] = (!L.known_af && kk < k) ? g_ud[(size_t)kk * mp + posc] : 0.0;
+        if (!L.known_af) mur = g_mu[posc];
 
         // the six off-diagonal sums start from the marker's "other base" constant (it is part of
         // every genotype pair's sum, h:299-303), so the epilogue needs no separate addition
@@ -569,16 +587,18 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         // their ds_reads go out as soon as they can and the LDS pipe stays busy, while the epilogue
         // waves fill the VALU slots in between (-0.8 % per launch measured; the other way round: +0.8 %)
         __builtin_amdgcn_s_setprio(1);
-        const uint2* cp = (W16 ? L.codes16 : L.codes) + (size_t)rec.x * kMtMarkers + m;
+        if (wprof) wt[1] = __builtin_readcyclecounter();
+        g_cuint2* cp = g_codes + (size_t)rec.x * kMtMarkers + m;
         const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
-        uint2 w[kPrefetch];
+        vuint2 w[kPrefetch];
 #pragma unroll
         for (int j = 0; j < kPrefetch; ++j) w[j] = cp[(size_t)j * kMtMarkers];
         for (int s0 = 0; s0 < rows; s0 += kPrefetch) {
+            if (wprof && s0 == kPrefetch) wt[2] = __builtin_readcyclecounter();       // (the first eight rows are done)
 #pragma unroll
             for (int u = 0; u < kPrefetch; ++u) {
                 if (s0 + u >= rows) break;
-                const uint2 w_cur = w[u];
+                const vuint2 w_cur = w[u];
                 w[u] = cp[(size_t)(s0 + u + kPrefetch) * kMtMarkers];
 #pragma unroll
                 for (int j = 0; j < (W16 ? 4 : 2); ++j) {
@@ -587,6 +607,9 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                     // double n} -- one add and one and, no multiply, no int -> double conversion.
                     // W16 (cohort steps): {low byte: dictionary index, next byte: n} -- two field
                     // extractions, a multiply-add and a conversion, for half the bytes from HBM
+                    // (Requesting a run's table values one run ahead of their use -- a software pipeline
+                    // across the per-row exit test -- was measured in round 3: 74 -> 96 us per 48-point
+                    // launch; the second set of twelve doubles does not fit the 128-register budget.)
                     double n;
                     uint32_t row_addr;
                     if constexpr (W16) {
@@ -612,6 +635,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         }
 
         __builtin_amdgcn_s_setprio(0);
+        if (wprof) wt[3] = __builtin_readcyclecounter();
         // ---- per-marker epilogue: this marker's likelihood as (mantissa, exponent) per point ----
         double lk_m[BTL];
         int lk_e[BTL];
@@ -620,7 +644,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (live) {
             double af1[BTL], af2[BTL];
             if (L.known_af) {
-                const double a = L.known_af[pos];
+                const double a = g_kaf[pos];
 #pragma unroll
                 for (int t = 0; t < BTL; ++t) af1[t] = af2[t] = a;
             } else {
@@ -643,7 +667,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
                     if (kk < k) project(kk, udr[kk]);                       // rows loaded before the read loop
-                for (int kk = 4; kk < k; ++kk) project(kk, L.ud[(size_t)kk * mp + pos]);
+                for (int kk = 4; kk < k; ++kk) project(kk, g_ud[(size_t)kk * mp + pos]);
                 const double mu = mur;
 #pragma unroll
                 for (int t = 0; t < BTL; ++t) {
@@ -734,6 +758,14 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 tile_llk[o] = lk_m[t];
                 tile_llk[o + 1] = (double)lk_e[t];
             }
+        }
+        if (wprof) {
+            wt[4] = __builtin_readcyclecounter();
+            if (lane == 0) {
+                unsigned long long* o = L.stamps + (size_t)(300 + wave) * 8;      // (blocks beyond the grid: unused slots)
+                o[0] = wt[0]; o[1] = wt[1]; o[2] = wt[2]; o[3] = wt[3]; o[4] = wt[4]; o[5] = (unsigned long long)rows;
+            }
+            ++wstamp_n;
         }
         // next work item of this workgroup, whichever wave gets there first
         uint32_t nxt = 0;
