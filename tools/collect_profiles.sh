@@ -4,7 +4,7 @@
 #   WRITE_SIZE, SQ counters, GRBM_GUI_ACTIVE; each in its own run, with --kernel-trace only),
 #   kernel stats of the other wave shapes (4-point / 1-point launches, cohort steps) and of a search.
 # Usage: bash tools/collect_profiles.sh r02
-R=${1:-r02}
+R=${1:-r03}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
@@ -21,5 +21,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_sq2 -o b -- $B $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm -o b -- $B $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_modes -o m -- python $GRAFT_REPO_ROOT/tools/prof_modes.py > $O/trace_modes.log 2>&1
+# HBM-side bytes of the cohort steps (32 samples; 1, 2, 4 and 8 points per sample): FETCH_SIZE of llk_eval_multi_kernel<*>
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_modes_fetch -o m -- python $GRAFT_REPO_ROOT/tools/prof_modes.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_opt -o o -- python $GRAFT_REPO_ROOT/tools/opt_time.py > $O/trace_opt.log 2>&1
 ls $O

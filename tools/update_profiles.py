@@ -5,7 +5,7 @@ search), PMC summary, batch sweep, and the two derived files bench.py reads back
 instructions per marker x point).
 Usage: python tools/update_profiles.py r02"""
 import csv, json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles", R)
 os.makedirs(dst, exist_ok=True)
@@ -72,6 +72,28 @@ v = {"_what": "VALU / LDS pipe occupancy of llk_eval_kernel<2,true> per launch o
      "valu_busy_frac": round(active * 4 / (1024 * cycles), 3) if cycles else None,
      "lds_busy_frac": round(lds_active / (256 * cycles), 3) if cycles else None}
 json.dump(v, open(os.path.join(dst, "valu_b%d.json" % B), "w"), indent=1)
+
+# cohort steps: FETCH_SIZE per launch of llk_eval_multi_kernel<MODE, ...> (MODE 4: 1 point per sample, 5: 2, 3: 4, 2: 8)
+cm = os.path.join(src, "pmc_modes_fetch")
+if os.path.isdir(cm):
+    import re
+    pth = [os.path.join(cm, f) for f in os.listdir(cm) if f.endswith("counter_collection.csv")][0]
+    acc = {}
+    for row in csv.DictReader(open(pth)):
+        mm = re.search(r"llk_eval_multi_kernel<(\d), (true|false)(?:, (true|false))?>", row["Kernel_Name"])
+        if mm and row["Counter_Name"] == "FETCH_SIZE":
+            acc.setdefault((int(mm.group(1)), mm.group(3) == "true"), []).append(float(row["Counter_Value"]))
+    np_of = {4: 1, 5: 2, 3: 4, 2: 8}
+    ct = {"_what": "HBM-side bytes of one lock-step cohort step of 32 C3-shaped samples, by points per sample: rocprofv3 --pmc "
+                   "FETCH_SIZE over tools/prof_modes.py, x2 (gfx950: FETCH_SIZE tallies 64 B per 128-B request), per launch of "
+                   "llk_eval_multi_kernel<MODE, true, W16> (MODE 4: 1 point, 5: 2, 3: 4, 2: 8; W16: the 16-bit run lists)",
+          "samples": int(os.environ.get("VB2_COHORT", "32")), "markers": markers, "traffic_bytes_per_step": {}, "kernels": {}}
+    for (mode, w16), vals in sorted(acc.items()):
+        b = int(2 * 1024 * sum(vals) / len(vals))
+        ct["traffic_bytes_per_step"][str(np_of[mode])] = b
+        ct["kernels"][str(np_of[mode])] = "llk_eval_multi_kernel<%d, true, %s>, %d launches" % (mode, "true" if w16 else "false", len(vals))
+    json.dump(ct, open(os.path.join(dst, "cohort_traffic.json"), "w"), indent=1)
+    print("cohort step traffic (bytes):", ct["traffic_bytes_per_step"])
 
 print("value %.0f evals/s, %.2f us/launch, frac %.3f, optimize %.2f ms, traffic %d B/launch, %s lane instr per marker x point, "
       "VALU busy %s, LDS busy %s" % (bench["value"], bench["roofline"]["device_us_per_launch"], bench["roofline"]["frac"],
