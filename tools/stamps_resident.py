@@ -37,16 +37,6 @@ print("blocks:", len(s), " t=0: round begun (loop top of the resident kernel)")
 for i, n in enumerate(names):
     col = us[:, i][s[:, i] > 0]
     if len(col): print("%-24s min %6.2f  median %6.2f  max %6.2f us" % (n, col.min(), np.median(col), col.max()))
-w = np.array(buf[:8 * nb], dtype=np.float64).reshape(nb, 8)[300:316]
-if nb >= 316 and w[:, 0].max() > 0:
-    t0w = w[w[:, 0] > 0][:, 0].min()
-    print("workgroup 1, first work item per wave, shader-clock cycles after the earliest wave entered its item:")
-    print("wave  item-start  loads-issued  8-rows-done  loop-done  item-done  rows")
-    for i in range(16):
-        if w[i, 0] > 0:
-            print("%4d  %10d  %12d  %11d  %9d  %9d  %4d" % (i, w[i, 0] - t0w, w[i, 1] - t0w, (w[i, 2] - t0w) if w[i, 2] else -1,
-                                                        w[i, 3] - t0w, w[i, 4] - t0w, w[i, 5]))
-
 if os.environ.get("VB2_STAMPS_DETAIL"):
     br = us[:, 5]
     order = np.argsort(-br)

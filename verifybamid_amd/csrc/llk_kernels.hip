@@ -529,7 +529,6 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         s_end = sch.off[blk * (uint32_t)nwave + (uint32_t)wave + 1];
     }
     uint32_t round = 0;
-    int wstamp_n = 0;
     if (hook_mine) hook.run();                            // (this wave takes no work items; the others cover for it)
     for (uint32_t idx = hook_mine ? nitem
                         : have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem)
@@ -552,10 +551,6 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             flush_wave(grp_wave);
             ++grp_wave;
         }
-        // profiling aid: the first work item of every wave of workgroup 1, in shader-clock cycles (blocks 300.. of the stamps)
-        const bool wprof = stamps && blk == 1 && wstamp_n == 0;
-        unsigned long long wt[6] = {0, 0, 0, 0, 0, 0};
-        if (wprof) wt[0] = __builtin_readcyclecounter();
         const vuint2 rec = g_rec[mt];                        // {first row, rows}; one scalar load when TPW == 1
         // per-marker constants: issued now, consumed after the read loop
         const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
@@ -587,14 +582,12 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         // their ds_reads go out as soon as they can and the LDS pipe stays busy, while the epilogue
         // waves fill the VALU slots in between (-0.8 % per launch measured; the other way round: +0.8 %)
         __builtin_amdgcn_s_setprio(1);
-        if (wprof) wt[1] = __builtin_readcyclecounter();
         g_cuint2* cp = g_codes + (size_t)rec.x * kMtMarkers + m;
         const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
         vuint2 w[kPrefetch];
 #pragma unroll
         for (int j = 0; j < kPrefetch; ++j) w[j] = cp[(size_t)j * kMtMarkers];
         for (int s0 = 0; s0 < rows; s0 += kPrefetch) {
-            if (wprof && s0 == kPrefetch) wt[2] = __builtin_readcyclecounter();       // (the first eight rows are done)
 #pragma unroll
             for (int u = 0; u < kPrefetch; ++u) {
                 if (s0 + u >= rows) break;
@@ -635,7 +628,6 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         }
 
         __builtin_amdgcn_s_setprio(0);
-        if (wprof) wt[3] = __builtin_readcyclecounter();
         // ---- per-marker epilogue: this marker's likelihood as (mantissa, exponent) per point ----
         double lk_m[BTL];
         int lk_e[BTL];
@@ -758,14 +750,6 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 tile_llk[o] = lk_m[t];
                 tile_llk[o + 1] = (double)lk_e[t];
             }
-        }
-        if (wprof) {
-            wt[4] = __builtin_readcyclecounter();
-            if (lane == 0) {
-                unsigned long long* o = L.stamps + (size_t)(300 + wave) * 8;      // (blocks beyond the grid: unused slots)
-                o[0] = wt[0]; o[1] = wt[1]; o[2] = wt[2]; o[3] = wt[3]; o[4] = wt[4]; o[5] = (unsigned long long)rows;
-            }
-            ++wstamp_n;
         }
         // next work item of this workgroup, whichever wave gets there first
         uint32_t nxt = 0;
