@@ -13,6 +13,9 @@ def rate(fn, n=400):
     for _ in range(n): fn()
     return 1e6 * (time.perf_counter() - t) / n
 with vb.LikelihoodContext(d) as ctx:
+    p48 = pts(48)
+    t_end = time.perf_counter() + 0.3           # an idle MI355X needs a few hundred ms of load to reach its clocks
+    while time.perf_counter() < t_end: ctx.llk(*p48)
     for B in (48, 4):
         p = pts(B)
         print("single context, synchronous host call, %2d points: %.1f us" % (B, rate(lambda: ctx.llk(*p))))
