@@ -311,7 +311,9 @@ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, uint32_t 
     return max_tiles_blk * (uint32_t)ngrp <= (uint32_t)(L.dyn_limit * nwave);
 }
 
-template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook>
+// STREAM: the launch reads its samples' run lists from HBM (cohort steps) rather than from L2: the prefetch never
+// runs past a tile's own rows then (see the read loop).
+template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -585,14 +587,19 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         g_cuint2* cp = g_codes + (size_t)rec.x * kMtMarkers + m;
         const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
         vuint2 w[kPrefetch];
+        // (STREAM: rows past the tile's last are the NEXT tiles' -- another workgroup's, at another time: fetched here
+        // they came from HBM twice, 573 MB instead of 356 MB per one-point step of 32 C3 samples (FETCH_SIZE, round 3).
+        // The row index is clamped to the tile's last row instead: the same cache line again, no new bytes.)
+        const int last_row = rows > 0 ? rows - 1 : 0;
 #pragma unroll
-        for (int j = 0; j < kPrefetch; ++j) w[j] = cp[(size_t)j * kMtMarkers];
+        for (int j = 0; j < kPrefetch; ++j) w[j] = cp[(size_t)(STREAM ? (j < last_row ? j : last_row) : j) * kMtMarkers];
         for (int s0 = 0; s0 < rows; s0 += kPrefetch) {
 #pragma unroll
             for (int u = 0; u < kPrefetch; ++u) {
                 if (s0 + u >= rows) break;
                 const vuint2 w_cur = w[u];
-                w[u] = cp[(size_t)(s0 + u + kPrefetch) * kMtMarkers];
+                w[u] = cp[(size_t)(STREAM ? (s0 + u + kPrefetch < last_row ? s0 + u + kPrefetch : last_row)
+                                          : s0 + u + kPrefetch) * kMtMarkers];
 #pragma unroll
                 for (int j = 0; j < (W16 ? 4 : 2); ++j) {
                     // one run: `n` reads of the same (class, quality) -> n * table row.  The run
@@ -952,7 +959,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
     const int stride = 2 * L.num_pc + 1;
     InlinePoints ip;
     ip.count = 0;
-    eval_body<MODE, HWMAP, W16>(L, ip, points + (size_t)s * NP * stride, nv,
+    eval_body<MODE, HWMAP, W16, NoHook, true>(L, ip, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1, use_ticket ? 0ull : done_seq,
