@@ -86,7 +86,7 @@ struct ScheduleProvider {
 
 struct LaunchGeom { int grid, block_waves; };
 // Workgroups / waves per workgroup used for a launch of 4*btl points.
-LaunchGeom launch_geom(const DeviceLayout& L, int btl);
+LaunchGeom launch_geom(const DeviceLayout& L, int btl, int ngrp = 1);
 constexpr int kMaxGridPerCU = 2;
 constexpr int kCodeSlackRows = 16;        // padding rows after the last tile: the read loop prefetches unconditionally
 inline int max_grid(const DeviceLayout& L) { return kMaxGridPerCU * L.num_cu; }

@@ -1014,7 +1014,7 @@ void set_geom_override(int btl, int max_waves, int blocks_per_cu)
     g_geom_override[btl - 1][1] = blocks_per_cu;
 }
 
-LaunchGeom launch_geom(const DeviceLayout& L, int btl)
+LaunchGeom launch_geom(const DeviceLayout& L, int btl, int ngrp)
 {
     int max_waves = btl == 1 ? Geom<1>::kMaxWaves : Geom<2>::kMaxWaves;
     int per_cu = btl == 1 ? Geom<1>::kBlocksPerCU : Geom<2>::kBlocksPerCU;
@@ -1027,6 +1027,14 @@ LaunchGeom launch_geom(const DeviceLayout& L, int btl)
     bw = bw < 4 ? 4 : (bw > max_waves ? max_waves : bw);
     int grid = (L.num_mt + bw - 1) / bw;
     grid = grid < 1 ? 1 : (grid > grid_target ? grid_target : grid);
+    // Several point groups: a workgroup's work items are (tile, group) pairs, so a small sample -- a marker shard
+    // of an 8-GPU run: 12 500 markers = 3-4 tiles per workgroup -- still has work for 16 waves, and 1 024 threads
+    // to build its six tables with (4-wave workgroups took 47 us for a 48-point launch on 12 500 markers, against
+    // 74 us on 100 000).  The grid, hence the tiles a workgroup owns, stays what it was.
+    if (ngrp > 1) {
+        const int items = ((L.num_mt + grid - 1) / grid) * ngrp;
+        if (items > bw) bw = items > max_waves ? max_waves : items;
+    }
     return LaunchGeom{grid, bw};
 }
 
@@ -1061,7 +1069,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
                              unsigned long long tag, hipStream_t stream, ScheduleProvider* sp)
 {
     constexpr int NP = ModeNp<MODE>::value;     // points per group
-    const LaunchGeom gm = launch_geom(L, MODE == 2 ? 2 : 1);
+    const LaunchGeom gm = launch_geom(L, MODE == 2 ? 2 : 1, ngrp);
     const Schedule sch = sp ? sp->get(MODE, ngrp, gm.grid, gm.block_waves) : Schedule{nullptr, nullptr};
     const size_t shmem = eval_shmem_np(L, NP, gm.grid, gm.block_waves, ngrp);
     {
@@ -1103,7 +1111,7 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         const double* p = d_points + (size_t)done * stride;
         const double* hp = h_points ? h_points + (size_t)done * stride : nullptr;
         // up to max_groups x 8 points per launch (more points amortise the fixed costs)
-        const LaunchGeom gm2 = launch_geom(L, 2);
+        const LaunchGeom gm2 = launch_geom(L, 2, kMaxGroups);
         // (8-point groups need the wide table rows; a context whose dictionary is too big for
         // 16-bit offsets into wide rows has narrow ones and evaluates 4 points per launch)
         const int cap = L.row_bytes == kRowBytesWide ? 8 * max_groups(L, 2, gm2.grid, gm2.block_waves) : 4;
