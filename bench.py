@@ -336,15 +336,32 @@ def main():
             if uid_error:
                 raise RuntimeError(uid_error)
             g2 = vb.ShardGroup(shared, device=local_rank, rank=rank, nranks=world, unique_id=uid)
+            step_sh, got_sh = g2.prepared_llk(pc1_h, pc2_h, al_h)          # (marshalling done once)
             for _ in range(20):
-                g2.llk(pc1_h, pc2_h, al_h)
+                step_sh()
             if dist is not None:
                 dist.barrier()
             n2 = 200
             t1 = time.perf_counter()
             for _ in range(n2):
-                got_sh = g2.llk(pc1_h, pc2_h, al_h)
+                step_sh()
             dt = time.perf_counter() - t1
+            # the same through ONE call of NCH x B points: the library queues the NCH launches back to back and
+            # reduces all their sums in ONE all-reduce (what multi-start / batched restarts hand over), so the
+            # launch, collective and host hand-off latencies are paid once per call instead of once per B points
+            NCH = 5
+            step_pl, got_pl = g2.prepared_llk(np.tile(pc1_h, (NCH, 1)), np.tile(pc2_h, (NCH, 1)), np.tile(al_h, NCH))
+            for _ in range(5):
+                step_pl()
+            if dist is not None:
+                dist.barrier()
+            n2p = 50
+            t1 = time.perf_counter()
+            for _ in range(n2p):
+                step_pl()
+            dtp = time.perf_counter() - t1
+            if not np.array_equal(got_pl[:B], got_sh):
+                raise RuntimeError("marker-sharded: the %d-point call and the %d-point call disagree" % (NCH * B, B))
             g2.optimize()
             t_opt = []
             for _ in range(3):
@@ -354,7 +371,7 @@ def main():
                 est_sh = g2.optimize()
                 t_opt.append(time.perf_counter() - t1)
             gi = g2.info()
-            vals = torch.tensor([dt, min(t_opt)], dtype=torch.float64, device="cuda")
+            vals = torch.tensor([dt, min(t_opt), dtp], dtype=torch.float64, device="cuda")
             if dist is not None:
                 dist.all_reduce(vals, op=dist.ReduceOp.MAX)
             result["marker_sharded"] = {
@@ -362,6 +379,9 @@ def main():
                         "step a launch per rank + one ncclAllReduce of %d doubles + host sync; strong scaling, "
                         "latency-bound" % (world, B),
                 "evals_per_s": B * n2 / float(vals[0]), "ms_per_step": 1e3 * float(vals[0]) / n2,
+                "pipelined": {"points_per_call": NCH * B, "launches_per_call": NCH, "allreduces_per_call": 1,
+                              "evals_per_s": NCH * B * n2p / float(vals[2]),
+                              "ms_per_%d_points" % B: 1e3 * float(vals[2]) / (n2p * NCH)},
                 "optimize_wall_ms": 1e3 * float(vals[1]), "alpha": est_sh["alpha"], "num_eval": est_sh["num_eval"],
                 "uses_rccl": gi["uses_rccl"], "allreduces": gi["num_allreduce"],
                 "shard_reads_rank0": gi["num_read"],
@@ -419,27 +439,17 @@ def main():
                 npt = np.full(S, 4, dtype=np.int32)
                 p1 = np.zeros((S, 8, k)); p2 = np.zeros((S, 8, k)); al = np.full((S, 8), 0.1)
                 p1[:, :4] = pts_h[:4, :k]; p2[:, :4] = pts_h[:4, k:2 * k]; al[:, :4] = pts_h[:4, 2 * k]
-                for _ in range(20):
-                    batch.eval(npt, p1, p2, al)
-                t1 = time.perf_counter()
-                n3 = 100
-                for _ in range(n3):
-                    batch.eval(npt, p1, p2, al)
-                dt4 = (time.perf_counter() - t1) / n3
-                npt1 = np.full(S, 1, dtype=np.int32)
-                for _ in range(20):
-                    batch.eval(npt1, p1, p2, al)
-                t1 = time.perf_counter()
-                for _ in range(n3):
-                    batch.eval(npt1, p1, p2, al)
-                dt1 = (time.perf_counter() - t1) / n3
-                npt2 = np.full(S, 2, dtype=np.int32)
-                for _ in range(20):
-                    batch.eval(npt2, p1, p2, al)
-                t1 = time.perf_counter()
-                for _ in range(n3):
-                    batch.eval(npt2, p1, p2, al)
-                dt2 = (time.perf_counter() - t1) / n3
+                def time_steps(npts_arr, n3=200):
+                    step_c, _ = batch.prepared_eval(npts_arr, p1, p2, al)     # (marshalling done once)
+                    for _ in range(20):
+                        step_c()
+                    t1 = time.perf_counter()
+                    for _ in range(n3):
+                        step_c()
+                    return (time.perf_counter() - t1) / n3
+                dt4 = time_steps(npt)
+                dt1 = time_steps(np.full(S, 1, dtype=np.int32))
+                dt2 = time_steps(np.full(S, 2, dtype=np.int32))
                 batch.optimize()
                 t1 = time.perf_counter()
                 ests = batch.optimize()

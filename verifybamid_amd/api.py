@@ -300,6 +300,24 @@ class CohortBatch:
                    "vb2_batch_eval")
         return out
 
+    def prepared_eval(self, num_point, pc1, pc2, alpha):
+        """The same call with the argument marshalling done once: returns (step, out) where step() makes one
+        vb2_batch_eval call on the captured arrays (bench.py times steps, not numpy conversions)."""
+        S, k = len(self.contexts), self.num_pc
+        npt = np.ascontiguousarray(num_point, dtype=np.int32)
+        pc1 = np.ascontiguousarray(pc1, dtype=np.float64).reshape(S, self.SLOTS, k)
+        pc2 = np.ascontiguousarray(pc2, dtype=np.float64).reshape(S, self.SLOTS, k)
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64).reshape(S, self.SLOTS)
+        out = np.zeros((S, self.SLOTS))
+        fn, h, a = self._lib.vb2_batch_eval, self._h, (_p(npt), _p(pc1), _p(pc2), _p(alpha), _p(out))
+        keep = (npt, pc1, pc2, alpha)
+
+        def step(_keep=keep):
+            rc = fn(h, *a)
+            if rc:
+                _abi.check(rc, "vb2_batch_eval")
+        return step, out
+
     def optimize(self, **model_kw):
         S = len(self.contexts)
         m, keep = _model(**model_kw)
@@ -372,6 +390,23 @@ class ShardGroup:
         _abi.check(self._lib.vb2_shard_group_eval(self._h, B, _p(pc1), _p(pc2), _p(alpha), _p(out)),
                    "vb2_shard_group_eval")
         return out
+
+    def prepared_llk(self, pc1, pc2, alpha):
+        """llk() with the argument marshalling done once: returns (step, out); step() makes one
+        vb2_shard_group_eval call on the captured arrays (bench.py times steps, not numpy conversions)."""
+        pc1 = np.ascontiguousarray(np.atleast_2d(np.asarray(pc1, dtype=np.float64)))
+        pc2 = np.ascontiguousarray(np.atleast_2d(np.asarray(pc2, dtype=np.float64)))
+        alpha = np.ascontiguousarray(np.atleast_1d(np.asarray(alpha, dtype=np.float64)))
+        B = alpha.shape[0]
+        assert pc1.shape == (B, self.num_pc) and pc2.shape == (B, self.num_pc)
+        out = np.zeros(B)
+        fn, h, a = self._lib.vb2_shard_group_eval, self._h, (_p(pc1), _p(pc2), _p(alpha), _p(out))
+
+        def step(_keep=(pc1, pc2, alpha)):
+            rc = fn(h, B, *a)
+            if rc:
+                _abi.check(rc, "vb2_shard_group_eval")
+        return step, out
 
     def optimize(self, trace_capacity=0, **model_kw):
         m, keep = _model(known_af=self.data.known_af is not None, **model_kw)
