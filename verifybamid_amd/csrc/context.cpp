@@ -895,6 +895,8 @@ bool Context::resident_begin()
         ResidentArgs ra;
         ra.h_cmd = d_cmd;
         ra.relay = d_relay;
+        ra.relay_reps = std::getenv("VB2_RELAY_REPS") ? std::max(1, std::min(kRelayReps, std::atoi(std::getenv("VB2_RELAY_REPS")))) : 8;
+        ra.own_rows = std::getenv("VB2_OWN_ROWS") ? std::atoi(std::getenv("VB2_OWN_ROWS")) : 1;
         ra.spec = d_relay + resident_words(num_pc);
         ra.h_out = d_out;
         ra.h_done = d_done;

@@ -170,6 +170,9 @@ struct ResidentArgs {
     unsigned long long epoch;            // distinguishes this launch's hand-off tags from any earlier one's
     int32_t state_off;                   // doubles from the start of dynamic LDS to workgroup 0's search state
     int32_t state_nmax;                  // largest simplex dimension the state was sized for (0 = no MINIMIZE)
+    int32_t relay_reps;                  // copies of the relay word in use (1..kRelayReps; VB2_RELAY_REPS)
+    int32_t own_rows;                    // 1: workgroup 0 starts a short-way round from its own copy of the rows sets
+                                         // without waiting for its relay word (VB2_OWN_ROWS, A/B knob)
 };
 constexpr unsigned long long kResidentMinimize = 0xffffffffull;   // mailbox word [1]: a Minimize() request
 constexpr int kDeviceSimplexMaxDim = 63;                           // one lane per coordinate, one per vertex (n + 1 <= 64)
@@ -193,7 +196,14 @@ inline __host__ __device__ int resident_words(int num_pc)
     const int rows = 4 * (2 * num_pc + 1), req = 6 * num_pc + 9;
     return 2 + (rows > req ? rows : req) + 1;
 }
-inline __host__ __device__ int resident_relay_words(int num_pc) { return resident_words(num_pc) + 2 * resident_spec_words(num_pc); }
+// The relay word every workgroup waits for exists in kRelayReps copies, kRelayRepStride words apart (one address polled
+// by all 256 workgroups is one memory channel's queue; workgroup b polls copy b % ResidentArgs::relay_reps)
+constexpr int kRelayReps = 64, kRelayRepStride = 512;
+inline __host__ __device__ int resident_rep_base(int num_pc)
+{
+    return (resident_words(num_pc) + 2 * resident_spec_words(num_pc) + kRelayRepStride - 1) / kRelayRepStride * kRelayRepStride;
+}
+inline __host__ __device__ int resident_relay_words(int num_pc) { return resident_rep_base(num_pc) + kRelayReps * kRelayRepStride; }
 // Words of dynamic LDS the resident kernel needs beyond the evaluation body's (search state + command image +
 // every workgroup's staging of the round's rows).
 size_t resident_state_doubles(int nmax, int num_pc);

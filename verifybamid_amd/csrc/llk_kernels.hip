@@ -772,9 +772,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (wave == nwave - 1) stamps[4] = wall_clock64();   // last wave done with its tiles
     }
     // ---- deterministic block reduction -> one partial per (point, block) ----
-    __syncthreads();
     const uint32_t nres = dyn ? ntile_blk : (uint32_t)nwave;   // result slots per group
-    for (int b = wave; b < NPT; b += nwave) {         // slots in index order, then a butterfly
+    auto reduce_point = [&](int b) {                  // slots in index order, then a butterfly
         const int grp = b / NP, bb = b - grp * NP;
         ScaledProd p{1.0, 0.0};
         for (uint32_t i = lane; i < nres; i += 64) {
@@ -791,9 +790,14 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         }
         // the only logarithm of this (workgroup, point): log(prod lk) = log(m) + e*ln2
         if (lane == 0) red[b] = log_nonneg(p.m) + p.e * 6.93147180559945286227e-01;
-    }
+    };
     __syncthreads();
-    if (stamps && tid == 0) stamps[5] = wall_clock64();
+    for (int b = wave; b < NPT; b += nwave) reduce_point(b);
+    __syncthreads();
+    if (stamps && tid == 0) {
+        stamps[5] = wall_clock64();
+        if (blk == 0 && nblk > 32) L.stamps[20 * 8 + 7] += stamps[5] - L.stamps[7];     // (accumulated: since "has the round")
+    }
     if (ticket == nullptr) {                     // two-kernel mode: llk_finalize_kernel follows
         if (tid < NPT) partials[(size_t)tid * nblk + blk] = red[tid];
         return;
@@ -907,7 +911,10 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (lane == 0) llk_out[b] = s;                   // NaN if a workgroup never reported
     }
     }
-    if (stamps && tid == 0) stamps[6] = wall_clock64();
+    if (stamps && tid == 0) {
+        stamps[6] = wall_clock64();
+        if (blk == 0 && nblk > 32) L.stamps[21 * 8 + 7] += stamps[6] - L.stamps[7];
+    }
     if (done_flag) {
         // host hand-off without a stream synchronisation: results (in mapped host memory)
         // first, then the sequence number the host is spinning on.  In a multi-sample launch
