@@ -380,6 +380,62 @@ def test_fast_scanner_equals_stringstream_statements(tmp_path, monkeypatch):
     monkeypatch.delenv("VB2_SLOW_PARSE")
 
 
+def test_avx2_pileup_scanner_equals_the_scalar_one(tmp_path, monkeypatch):
+    """read_pileup classifies the bases column 32 characters at a time (AVX2) and copies runs of kept
+    characters with their qualities as blocks.  Differential test against the scalar scanner
+    (VB2_SCALAR_PARSE=1) and the stringstream statements (VB2_SLOW_PARSE=1): long columns (runs that
+    cross block boundaries), read-start / read-end marks, indels with one- and two-digit lengths, '*' / '#'
+    placeholders, fewer qualities than bases, a last line without a newline, lines outside the panel."""
+    rng = np.random.default_rng(4242)
+    for trial in range(int(os.environ.get("VB2_FUZZ_TRIALS", "12"))):
+        pre = str(tmp_path / ("g%d" % trial))
+        M = int(rng.integers(5, 60))
+        with open(pre + ".bed", "w") as f:
+            for i in range(M):
+                f.write("1\t%d\t%d\tA\tC\n" % (99 + 10 * i, 100 + 10 * i))
+        with open(pre + ".UD", "w") as f:
+            for i in range(M):
+                f.write("%r\t%r\n" % (float(rng.normal()), float(rng.normal())))
+        with open(pre + ".mu", "w") as f:
+            for i in range(M):
+                f.write("m%d\t%r\n" % (i, float(rng.uniform(0.1, 1.9))))
+        lines = []
+        for i in range(M + 3):
+            pos = 100 + 10 * i if i < M else 55 + i                 # the last three: not in the panel
+            depth = int(rng.choice([0, 1, 7, 31, 32, 33, 63, 64, 65, 100, int(rng.integers(0, 130))]))
+            seq, nread = [], 0
+            while nread < depth:
+                r = rng.random()
+                if r < 0.80:
+                    seq.append(str(rng.choice(list(".,ACGTNacgtn")))); nread += 1
+                elif r < 0.84:
+                    seq.append("^" + chr(int(rng.integers(33, 127))))
+                elif r < 0.88:
+                    seq.append("$")
+                elif r < 0.92:
+                    seq.append(str(rng.choice(["*", "#"]))); nread += 1
+                else:
+                    L = int(rng.choice([1, 2, 9, 10, 12]))
+                    seq.append(str(rng.choice(["+", "-"])) + str(L) + "".join(rng.choice(list("ACGTNacgt"), size=L)))
+            seq = "".join(seq) or "*"
+            nq = max(1, nread - (int(rng.integers(0, 4)) if rng.random() < 0.2 else 0))
+            qual = "".join(chr(int(x)) for x in rng.integers(33, 127, size=nq))
+            lines.append("1\t%d\tA\t%d\t%s\t%s\n" % (pos, depth, seq, qual))
+        if trial % 2:
+            lines[-1] = lines[-1].rstrip("\n")
+        with open(pre + ".pileup", "w", newline="") as f:
+            f.write("".join(lines))
+        out = []
+        for var in (None, "VB2_SCALAR_PARSE", "VB2_SLOW_PARSE"):
+            if var:
+                monkeypatch.setenv(var, "1")
+            out.append(_load_arrays(pre, 2, disable_sanity=True))
+            if var:
+                monkeypatch.delenv(var)
+        assert out[0] == out[1] == out[2], trial
+        assert out[0]["nb"] > 0
+
+
 def _tiny_panel(pre):
     open(pre + ".bed", "w").write("1\t0\t1\tA\tC\n1\t9\t10\tG\tT\n")
     open(pre + ".UD", "w").write("0.5 0.25\n-0.5 0.125\n")

@@ -981,12 +981,13 @@ def test_cohort_steps_on_16bit_run_lists_are_bit_identical():
 def test_c5_sized_cohort_on_one_gpu():
     """BASELINE.json configs[4] per GPU: 32 samples of 100 000 markers x depth 30, --NumPC 4, in ONE
     lock-step batch (static deal, ~49 work items per wave).  batch.eval equals every context's own
-    evaluation, two samples are checked against the oracle, and batch.optimize gives every sample
+    evaluation, every distinct sample is checked against the oracle in each step shape, and batch.optimize gives every sample
     the estimate of its single-context search.  (8 distinct synthetic samples, each uploaded four
     times: 32 independent contexts in HBM.)"""
     k, S = 4, 32
     distinct = [vb.synth.make_pileup(100000, 30, k, alpha_true=0.01 + 0.02 * s, seed=1000 + s) for s in range(8)]
     ctxs = [vb.LikelihoodContext(distinct[s % 8]) for s in range(S)]
+    ods = [oracle_data(dd) for dd in distinct]
     try:
         rng = np.random.default_rng(17)
         with vb.CohortBatch(ctxs) as batch:
@@ -1002,11 +1003,13 @@ def test_c5_sized_cohort_on_one_gpu():
                 for s in range(S):
                     want = ctxs[s].llk(pc1[s, :n], pc2[s, :n], al[s, :n])
                     assert rel_err(got[s, :n], want) <= LLK_RTOL, (n, s)
-                for s in (0, 13):
-                    od = oracle_data(distinct[s % 8])
-                    ref = np.array([od.llk(pc1[s, j], pc2[s, j], al[s, j], num_thread=os.cpu_count() or 1)
-                                    for j in range(min(n, 2))])
-                    assert rel_err(got[s, :len(ref)], ref) <= LLK_RTOL, (n, s)
+                # against the oracle: every distinct sample, at several positions of the cohort, the first and the
+                # last point of the step's shape
+                for s in (0, 1, 2, 3, 4, 5, 6, 7, 13, 22, 31):
+                    od = ods[s % 8]
+                    js = sorted({0, n - 1})
+                    ref = np.array([od.llk(pc1[s, j], pc2[s, j], al[s, j], num_thread=os.cpu_count() or 1) for j in js])
+                    assert rel_err(got[s, js], ref) <= LLK_RTOL, (n, s)
             ests = batch.optimize()
         singles = [ctxs[s].optimize() for s in range(8)]
         for s in range(S):

@@ -976,7 +976,7 @@ bool Context::resident_collect(int n, double* out)
         __builtin_ia32_pause();
     }
     // A NaN can only be the kernel's own "a workgroup never reported" marker (the partial-sum
-    // hand-off waited two seconds): part of the grid is not on the CUs.  Same treatment as no
+    // hand-off gave up after a quarter of a second): part of the grid is not on the CUs.  Same treatment as no
     // answer at all.
     if (seen)
         for (int b = 0; b < n; ++b)

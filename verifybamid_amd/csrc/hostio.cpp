@@ -17,6 +17,9 @@
 #include <vector>
 
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "context.h"   // set_error
 
@@ -33,7 +36,9 @@ int io_error(const std::string& what)
 // Whole file -> memory.  Like the reference's InputFile (statgen/InputFile.cpp: ifopen picks
 // GzipFileType by the magic bytes), a gzip'd file is inflated transparently and anything else is
 // read as it is -- zlib's gzread does both.
-bool slurp(const std::string& path, std::string* all)
+// `pad`: capacity kept free behind the contents (read_pileup appends that many newlines: its AVX2 scanner loads
+// whole 32-byte blocks)
+bool slurp(const std::string& path, std::string* all, size_t pad = 0)
 {
     // plain files (everything but the gzip'd panels the reference's InputFile also accepts) are
     // read in one go; zlib's transparent mode would copy them through its own buffers
@@ -45,6 +50,7 @@ bool slurp(const std::string& path, std::string* all)
         const bool regular = ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
         const ssize_t got = regular ? ::pread(fd, magic, 2, 0) : 0;
         if (regular && !(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+            all->reserve((size_t)st.st_size + pad);
             all->resize((size_t)st.st_size);
             size_t done = 0;
             while (done < all->size()) {
@@ -191,6 +197,20 @@ inline bool plain_double(const char* b, const char* e, double* out)
 // through statgen's InputFile::readLine, which reports EOF (and so drops the data) for a last
 // line that lacks '\n' (statgen/InputFile.cpp:112-130); with_unterminated = true is the
 // std::getline behaviour instead (an unterminated last line counts).
+template <class F>
+void for_each_line_n(const char* p, size_t len, bool with_unterminated, F fn)
+{
+    const char* end = p + len;
+    while (p < end) {
+        const char* nl = static_cast<const char*>(std::memchr(p, '\n', (size_t)(end - p)));
+        if (!nl) {
+            if (with_unterminated) fn(p, end);
+            break;
+        }
+        fn(p, nl);
+        p = nl + 1;
+    }
+}
 template <class F>
 void for_each_line(const std::string& all, bool with_unterminated, F fn)
 {
@@ -488,6 +508,127 @@ bool parse_bases(const std::string& seq, const std::string& qual, std::string* p
     pqual->resize(o);
     return true;
 }
+
+#if defined(__x86_64__)
+// ---- the same with AVX2 (run-time dispatch; VB2_SCALAR_PARSE=1 keeps the scalar statements) ------------------
+// A pileup is ~80 % bases and qualities.  The kept characters (". , A C G T N a c g t n") come in long runs, so the
+// bases column is classified 32 characters at a time (two nibble look-ups) and every run of kept characters is
+// copied as a block together with its qualities; a character of any other class goes through the scalar
+// statements above, one at a time.  Loads may run up to 31 bytes past a field: the caller pads its buffer.
+inline bool cpu_has_avx2()
+{
+    static const bool hw = __builtin_cpu_supports("avx2");
+    const char* e = std::getenv("VB2_SCALAR_PARSE");           // (read per call: the differential tests switch it)
+    return hw && !(e && e[0] == '1');
+}
+
+__attribute__((target("avx2"))) inline unsigned nonkeep_mask32(__m256i x)
+{
+    // keep iff (lo_tab[low nibble] & hi_tab[high nibble]) != 0; classes: bit0 0x2_, bit1 0x4_ / 0x6_, bit2 0x5_ / 0x7_
+    const __m256i lo_tab = _mm256_setr_epi8(0, 2, 0, 2, 4, 0, 0, 2, 0, 0, 0, 0, 1, 0, 3, 0,
+                                            0, 2, 0, 2, 4, 0, 0, 2, 0, 0, 0, 0, 1, 0, 3, 0);
+    const __m256i hi_tab = _mm256_setr_epi8(0, 0, 1, 0, 2, 4, 2, 4, 0, 0, 0, 0, 0, 0, 0, 0,
+                                            0, 0, 1, 0, 2, 4, 2, 4, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i nib = _mm256_set1_epi8(0x0f);
+    const __m256i lo = _mm256_shuffle_epi8(lo_tab, _mm256_and_si256(x, nib));
+    const __m256i hi = _mm256_shuffle_epi8(hi_tab, _mm256_and_si256(_mm256_srli_epi16(x, 4), nib));
+    const __m256i k = _mm256_and_si256(lo, hi);
+    return (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(k, _mm256_setzero_si256()));
+}
+
+// bytes <= 0x20 (every whitespace character of the "C" locale is one) among the 32 at p
+__attribute__((target("avx2"))) inline unsigned blank_mask32(const char* p)
+{
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+    const __m256i sp = _mm256_set1_epi8(0x20);
+    return (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_max_epu8(x, sp), sp));
+}
+
+// parse_bases_raw's result; ps / pq need room for n + 32 characters, seq / qual 31 readable bytes past their ends
+__attribute__((target("avx2")))
+bool parse_bases_avx2(const char* seq, size_t n, const char* qual, size_t nq, char* ps, char* pq, size_t* out)
+{
+    size_t i = 0, iq = 0, o = 0;
+    while (i < n) {
+        const size_t rem = n - i;
+        const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(seq + i));
+        unsigned nk = nonkeep_mask32(x);
+        if (rem < 32) nk |= ~0u << rem;
+        const unsigned run = nk ? (unsigned)__builtin_ctz(nk) : 32u;
+        if (run) {
+            _mm256_storeu_si256(reinterpret_cast<__m256i*>(ps + o), x);
+            if (iq + run <= nq) {
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(pq + o),
+                                    _mm256_loadu_si256(reinterpret_cast<const __m256i*>(qual + iq)));
+            } else {                                           // fewer qualities than bases: '!' (the scalar rule)
+                const size_t have = iq < nq ? nq - iq : 0;
+                std::memcpy(pq + o, qual + iq, have);
+                std::memset(pq + o + have, '!', run - have);
+            }
+            o += run;
+            i += run;
+            iq += run;
+        }
+        if (run < 32 && i < n) {                               // one character of another class
+            const char c = seq[i];
+            if (c == '*' || c == '#') {
+                ++iq;
+            } else if (c == '+' || c == '-') {
+                size_t j = i + 1;
+                while (j != n && std::isdigit((unsigned char)seq[j])) j++;
+                const size_t digit_len = j - (i + 1);
+                if (digit_len == 0) return false;              // stoi(""): invalid_argument
+                long long clip = 0;
+                for (size_t d = i + 1; d < j; ++d) {
+                    clip = clip * 10 + (seq[d] - '0');
+                    if (clip > 2147483647ll) return false;     // stoi: out_of_range
+                }
+                i += digit_len + (size_t)clip;
+            } else if (c == '^') {
+                i += 1;
+            }
+            ++i;
+        }
+    }
+    *out = o;
+    return true;
+}
+
+// A line of exactly six tab-separated, non-empty fields without any other blank: their bounds.  False: not such
+// a line (the caller's general statements decide).  31 readable bytes past `e` required.
+__attribute__((target("avx2")))
+bool split_six_fields(const char* b, const char* e, const char** f0, const char** f1)
+{
+    const char* p = b;
+    for (int k = 0; k < 4; ++k) {                              // chromosome, position, reference base, depth: short
+        f0[k] = p;
+        while (p < e && (unsigned char)*p > 0x20) ++p;
+        f1[k] = p;
+        if (p >= e || *p != '\t' || f1[k] == f0[k]) return false;
+        ++p;
+    }
+    f0[4] = p;                                                 // bases: up to the next blank, which must be a tab
+    for (;;) {
+        if (p >= e) return false;
+        const unsigned m = blank_mask32(p);
+        if (m) { p += __builtin_ctz(m); break; }
+        p += 32;
+    }
+    if (p >= e || *p != '\t' || p == f0[4]) return false;
+    f1[4] = p;
+    ++p;
+    f0[5] = p;                                                 // qualities: the rest of the line, no blank in it
+    if (p >= e) return false;
+    for (const char* q = p; q < e; q += 32) {
+        unsigned m = blank_mask32(q);
+        const size_t rem = (size_t)(e - q);
+        if (rem < 32) m &= ~(~0u << rem);
+        if (m) return false;
+    }
+    f1[5] = e;
+    return true;
+}
+#endif
 }  // namespace
 
 // SimplePileupViewer.cpp:748-833.
@@ -501,10 +642,13 @@ bool parse_bases(const std::string& seq, const std::string& qual, std::string* p
 int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v)
 {
     std::string all;
-    if (!slurp(path, &all)) return io_error("open file " + path + " failed!");
+    constexpr size_t kPad = 64;
+    if (!slurp(path, &all, kPad)) return io_error("open file " + path + " failed!");
+    const size_t all_len = all.size();
+    all.append(kPad, '\n');                                 // (lines are cut from the first all_len bytes only)
     v->init(panel);
-    v->basePool.reserve(all.size() / 3);
-    v->qualPool.reserve(all.size() / 3);
+    v->basePool.reserve(all_len / 3);
+    v->qualPool.reserve(all_len / 3);
     v->siteOff.reserve(panel.num_slot() + 1);
     std::string chr, ref, seq, qual, pseq, pqual;          // the reference's persistent variables
     int pos = 0, depth = 0;
@@ -570,8 +714,74 @@ int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v)
         next_slot = slot + 1;
     };
     const bool slow = slow_parse();
-    for_each_line(all, true, [&](const char* b, const char* e) {
+#if defined(__x86_64__)
+    // The AVX2 path writes the parsed characters straight behind the pools' contents, a block at a time: the pools
+    // are kept at a generous size while it is in use (`used` = the real length), and cut back for the statements
+    // that go through the string interface.
+    const bool simd = !slow && cpu_has_avx2();
+    size_t used = 0, cap = 0;
+    auto pools_up = [&](size_t need) {                      // room for `need` more characters (+ a block of slack)
+        if (used + need + 32 <= cap) return;
+        cap = std::max(used + need + 32, std::max<size_t>(cap * 2, all_len / 2 + 4096));
+        v->basePool.resize(cap);
+        v->qualPool.resize(cap);
+    };
+    auto pools_down = [&]() {                               // back to the string interface
+        if (cap == 0) return;
+        v->basePool.resize(used);
+        v->qualPool.resize(used);
+        cap = 0;
+    };
+#endif
+    const char* const all_b = all.data();
+    for_each_line_n(all_b, all_len, true, [&](const char* b, const char* e) {
         if (rc) return;
+#if defined(__x86_64__)
+        const char *g0[6], *g1[6];
+        int ppos_s = 0, pdepth_s = 0;
+        if (simd && split_six_fields(b, e, g0, g1) && plain_int(g0[1], g1[1], &ppos_s) && plain_int(g0[3], g1[3], &pdepth_s)) {
+            const char *s0 = g0[4], *s1 = g1[4], *q0 = g0[5], *q1 = g1[5];
+            const size_t n = (size_t)(s1 - s0);
+            if (g1[2] - g0[2] == 1 && *g0[2] == '.' && (std::memchr(s0, '.', n) || std::memchr(s0, ',', n))) {
+                set_error("Pileup format error: cannot find ref allele, exit!");
+                rc = VB2_ERR_INVALID;
+                return;
+            }
+            if (cap == 0) used = v->basePool.size();
+            if (used + n > 0xffffffffull) {                 // (site offsets are 32-bit: 4 GiB of kept bases per sample)
+                set_error("pileup too large: more than 4 GiB of bases at the panel's sites");
+                rc = VB2_ERR_INVALID;
+                return;
+            }
+            pools_up(n);
+            size_t kept = 0;
+            if (!parse_bases_avx2(s0, n, q0, (size_t)(q1 - q0), &v->basePool[used], &v->qualPool[used], &kept)) {
+                set_error("Pileup format error: indel marker without a valid length in the bases column of " +
+                          std::string(g0[0], g1[0]) + ":" + std::to_string(ppos_s));
+                rc = VB2_ERR_INVALID;
+                return;
+            }
+            const int32_t slot = slot_of(g0[0], g1[0], ppos_s);
+            last.pending = true;
+            last.in_bed = slot >= 0;
+            last.c0 = g0[0]; last.c1 = g1[0]; last.r0 = g0[2]; last.r1 = g1[2]; last.s0 = s0; last.s1 = s1; last.q0 = q0; last.q1 = q1;
+            last.pos = ppos_s;
+            if (slot >= 0) {
+                if (v->siteOfSlot[slot] < 0) {              // a new site: the parsed characters stay
+                    v->siteOfSlot[slot] = v->num_site();
+                    used += kept;
+                    v->siteOff.push_back((uint32_t)used);
+                    v->numBases += (int)kept;
+                    v->effectiveNumSite++;
+                    next_slot = slot + 1;
+                } else {
+                    record(slot, nullptr, nullptr, kept);   // a duplicated line: warning, counters (quirk vii)
+                }
+            }
+            return;
+        }
+        pools_down();
+#endif
         Scan sc{b, e};
         const char *c0, *c1, *p0, *p1, *r0, *r1, *d0, *d1, *s0, *s1, *q0, *q1;
         int ppos = 0, pdepth = 0;
@@ -648,6 +858,9 @@ int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v)
         seq = "";
         qual = "";
     });
+#if defined(__x86_64__)
+    pools_down();
+#endif
     if (rc) return rc;
     v->avgDepth = (double)v->numBases / v->effectiveNumSite;
     return VB2_OK;

@@ -174,6 +174,7 @@ struct ResidentArgs {
     int32_t own_rows;                    // 1: workgroup 0 starts a short-way round from its own copy of the rows sets
                                          // without waiting for its relay word (VB2_OWN_ROWS, A/B knob)
 };
+constexpr unsigned long long kHandoffGiveUpTicks = 25000000ull;   // 0.25 s of the 100 MHz wall clock (tagged hand-off)
 constexpr unsigned long long kResidentMinimize = 0xffffffffull;   // mailbox word [1]: a Minimize() request
 constexpr int kDeviceSimplexMaxDim = 63;                           // one lane per coordinate, one per vertex (n + 1 <= 64)
 __host__ __device__ inline unsigned long long resident_mix(unsigned long long seq)

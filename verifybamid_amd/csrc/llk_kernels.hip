@@ -884,7 +884,10 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                     }
                 }
                 if (x == want) break;
-                if ((it & 63) == 63 && wall_clock64() - t_wait > 200000000ull) {   // 2 s: a workgroup is missing
+                // a quarter of a second (100 MHz ticks): a workgroup is missing -- part of the grid is not on the CUs
+                // (a shared GPU).  The caller sees NaN and redoes the step with the arrival-ticket hand-off, which
+                // waits for nobody.  (Round 2 waited two seconds: the hiccup of a co-residency failure is this wait.)
+                if ((it & 63) == 63 && wall_clock64() - t_wait > kHandoffGiveUpTicks) {
                     for (int w = 0; w < NPT; ++w) stage[(size_t)w * nb + b] = __builtin_nan("");
                     break;
                 }
