@@ -34,10 +34,6 @@ if nb > 22 and s[4, 7] > 0:
     n = s[4, 7]
     print("workgroup 0, averaged over the rounds, since it has the round: own block reduced %.2f us, all sets in + summed %.2f us"
           % (s[20, 7] / n / 100.0, s[21, 7] / n / 100.0))
-if nb > 26 and s[4, 7] > 0:
-    n = s[4, 7]
-    print("workgroup 9, averaged: published -> has the round %.2f us, has the round -> block reduced %.2f us; control wave: sums -> published %.2f us"
-          % (s[23, 7] / n / 100.0, s[24, 7] / n / 100.0, s[25, 7] / n / 100.0))
 s = s[s[:, 0] > 0]
 us = (s - t0) / 100.0
 names = ["entry", "points in LDS", "table built", "wave0 tiles done", "last wave tiles done", "block reduced", "finalized (last block)"]
