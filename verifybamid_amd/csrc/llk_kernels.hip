@@ -10,7 +10,7 @@
 //   * a marker's reads are run-length coded over the (class x quality) dictionary: one 32-bit run
 //     word per distinct code (low half = LDS byte offset of the code's table row, high half = the
 //     top 16 bits of double(count), count <= 31), two per uint2, stored [micro-tile][step/2][marker]:
-//     a wave load is one contiguous 128-byte row, rows are prefetched kPrefetch = 8 deep;
+//     a wave load is one contiguous 128-byte row, rows are prefetched 8 deep in cohort steps (HBM), 2-4 deep otherwise;
 //   * the per-alpha log-likelihood table (h:213-229) is rebuilt per launch in LDS,
 //     restricted to the codes that occur in the data and to the six OFF-diagonal
 //     genotype pairs: the diagonal (g1==g2) and the "other base" class do not
@@ -586,20 +586,32 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         __builtin_amdgcn_s_setprio(1);
         g_cuint2* cp = g_codes + (size_t)rec.x * kMtMarkers + m;
         const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
-        vuint2 w[kPrefetch];
+        // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
+        // tile's last row -- up to kPf useless row loads per item of 6..16 rows -- and every block of kPf rows begins
+        // by waiting for all of them.  Measured on one box, depth 8 / 4 / 2: 48-point launch 74.9 / 74.4 / 76.6 us;
+        // OptimizeLLK at C3 (one 4-point item per wave and round) 7.8 / 7.55 / 7.35 ms, at 10 000 markers 2.39 /
+        // 2.31 / 2.43 ms.)
+#ifndef VB2_PF_M2
+#define VB2_PF_M2 4
+#endif
+#ifndef VB2_PF_SEARCH
+#define VB2_PF_SEARCH 2
+#endif
+        constexpr int kPf = STREAM ? kPrefetch : MODE == 2 ? VB2_PF_M2 : VB2_PF_SEARCH;
+        vuint2 w[kPf];
         // (STREAM: rows past the tile's last are the NEXT tiles' -- another workgroup's, at another time: fetched here
         // they came from HBM twice, 573 MB instead of 356 MB per one-point step of 32 C3 samples (FETCH_SIZE, round 3).
         // The row index is clamped to the tile's last row instead: the same cache line again, no new bytes.)
         const int last_row = rows > 0 ? rows - 1 : 0;
 #pragma unroll
-        for (int j = 0; j < kPrefetch; ++j) w[j] = cp[(size_t)(STREAM ? (j < last_row ? j : last_row) : j) * kMtMarkers];
-        for (int s0 = 0; s0 < rows; s0 += kPrefetch) {
+        for (int j = 0; j < kPf; ++j) w[j] = cp[(size_t)(STREAM ? (j < last_row ? j : last_row) : j) * kMtMarkers];
+        for (int s0 = 0; s0 < rows; s0 += kPf) {
 #pragma unroll
-            for (int u = 0; u < kPrefetch; ++u) {
+            for (int u = 0; u < kPf; ++u) {
                 if (s0 + u >= rows) break;
                 const vuint2 w_cur = w[u];
-                w[u] = cp[(size_t)(STREAM ? (s0 + u + kPrefetch < last_row ? s0 + u + kPrefetch : last_row)
-                                          : s0 + u + kPrefetch) * kMtMarkers];
+                w[u] = cp[(size_t)(STREAM ? (s0 + u + kPf < last_row ? s0 + u + kPf : last_row)
+                                          : s0 + u + kPf) * kMtMarkers];
 #pragma unroll
                 for (int j = 0; j < (W16 ? 4 : 2); ++j) {
                     // one run: `n` reads of the same (class, quality) -> n * table row.  The run
