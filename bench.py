@@ -360,7 +360,9 @@ def main():
             for _ in range(n2p):
                 step_pl()
             dtp = time.perf_counter() - t1
-            if not np.array_equal(got_pl[:B], got_sh):
+            # (one rank: bit for bit; several: the collective may add a 240-element and a 48-element buffer in different orders)
+            if not (np.array_equal(got_pl[:B], got_sh) if world == 1 else
+                    np.allclose(got_pl[:B], got_sh, rtol=1e-12, atol=0.0)):
                 raise RuntimeError("marker-sharded: the %d-point call and the %d-point call disagree" % (NCH * B, B))
             g2.optimize()
             t_opt = []
