@@ -1,6 +1,9 @@
 """In-kernel timeline of llk_eval_kernel from per-workgroup wall-clock stamps (VB2_STAMPS=1)."""
 import os, sys, ctypes as C
 os.environ["VB2_STAMPS"] = "1"
+_stamps_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "verifybamid_amd", "libvb2_stamps.so")
+if os.path.exists(_stamps_lib):
+    os.environ.setdefault("VB2_LIB_PATH", _stamps_lib)      # (the stamps are compiled out of libvb2.so)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import verifybamid_amd as vb

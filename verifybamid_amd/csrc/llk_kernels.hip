@@ -230,6 +230,14 @@ __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
 // slots for ds_read_b128 (bank = (addr/4) % 64).
 
 constexpr int kExpTabDoubles = 64 * 32;    // exp_nonpos's table in LDS (16 KiB)
+// The in-kernel profiling stamps (tools/stamps*.py) are compiled in only with -DVB2_WITH_STAMPS (csrc/Makefile builds
+// that variant as libvb2_stamps.so): the tests they leave behind in every kernel cost 0.6 % of a 48-point launch
+// and 4 % of a small sample's search.
+#ifdef VB2_WITH_STAMPS
+#define VB2_STAMPS_OF(L) ((L).stamps)
+#else
+#define VB2_STAMPS_OF(L) (static_cast<unsigned long long*>(nullptr))
+#endif
 constexpr int kPrefetch = 8;               // rows of run dwords in flight per lane
 
 // Lane -> (marker m in the micro-tile, candidate slot g).
@@ -361,8 +369,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     lane_map<HWMAP>(lane, m, g4);
     const int g = g4 & (SLOTS - 1);              // candidate slot
     const int half = TPW == 1 ? 0 : g4 / SLOTS;  // which of the item's TPW micro-tiles
-    // profiling aid: 100 MHz wall-clock stamps per workgroup (L.stamps == nullptr normally)
-    unsigned long long* stamps = L.stamps ? L.stamps + (size_t)blk * 8 : nullptr;
+    // profiling aid: 100 MHz wall-clock stamps per workgroup (stamps pointer null normally)
+    unsigned long long* stamps = VB2_STAMPS_OF(L) ? VB2_STAMPS_OF(L) + (size_t)blk * 8 : nullptr;
     if (stamps && tid == 0) stamps[0] = wall_clock64();
 
     const bool hook_blk = hook.on_block(), hook_mine = hook.mine();
@@ -808,7 +816,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     __syncthreads();
     if (stamps && tid == 0) {
         stamps[5] = wall_clock64();
-        if (blk == 0 && nblk > 32) L.stamps[20 * 8 + 7] += stamps[5] - L.stamps[7];     // (accumulated: since "has the round")
+        if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[20 * 8 + 7] += stamps[5] - VB2_STAMPS_OF(L)[7];     // (accumulated: since "has the round")
     }
     if (ticket == nullptr) {                     // two-kernel mode: llk_finalize_kernel follows
         if (tid < NPT) partials[(size_t)tid * nblk + blk] = red[tid];
@@ -928,7 +936,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     }
     if (stamps && tid == 0) {
         stamps[6] = wall_clock64();
-        if (blk == 0 && nblk > 32) L.stamps[21 * 8 + 7] += stamps[6] - L.stamps[7];
+        if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[21 * 8 + 7] += stamps[6] - VB2_STAMPS_OF(L)[7];
     }
     if (done_flag) {
         // host hand-off without a stream synchronisation: results (in mapped host memory)
