@@ -310,6 +310,7 @@ struct NoHook {
     __device__ bool on_block() const { return false; }
     __device__ bool mine() const { return false; }
     __device__ void run() {}
+    __device__ bool keep_etab() const { return false; }     // (the 2^(j/64) table of an earlier call is still in LDS)
 };
 // The waves of a workgroup pull (tile, group) items through the LDS queue (per-item result slots) when there
 // are at most dyn_limit of them per wave; else the static deal (cohort launches).
@@ -392,10 +393,11 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // 2^(j/64) table of exp_nonpos, one copy per pair of LDS banks (see there)
     // (entry j = e / 32 is the same for a half-wave: two SCALAR loads per step, no vector-memory
     // round trip before the first barrier)
-    for (int jb = 2 * wave; jb < 64; jb += 2 * nwave) {
-        const double t0 = kExp2Tab[jb], t1 = kExp2Tab[jb + 1];
-        etab[jb * 32 + lane] = lane < 32 ? t0 : t1;
-    }
+    if (!hook.keep_etab())
+        for (int jb = 2 * wave; jb < 64; jb += 2 * nwave) {
+            const double t0 = kExp2Tab[jb], t1 = kExp2Tab[jb + 1];
+            etab[jb * 32 + lane] = lane < 32 ? t0 : t1;
+        }
     // With several groups a thread builds several table entries: the primary-code records (a
     // few dozen) go to LDS first so that the loop below does not wait on a global load per
     // entry.  With one group each thread builds about one entry and loads its record directly.
