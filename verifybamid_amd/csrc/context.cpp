@@ -565,7 +565,9 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // word of a double whose low word is 0).  Unused slots: the padding row (zeros) with count +0.0.
     // Two runs per (row, marker) entry.  16-bit offsets reach 163 wide rows; a bigger dictionary
     // gets the narrow rows (and 4-point launches only).
-    const int row_bytes = num_code <= kMaxWideCodes ? kRowBytesWide : kRowBytesNarrow;
+    // (VB2_FORCE_NARROW=1: an experiment knob -- narrow table rows although the dictionary would fit wide ones)
+    static const bool force_narrow = std::getenv("VB2_FORCE_NARROW") && std::getenv("VB2_FORCE_NARROW")[0] == '1';
+    const int row_bytes = (num_code <= kMaxWideCodes && !force_narrow) ? kRowBytesWide : kRowBytesNarrow;
     auto run_word = [&](int d, uint32_t n) {
         const double nd = (double)n;
         unsigned long long bits;

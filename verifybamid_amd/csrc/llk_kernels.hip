@@ -274,7 +274,11 @@ __device__ __forceinline__ int lane_of(int m, int g)
 // workgroup, and that redundant work is 9 % of a launch's transcendentals at one
 // workgroup per CU but 18 % at two.
 template <int MODE> struct Geom;
+#ifdef VB2_M1_W8     // (experiment: the one-point-per-lane shape held to 64 registers, two workgroups per CU)
+template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 8; };
+#else
 template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
+#endif
 template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<3> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<4> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
@@ -1151,9 +1155,14 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         const LaunchGeom gm2 = launch_geom(L, 2, kMaxGroups);
         // (8-point groups need the wide table rows; a context whose dictionary is too big for
         // 16-bit offsets into wide rows has narrow ones and evaluates 4 points per launch)
-        const int cap = L.row_bytes == kRowBytesWide ? 8 * max_groups(L, 2, gm2.grid, gm2.block_waves) : 4;
+        // (VB2_ONE_POINT=n, an experiment knob for narrow-row contexts: n groups of FOUR points per launch in the
+        // one-point-per-lane shape)
+        static const int one_point = std::getenv("VB2_ONE_POINT") ? std::atoi(std::getenv("VB2_ONE_POINT")) : 0;
+        const bool m1 = one_point > 0 && L.row_bytes != kRowBytesWide;
+        const int cap = m1 ? 4 * std::min(one_point, max_groups(L, 1, gm2.grid, gm2.block_waves))
+                           : L.row_bytes == kRowBytesWide ? 8 * max_groups(L, 2, gm2.grid, gm2.block_waves) : 4;
         const int step = left < cap ? left : cap;
-        const int ngrp = step > 4 ? (step + 7) / 8 : 1;
+        const int ngrp = step > 4 ? (m1 ? (step + 3) / 4 : (step + 7) / 8) : 1;
         unsigned long long* df = (done + step >= num_point) ? done_flag : nullptr;   // last launch signals
         unsigned long long* df_eval = tk ? df : nullptr;
         hipError_t e;
@@ -1161,7 +1170,9 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         // matters), arrival ticket for bigger batches (cheaper per point); VB2_REDUCE overrides
         const bool tagged = reduce_mode == 2 || (reduce_mode == 0 && step <= 4);
         const unsigned long long tag = tagged ? ++*tag_counter : 0ull;   // unique per launch on this buffer
-        if (step > 4)
+        if (step > 4 && m1)
+            e = launch_btl<1, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
+        else if (step > 4)
             e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched)
                         : launch_btl<2, false>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
         else if (g_paired && step == 1)
