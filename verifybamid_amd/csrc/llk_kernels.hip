@@ -329,13 +329,16 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // QUEUE: 1 = the launch is known (on the host, by eval_is_dynamic) to take its work items through the LDS queue, 0 = the
 // static deal, -1 = decided in the kernel.  The single-sample kernels are compiled for both: with the other way's code
 // gone a 48-point launch is 1.8 % shorter and a search round 5 % (fewer scalar registers spilled to vector lanes).
-template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1>
+// ONEGRP: the launch is known to carry ONE group of points (every shape but the 8-point one always does; cohort steps
+// and search rounds too): the group loops and the item -> (group, unit) division go at compile time.
+template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1,
+          bool ONEGRP = (MODE >= 3)>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
           unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
           unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
-          unsigned int* __restrict__ batch_done, unsigned int batch_active, const int ngrp,
+          unsigned int* __restrict__ batch_done, unsigned int batch_active, const int ngrp_in,
           const unsigned long long tag, const Schedule sch, const bool coherent_points = false,
           const int tid_in = -1, const double* lds_rows = nullptr /* the parameter rows, already in LDS */,
           Hook hook = Hook())
@@ -354,6 +357,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // A launch carries ngrp groups of NP points; each group has its own table and the
     // (tile, group) pairs are the work items, so a bigger batch re-reads the pileup from
     // L2 per group but pays launch, prologue and reduction once.
+    const int ngrp = ONEGRP ? 1 : ngrp_in;
     const int NPT = NP * ngrp;                  // points of this launch
     double* etab = lds;                         // [64][32] exp_nonpos's 2^(j/64), bank-replicated; at LDS address 0
     double* tab = lds + kExpTabDoubles;         // [ngrp][nrow][RS]
@@ -1003,7 +1007,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
     const int stride = 2 * L.num_pc + 1;
     InlinePoints ip;
     ip.count = 0;
-    eval_body<MODE, HWMAP, W16, NoHook, true>(L, ip, points + (size_t)s * NP * stride, nv,
+    eval_body<MODE, HWMAP, W16, NoHook, true, -1, true>(L, ip, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1, use_ticket ? 0ull : done_seq,
