@@ -331,8 +331,10 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // gone a 48-point launch is 1.8 % shorter and a search round 5 % (fewer scalar registers spilled to vector lanes).
 // ONEGRP: the launch is known to carry ONE group of points (every shape but the 8-point one always does; cohort steps
 // and search rounds too): the group loops and the item -> (group, unit) division go at compile time.
+// KAF: 0 = the context is known to have no known-allele-frequency column (the usual case: AF from UD x PC): its tests go
+// at compile time (+1.2 % on the 48-point launch, the only shape compiled this way); -1 = decided in the kernel.
 template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1,
-          bool ONEGRP = (MODE >= 3)>
+          bool ONEGRP = (MODE >= 3), int KAF = -1>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -358,6 +360,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // (tile, group) pairs are the work items, so a bigger batch re-reads the pileup from
     // L2 per group but pays launch, prologue and reduction once.
     const int ngrp = ONEGRP ? 1 : ngrp_in;
+    const double* const known_af_p = KAF == 0 ? nullptr : L.known_af;
     const int NPT = NP * ngrp;                  // points of this launch
     double* etab = lds;                         // [64][32] exp_nonpos's 2^(j/64), bank-replicated; at LDS address 0
     double* tab = lds + kExpTabDoubles;         // [ngrp][nrow][RS]
@@ -490,7 +493,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     g_cdouble* const g_ediag = (g_cdouble*)L.ediag;
     g_cdouble* const g_ud = (g_cdouble*)L.ud;
     g_cdouble* const g_mu = (g_cdouble*)L.mu;
-    g_cdouble* const g_kaf = (g_cdouble*)L.known_af;
+    g_cdouble* const g_kaf = (g_cdouble*)known_af_p;
     // The per-marker likelihoods of a work item are MULTIPLIED (mantissa x 2^exponent): over
     // the 16 markers of the tile by a butterfly, then slot by slot in the block reduction.
     auto tile_product = [&](ScaledProd* p, bool cross) {  // over the 16 lanes sharing slot g (+ the item's other tiles)
@@ -590,8 +593,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         // (the panel row of the marker too: up to four UD columns and the mean)
         double udr[4], mur = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) udr[kk] = (!L.known_af && kk < k) ? g_ud[(size_t)kk * mp + posc] : 0.0;
-        if (!L.known_af) mur = g_mu[posc];
+        for (int kk = 0; kk < 4; ++kk) udr[kk] = (!known_af_p && kk < k) ? g_ud[(size_t)kk * mp + posc] : 0.0;
+        if (!known_af_p) mur = g_mu[posc];
 
         // the six off-diagonal sums start from the marker's "other base" constant (it is part of
         // every genotype pair's sum, h:299-303), so the epilogue needs no separate addition
@@ -680,7 +683,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         for (int t = 0; t < BTL; ++t) { lk_m[t] = 1.0; lk_e[t] = 0; }
         if (live) {
             double af1[BTL], af2[BTL];
-            if (L.known_af) {
+            if (known_af_p) {
                 const double a = g_kaf[pos];
 #pragma unroll
                 for (int t = 0; t < BTL; ++t) af1[t] = af2[t] = a;
@@ -976,14 +979,14 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     }
 }
 
-template <int MODE, bool HWMAP, int QUEUE>
+template <int MODE, bool HWMAP, int QUEUE, int KAF = -1>
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
                 int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
                 unsigned long long done_seq, int ngrp, unsigned long long tag, const Schedule sch)
 {
-    eval_body<MODE, HWMAP, false, NoHook, false, QUEUE>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
+    eval_body<MODE, HWMAP, false, NoHook, false, QUEUE, (MODE >= 3), KAF>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
                            blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
 }
 
@@ -1093,7 +1096,7 @@ void set_lane_mapping(bool hw) { g_hwmap = hw; }
 // object is per device in the runtime), so the flag is kept per (function slot, device).
 static hipError_t raise_lds_limit(const void* fn, int slot)
 {
-    constexpr int kSlots = 48, kDevs = 64;
+    constexpr int kSlots = 68, kDevs = 64;
     static std::atomic<unsigned char> done[kSlots][kDevs];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1122,11 +1125,14 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
     const size_t shmem = eval_shmem_np(L, NP, gm.grid, gm.block_waves, ngrp);
     // (the plain lane map is an A/B knob: one kernel that decides in the kernel; the hardware lane map: one per way)
     const bool dyn = eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, ngrp);
+    const bool no_kaf = MODE == 2 && HWMAP && L.known_af == nullptr;      // (the 8-point shape: also compiled without that column)
     const void* fn = !HWMAP ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, -1>)
+                     : no_kaf ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, (MODE == 2 ? 0 : -1)>)
+                                     : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0, (MODE == 2 ? 0 : -1)>))
                      : dyn  ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1>)
                             : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0>);
     {
-        hipError_t e = raise_lds_limit(fn, 28 + ((MODE - 1) * 2 + (HWMAP ? 1 : 0)) * 2 + (dyn ? 1 : 0));
+        hipError_t e = raise_lds_limit(fn, (no_kaf ? 48 : 28) + ((MODE - 1) * 2 + (HWMAP ? 1 : 0)) * 2 + (dyn ? 1 : 0));
         if (e != hipSuccess) return e;
     }
     InlinePoints ip;
