@@ -333,8 +333,10 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // and search rounds too): the group loops and the item -> (group, unit) division go at compile time.
 // KAF: 0 = the context is known to have no known-allele-frequency column (the usual case: AF from UD x PC): its tests go
 // at compile time (+1.2 % on the 48-point launch, the only shape compiled this way); -1 = decided in the kernel.
+// KSEL: --NumPC when it is 2 (the reference's default) or 4 (its usual setting), else 0 = read from the layout: the
+// guards and address multiples of the projection go at compile time (+1.4 % on the 48-point launch; that shape only).
 template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1,
-          bool ONEGRP = (MODE >= 3), int KAF = -1>
+          bool ONEGRP = (MODE >= 3), int KAF = -1, int KSEL = 0>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -354,7 +356,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const int nrow = L.num_code + 1;
     const int nthread = blockDim.x;
     const int nwave = nthread >> 6;
-    const int k = L.num_pc;
+    const int k = KSEL > 0 ? KSEL : L.num_pc;
     const int stride = 2 * k + 1;
     // A launch carries ngrp groups of NP points; each group has its own table and the
     // (tile, group) pairs are the work items, so a bigger batch re-reads the pileup from
@@ -979,14 +981,14 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     }
 }
 
-template <int MODE, bool HWMAP, int QUEUE, int KAF = -1>
+template <int MODE, bool HWMAP, int QUEUE, int KAF = -1, int KSEL = 0>
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
                 int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
                 unsigned long long done_seq, int ngrp, unsigned long long tag, const Schedule sch)
 {
-    eval_body<MODE, HWMAP, false, NoHook, false, QUEUE, (MODE >= 3), KAF>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
+    eval_body<MODE, HWMAP, false, NoHook, false, QUEUE, (MODE >= 3), KAF, KSEL>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
                            blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
 }
 
@@ -1096,7 +1098,7 @@ void set_lane_mapping(bool hw) { g_hwmap = hw; }
 // object is per device in the runtime), so the flag is kept per (function slot, device).
 static hipError_t raise_lds_limit(const void* fn, int slot)
 {
-    constexpr int kSlots = 68, kDevs = 64;
+    constexpr int kSlots = 108, kDevs = 64;
     static std::atomic<unsigned char> done[kSlots][kDevs];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1126,13 +1128,19 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
     // (the plain lane map is an A/B knob: one kernel that decides in the kernel; the hardware lane map: one per way)
     const bool dyn = eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, ngrp);
     const bool no_kaf = MODE == 2 && HWMAP && L.known_af == nullptr;      // (the 8-point shape: also compiled without that column)
+    constexpr int kKaf0 = MODE == 2 ? 0 : -1, kK2 = MODE == 2 ? 2 : 0, kK4 = MODE == 2 ? 4 : 0;
+    const int ksel = no_kaf ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
     const void* fn = !HWMAP ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, -1>)
-                     : no_kaf ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, (MODE == 2 ? 0 : -1)>)
-                                     : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0, (MODE == 2 ? 0 : -1)>))
+                     : ksel == 4 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKaf0, kK4>)
+                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0, kKaf0, kK4>))
+                     : ksel == 2 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKaf0, kK2>)
+                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0, kKaf0, kK2>))
+                     : no_kaf ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKaf0>)
+                                     : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0, kKaf0>))
                      : dyn  ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1>)
                             : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0>);
     {
-        hipError_t e = raise_lds_limit(fn, (no_kaf ? 48 : 28) + ((MODE - 1) * 2 + (HWMAP ? 1 : 0)) * 2 + (dyn ? 1 : 0));
+        hipError_t e = raise_lds_limit(fn, (ksel == 4 ? 88 : ksel == 2 ? 68 : no_kaf ? 48 : 28) + ((MODE - 1) * 2 + (HWMAP ? 1 : 0)) * 2 + (dyn ? 1 : 0));
         if (e != hipSuccess) return e;
     }
     InlinePoints ip;
