@@ -352,7 +352,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     constexpr int TPW = MODE == 3 ? 2 : (MODE == 4 || MODE == 5) ? 4 : 1;   // micro-tiles per wave
     constexpr int SLOTS = 4 / TPW;                           // candidate slots per wave
     constexpr int NP = SLOTS * BTL;
-    const int RS = L.row_bytes >> 3;            // doubles per table row (>= 6 * NP + 2)
+    const int row_bytes = MODE == 2 ? kRowBytesWide : L.row_bytes;      // (the 8-point shape needs the wide rows: the launcher sees to it)
+    const int RS = row_bytes >> 3;              // doubles per table row (>= 6 * NP + 2)
     const int nrow = L.num_code + 1;
     const int nthread = blockDim.x;
     const int nwave = nthread >> 6;
@@ -578,7 +579,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         const uint32_t it = TPW * unit + (uint32_t)half;     // index in this workgroup's tile list
         const bool have_tile = TPW == 1 || it < ntile_blk;   // TPW > 1: the list's end may leave lanes idle
         const uint32_t mt = have_tile ? blk + it * nblk : blk;
-        const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)L.row_bytes + (uint32_t)g * (6 * BTL * 8));
+        const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)row_bytes + (uint32_t)g * (6 * BTL * 8));
         const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
         while (!dyn && grp_wave < grp) {                     // wave-uniform
             flush_wave(grp_wave);
@@ -660,7 +661,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                         const uint32_t idx = (j & 1) ? ((w2 >> 16) & 0xffu) : (w2 & 0xffu);
                         const uint32_t cnt = (j & 1) ? (w2 >> 24) : ((w2 >> 8) & 0xffu);
                         n = (double)cnt;
-                        row_addr = my_tab + idx * (uint32_t)L.row_bytes;
+                        row_addr = my_tab + idx * (uint32_t)row_bytes;
                     } else {
                         const uint32_t rw = j ? w_cur.y : w_cur.x;
                         n = __hiloint2double((int)(rw & 0xffff0000u), 0);
