@@ -333,6 +333,11 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     ml.shmem = shmem_[shape];
     ml.force_ticket = false;
     ml.w16 = w16_;
+    {   // (the cohort kernels compiled for --NumPC 2 / 4 without a known-AF column)
+        bool plain = num_pc == 2 || num_pc == 4;
+        for (int s2 = 0; s2 < num_sample && plain; ++s2) plain = ctx_[s2]->L.known_af == nullptr;
+        ml.ksel = plain ? num_pc : 0;
+    }
     VB2_HIP(launch_llk_eval_multi(ml, stream_));
     ++num_launch;
     in_flight_ = true;

@@ -126,6 +126,8 @@ struct MultiLaunch {
     int np;                          // points per sample of this step: 1, 2, 4 or 8 (picks the wave shape)
     bool force_ticket;               // arrival-ticket hand-off instead of tagged sets (the retry after a NaN)
     bool w16;                        // every sample has codes16: stream the 16-bit run lists
+    int ksel;                        // 2 or 4: every sample has --NumPC of that and no known-AF column (the kernels compiled
+                                     // for it); 0: the general kernels
     size_t shmem;
 };
 size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);   // groups of 4*btl points

@@ -996,7 +996,7 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
 // w / bps as that sample's workgroup w % bps.  Every sample has its own layout, parameter rows,
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
-template <int MODE, bool HWMAP, bool W16>
+template <int MODE, bool HWMAP, bool W16, int KSEL = 0>     // KSEL 2 / 4: every sample has that --NumPC and no known-AF column
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* __restrict__ scheds,
                       const double* __restrict__ points,
@@ -1013,7 +1013,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
     const int stride = 2 * L.num_pc + 1;
     InlinePoints ip;
     ip.count = 0;
-    eval_body<MODE, HWMAP, W16, NoHook, true, -1, true>(L, ip, points + (size_t)s * NP * stride, nv,
+    eval_body<MODE, HWMAP, W16, NoHook, true, -1, true, (KSEL > 0 ? 0 : -1), KSEL>(L, ip, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1, use_ticket ? 0ull : done_seq,
@@ -1099,7 +1099,7 @@ void set_lane_mapping(bool hw) { g_hwmap = hw; }
 // object is per device in the runtime), so the flag is kept per (function slot, device).
 static hipError_t raise_lds_limit(const void* fn, int slot)
 {
-    constexpr int kSlots = 108, kDevs = 64;
+    constexpr int kSlots = 200, kDevs = 64;
     static std::atomic<unsigned char> done[kSlots][kDevs];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1129,13 +1129,15 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
     // (the plain lane map is an A/B knob: one kernel that decides in the kernel; the hardware lane map: one per way)
     const bool dyn = eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, ngrp);
     const bool no_kaf = MODE == 2 && HWMAP && L.known_af == nullptr;      // (the 8-point shape: also compiled without that column)
-    constexpr int kKaf0 = MODE == 2 ? 0 : -1, kK2 = MODE == 2 ? 2 : 0, kK4 = MODE == 2 ? 4 : 0;
-    const int ksel = no_kaf ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
+    constexpr bool kSpecK = MODE >= 2;                                       // (not the A/B shape 1)
+    constexpr int kKaf0 = MODE == 2 ? 0 : -1, kKafK = kSpecK ? 0 : -1, kK2 = kSpecK ? 2 : 0, kK4 = kSpecK ? 4 : 0;
+    const bool plain_ctx = HWMAP && L.known_af == nullptr;
+    const int ksel = plain_ctx && kSpecK && (MODE == 2 || dyn) ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
     const void* fn = !HWMAP ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, -1>)
-                     : ksel == 4 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKaf0, kK4>)
-                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0, kKaf0, kK4>))
-                     : ksel == 2 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKaf0, kK2>)
-                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0, kKaf0, kK2>))
+                     : ksel == 4 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKafK, kK4>)
+                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, (MODE == 2 ? 0 : 1), kKafK, kK4>))
+                     : ksel == 2 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKafK, kK2>)
+                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, (MODE == 2 ? 0 : 1), kKafK, kK2>))
                      : no_kaf ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKaf0>)
                                      : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0, kKaf0>))
                      : dyn  ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1>)
@@ -1264,18 +1266,30 @@ static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream, i
     constexpr bool kHas16 = MODE == 4 || MODE == 5;
     const int variant = !g_hwmap ? 0 : (kHas16 && ml.w16) ? 2 : 1;
     const int use_ticket = ml.force_ticket ? 1 : 0;
-    auto go = [&](auto kernel) -> hipError_t {
-        hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kernel), slot_base + variant);
+    auto go = [&](auto kernel, int kslot) -> hipError_t {
+        hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kernel), 108 + (slot_base + variant) * 3 + kslot);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, grid, block, ml.shmem, stream, ml.d_layouts, ml.d_scheds, ml.d_points,
                            ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps, ml.done_flag, ml.done_seq,
                            ml.d_batch_done, ml.batch_active, use_ticket);
         return hipGetLastError();
     };
-    if (variant == 0) return go(&llk_eval_multi_kernel<MODE, false, false>);
-    if constexpr (kHas16)
-        if (variant == 2) return go(&llk_eval_multi_kernel<MODE, true, true>);
-    return go(&llk_eval_multi_kernel<MODE, true, false>);
+    if (variant == 0) return go(&llk_eval_multi_kernel<MODE, false, false>, 0);
+    // (the shapes a cohort search uses -- not the A/B shape 1 -- also compiled for --NumPC 2 / 4 without a known-AF
+    // column: one-point steps of 32 samples 99 -> 94 us)
+    constexpr bool kSpec = MODE >= 2;
+    if constexpr (kHas16) {
+        if (variant == 2) {
+            if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, true, 4>, 1);
+            if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, true, 2>, 2);
+            return go(&llk_eval_multi_kernel<MODE, true, true>, 0);
+        }
+    }
+    if constexpr (kSpec) {
+        if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, false, 4>, 1);
+        if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, false, 2>, 2);
+    }
+    return go(&llk_eval_multi_kernel<MODE, true, false>, 0);
 }
 
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
@@ -1407,7 +1421,10 @@ hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, doubl
     }
     if (shmem > (size_t)kLdsLimitBytes || gm.grid > L.num_cu) return hipErrorInvalidConfiguration;
     const bool dyn = eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, 1);
-    const void* fn = g_paired ? (!g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<3, false, -1>)
+    const int ksel = (g_paired && g_hwmap && dyn && L.known_af == nullptr) ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
+    const void* fn = ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 4>)
+                     : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 2>)
+                     : g_paired ? (!g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<3, false, -1>)
                                  : dyn    ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1>)
                                           : reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 0>))
                               : (!g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<1, false, -1>)
