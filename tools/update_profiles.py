@@ -80,7 +80,7 @@ if os.path.isdir(cm):
     pth = [os.path.join(cm, f) for f in os.listdir(cm) if f.endswith("counter_collection.csv")][0]
     acc = {}
     for row in csv.DictReader(open(pth)):
-        mm = re.search(r"llk_eval_multi_kernel<(\d), (true|false)(?:, (true|false))?>", row["Kernel_Name"])
+        mm = re.search(r"llk_eval_multi_kernel<(\d), (true|false)(?:, (true|false))?(?:, \d+)?>", row["Kernel_Name"])
         if mm and row["Counter_Name"] == "FETCH_SIZE":
             acc.setdefault((int(mm.group(1)), mm.group(3) == "true"), []).append(float(row["Counter_Value"]))
     np_of = {4: 1, 5: 2, 3: 4, 2: 8}
