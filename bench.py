@@ -300,7 +300,10 @@ def main():
             valu_frac = issue_us / step_us
             valu["issue_us_per_launch"] = issue_us
         result["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            # `bound` names what binds this kernel (the nominal roofline of SURVEY 8d is HBM and
+            # achieved / peak / frac are quoted against it, but 48 points re-use ONE L2/LDS-resident copy of the
+            # pileup: the HBM side runs at 3-4 % of peak and the FP64 VALU issue rate is the ceiling -- valu_frac)
+            "bound": "valu_fp64", "nominal_bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "valu_frac": valu_frac,
             "traffic": traffic, "traffic_source": traffic_src,
             "hbm_actual_GBps": (traffic / (step_us * 1e-6) / 1e9) if traffic else None,
@@ -403,6 +406,40 @@ def main():
                 sp["points_%d" % nb] = {"device_us_per_launch": us, "evals_per_s": nb / us * 1e6,
                                         "frac": info["algorithmic_bytes_per_eval"] * nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
             result["search_point"] = sp
+            # the unfavourable quality alphabet (VERDICT r3 missing #3): the same sample shape with BAQ-like
+            # qualities 2..60 -- what BAM-derived pileups look like (the reference's own pileup applies BAQ and a
+            # min-BQ of 13: SimplePileupViewer.cpp:457-476) -- 118 dictionary codes, ~29 runs per marker instead of
+            # ~21: the cost of the path is per RUN, so this is where it is slowest.  Same 48 points, same launch.
+            wide = vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.05, seed=2, q_lo=2, q_hi=60)
+            wctx = vb.LikelihoodContext(wide, device=local_rank, stream=stream.cuda_stream)
+            winfo = wctx.info()
+            wout = torch.zeros(B, dtype=torch.float64, device="cuda")
+            w_us = timed_launches(wctx, pts, wout, B, stream, 1000, torch)
+            wide_llk = wout.cpu().numpy().copy()
+            wopt = None
+            if not args.no_optimize:
+                wctx.optimize()
+                t_w = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    west = wctx.optimize()
+                    t_w.append(time.perf_counter() - t1)
+                wopt = {"wall_ms_to_converged_alpha": 1e3 * min(t_w), "alpha": west["alpha"], "num_eval": west["num_eval"]}
+            wctx.close()
+            wj, wsrc = latest_profile("valu_b%d_wide.json" % B)
+            result["roofline_wide_alphabet"] = {
+                "what": "the headline launch on the same sample shape with base qualities uniform in 2..60 "
+                        "(BAQ-like; %d dictionary codes instead of %d)" % (winfo["num_code"], info["num_code"]),
+                "distinct_codes": int(winfo["num_code"]), "reads": int(winfo["num_read"]),
+                "device_us_per_launch": w_us, "evals_per_s": B / w_us * 1e6,
+                "achieved": winfo["algorithmic_bytes_per_eval"] * B / (w_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": winfo["algorithmic_bytes_per_eval"] * B / (w_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                "ratio_to_headline": (B / w_us * 1e6) / (B / (1e3 * dev_ms / args.steps) * 1e6),
+                "lane_instr_per_marker_point": wj.get("lane_instr_per_marker_point") if wj else None,
+                "valu_busy_frac": wj.get("valu_busy_frac") if wj else None,
+                "lds_busy_frac": wj.get("lds_busy_frac") if wj else None, "pmc_source": wsrc,
+                "optimize": wopt,
+            }
         if world == 1 and not args.no_optimize:
             # second half of the metric: wall-clock of OptimizeLLK (Initialize + Homo + Heter +
             # LLK0), best of 3; measured before the CPU leg so no OpenMP threads are around
@@ -499,9 +536,14 @@ def main():
                 pre = vb.synth.write_files(base, os.path.join(tmp, "panel"))
                 piles = []
                 for s_ in range(8):
-                    dd = vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.01 * (1 + s_), seed=2000 + s_)
-                    dd = vb.PileupData(k, base.ud, base.means, dd.read_off, dd.bases, dd.quals, base.alt_base, None,
-                                       dd.avg_depth, dd.sd_depth, True, dict(base.meta))
+                    # reads drawn ON the panel the files are run against (round 3 drew each pileup with its own
+                    # random panel and alleles and then swapped the panel in: the bytes were right, the likelihood
+                    # surface -- hence the search length -- was not)
+                    off_, ch_, qu_ = vb.synth.reads_on_panel(base.means, base.meta["ref_base"], base.alt_base,
+                                                             args.depth, alpha_true=0.01 * (1 + s_), seed=2000 + s_)
+                    dep_ = np.diff(off_).astype(np.float64)
+                    dd = vb.PileupData(k, base.ud, base.means, off_, ch_, qu_, base.alt_base, None,
+                                       float(dep_[dep_ > 0].mean()), 0.0, True, dict(base.meta))
                     piles.append(vb.synth.write_files(dd, os.path.join(tmp, "s%d" % s_)) + ".pileup")
                 nf = args.cohort_files
                 paths = [piles[i % len(piles)] for i in range(nf)]
@@ -521,17 +563,32 @@ def main():
                     "what": "vb2_cohort_run on %d C3-shaped text pileups (7.6 MB each) + one panel, outputs written; "
                             "wall-clock of the call" % nf,
                     "samples": nf, "samples_ok": ok, "seconds": dtf, "samples_per_s": nf / dtf,
-                    "alpha_first": res[0]["alpha"],
+                    "alpha_first": res[0]["alpha"], "alpha_true_first": 0.01,
+                    "alpha_by_distinct_sample": [res[i]["alpha"] for i in range(min(nf, 8))],
+                    "alpha_true_by_distinct_sample": [0.01 * (1 + i) for i in range(min(nf, 8))],
                 }
+                # (the reads belong to the panel: every estimate sits next to the value the reads were drawn with)
+                if ok and abs(res[0]["alpha"] - 0.01) > 5e-3:
+                    result["cohort"]["from_text"]["error"] = "alpha_first %.4g is not within 5e-3 of 0.01" % res[0]["alpha"]
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
         # small parity probe against the oracle (checker only; after the GPU legs: its OpenMP threads
         # spin for a while after the call and would slow the launching thread down)
         from oracle.bridge import oracle_data
         od = oracle_data(data)
+        # every timed point (round 3 probed the first two of the 48)
         want = np.array([od.llk(pts_h[i, :k], pts_h[i, k:2 * k], pts_h[i, 2 * k],
-                                num_thread=min(os.cpu_count() or 1, 16)) for i in range(min(B, 2))])
+                                num_thread=min(os.cpu_count() or 1, 16)) for i in range(B)])
         result["parity_probe_max_rel_err"] = float(np.max(np.abs(llk_dev[:len(want)] - want) / np.abs(want)))
+        result["parity_probe_points"] = int(len(want))
+        if world == 1 and "roofline_wide_alphabet" in result:
+            odw = oracle_data(wide)
+            nw = min(B, 8)
+            want_w = np.array([odw.llk(pts_h[i, :k], pts_h[i, k:2 * k], pts_h[i, 2 * k],
+                                       num_thread=min(os.cpu_count() or 1, 16)) for i in range(nw)])
+            result["roofline_wide_alphabet"]["parity_probe_max_rel_err"] = float(
+                np.max(np.abs(wide_llk[:nw] - want_w) / np.abs(want_w)))
+            result["roofline_wide_alphabet"]["parity_probe_points"] = nw
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample (~10 s wall): the C oracle on the SAME pileup, OpenMP over
             # markers like the reference; thread counts 1, 4 (the reference's default

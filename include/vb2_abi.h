@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VB2_ABI_VERSION 4
+#define VB2_ABI_VERSION 5
 
 typedef enum vb2_status {
     VB2_OK = 0,
@@ -261,10 +261,13 @@ int vb2_shard_group_create(const vb2_input *in, const int32_t *devices, int32_t 
  * the caller broadcasts the 128 bytes by its own means, then every rank builds the group with the
  * WHOLE sample, its device, its rank.  Every evaluation is launch + ncclAllReduce on the
  * context's stream; all ranks receive identical sums and take identical search decisions.
- * id128 == NULL gives a group without a communicator: vb2_shard_group_eval then returns this rank's
- * PARTIAL sums (the whole sums when nranks == 1) and the caller reduces them over its own transport
- * (torch.distributed, MPI); vb2_shard_group_optimize_llk needs whole sums and refuses such a group
- * when nranks > 1. */
+ * id128 == VB2_SHARD_PARTIAL_SUMS asks for a group WITHOUT a communicator: vb2_shard_group_eval then
+ * returns this rank's PARTIAL sums and the caller reduces them over its own transport
+ * (torch.distributed, MPI); vb2_shard_group_optimize_llk needs whole sums and refuses such a group.
+ * id128 == NULL is accepted with nranks == 1 only (one rank needs no communicator); with more ranks it
+ * is VB2_ERR_INVALID -- since ABI 5: a forgotten id used to yield plausible but partial LLKs silently.
+ * vb2_shard_info.partial_sums says which kind a group is. */
+#define VB2_SHARD_PARTIAL_SUMS ((const void *)(uintptr_t)1)
 int vb2_rccl_unique_id(void *id128 /* 128 bytes out */);
 int vb2_shard_group_create_rank(const vb2_input *in, int32_t device, int32_t rank, int32_t nranks,
                                 const void *id128, vb2_shard_group **out);
@@ -282,6 +285,9 @@ typedef struct vb2_shard_info {
     int32_t marker_lo[64];     /* marker range of each owned shard                 */
     int32_t marker_hi[64];
     int64_t num_read[64];      /* reads of each owned shard                        */
+    int32_t partial_sums;      /* 1: no communicator by request (VB2_SHARD_PARTIAL_SUMS): eval = this rank's part */
+    int32_t rccl_stub;         /* 1: the collective library bound at run time is the test stand-in
+                                * (VB2_RCCL_LIB=tests/stub_rccl/librccl_stub.so), not librccl                */
 } vb2_shard_info;
 int vb2_shard_group_info(const vb2_shard_group *g, vb2_shard_info *info);
 /* The partition itself (no device needed): shard `rank` of `nranks` owns markers [*lo, *hi), cut so

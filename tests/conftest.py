@@ -16,11 +16,12 @@ def _ensure_built():
     need = [os.path.join(ROOT, "verifybamid_amd", "libvb2.so"),
             os.path.join(ROOT, "verifybamid_amd", "bin", "VerifyBamID"),
             os.path.join(ROOT, "oracle", "liboracle.so"),
-            os.path.join(ROOT, "oracle", "_check_exp.bin")]
+            os.path.join(ROOT, "oracle", "_check_exp.bin"),
+            os.path.join(ROOT, "tests", "stub_rccl", "librccl_stub.so")]
     # ... and rebuilds them whenever a source is newer than the oldest artefact: a stale binary
     # must not mask a broken source file (make itself only recompiles what changed)
     srcs = []
-    for d in ("verifybamid_amd/csrc", "include", "oracle"):
+    for d in ("verifybamid_amd/csrc", "include", "oracle", "tests/stub_rccl"):
         for f in os.listdir(os.path.join(ROOT, d)):
             if f.endswith((".cpp", ".hip", ".inc", ".h", ".c", "Makefile")):
                 srcs.append(os.path.join(ROOT, d, f))

@@ -845,7 +845,7 @@ def test_c4_marker_shards_at_full_size(golden_dir, c3):
     parts = []
     reads = 0
     for r in range(8):
-        with vb.ShardGroup(c3, device=0, rank=r, nranks=8, unique_id=None) as gr:
+        with vb.ShardGroup(c3, device=0, rank=r, nranks=8, unique_id=vb.ShardGroup.PARTIAL_SUMS) as gr:
             ir = gr.info()
             assert ir["num_shard"] == 1 and ir["nranks"] == 8 and ir["rank"] == r
             assert (ir["marker_lo"][0], ir["marker_hi"][0]) == (info["marker_lo"][r], info["marker_hi"][r])
@@ -863,6 +863,97 @@ def test_c4_marker_shards_at_full_size(golden_dir, c3):
         assert g1.info()["num_allreduce"] >= 1
         e1 = g1.optimize()                    # (one rank: the search runs against the resident kernel, no collective)
         assert e1["alpha"] == one["alpha"] and e1["num_eval"] == one["num_eval"] and e1["llk1"] == one["llk1"]
+
+
+STUB_RCCL = os.path.join(ROOT, "tests", "stub_rccl", "librccl_stub.so")
+
+
+def _stub_case(*args, timeout=900):
+    """One N > 1 case in a fresh process whose run-time binding of the collective library is the in-process
+    stand-in (tests/stub_rccl: ranks that may share the one device of this box)."""
+    import sys
+    assert os.path.exists(STUB_RCCL), "tests/stub_rccl/librccl_stub.so not built (__graft_entry__.build())"
+    # (more hardware queues than shard streams: two streams of one queue would run a rank's all-reduce kernel
+    # BEHIND the one that waits for it)
+    env = dict(os.environ, VB2_RCCL_LIB=STUB_RCCL, GPU_MAX_HW_QUEUES="8")
+    env.pop("VB2_SHARD_REDUCE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stub_rccl", "run_case.py")] + [str(a) for a in args],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def _est_ok(e, r):
+    assert abs(float.fromhex(e["alpha_hex"]) - float.fromhex(r["want_alpha_hex"])) <= 1e-9
+    l1 = float.fromhex(e["llk1_hex"])
+    assert abs(l1 - float.fromhex(r["want_llk1_hex"])) <= LLK_RTOL * abs(l1)
+    assert e["num_eval"] == r["want_num_eval"]
+
+
+@pytest.mark.parametrize("size,n", [("c2", 2), ("c2", 4), ("c3", 4)])
+def test_shard_group_of_n_shards_through_the_grouped_all_reduce(size, n):
+    """The N > 1 control flow of the one-process form, executed: vb2_shard_group_create over n
+    shards with `uses_rccl` -- ncclCommInitAll over n communicators, per batch n launches, the grouped
+    all-reduce loop over more than one communicator (shard.cpp), n publish kernels, one host wait per shard; the
+    search through the same path (launch + all-reduce per step).  The collective library is the in-process
+    stand-in (real RCCL refuses two ranks on one device).  LLKs: the committed oracle fixture to 1e-12, and bit
+    for bit the host-summed path's (the stand-in adds in rank order); alpha / num_eval: the fixture's."""
+    r = _stub_case("group", size, n)
+    assert r["info"] == {"num_shard": n, "nranks": 1, "uses_rccl": True, "rccl_stub": True, "partial_sums": False}
+    assert r["rel_vs_fixture"] <= LLK_RTOL
+    assert r["equals_host_sum"] and r["big_equals_tiled"]
+    assert r["allreduces_after_eval"] >= 2                     # one per call (a call's launches share ONE all-reduce)
+    assert r["allreduces_after_search"] > r["allreduces_after_eval"] + 100     # the search went through the collective
+    _est_ok(r["est"], r)
+    assert r["est"] == r["est_host"]                           # same sums, same trajectory
+
+
+@pytest.mark.parametrize("size,n", [("c2", 2), ("c3", 2), ("c2", 3)])
+def test_shard_group_rank_mode_with_several_ranks(size, n):
+    """The rank-per-process form with nranks > 1, executed: n threads of one process, each its own
+    vb2_shard_group_create_rank(rank r of n, the same 128-byte id) -- ncclCommInitRank with nranks > 1 -- each
+    evaluating and searching on its own: launch -> ncclAllReduce on the context's stream -> publish -> spin.
+    Every rank receives the same sums (the fixture's to 1e-12, the host-summed shards' bit for bit) and takes the
+    same decisions (alpha, num_eval: the fixture's)."""
+    r = _stub_case("ranks", size, n)
+    assert not any(r["errors"]), r["errors"]
+    assert r["all_ranks_equal"] and r["equals_host_sum"]
+    for q, rk in enumerate(r["ranks"]):
+        assert rk["info"] == {"num_shard": 1, "nranks": n, "rank": q, "uses_rccl": True, "rccl_stub": True,
+                              "partial_sums": False}
+        assert rk["rel_vs_fixture"] <= LLK_RTOL
+        assert rk["allreduces"] > 100
+        _est_ok(rk["est"], r)
+    assert all(rk["est"] == r["ranks"][0]["est"] for rk in r["ranks"])
+
+
+def test_rank_mode_without_an_id_is_refused_unless_partial_sums_are_asked_for(c2):
+    """nranks > 1 with a NULL id used to return this rank's partial sums without a word."""
+    d, _ = c2
+    with pytest.raises(_abi.Vb2Error):
+        vb.ShardGroup(d, device=0, rank=0, nranks=2, unique_id=None)
+    with vb.ShardGroup(d, device=0, rank=0, nranks=2, unique_id=vb.ShardGroup.PARTIAL_SUMS) as g:
+        i = g.info()
+        assert i["partial_sums"] and not i["uses_rccl"]
+        with pytest.raises(_abi.Vb2Error):
+            g.optimize()
+
+
+def test_bench_two_ranks_sharing_the_gpu_plumbing():
+    """`bench.py --gpus 2` on a one-GPU box (VB2_BENCH_SHARE_GPU=1: both ranks on device 0, gloo between them):
+    the self-spawn, the rendezvous on 127.0.0.1, barrier + max-over-ranks timing and the ONE JSON line."""
+    import sys
+    env = dict(os.environ, VB2_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10",
+                        "--markers", "20000", "--no-cpu-baseline", "--no-optimize", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 50 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["config"]["shared_gpu_plumbing_check"] is True and r["config"]["launched_by"] == "self-spawned ranks"
+    assert r["parity_probe_max_rel_err"] <= LLK_RTOL
 
 
 def test_shard_group_two_devices_rccl_all_reduce(c2):

@@ -2,7 +2,11 @@
 left behind are those of the last evaluation of the search."""
 import os, sys, ctypes as C
 os.environ["VB2_STAMPS"] = "1"
-_stamps_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "verifybamid_amd", "libvb2_stamps.so")
+# VB2_STAMPS_ROUND=1: the build whose per-workgroup stamps are those of round 200 (make stamps_round), times from
+# workgroup 0's entry into that round's evaluation
+_round = os.environ.get("VB2_STAMPS_ROUND", "") == "1"
+_stamps_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "verifybamid_amd",
+                           "libvb2_stamps_r.so" if _round else "libvb2_stamps.so")
 if os.path.exists(_stamps_lib):
     os.environ.setdefault("VB2_LIB_PATH", _stamps_lib)      # (the stamps are compiled out of libvb2.so)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +22,7 @@ buf = (C.c_ulonglong * (8 * 512))()
 lib.vb2_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 nb = lib.vb2_debug_read_stamps(ctx._h, buf, 512)
 s = np.array(buf[:8 * nb], dtype=np.float64).reshape(nb, 8)
-t0 = s[0, 7]
+t0 = s[0, 0] if _round else s[0, 7]
 if nb > 4 and s[4, 7] > 0:
     n = s[4, 7]
     print("device-side search, %d rounds, per round: control step %.2f us, relay hop (control done -> workgroup 0 has the "
@@ -39,8 +43,8 @@ if nb > 22 and s[4, 7] > 0:
           % (s[20, 7] / n / 100.0, s[21, 7] / n / 100.0))
 s = s[s[:, 0] > 0]
 us = (s - t0) / 100.0
-names = ["entry", "points in LDS", "table built", "wave0 tiles done", "last wave tiles done", "block reduced", "finalized (last block)"]
-print("blocks:", len(s), " t=0: round begun (loop top of the resident kernel)")
+names = ["entry", "points in LDS", "table built", "wave 1 out of its read loop", "slowest wave done", "block reduced", "finalized (last block)"]
+print("blocks:", len(s), " t=0: " + ("workgroup 0 enters the evaluation of round 200" if _round else "round begun (loop top of the resident kernel)"))
 for i, n in enumerate(names):
     col = us[:, i][s[:, i] > 0]
     if len(col): print("%-24s min %6.2f  median %6.2f  max %6.2f us" % (n, col.min(), np.median(col), col.max()))

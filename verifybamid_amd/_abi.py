@@ -104,7 +104,7 @@ class ShardInfo(C.Structure):
     _fields_ = [
         ("num_shard", C.c_int32), ("nranks", C.c_int32), ("rank", C.c_int32), ("uses_rccl", C.c_int32),
         ("num_allreduce", C.c_int64), ("marker_lo", C.c_int32 * 64), ("marker_hi", C.c_int32 * 64),
-        ("num_read", C.c_int64 * 64),
+        ("num_read", C.c_int64 * 64), ("partial_sums", C.c_int32), ("rccl_stub", C.c_int32),
     ]
 
 

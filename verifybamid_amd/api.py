@@ -334,7 +334,10 @@ class ShardGroup:
     ShardGroup(data, devices=[0, 1, ...])            one process drives all devices
     ShardGroup(data, device=d, rank=r, nranks=n, unique_id=b)   one process per GPU; rank 0 gets the
         128-byte id from ShardGroup.unique_id() and the caller broadcasts it (torch.distributed,
-        MPI, a file ...)."""
+        MPI, a file ...).  unique_id=ShardGroup.PARTIAL_SUMS: no communicator, llk() returns this rank's
+        partial sums (the caller reduces them); unique_id=None is accepted with nranks == 1 only."""
+
+    PARTIAL_SUMS = "partial-sums"
 
     def __init__(self, data: PileupData, devices=None, device=0, rank=0, nranks=1, unique_id=None):
         self._lib = _abi.lib()
@@ -347,7 +350,10 @@ class ShardGroup:
             _abi.check(self._lib.vb2_shard_group_create(C.byref(inp), arr, len(devices), C.byref(h)),
                        "vb2_shard_group_create")
         else:
-            idbuf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), 128)
+            if isinstance(unique_id, str) and unique_id == self.PARTIAL_SUMS:
+                idbuf = C.c_void_p(1)                      # VB2_SHARD_PARTIAL_SUMS
+            else:
+                idbuf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), 128)
             _abi.check(self._lib.vb2_shard_group_create_rank(C.byref(inp), int(device), int(rank), int(nranks),
                                                              idbuf, C.byref(h)),
                        "vb2_shard_group_create_rank")
@@ -377,6 +383,7 @@ class ShardGroup:
         _abi.check(self._lib.vb2_shard_group_info(self._h, C.byref(i)), "vb2_shard_group_info")
         n = i.num_shard
         return dict(num_shard=n, nranks=i.nranks, rank=i.rank, uses_rccl=bool(i.uses_rccl),
+                    partial_sums=bool(i.partial_sums), rccl_stub=bool(i.rccl_stub),
                     num_allreduce=int(i.num_allreduce), marker_lo=list(i.marker_lo[:n]),
                     marker_hi=list(i.marker_hi[:n]), num_read=[int(x) for x in i.num_read[:n]])
 

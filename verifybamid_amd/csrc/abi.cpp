@@ -605,6 +605,8 @@ int vb2_shard_group_info(const vb2_shard_group* g, vb2_shard_info* info)
     info->rank = sg.rank;
     info->uses_rccl = sg.use_rccl ? 1 : 0;
     info->num_allreduce = sg.num_allreduce;
+    info->partial_sums = sg.partial_sums ? 1 : 0;
+    info->rccl_stub = (sg.use_rccl && vb2::rccl_is_stub()) ? 1 : 0;
     for (size_t s = 0; s < sg.ctx.size() && s < 64; ++s) {
         info->marker_lo[s] = sg.lo[s];
         info->marker_hi[s] = sg.hi[s];

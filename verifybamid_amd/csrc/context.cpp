@@ -921,6 +921,10 @@ bool Context::resident_begin()
             const LaunchGeom gm = launch_geom(L, 1);
             ra.sched_multi = get(paired_mode() ? 3 : 1, 1, gm.grid, gm.block_waves);
             ra.sched_single = paired_mode() ? get(4, 1, gm.grid, gm.block_waves) : ra.sched_multi;
+            // the workgroups' own run lists in LDS for the whole search, if they fit (VB2_LDS_CACHE=0: the A/B knob)
+            static const bool lds_cache = !(std::getenv("VB2_LDS_CACHE") && std::atoi(std::getenv("VB2_LDS_CACHE")) == 0);
+            ra.cache_tiles = (L.num_mt + gm.grid - 1) / gm.grid;
+            ra.cache_rows = lds_cache ? (int32_t)resident_cache_rows(h_mt_rows.data(), L.num_mt, gm.grid) : 0;
         }
         ok = launch_llk_resident(L, &ra, d_partials, d_ticket, stream) == hipSuccess;
         if (!ok) (void)hipGetLastError();
@@ -1194,7 +1198,13 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
 
 int Context::ensure_codes16()
 {
+    //  two threads may build batches over one context: one of them makes the copy, the other waits
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (L.codes16 || L.num_mt == 0) return VB2_OK;
+    // the pack kernel goes on this context's stream: behind a resident search kernel it would only start when that
+    // kernel gives up after its idle second (and end the session without a word) -- end the session first
+    if (resident_active) resident_end();
     VB2_HIP(hipSetDevice(device));
     std::vector<uint2> rec16(L.num_mt);
     uint64_t total16 = 0;
@@ -1207,11 +1217,20 @@ int Context::ensure_codes16()
     const size_t bytes = rec_bytes + (size_t)(total16 + kCodeSlackRows) * kMtMarkers * sizeof(uint2);
     VB2_HIP(hipMalloc(&d_codes16_own, bytes));
     char* base = static_cast<char*>(d_codes16_own);
-    VB2_HIP(hipMemcpyAsync(base, rec16.data(), rec16.size() * sizeof(uint2), hipMemcpyHostToDevice, stream));
     const uint2* d_rec = reinterpret_cast<const uint2*>(base);
     uint2* d16 = reinterpret_cast<uint2*>(base + rec_bytes);
-    VB2_HIP(launch_pack_codes16(L, d16, d_rec, (uint32_t)total16, stream));
-    VB2_HIP(hipStreamSynchronize(stream));                 // (rec16 is a pageable source; and the lists must be complete)
+    {
+        // a failure after the allocation must not leave the block behind (the next call would allocate again)
+        hipError_t e = hipMemcpyAsync(base, rec16.data(), rec16.size() * sizeof(uint2), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = launch_pack_codes16(L, d16, d_rec, (uint32_t)total16, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // (rec16 is a pageable source; and the lists must be complete)
+        if (e != hipSuccess) {
+            (void)hipFree(d_codes16_own);
+            d_codes16_own = nullptr;
+            set_error(std::string("vb2_batch_create: building the 16-bit run lists failed: ") + hipGetErrorString(e));
+            return VB2_ERR_HIP;
+        }
+    }
     L.mt_rec16 = d_rec;
     L.codes16 = d16;
     int64_t rows32 = 0;

@@ -175,7 +175,19 @@ struct ResidentArgs {
     int32_t relay_reps;                  // copies of the relay word in use (1..kRelayReps; VB2_RELAY_REPS)
     int32_t own_rows;                    // 1: workgroup 0 starts a short-way round from its own copy of the rows sets
                                          // without waiting for its relay word (VB2_OWN_ROWS, A/B knob)
+    // LDS areas behind the search state (offsets in doubles from the start of dynamic LDS; filled in by
+    // launch_llk_resident): workgroup 0's staging of the partial sums ([4][grid]; 0 = over the dead tables, round 3),
+    // and the workgroup's own run lists (LCACHE, resident_kernel.inc: cache_start).
+    int32_t sum_stage_off;
+    int32_t cache_off;
+    // in: what the run-list cache needs -- the most micro-tiles a workgroup owns (rounded up to even) and the most rows
+    // (placement pads and 4 slack rows included); 0 rows = no cache (VB2_LDS_CACHE=0, or the host saw it cannot fit)
+    int32_t cache_tiles;
+    int32_t cache_rows;
 };
+// Rows of LDS a workgroup's run-list cache takes (the placement rule of resident_kernel.inc on the host):
+// rows[] = rows per micro-tile, workgroup b of nblk owns tiles b, b + nblk, ...
+uint32_t resident_cache_rows(const uint32_t* rows, int num_mt, int nblk);
 constexpr unsigned long long kHandoffGiveUpTicks = 25000000ull;   // 0.25 s of the 100 MHz wall clock (tagged hand-off)
 constexpr unsigned long long kResidentMinimize = 0xffffffffull;   // mailbox word [1]: a Minimize() request
 constexpr int kDeviceSimplexMaxDim = 63;                           // one lane per coordinate, one per vertex (n + 1 <= 64)

@@ -315,6 +315,10 @@ struct NoHook {
     __device__ bool mine() const { return false; }
     __device__ void run() {}
     __device__ bool keep_etab() const { return false; }     // (the 2^(j/64) table of an earlier call is still in LDS)
+    __device__ bool prim_in_lds() const { return false; }   // the primary-code records live in LDS across calls ...
+    __device__ bool keep_prim() const { return false; }     // ... and an earlier call left them there
+    __device__ double* sum_stage() const { return nullptr; } // where workgroup 0 stages the partial sums (nullptr: over the dead tables)
+    __device__ uint32_t cache_rec() const { return 0u; }    // LCACHE: LDS byte address of this workgroup's tile records
 };
 // The waves of a workgroup pull (tile, group) items through the LDS queue (per-item result slots) when there
 // are at most dyn_limit of them per wave; else the static deal (cohort launches).
@@ -335,8 +339,11 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // at compile time (+1.2 % on the 48-point launch, the only shape compiled this way); -1 = decided in the kernel.
 // KSEL: --NumPC when it is 2 (the reference's default) or 4 (its usual setting), else 0 = read from the layout: the
 // guards and address multiples of the projection go at compile time (+1.4 % on the 48-point launch; that shape only).
+// LCACHE (the resident search kernel): this workgroup's run lists and tile records were copied to LDS when the kernel
+// started (a workgroup owns the same micro-tiles in every round), so a round's read loops begin without the two dependent
+// trips to L2 (tile record, then its first rows) and never wait for a row again.
 template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1,
-          bool ONEGRP = (MODE >= 3), int KAF = -1, int KSEL = 0>
+          bool ONEGRP = (MODE >= 3), int KAF = -1, int KSEL = 0, bool LCACHE = false>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -388,8 +395,14 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const int g = g4 & (SLOTS - 1);              // candidate slot
     const int half = TPW == 1 ? 0 : g4 / SLOTS;  // which of the item's TPW micro-tiles
     // profiling aid: 100 MHz wall-clock stamps per workgroup (stamps pointer null normally)
-    unsigned long long* stamps = VB2_STAMPS_OF(L) ? VB2_STAMPS_OF(L) + (size_t)blk * 8 : nullptr;
-    if (stamps && tid == 0) stamps[0] = wall_clock64();
+    // (-DVB2_STAMP_ROUND=n: the per-workgroup stamps are those of round n of the resident kernel -- a search round that
+    // took the short way -- instead of the last evaluation's; the accumulated figures cover every round either way)
+#ifndef VB2_STAMP_ROUND
+#define VB2_STAMP_ROUND 0
+#endif
+    const bool stamp_this = VB2_STAMP_ROUND == 0 || (unsigned)(tag & 0xffffffffull) == (unsigned)VB2_STAMP_ROUND;
+    unsigned long long* stamps = (VB2_STAMPS_OF(L) && stamp_this) ? VB2_STAMPS_OF(L) + (size_t)blk * 8 : nullptr;
+    if (stamps && tid == 0) { stamps[0] = wall_clock64(); stamps[4] = 0; }
 
     const bool hook_blk = hook.on_block(), hook_mine = hook.mine();
     if (tid == 0) *queue = (unsigned int)(nwave - (hook_blk ? 1 : 0));      // waves start on tiles 0..nwave-1
@@ -418,7 +431,9 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // With several groups a thread builds several table entries: the primary-code records (a
     // few dozen) go to LDS first so that the loop below does not wait on a global load per
     // entry.  With one group each thread builds about one entry and loads its record directly.
-    const bool staged = ngrp > 1;
+    // (the resident kernel keeps them in LDS from its first round on: a round's table then starts without a trip to L2)
+    const bool prim_kept = hook.prim_in_lds() && hook.keep_prim();
+    const bool staged = ngrp > 1 || (hook.prim_in_lds() && !prim_kept);
     if (staged)
         for (int e = tid; e < L.num_prim; e += nthread) prim_lds[e] = L.prim[e];
     // A search round (its rows are in LDS since the round's staging barrier) builds its one table without waiting
@@ -440,7 +455,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         const int pi = e / (6 * NP);
         const int bp = e - pi * (6 * NP);
         const int bb = bp / 6, p = bp - bb * 6;
-        const double2 rec = staged ? prim_lds[pi] : L.prim[pi];       // {signed pErr, code | twin << 16}
+        const double2 rec = (staged || prim_kept) ? prim_lds[pi] : L.prim[pi];       // {signed pErr, code | twin << 16}
         const uint32_t pr = (uint32_t)__double_as_longlong(rec.y);
         const int dc = (int)(pr & 0xffffu), twin = (int)(pr >> 16);
         int g1, g2;
@@ -585,7 +600,11 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             flush_wave(grp_wave);
             ++grp_wave;
         }
-        const vuint2 rec = g_rec[mt];                        // {first row, rows}; one scalar load when TPW == 1
+        typedef __attribute__((address_space(3))) const vuint2 lds_cuint2v;
+        // {first row, rows}; one scalar load when TPW == 1.  LCACHE: {LDS byte address of the tile's first row, rows}
+        vuint2 rec;
+        if constexpr (LCACHE) rec = *reinterpret_cast<lds_cuint2v*>(hook.cache_rec() + (have_tile ? it : 0u) * 8u);
+        else rec = g_rec[mt];
         // per-marker constants: issued now, consumed after the read loop
         const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
         const bool live = have_tile && pos < (size_t)L.num_active;
@@ -616,7 +635,8 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         // their ds_reads go out as soon as they can and the LDS pipe stays busy, while the epilogue
         // waves fill the VALU slots in between (-0.8 % per launch measured; the other way round: +0.8 %)
         __builtin_amdgcn_s_setprio(1);
-        g_cuint2* cp = g_codes + (size_t)rec.x * kMtMarkers + m;
+        g_cuint2* cp = g_codes + (LCACHE ? (size_t)0 : (size_t)rec.x * kMtMarkers + m);
+        const uint32_t crow = rec.x + (uint32_t)m * 8u;      // (LCACHE: this lane's word of the tile's first row, LDS)
         const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
         // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
         // tile's last row -- up to kPf useless row loads per item of 6..16 rows -- and every block of kPf rows begins
@@ -635,15 +655,18 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         // they came from HBM twice, 573 MB instead of 356 MB per one-point step of 32 C3 samples (FETCH_SIZE, round 3).
         // The row index is clamped to the tile's last row instead: the same cache line again, no new bytes.)
         const int last_row = rows > 0 ? rows - 1 : 0;
+        auto load_row = [&](int j) -> vuint2 {               // row j of this lane's run words
+            if constexpr (LCACHE) return *reinterpret_cast<lds_cuint2v*>(crow + (uint32_t)j * (kMtMarkers * 8u));
+            else return cp[(size_t)(STREAM ? (j < last_row ? j : last_row) : j) * kMtMarkers];
+        };
 #pragma unroll
-        for (int j = 0; j < kPf; ++j) w[j] = cp[(size_t)(STREAM ? (j < last_row ? j : last_row) : j) * kMtMarkers];
+        for (int j = 0; j < kPf; ++j) w[j] = load_row(j);
         for (int s0 = 0; s0 < rows; s0 += kPf) {
 #pragma unroll
             for (int u = 0; u < kPf; ++u) {
                 if (s0 + u >= rows) break;
                 const vuint2 w_cur = w[u];
-                w[u] = cp[(size_t)(STREAM ? (s0 + u + kPf < last_row ? s0 + u + kPf : last_row)
-                                          : s0 + u + kPf) * kMtMarkers];
+                w[u] = load_row(s0 + u + kPf);
 #pragma unroll
                 for (int j = 0; j < (W16 ? 4 : 2); ++j) {
                     // one run: `n` reads of the same (class, quality) -> n * table row.  The run
@@ -679,6 +702,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         }
 
         __builtin_amdgcn_s_setprio(0);
+        if (stamps && lane == 0 && wave == 1) stamps[3] = wall_clock64();      // wave 1: out of its (first) read loop
         // ---- per-marker epilogue: this marker's likelihood as (mantissa, exponent) per point ----
         double lk_m[BTL];
         int lk_e[BTL];
@@ -811,10 +835,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         for (uint32_t grp = grp_wave; grp < (uint32_t)ngrp; ++grp) flush_wave(grp);
     }
 
-    if (stamps && lane == 0) {
-        if (wave == 0) stamps[3] = wall_clock64();           // wave 0 done with its tiles
-        if (wave == nwave - 1) stamps[4] = wall_clock64();   // last wave done with its tiles
-    }
+    if (stamps && lane == 0 && !hook_mine) atomicMax(&stamps[4], wall_clock64());   // the wave that is done with its tiles last
     // ---- deterministic block reduction -> one partial per (point, block) ----
     const uint32_t nres = dyn ? ntile_blk : (uint32_t)nwave;   // result slots per group
     auto reduce_point = [&](int b) {                  // slots in index order, then a butterfly
@@ -838,9 +859,10 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     __syncthreads();
     for (int b = wave; b < NPT; b += nwave) reduce_point(b);
     __syncthreads();
-    if (stamps && tid == 0) {
-        stamps[5] = wall_clock64();
-        if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[20 * 8 + 7] += stamps[5] - VB2_STAMPS_OF(L)[7];     // (accumulated: since "has the round")
+    if (VB2_STAMPS_OF(L) && tid == 0) {
+        const unsigned long long t5 = wall_clock64();
+        if (stamps) stamps[5] = t5;
+        if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[20 * 8 + 7] += t5 - VB2_STAMPS_OF(L)[7];     // (accumulated: since "has the round")
     }
     if (ticket == nullptr) {                     // two-kernel mode: llk_finalize_kernel follows
         if (tid < NPT) partials[(size_t)tid * nblk + blk] = red[tid];
@@ -904,13 +926,26 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                                __HIP_MEMORY_SCOPE_AGENT);
     }
     if (blk != 0) return;
-    __syncthreads();                                   // the table is dead: its space stages the partials
+    if (!hook.sum_stage()) __syncthreads();            // the table is dead: its space stages the partials
     const int nb = (int)nblk;
-    double* stage = lds;                               // [NPT][nb]
+    double* stage = hook.sum_stage() ? hook.sum_stage() : lds;      // [NPT][nb]
     {
         const unsigned long long want = resident_mix(tag);
         const unsigned long long t_wait = wall_clock64();
         for (int b = tid; b < nb; b += nthread) {      // one thread per workgroup's set
+            // This workgroup's own sums are in its LDS (red[]) since the block reduction's closing barrier: its own set
+            // -- the one stored LAST, by definition, when this workgroup is the slowest, and a store needs a trip to
+            // memory before the poll's trip can find it (~2 us from the block reduction to "all sets in" even when
+            // every other set has been there for microseconds: round 4, 10 000-marker timeline) -- is not waited for.
+            // No branch: the thread polls like the others and overrides what it loaded.  MEASURED AND DROPPED (round 4, like
+            // round 3's branchy version): OptimizeLLK 6.41 -> 6.48 ms at C3, 6.30 -> 6.48 ms at 10 000 markers on the same
+            // box -- the set that arrives last is not this workgroup's own; compiled out unless -DVB2_OWN_SUMS=1.
+#ifndef VB2_OWN_SUMS
+#define VB2_OWN_SUMS 0
+#endif
+            // (only while red[] is not under the staging area: a forced tagged hand-off of many points stages over it)
+            const bool own = VB2_OWN_SUMS && b == (int)blk &&
+                             (hook.sum_stage() != nullptr || (size_t)NPT * (size_t)nb <= (size_t)(red - lds));
             for (unsigned it = 0;; ++it) {
                 // check word and the first words are requested together, NP + 1 loads in flight
                 unsigned long long x = __hip_atomic_load(&pw[(size_t)NPT * nb + b], __ATOMIC_RELAXED,
@@ -923,11 +958,12 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                                                  __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int u = 0; u < NP; ++u) {
+                        if (own) v[u] = (unsigned long long)__double_as_longlong(red[w0 + u]);
                         x ^= word_hash(v[u], (unsigned)(w0 + u));
                         stage[(size_t)(w0 + u) * nb + b] = __longlong_as_double((long long)v[u]);
                     }
                 }
-                if (x == want) break;
+                if (x == want || own) break;
                 // a quarter of a second (100 MHz ticks): a workgroup is missing -- part of the grid is not on the CUs
                 // (a shared GPU).  The caller sees NaN and redoes the step with the arrival-ticket hand-off, which
                 // waits for nobody.  (Round 2 waited two seconds: the hiccup of a co-residency failure is this wait.)
@@ -958,9 +994,10 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (lane == 0) llk_out[b] = s;                   // NaN if a workgroup never reported
     }
     }
-    if (stamps && tid == 0) {
-        stamps[6] = wall_clock64();
-        if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[21 * 8 + 7] += stamps[6] - VB2_STAMPS_OF(L)[7];
+    if (VB2_STAMPS_OF(L) && tid == 0) {
+        const unsigned long long t6 = wall_clock64();
+        if (stamps) stamps[6] = t6;
+        if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[21 * 8 + 7] += t6 - VB2_STAMPS_OF(L)[7];
     }
     if (done_flag) {
         // host hand-off without a stream synchronisation: results (in mapped host memory)
@@ -1406,13 +1443,28 @@ size_t resident_state_doubles(int nmax, int num_pc)
            (size_t)resident_stage_doubles(nmax, num_pc);
 }
 
+uint32_t resident_cache_rows(const uint32_t* rows, int num_mt, int nblk)
+{
+    uint32_t most = 0;
+    for (int b = 0; b < nblk && b < num_mt; ++b) {
+        uint32_t off = 0, prev = 0, it = 0;
+        for (int t = b; t < num_mt; t += nblk, ++it) {
+            const uint32_t start = cache_start(off, prev, it);
+            off = start + rows[t];
+            prev = start;
+        }
+        most = std::max(most, off);
+    }
+    return most + 4;        // slack: the read loop requests up to VB2_PF_SEARCH rows past a tile's last
+}
+
 hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, double* d_partials,
                                unsigned int* d_ticket, hipStream_t stream)
 {
     const LaunchGeom gm = launch_geom(L, 1);
     // dynamic LDS: the evaluation body's, then workgroup 0's search state (16-byte aligned)
     size_t shmem = (eval_shmem_bytes(L, 1, gm.grid, gm.block_waves, 1) + 15) / 16 * 16;
-    ResidentArgs& ra = *ra_io;           // state_off / state_nmax are filled in here
+    ResidentArgs& ra = *ra_io;           // state_off / state_nmax and the LDS areas behind the state are filled in here
     ra.state_off = (int32_t)(shmem / sizeof(double));
     shmem += sizeof(double) * resident_state_doubles(ra.state_nmax, L.num_pc);
     if (shmem > (size_t)kLdsLimitBytes && ra.state_nmax > 0) {      // no room: search on the host
@@ -1420,9 +1472,35 @@ hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, doubl
         shmem = ra.state_off * sizeof(double) + sizeof(double) * resident_state_doubles(0, L.num_pc);
     }
     if (shmem > (size_t)kLdsLimitBytes || gm.grid > L.num_cu) return hipErrorInvalidConfiguration;
+    // workgroup 0's own staging area for the partial sums, if there is room (else over the dead tables, as in round 3)
+    ra.sum_stage_off = 0;
+    {
+        const size_t at = (shmem + 15) / 16 * 16, need = sizeof(double) * 4 * (size_t)gm.grid;
+        if (at + need <= (size_t)kLdsLimitBytes) {
+            ra.sum_stage_off = (int32_t)(at / sizeof(double));
+            shmem = at + need;
+        }
+    }
     const bool dyn = eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, 1);
     const int ksel = (g_paired && g_hwmap && dyn && L.known_af == nullptr) ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
-    const void* fn = ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 4>)
+    // the run-list cache: the paired shape on the work queue (what a search on one device runs), at most 8 tiles per wave
+    bool lcache = false;
+    ra.cache_off = 0;
+    if (ra.cache_rows > 0 && g_paired && g_hwmap && dyn && ra.cache_tiles <= 8 * gm.block_waves) {
+        ra.cache_tiles = (ra.cache_tiles + 1) & ~1;
+        const size_t at = (shmem + 15) / 16 * 16;
+        const size_t need = (size_t)ra.cache_tiles * 8 + (size_t)ra.cache_rows * kMtMarkers * 8;
+        if (at + need <= (size_t)kLdsLimitBytes) {
+            ra.cache_off = (int32_t)(at / sizeof(double));
+            shmem = at + need;
+            lcache = true;
+        }
+    }
+    if (!lcache) ra.cache_rows = 0;
+    const void* fn = lcache ? (ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 4, true>)
+                               : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 2, true>)
+                                           : reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 0, true>))
+                     : ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 4>)
                      : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 2>)
                      : g_paired ? (!g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<3, false, -1>)
                                  : dyn    ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1>)

@@ -39,6 +39,7 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
+    bool stub = false;          // the test-only in-process stand-in (tests/stub_rccl) was bound, not librccl
     std::string why;
 };
 
@@ -48,9 +49,21 @@ Rccl& rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         void* h = nullptr;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (h) break;
+        // VB2_RCCL_LIB=<path>: bind THAT library instead (tests/stub_rccl: an in-process stand-in whose ranks may
+        // share a device, so that a one-GPU box can execute the N > 1 control flow; never set in production)
+        const char* forced = std::getenv("VB2_RCCL_LIB");
+        if (forced && *forced) {
+            h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!h) {
+                r.why = std::string("VB2_RCCL_LIB not loadable: ") + (dlerror() ? dlerror() : "?");
+                return;
+            }
+            r.stub = dlsym(h, "vb2_rccl_stub_marker") != nullptr;
+        } else {
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h) break;
+            }
         }
         if (!h) {
             r.why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?");
@@ -101,6 +114,12 @@ int rccl_unique_id(void* id128)
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
     std::memcpy(id128, &id, sizeof(id));
     return VB2_OK;
+}
+
+bool rccl_is_stub()
+{
+    Rccl& r = rccl();
+    return r.ok && r.stub;
 }
 
 void shard_range(const vb2_input* in, int r, int n, int* lo, int* hi)
@@ -156,9 +175,11 @@ int ShardGroup::create(const vb2_input* in, const int32_t* devices, int num_devi
     g->num_marker = in->num_marker;
     const std::set<int> distinct(devices, devices + num_device);
     // a real all-reduce needs one rank per DEVICE; shards that share a device (tests on one GPU)
-    // are summed on the host instead
-    g->use_rccl = (int)distinct.size() == num_device && !(std::getenv("VB2_SHARD_REDUCE") &&
-                                                          !std::strcmp(std::getenv("VB2_SHARD_REDUCE"), "host"));
+    // are summed on the host instead -- unless the test stand-in for librccl is bound (VB2_RCCL_LIB), whose
+    // ranks may share a device: then the launch -> grouped all-reduce -> publish path runs with N > 1 there too
+    const bool host_forced = std::getenv("VB2_SHARD_REDUCE") && !std::strcmp(std::getenv("VB2_SHARD_REDUCE"), "host");
+    const bool shared_ok = (int)distinct.size() < num_device && std::getenv("VB2_RCCL_LIB") && rccl().ok && rccl().stub;
+    g->use_rccl = ((int)distinct.size() == num_device || shared_ok) && !host_forced;
     for (int d = 0; d < num_device; ++d) {
         int lo, hi;
         shard_range(in, d, num_device, &lo, &hi);
@@ -201,6 +222,11 @@ int ShardGroup::create_rank(const vb2_input* in, int device, int rank, int nrank
         set_error("vb2_shard_group_create_rank: invalid argument");
         return VB2_ERR_INVALID;
     }
+    if (id128 == nullptr && nranks > 1) {
+        set_error("vb2_shard_group_create_rank: nranks > 1 needs the communicator id (vb2_rccl_unique_id), or "
+                  "VB2_SHARD_PARTIAL_SUMS for a group that returns this rank's partial sums");
+        return VB2_ERR_INVALID;
+    }
     std::unique_ptr<ShardGroup> g(new ShardGroup());
     g->num_pc = in->num_pc;
     g->num_marker = in->num_marker;
@@ -217,7 +243,12 @@ int ShardGroup::create_rank(const vb2_input* in, int device, int rank, int nrank
     g->ctx.push_back(c);
     g->lo.push_back(lo);
     g->hi.push_back(hi);
-    g->use_rccl = id128 != nullptr;       // (nranks == 1 with an id: a one-rank communicator, for tests)
+    // id128: the communicator's id; VB2_SHARD_PARTIAL_SUMS: none, by request (the caller reduces this rank's partial
+    // sums over its own transport); NULL: none needed with one rank -- with more it is refused (a forgotten
+    // id used to yield plausible but partial LLKs without a word)
+    const bool want_partial = id128 == VB2_SHARD_PARTIAL_SUMS;
+    g->use_rccl = id128 != nullptr && !want_partial;       // (nranks == 1 with an id: a one-rank communicator, for tests)
+    g->partial_sums = nranks > 1 && !g->use_rccl;
     if (g->use_rccl) {
         Rccl& r = rccl();
         if (!r.ok) {
@@ -409,11 +440,18 @@ int ShardGroup::optimize(const vb2_model* model, vb2_estimate* out, vb2_trace* t
                   "it yields partial sums only");
         return VB2_ERR_INVALID;
     }
+    // ONE shard in one process is the plain single-context search: each Minimize() on the device itself
+    // (resident_kernel.inc), like vb2_ctx_optimize_llk -- round 3 drove the resident kernel from the host optimiser
+    // here, one mailbox round trip per iteration: 8.4 ms against 6.5 for the same 780 evaluations.
+    const bool single = ctx.size() == 1 && nranks == 1;
+    if (single && trace && trace->capacity > 0 && ctx[0]->device_simplex_enabled) (void)ctx[0]->reserve_trace(trace->capacity);
     const bool res = begin_resident() != 0;
     Estimator est(num_pc, group_eval_cb, this);
     apply_model(est, *model, ctx[0]->L.known_af != nullptr);
     est.trace = trace;
     if (trace) trace->count = 0;
+    if (single && res && ctx[0]->device_simplex_dim() > 0 && !(trace && ctx[0]->trace_stage_rows < trace->capacity))
+        est.dev_ctx = ctx[0];
     const int rc = est.OptimizeLLK();
     if (res && resident_) end_resident();
     if (rc) return rc;

@@ -27,6 +27,8 @@ namespace vb2 {
 
 // ncclGetUniqueId through the run-time binding (128 bytes out).
 int rccl_unique_id(void* id128);
+// The run-time binding found the test stand-in (VB2_RCCL_LIB=tests/stub_rccl/...), not librccl.
+bool rccl_is_stub();
 // Contiguous marker range [lo, hi) of shard r of n, balanced on READS (not markers).
 void shard_range(const vb2_input* in, int r, int n, int* lo, int* hi);
 // The sub-view of `in` for markers [lo, hi): pointers into the caller's arrays, nothing copied.
@@ -47,6 +49,7 @@ public:
     int num_pc = 0, num_marker = 0;
     int rank = 0, nranks = 1;              // process-per-GPU mode; (0, 1) in single-process mode
     bool use_rccl = false;                 // partial sums meet in ncclAllReduce (else: host sum)
+    bool partial_sums = false;             // nranks > 1 without a communicator (by request): eval() yields this rank's part
     std::vector<Context*> ctx;             // the shards this process owns
     std::vector<int> lo, hi;               // their marker ranges
     int64_t num_allreduce = 0;
