@@ -333,6 +333,12 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     ml.shmem = shmem_[shape];
     ml.force_ticket = false;
     ml.w16 = w16_;
+    {   // (the pipelined item loop is compiled for the static deal: every sample of the cohort must run it)
+        bool st = true;
+        for (int s2 = 0; s2 < num_sample && st; ++s2)
+            st = ctx_[s2]->L.num_mt == 0 || !eval_takes_the_queue(ctx_[s2]->L, bps_, block_waves_, 1);
+        ml.all_static = st;
+    }
     {   // (the cohort kernels compiled for --NumPC 2 / 4 without a known-AF column)
         bool plain = num_pc == 2 || num_pc == 4;
         for (int s2 = 0; s2 < num_sample && plain; ++s2) plain = ctx_[s2]->L.known_af == nullptr;

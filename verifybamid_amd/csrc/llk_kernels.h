@@ -38,10 +38,13 @@ struct DeviceLayout {
                                   // twin << 16}, twin = the alt code of the same quality (its row is the mirror
                                   // image of this one) or 0xffff
     // The cohort-step copy of the run lists (nullptr unless built: Context::ensure_codes16): the same runs in
-    // the same order as 16-bit words -- dictionary index | count << 8 -- four per uint2, stored
+    // the same order as 16-bit words -- dictionary index | count code << 8, count code = (top 16 bits of
+    // double(count)) - 0x3ff0, i.e. exponent offset << 4 | top four mantissa bits -- four per uint2, stored
     // [micro-tile][step/4][marker].  Half the bytes of `codes`; the kernel pays one multiply and one
     // conversion per run to expand them, which a cohort step (every sample's lists streamed from HBM once per
     // step, 1-2 points each) can afford and a single-sample launch (lists in L2, VALU-bound) cannot.
+    // (round 4: one byte permute rebuilds the double 2 * count and one 24-bit multiply the row offset: two
+    // instructions per run instead of five; the table of a 16-bit step holds T / 2)
     const uint2* codes16;
     const uint2* mt_rec16;        // [num_mt] {first row, rows = ceil(most runs in the tile / 4)} of codes16
     int32_t num_code;
@@ -126,10 +129,14 @@ struct MultiLaunch {
     int np;                          // points per sample of this step: 1, 2, 4 or 8 (picks the wave shape)
     bool force_ticket;               // arrival-ticket hand-off instead of tagged sets (the retry after a NaN)
     bool w16;                        // every sample has codes16: stream the 16-bit run lists
+    bool all_static;                 // every sample runs the static deal (eval_takes_the_queue is false for all): the
+                                     // 16-bit one- and two-point steps then take the kernels with the pipelined item loop
     int ksel;                        // 2 or 4: every sample has --NumPC of that and no known-AF column (the kernels compiled
                                      // for it); 0: the general kernels
     size_t shmem;
 };
+// a launch of this geometry pulls its work items through the LDS queue (else: the static deal)
+bool eval_takes_the_queue(const DeviceLayout& L, int nblk, int nwave, int ngrp);
 size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);   // groups of 4*btl points
 size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp);
 int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves);

@@ -412,10 +412,14 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         const int src = b < num_valid ? b : num_valid - 1;
         const int idx = src * stride + (e - b * stride);
         // resident mode: the rows were just written by another workgroup -> L1-bypassing loads
+#ifdef VB2_ABL_NOMAP
+        const double v = 0.01 * (double)(1 + idx % 7);
+#else
         const double v = lds_rows ? lds_rows[idx]
                          : ip.count > 0 ? ip.v[idx]
                          : coherent_points ? __hip_atomic_load(&points[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                            : points[idx];
+#endif
         pts[e] = v;
         const int c = e - b * stride;                       // 0..2k-1: a PC coordinate, 2k: alpha
         if (c < 2 * k) ptq[((b / BTL) * 2 * k + c) * BTL + (b % BTL)] = v;
@@ -451,7 +455,11 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     // it into the alt twin's row: half the logarithms, and no barrier in between.
     // (a thread's entries for the different groups are independent: computed side by side so
     // that their long dependent logarithm chains overlap)
+#ifdef VB2_ABL_NOTABLE   // (ablation build)
+    for (int e = tid; e < 0; e += nthread) {
+#else
     for (int e = tid; e < L.num_prim * 6 * NP; e += nthread) {
+#endif
         const int pi = e / (6 * NP);
         const int bp = e - pi * (6 * NP);
         const int bb = bp / 6, p = bp - bb * 6;
@@ -466,12 +474,16 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             if (grp_e < ngrp)
                 v[grp_e] = table_entry(early_table ? lds_rows[(bb < num_valid ? bb : num_valid - 1) * stride + 2 * k]
                                                    : pts[(grp_e * NP + bb) * stride + 2 * k], rec.x, g1, g2);
+        // W16 (cohort steps on the 16-bit run lists): the run word's count field decodes to the double 2 * n with ONE
+        // byte permute (see the read loop), so the table holds T / 2 -- both scalings are exact (powers of two), and
+        // fma(2n, T/2, acc) rounds the same real number as fma(n, T, acc): bit-identical to the 32-bit lists.
 #pragma unroll
         for (int grp_e = 0; grp_e < kMaxGroups; ++grp_e)
             if (grp_e < ngrp) {
                 double* gtab = tab + (size_t)grp_e * nrow * RS;
-                gtab[dc * RS + bp] = v[grp_e];
-                if (twin != 0xffff) gtab[twin * RS + bb * 6 + (5 - p)] = v[grp_e];
+                const double tv = W16 ? 0.5 * v[grp_e] : v[grp_e];
+                gtab[dc * RS + bp] = tv;
+                if (twin != 0xffff) gtab[twin * RS + bb * 6 + (5 - p)] = tv;
             }
     }
     for (int e = tid; e < ngrp * RS; e += nthread) {                  // padding code: zero rows
@@ -493,7 +505,11 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     const size_t mp = L.m_pad;
     // work items: (tile, group), or (TPW consecutive owned tiles, group)
     const uint32_t nunit = (ntile_blk + TPW - 1) / TPW;
+#ifdef VB2_ABL_ITEMS     // (ablation build: no work items at all -- what is left is the launch's fixed cost)
+    const uint32_t nitem = 0u * nunit * (uint32_t)ngrp;
+#else
     const uint32_t nitem = nunit * (uint32_t)ngrp;
+#endif
     const float inv_nunit = 1.0f / (float)(nunit ? nunit : 1u);
     // Decided on ceil(tiles / workgroups), the same for every workgroup and exactly what
     // eval_shmem_np sized the result slots for (a workgroup with one tile fewer must not choose
@@ -579,135 +595,106 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
     }
     uint32_t round = 0;
     if (hook_mine) hook.run();                            // (this wave takes no work items; the others cover for it)
-    for (uint32_t idx = hook_mine ? nitem
-                        : have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem)
-                                     : (uint32_t)(wave - (hook_blk ? 1 : 0));
-         idx < nitem;) {
-        // grp = idx / nunit without the ~25-instruction integer division: float estimate (exact for
-        // these magnitudes up to one) and a correction step
-        uint32_t grp = ngrp == 1 ? 0u : (uint32_t)(((float)idx + 0.5f) * inv_nunit);
-        if (ngrp != 1) {
-            if (grp * nunit > idx) --grp;
-            else if ((grp + 1) * nunit <= idx) ++grp;
-        }
-        const uint32_t unit = idx - grp * nunit;
-        const uint32_t it = TPW * unit + (uint32_t)half;     // index in this workgroup's tile list
-        const bool have_tile = TPW == 1 || it < ntile_blk;   // TPW > 1: the list's end may leave lanes idle
-        const uint32_t mt = have_tile ? blk + it * nblk : blk;
-        const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)row_bytes + (uint32_t)g * (6 * BTL * 8));
-        const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
-        while (!dyn && grp_wave < grp) {                     // wave-uniform
-            flush_wave(grp_wave);
-            ++grp_wave;
-        }
-        typedef __attribute__((address_space(3))) const vuint2 lds_cuint2v;
-        // {first row, rows}; one scalar load when TPW == 1.  LCACHE: {LDS byte address of the tile's first row, rows}
-        vuint2 rec;
-        if constexpr (LCACHE) rec = *reinterpret_cast<lds_cuint2v*>(hook.cache_rec() + (have_tile ? it : 0u) * 8u);
-        else rec = g_rec[mt];
-        // per-marker constants: issued now, consumed after the read loop
-        const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
-        const bool live = have_tile && pos < (size_t)L.num_active;
-        const size_t posc = live ? pos : 0;
-        const double cst = g_ediag[posc];
-        const double e0 = g_ediag[mp + posc], e1 = g_ediag[2 * mp + posc], e2 = g_ediag[3 * mp + posc];
-
-        // (the panel row of the marker too: up to four UD columns and the mean)
-        double udr[4], mur = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) udr[kk] = (!known_af_p && kk < k) ? g_ud[(size_t)kk * mp + posc] : 0.0;
-        if (!known_af_p) mur = g_mu[posc];
-
-        // the six off-diagonal sums start from the marker's "other base" constant (it is part of
-        // every genotype pair's sum, h:299-303), so the epilogue needs no separate addition
-        double acc[BTL * 6];
-#pragma unroll
-        for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
-
-        // ---- per-read accumulate (h:288-303), one step per run ----
-        // Rows are prefetched kPrefetch deep: with one sample its pileup sits in L2, but a cohort
-        // launch streams every sample's rows from HBM once, and two rows ahead (~0.6 us of work)
-        // does not cover that latency.  The loads are unconditional: a prefetch past the tile's
-        // last row reads the next tile's rows (never consumed), and the array ends in
-        // 2 * kPrefetch padding rows (context.cpp).
-        // The read loop is bound by the LDS pipe, the epilogue by the FP64 VALU, and the waves of a CU
-        // are spread over both phases at any time: waves in the read loop get issue priority, so that
-        // their ds_reads go out as soon as they can and the LDS pipe stays busy, while the epilogue
-        // waves fill the VALU slots in between (-0.8 % per launch measured; the other way round: +0.8 %)
-        __builtin_amdgcn_s_setprio(1);
-        g_cuint2* cp = g_codes + (LCACHE ? (size_t)0 : (size_t)rec.x * kMtMarkers + m);
-        const uint32_t crow = rec.x + (uint32_t)m * 8u;      // (LCACHE: this lane's word of the tile's first row, LDS)
-        const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
-        // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
-        // tile's last row -- up to kPf useless row loads per item of 6..16 rows -- and every block of kPf rows begins
-        // by waiting for all of them.  Measured on one box, depth 8 / 4 / 2: 48-point launch 74.9 / 74.4 / 76.6 us;
-        // OptimizeLLK at C3 (one 4-point item per wave and round) 7.8 / 7.55 / 7.35 ms, at 10 000 markers 2.39 /
-        // 2.31 / 2.43 ms.)
 #ifndef VB2_PF_M2
 #define VB2_PF_M2 4
 #endif
 #ifndef VB2_PF_SEARCH
 #define VB2_PF_SEARCH 2
 #endif
-        constexpr int kPf = STREAM ? kPrefetch : MODE == 2 ? VB2_PF_M2 : VB2_PF_SEARCH;
-        vuint2 w[kPf];
-        // (STREAM: rows past the tile's last are the NEXT tiles' -- another workgroup's, at another time: fetched here
-        // they came from HBM twice, 573 MB instead of 356 MB per one-point step of 32 C3 samples (FETCH_SIZE, round 3).
-        // The row index is clamped to the tile's last row instead: the same cache line again, no new bytes.)
-        const int last_row = rows > 0 ? rows - 1 : 0;
-        auto load_row = [&](int j) -> vuint2 {               // row j of this lane's run words
-            if constexpr (LCACHE) return *reinterpret_cast<lds_cuint2v*>(crow + (uint32_t)j * (kMtMarkers * 8u));
-            else return cp[(size_t)(STREAM ? (j < last_row ? j : last_row) : j) * kMtMarkers];
-        };
+    typedef __attribute__((address_space(3))) const vuint2 lds_cuint2v;
+    constexpr int kPf = STREAM ? kPrefetch : MODE == 2 ? VB2_PF_M2 : VB2_PF_SEARCH;
+    vuint2 w[kPf];                                        // this lane's run words, kPf rows in flight
+    // PIPE (a cohort step under the static deal: every sample's lists come from HBM, one item = ~8 KB per wave, and a
+    // wave of round 3 requested an item's bytes, waited ~2 us for ALL of them -- the compiler's vmcnt(0) at the head of
+    // the row loop --, computed for ~2 us and only then requested the next item's: half its time waiting, and four waves
+    // per SIMD do not cover that).  Now the next item's run words are requested BEFORE this item's epilogue and its tile
+    // record an item earlier still; this item's per-marker constants are requested at its top and awaited at its epilogue;
+    // the first kPf rows of an item are walked in straight-line code, where the compiler counts the loads in flight
+    // instead of draining them.
+#ifndef VB2_PIPE
+#define VB2_PIPE 1
+#endif
+    // (compiled for the static deal only -- QUEUE == 0 --: with the way of dealing decided at run time the carried
+    // registers of the two ways meet in copies after every item, and a copy of a register that is being loaded drains the
+    // loads: the 4-point cohort step, whose kernel decides at run time, went 199 -> 228 us that way)
+    constexpr bool PIPE = VB2_PIPE && STREAM && ONEGRP && !LCACHE && QUEUE == 0;
+    const bool pipe = PIPE && !dyn;
+    // the item after position (s_pos, rnd) of this wave's static deal
+    auto static_item = [&](uint32_t s_pos, uint32_t rnd) -> uint32_t {
+        if (have_sched) return s_pos < s_end ? (uint32_t)sch.item[s_pos] : nitem;
+        return rnd * (uint32_t)nwave + ((rnd & 1u) ? (uint32_t)(nwave - 1 - wave) : (uint32_t)wave);
+    };
+    // (one group) item -> this lane's micro-tile
+    auto tile_of = [&](uint32_t idx_, bool& have_) -> uint32_t {
+        const uint32_t it_ = TPW * idx_ + (uint32_t)half;
+        have_ = idx_ < nitem && (TPW == 1 || it_ < ntile_blk);
+        return have_ ? blk + it_ * nblk : blk;
+    };
+    auto issue_rows = [&](const vuint2 rec_, bool have_) {           // the first kPf rows of a tile (clamped to its own)
+        g_cuint2* cp_ = g_codes + (size_t)rec_.x * kMtMarkers + m;
+        const int rows_ = have_ ? (int)rec_.y : 0;
+        const int last_ = rows_ > 0 ? rows_ - 1 : 0;
 #pragma unroll
-        for (int j = 0; j < kPf; ++j) w[j] = load_row(j);
-        for (int s0 = 0; s0 < rows; s0 += kPf) {
+        for (int j = 0; j < kPf; ++j) w[j] = cp_[(size_t)(j < last_ ? j : last_) * kMtMarkers];
+    };
+    // ---- one uint2 of run words (2 runs, or 4 of the 16-bit lists) into the accumulators ----
+    auto walk_word = [&](const vuint2 w_cur, double* acc, const uint32_t my_tab, const uint32_t my_tab_w16) {
+#ifdef VB2_ABL_LOOP      // (ablation build: the run words are consumed, the table is not read)
+        acc[0] += __hiloint2double((int)((w_cur.x ^ w_cur.y) & 0x000f0000u) | 0x3ff00000, 0);
+        return;
+#endif
 #pragma unroll
-            for (int u = 0; u < kPf; ++u) {
-                if (s0 + u >= rows) break;
-                const vuint2 w_cur = w[u];
-                w[u] = load_row(s0 + u + kPf);
+        for (int j = 0; j < (W16 ? 4 : 2); ++j) {
+            // one run: `n` reads of the same (class, quality) -> n * table row.  The run
+            // word is {low half: byte offset of the row, high half: the top 16 bits of the
+            // double n} -- one add and one and, no multiply, no int -> double conversion.
+            // W16 (cohort steps): {low byte: dictionary index, next byte: n} -- two field
+            // extractions, a multiply-add and a conversion, for half the bytes from HBM
+            // (Requesting a run's table values one run ahead of their use -- a software pipeline
+            // across the per-row exit test -- was measured in round 3: 74 -> 96 us per 48-point
+            // launch; the second set of twelve doubles does not fit the 128-register budget.)
+            double n;
+            uint32_t row_addr;
+            if constexpr (W16) {
+                // 16-bit run word = dictionary index | count code << 8, count code = (top 16 bits of double(n)) -
+                // 0x3ff0 = exponent offset << 4 | top four mantissa bits (n <= 31: that IS the double).  The
+                // high dword of 2 * n is 0x40 | code | 00 | 00: ONE byte permute (every VALU instruction costs
+                // the same issue slot on gfx950 -- tools/ubench/int_rates.hip -- so what counts is their number:
+                // round 3 spent five per run on the decode, and - 1 point per lane - six on the arithmetic);
+                // the row address is one 24-bit multiply of the index byte, the table's base rides in the
+                // ds_read's immediate offset.
+                const uint32_t w2 = (j & 2) ? w_cur.y : w_cur.x;
+                const uint32_t idx = (j & 1) ? ((w2 >> 16) & 0xffu) : (w2 & 0xffu);
+                const uint32_t hi = __builtin_amdgcn_perm(0x40000000u, w2, (j & 1) ? 0x07030c0cu : 0x07010c0cu);
+                n = __hiloint2double((int)hi, 0);
+                row_addr = my_tab_w16 + __umul24(idx, (uint32_t)row_bytes);
+            } else {
+                const uint32_t rw = j ? w_cur.y : w_cur.x;
+                n = __hiloint2double((int)(rw & 0xffff0000u), 0);
+                row_addr = my_tab + (rw & 0xffffu);
+            }
+            lds_cdouble2* row = reinterpret_cast<lds_cdouble2*>(row_addr);
 #pragma unroll
-                for (int j = 0; j < (W16 ? 4 : 2); ++j) {
-                    // one run: `n` reads of the same (class, quality) -> n * table row.  The run
-                    // word is {low half: byte offset of the row, high half: the top 16 bits of the
-                    // double n} -- one add and one and, no multiply, no int -> double conversion.
-                    // W16 (cohort steps): {low byte: dictionary index, next byte: n} -- two field
-                    // extractions, a multiply-add and a conversion, for half the bytes from HBM
-                    // (Requesting a run's table values one run ahead of their use -- a software pipeline
-                    // across the per-row exit test -- was measured in round 3: 74 -> 96 us per 48-point
-                    // launch; the second set of twelve doubles does not fit the 128-register budget.)
-                    double n;
-                    uint32_t row_addr;
-                    if constexpr (W16) {
-                        const uint32_t w2 = (j & 2) ? w_cur.y : w_cur.x;
-                        const uint32_t idx = (j & 1) ? ((w2 >> 16) & 0xffu) : (w2 & 0xffu);
-                        const uint32_t cnt = (j & 1) ? (w2 >> 24) : ((w2 >> 8) & 0xffu);
-                        n = (double)cnt;
-                        row_addr = my_tab + idx * (uint32_t)row_bytes;
-                    } else {
-                        const uint32_t rw = j ? w_cur.y : w_cur.x;
-                        n = __hiloint2double((int)(rw & 0xffff0000u), 0);
-                        row_addr = my_tab + (rw & 0xffffu);
-                    }
-                    lds_cdouble2* row = reinterpret_cast<lds_cdouble2*>(row_addr);
-#pragma unroll
-                    for (int i = 0; i < 3 * BTL; ++i) {
-                        const vdouble2 t = row[i];
-                        acc[2 * i] = fma(n, t.x, acc[2 * i]);
-                        acc[2 * i + 1] = fma(n, t.y, acc[2 * i + 1]);
-                    }
-                }
+            for (int i = 0; i < 3 * BTL; ++i) {
+                const vdouble2 t = row[i];
+                acc[2 * i] = fma(n, t.x, acc[2 * i]);
+                acc[2 * i + 1] = fma(n, t.y, acc[2 * i + 1]);
             }
         }
-
-        __builtin_amdgcn_s_setprio(0);
-        if (stamps && lane == 0 && wave == 1) stamps[3] = wall_clock64();      // wave 1: out of its (first) read loop
-        // ---- per-marker epilogue: this marker's likelihood as (mantissa, exponent) per point ----
-        double lk_m[BTL];
-        int lk_e[BTL];
+    };
+    // ---- per-marker epilogue: a marker's likelihood as (mantissa, exponent) per point, from its six sums per point ----
+    auto marker_lk = [&](const bool live, const size_t pos, const double* acc, const double e0, const double e1, const double e2,
+                         const double* udr, const double mur, const uint32_t my_ptq, double* lk_m, int* lk_e) {
 #pragma unroll
         for (int t = 0; t < BTL; ++t) { lk_m[t] = 1.0; lk_e[t] = 0; }
+#ifdef VB2_ABL_EPI       // (ablation build: the sums and the constants are consumed, nothing is computed from them)
+        {
+            double z = e0 + e1 + e2 + mur + udr[0] + udr[1] + udr[2] + udr[3];
+            for (int i = 0; i < BTL * 6; ++i) z += acc[i];
+            if (z == 12345.678) lk_m[0] = 0.75;
+            return;
+        }
+#endif
         if (live) {
             double af1[BTL], af2[BTL];
             if (known_af_p) {
@@ -786,6 +773,145 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 lk_e[t] = __builtin_amdgcn_frexp_exp(lk);
             }
         }
+    };
+    vuint2 rec_nx;                                        // PIPE: the record of the item about to be processed ...
+    rec_nx.x = rec_nx.y = 0u;
+    double cst_nx = 0.0;                                  // ... and its markers' "other base" constants (the accumulators start from them)
+    auto other_const = [&](uint32_t mt_, bool have_) -> double {
+        const size_t pos_ = (size_t)mt_ * kMtMarkers + m;
+        return g_ediag[(have_ && pos_ < (size_t)L.num_active) ? pos_ : 0];
+    };
+    const uint32_t idx_first = hook_mine ? nitem
+                               : have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem)
+                                            : (uint32_t)(wave - (hook_blk ? 1 : 0));
+    if (pipe && idx_first < nitem) {
+        bool h0;
+        const uint32_t mt0 = tile_of(idx_first, h0);
+        rec_nx = g_rec[mt0];
+        cst_nx = other_const(mt0, h0);
+        issue_rows(rec_nx, h0);
+    }
+    for (uint32_t idx = idx_first; idx < nitem;) {
+        // grp = idx / nunit without the ~25-instruction integer division: float estimate (exact for
+        // these magnitudes up to one) and a correction step
+        uint32_t grp = ngrp == 1 ? 0u : (uint32_t)(((float)idx + 0.5f) * inv_nunit);
+        if (ngrp != 1) {
+            if (grp * nunit > idx) --grp;
+            else if ((grp + 1) * nunit <= idx) ++grp;
+        }
+        const uint32_t unit = idx - grp * nunit;
+        const uint32_t it = TPW * unit + (uint32_t)half;     // index in this workgroup's tile list
+        const bool have_tile = TPW == 1 || it < ntile_blk;   // TPW > 1: the list's end may leave lanes idle
+        const uint32_t mt = have_tile ? blk + it * nblk : blk;
+        const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)row_bytes + (uint32_t)g * (6 * BTL * 8));
+        const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
+        // (one slot, one group: the table's address is the constant behind the exp table -- this file has no static LDS --
+        // and the compiler folds it into the reads' immediate offsets)
+        const uint32_t my_tab_w16 = (SLOTS == 1 && ONEGRP) ? (uint32_t)(kExpTabDoubles * sizeof(double)) : my_tab;
+        while (!dyn && grp_wave < grp) {                     // wave-uniform
+            flush_wave(grp_wave);
+            ++grp_wave;
+        }
+        // {first row, rows}; one scalar load when TPW == 1.  LCACHE: {LDS byte address of the tile's first row, rows}
+        vuint2 rec;
+        if constexpr (LCACHE) rec = *reinterpret_cast<lds_cuint2v*>(hook.cache_rec() + (have_tile ? it : 0u) * 8u);
+        else if (pipe) rec = rec_nx;
+        else rec = g_rec[mt];
+        // PIPE: the next item's record, requested now, needed when this item's rows have been walked
+        uint32_t idx_next = nitem;
+        bool have_next = false;
+        uint32_t mt_next = blk;
+        vuint2 rec_n2;
+        rec_n2.x = rec_n2.y = 0u;
+        if (pipe) {
+            idx_next = static_item(s_i + 1, round + 1);
+            mt_next = tile_of(idx_next, have_next);
+            rec_n2 = g_rec[mt_next];
+        }
+        // per-marker constants: issued now, consumed after the read loop
+        const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
+        const bool live = have_tile && pos < (size_t)L.num_active;
+        const size_t posc = live ? pos : 0;
+        const double cst = pipe ? cst_nx : g_ediag[posc];
+        const double e0 = g_ediag[mp + posc], e1 = g_ediag[2 * mp + posc], e2 = g_ediag[3 * mp + posc];
+
+        // (the panel row of the marker too: up to four UD columns and the mean)
+        double udr[4], mur = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) udr[kk] = (!known_af_p && kk < k) ? g_ud[(size_t)kk * mp + posc] : 0.0;
+        if (!known_af_p) mur = g_mu[posc];
+
+        // the six off-diagonal sums start from the marker's "other base" constant (it is part of
+        // every genotype pair's sum, h:299-303), so the epilogue needs no separate addition
+        double acc[BTL * 6];
+#pragma unroll
+        for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
+
+        // ---- per-read accumulate (h:288-303), one step per run ----
+        // Rows are prefetched kPrefetch deep: with one sample its pileup sits in L2, but a cohort
+        // launch streams every sample's rows from HBM once, and two rows ahead (~0.6 us of work)
+        // does not cover that latency.  The loads are unconditional: a prefetch past the tile's
+        // last row reads the next tile's rows (never consumed), and the array ends in
+        // 2 * kPrefetch padding rows (context.cpp).
+        // The read loop is bound by the LDS pipe, the epilogue by the FP64 VALU, and the waves of a CU
+        // are spread over both phases at any time: waves in the read loop get issue priority, so that
+        // their ds_reads go out as soon as they can and the LDS pipe stays busy, while the epilogue
+        // waves fill the VALU slots in between (-0.8 % per launch measured; the other way round: +0.8 %)
+        __builtin_amdgcn_s_setprio(1);
+        g_cuint2* cp = g_codes + (LCACHE ? (size_t)0 : (size_t)rec.x * kMtMarkers + m);
+        const uint32_t crow = rec.x + (uint32_t)m * 8u;      // (LCACHE: this lane's word of the tile's first row, LDS)
+        const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
+        // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
+        // tile's last row -- up to kPf useless row loads per item of 6..16 rows -- and every block of kPf rows begins
+        // by waiting for all of them.  Measured on one box, depth 8 / 4 / 2: 48-point launch 74.9 / 74.4 / 76.6 us;
+        // OptimizeLLK at C3 (one 4-point item per wave and round) 7.8 / 7.55 / 7.35 ms, at 10 000 markers 2.39 /
+        // 2.31 / 2.43 ms.)
+        // (STREAM: rows past the tile's last are the NEXT tiles' -- another workgroup's, at another time: fetched here
+        // they came from HBM twice, 573 MB instead of 356 MB per one-point step of 32 C3 samples (FETCH_SIZE, round 3).
+        // The row index is clamped to the tile's last row instead: the same cache line again, no new bytes.)
+        const int last_row = rows > 0 ? rows - 1 : 0;
+        auto load_row = [&](int j) -> vuint2 {               // row j of this lane's run words
+            if constexpr (LCACHE) return *reinterpret_cast<lds_cuint2v*>(crow + (uint32_t)j * (kMtMarkers * 8u));
+            else return cp[(size_t)(STREAM ? (j < last_row ? j : last_row) : j) * kMtMarkers];
+        };
+        if (!pipe) {
+#pragma unroll
+            for (int j = 0; j < kPf; ++j) w[j] = load_row(j);
+        }
+        auto walk_block = [&](const int s0, const bool refill) {     // rows s0 .. s0 + kPf - 1 of the tile
+#pragma unroll
+            for (int u = 0; u < kPf; ++u) {
+                if (s0 + u >= rows) break;
+                const vuint2 w_cur = w[u];
+                if (refill) w[u] = load_row(s0 + u + kPf);
+                walk_word(w_cur, acc, my_tab, my_tab_w16);
+            }
+        };
+        if constexpr (PIPE) {
+            if (pipe) {
+                // the first kPf rows outside any loop (loads in flight are counted, not drained); an item with more
+                // rows -- wide quality alphabets -- refills the ring as before
+                const bool more = __any(rows > kPf);
+                walk_block(0, more);
+                if (more)
+                    for (int s0 = kPf; s0 < rows; s0 += kPf) walk_block(s0, true);
+                // this item's rows are walked: the next item's go out now, under the epilogue
+                issue_rows(rec_n2, have_next);
+                cst_nx = other_const(mt_next, have_next);
+                rec_nx = rec_n2;
+            } else {
+                for (int s0 = 0; s0 < rows; s0 += kPf) walk_block(s0, true);
+            }
+        } else {
+            for (int s0 = 0; s0 < rows; s0 += kPf) walk_block(s0, true);
+        }
+
+        __builtin_amdgcn_s_setprio(0);
+        if (stamps && lane == 0 && wave == 1) stamps[3] = wall_clock64();      // wave 1: out of its (first) read loop
+        // ---- per-marker epilogue: this marker's likelihood as (mantissa, exponent) per point ----
+        double lk_m[BTL];
+        int lk_e[BTL];
+        marker_lk(live, pos, acc, e0, e1, e2, udr, mur, my_ptq, lk_m, lk_e);
         if (!dyn) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {               // running product, renormalised lazily
@@ -795,7 +921,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             if (++nfactor == kLazyRenorm) renorm_wave();
             if (have_sched) {
                 ++s_i;
-                idx = s_i < s_end ? (uint32_t)sch.item[s_i] : nitem;
+                idx = pipe ? idx_next : (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem);
                 continue;
             }
             // next round, direction reversed: the items are depth-sorted, and a plain deal would
@@ -864,6 +990,14 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (stamps) stamps[5] = t5;
         if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[20 * 8 + 7] += t5 - VB2_STAMPS_OF(L)[7];     // (accumulated: since "has the round")
     }
+    // A result that the host waits for (done_flag: llk_out is mapped host memory) is stored THROUGH the caches (a relaxed
+    // system-scope store); before the flag goes out the storing lanes wait for their stores' acknowledgements (vmcnt).
+    // Round 3 stored plainly and then fenced -- __threadfence_system, an ACQ_REL counter and a RELEASE flag store: three
+    // write-backs / invalidations of the whole L2 -- which was 10 of the 20 us an EMPTY cohort step took (round 4 ablation).
+    auto put_result = [&](int b, double v) {
+        if (done_flag) __hip_atomic_store(&llk_out[b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else llk_out[b] = v;
+    };
     if (ticket == nullptr) {                     // two-kernel mode: llk_finalize_kernel follows
         if (tid < NPT) partials[(size_t)tid * nblk + blk] = red[tid];
         return;
@@ -902,7 +1036,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
                 for (int q = 0; q < 8; ++q) s += x[q];
             }
             s = wave_sum(s);
-            if (lane == 0) llk_out[b] = s;
+            if (lane == 0) put_result(b, s);
         }
         if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -991,7 +1125,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
             for (int q = 0; q < 8; ++q) s += x[q];
         }
         s = wave_sum(s);
-        if (lane == 0) llk_out[b] = s;                   // NaN if a workgroup never reported
+        if (lane == 0) put_result(b, s);                 // NaN if a workgroup never reported
     }
     }
     if (VB2_STAMPS_OF(L) && tid == 0) {
@@ -999,22 +1133,27 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         if (stamps) stamps[6] = t6;
         if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[21 * 8 + 7] += t6 - VB2_STAMPS_OF(L)[7];
     }
+#ifdef VB2_ABL_NOSIGNAL  // (ablation build: no hand-off to the host)
+    if (false) {
+#else
     if (done_flag) {
+#endif
         // host hand-off without a stream synchronisation: results (in mapped host memory)
         // first, then the sequence number the host is spinning on.  In a multi-sample launch
         // the sample that completes last (batch_done counter) is the one that signals.
+        // (every sample's results are acknowledged before its count goes up; the counter's own order then puts the
+        // last sample's flag behind all of them.  Relaxed operations: nothing else of this launch is read by the host.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __threadfence_system();
             bool signal = true;
             if (batch_done) {
-                const unsigned int t = __hip_atomic_fetch_add(batch_done, 1u, __ATOMIC_ACQ_REL,
-                                                              __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int t = __hip_atomic_fetch_add(batch_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 signal = (t == batch_active - 1);
                 if (signal) __hip_atomic_store(batch_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (signal)
-                __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -1033,7 +1172,9 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
 // w / bps as that sample's workgroup w % bps.  Every sample has its own layout, parameter rows,
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
-template <int MODE, bool HWMAP, bool W16, int KSEL = 0>     // KSEL 2 / 4: every sample has that --NumPC and no known-AF column
+// STATIC: every sample of the launch is known (on the host) to run the static deal: the item loop is compiled for it
+// alone, and pipelined across items (eval_body: PIPE).
+template <int MODE, bool HWMAP, bool W16, int KSEL = 0, int STATIC = 0>     // KSEL 2 / 4: every sample has that --NumPC and no known-AF column
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* __restrict__ scheds,
                       const double* __restrict__ points,
@@ -1044,13 +1185,17 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
 {
     constexpr int NP = ModeNp<MODE>::value;
     const int s = blockIdx.x / bps;
+#ifdef VB2_ABL_NOMAP     // (ablation build: nothing is read from mapped host memory)
+    const int nv = NP;
+#else
     const int nv = num_valid[s];
+#endif
     if (nv <= 0) return;                                   // uniform for the workgroup
     const DeviceLayout L = layouts[s];
     const int stride = 2 * L.num_pc + 1;
     InlinePoints ip;
     ip.count = 0;
-    eval_body<MODE, HWMAP, W16, NoHook, true, -1, true, (KSEL > 0 ? 0 : -1), KSEL>(L, ip, points + (size_t)s * NP * stride, nv,
+    eval_body<MODE, HWMAP, W16, NoHook, true, (STATIC ? 0 : -1), true, (KSEL > 0 ? 0 : -1), KSEL>(L, ip, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1, use_ticket ? 0ull : done_seq,
@@ -1084,20 +1229,26 @@ llk_finalize_kernel(const double* __restrict__ partials, int nb, int num_point,
             for (int u = 0; u < 8; ++u) s += x[u];
         }
         s = wave_sum(s);
-        if (lane == 0) llk_out[b] = s;
-    }
-    if (done_flag) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence_system();
-            __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) {
+            if (done_flag) __hip_atomic_store(&llk_out[b], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else llk_out[b] = s;
         }
+    }
+    if (done_flag) {                    // (stores through the caches, acknowledged, then the flag: see eval_body)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
+bool eval_takes_the_queue(const DeviceLayout& L, int nblk, int nwave, int ngrp)
+{
+    return eval_is_dynamic(L, (uint32_t)nblk, nwave, ngrp);
+}
+
 static int g_geom_override[2][2] = {{0, 0}, {0, 0}};
 void set_geom_override(int btl, int max_waves, int blocks_per_cu)
 {
@@ -1134,18 +1285,30 @@ void set_lane_mapping(bool hw) { g_hwmap = hw; }
 
 // More than 64 KiB of dynamic LDS is an opt-in per kernel function AND per device (the function
 // object is per device in the runtime), so the flag is kept per (function slot, device).
-static hipError_t raise_lds_limit(const void* fn, int slot)
+// (keyed by the function's address and the device -- ADVICE r3: the hand-numbered slots of round 3 were one
+// specialisation away from a collision --: an open-addressed table of (function, device) keys, lock-free, a few dozen
+// entries ever)
+static hipError_t raise_lds_limit(const void* fn)
 {
-    constexpr int kSlots = 200, kDevs = 64;
-    static std::atomic<unsigned char> done[kSlots][kDevs];
+    constexpr unsigned kCap = 1024;
+    static std::atomic<uintptr_t> keys[kCap];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    const bool tracked = slot >= 0 && slot < kSlots && dev >= 0 && dev < kDevs;
-    if (tracked && done[slot][dev].load(std::memory_order_acquire)) return hipSuccess;
+    const uintptr_t key = (reinterpret_cast<uintptr_t>(fn) << 8) ^ (uintptr_t)(dev + 1);     // (never 0)
+    unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) % kCap;
+    for (unsigned probe = 0; probe < kCap; ++probe, h = (h + 1) % kCap) {
+        const uintptr_t seen = keys[h].load(std::memory_order_acquire);
+        if (seen == key) return hipSuccess;
+        if (seen == 0) break;
+    }
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess && tracked) done[slot][dev].store(1, std::memory_order_release);
-    return e;
+    if (e != hipSuccess) return e;
+    for (unsigned probe = 0; probe < kCap; ++probe, h = (h + 1) % kCap) {
+        uintptr_t expect = 0;
+        if (keys[h].compare_exchange_strong(expect, key, std::memory_order_acq_rel) || expect == key) break;
+    }
+    return hipSuccess;
 }
 
 static bool g_paired = true;          // 4-point launches: MODE 3 (two micro-tiles per wave) or MODE 1
@@ -1163,6 +1326,9 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
     const LaunchGeom gm = launch_geom(L, MODE == 2 ? 2 : 1, ngrp);
     const Schedule sch = sp ? sp->get(MODE, ngrp, gm.grid, gm.block_waves) : Schedule{nullptr, nullptr};
     const size_t shmem = eval_shmem_np(L, NP, gm.grid, gm.block_waves, ngrp);
+    // (the group cap of launch_llk_eval is worked out on the geometry of a kMaxGroups launch; this launch's own
+    // geometry -- fewer groups, maybe fewer waves -- needs no more LDS than that today, but nothing else says so)
+    if (shmem > (size_t)kLdsLimitBytes) return hipErrorInvalidConfiguration;
     // (the plain lane map is an A/B knob: one kernel that decides in the kernel; the hardware lane map: one per way)
     const bool dyn = eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, ngrp);
     const bool no_kaf = MODE == 2 && HWMAP && L.known_af == nullptr;      // (the 8-point shape: also compiled without that column)
@@ -1180,7 +1346,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
                      : dyn  ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1>)
                             : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0>);
     {
-        hipError_t e = raise_lds_limit(fn, (ksel == 4 ? 88 : ksel == 2 ? 68 : no_kaf ? 48 : 28) + ((MODE - 1) * 2 + (HWMAP ? 1 : 0)) * 2 + (dyn ? 1 : 0));
+        hipError_t e = raise_lds_limit(fn);
         if (e != hipSuccess) return e;
     }
     InlinePoints ip;
@@ -1304,7 +1470,8 @@ static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream, i
     const int variant = !g_hwmap ? 0 : (kHas16 && ml.w16) ? 2 : 1;
     const int use_ticket = ml.force_ticket ? 1 : 0;
     auto go = [&](auto kernel, int kslot) -> hipError_t {
-        hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kernel), 108 + (slot_base + variant) * 3 + kslot);
+        (void)kslot;
+        hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kernel));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, grid, block, ml.shmem, stream, ml.d_layouts, ml.d_scheds, ml.d_points,
                            ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps, ml.done_flag, ml.done_seq,
@@ -1317,6 +1484,11 @@ static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream, i
     constexpr bool kSpec = MODE >= 2;
     if constexpr (kHas16) {
         if (variant == 2) {
+            if (ml.all_static) {          // (the pipelined item loop: compiled for the static deal only)
+                if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, true, 4, 1>, 3);
+                if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, true, 2, 1>, 4);
+                return go(&llk_eval_multi_kernel<MODE, true, true, 0, 1>, 5);
+            }
             if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, true, 4>, 1);
             if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, true, 2>, 2);
             return go(&llk_eval_multi_kernel<MODE, true, true>, 0);
@@ -1345,7 +1517,7 @@ hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
 }
 
 // One thread per (micro-tile, row of four runs, marker): the 32-bit run words of `codes` re-coded as
-// dictionary index | count << 8.  Rows past a tile's own (and the slack rows at the end) hold padding
+// dictionary index | count code << 8 (count code: llk_kernels.h, codes16).  Rows past a tile's own (and the slack rows at the end) hold padding
 // words: the zero table row with count 0.
 __global__ void __launch_bounds__(256)
 pack_codes16_kernel(const DeviceLayout L, uint2* __restrict__ codes16, const uint2* __restrict__ mt_rec16,
@@ -1373,8 +1545,11 @@ pack_codes16_kernel(const DeviceLayout L, uint2* __restrict__ codes16, const uin
             for (int j = 0; j < 2; ++j) {
                 const uint32_t rw = j ? v.y : v.x;
                 const uint32_t idx = (rw & 0xffffu) / (uint32_t)L.row_bytes;
-                const uint32_t cnt = (uint32_t)__hiloint2double((int)(rw & 0xffff0000u), 0);
-                w[2 * h + j] = have ? (idx | (cnt << 8)) : pad;
+                // count code: the run word's top half IS the top half of double(n); relative to that of 1.0 it fits a byte
+                // (n <= 31 -> <= 0x4f); a padding run (count 0, the zero table row) gets code 0
+                const uint32_t top = rw >> 16;
+                const uint32_t code = top >= 0x3ff0u ? (top - 0x3ff0u) & 0xffu : 0u;
+                w[2 * h + j] = have ? (idx | (code << 8)) : pad;
             }
         }
         codes16[((size_t)r16.x + row) * kMtMarkers + m] = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
@@ -1536,11 +1711,15 @@ __global__ void __launch_bounds__(64)
 publish_kernel(const double* __restrict__ src, double* __restrict__ dst_mapped, int n,
                unsigned long long* __restrict__ done_flag, unsigned long long done_seq)
 {
-    for (int j = threadIdx.x; j < n; j += 64) dst_mapped[j] = src[j];
-    __threadfence_system();
+    // (the collective's output is read past the caches -- another kernel, maybe another agent, wrote it --, the copies
+    // go through them to host memory, are acknowledged, and then the flag goes out: no cache-wide fence)
+    for (int j = threadIdx.x; j < n; j += 64)
+        __hip_atomic_store(&dst_mapped[j], __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0)
-        __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 hipError_t launch_publish(const double* d_src, double* d_dst_mapped, int n, unsigned long long* done_flag,
