@@ -107,8 +107,12 @@ REAL = {
     # BASELINE.json configs[0] names this panel; configs[2] is the shape of its 100k sibling
     "10k_k2": dict(panel="1000g.phase3.10k.b37.vcf.gz.dat", num_pc=2, depth=30, alpha_true=0.05, seed=11, points=8),
     "10k_k4": dict(panel="1000g.phase3.10k.b37.vcf.gz.dat", num_pc=4, depth=30, alpha_true=0.08, seed=12, points=8),
-    "100k_k4": dict(panel="1000g.phase3.100k.b37.vcf.gz.dat", num_pc=4, depth=30, alpha_true=0.03, seed=13, points=3),
+    # (round 4: the other model branches of ContaminationEstimator.cpp:98-150 at this size too -- --WithinAncestry on the
+    # 100k panel, and --KnownAF, which main.cpp:314-319 turns into a one-parameter search over alpha)
+    "100k_k4": dict(panel="1000g.phase3.100k.b37.vcf.gz.dat", num_pc=4, depth=30, alpha_true=0.03, seed=13, points=3,
+                    extra_models=("within", "known_af")),
 }
+KNOWN_AF_SEED = 77
 
 
 def file_sha(path):
@@ -172,6 +176,31 @@ def real_panel_fixture(spec, tmpdir):
         num_eval=a["num_eval"], pc_hex=[float(x).hex() for x in a["pc"]], pc2_hex=[float(x).hex() for x in a["pc2"]],
         trace_sha256=trace_digest(a["trace"]), trace_head_llk_hex=[float(x).hex() for x in a["trace"]["llk"][:6]],
         cross_checked_with_reference_minimiser=have_ref)
+    def model_record(od_, args, label):
+        a_ = od_.optimize(num_thread=1, minimizer="oracle", trace_capacity=1 << 14, **args)
+        if have_ref:
+            b_ = od_.optimize(num_thread=1, minimizer="reference", trace_capacity=1 << 14, **args)
+            if not (a_["alpha"] == b_["alpha"] and a_["llk1"] == b_["llk1"] and a_["llk0"] == b_["llk0"] and
+                    a_["num_eval"] == b_["num_eval"] and trace_digest(a_["trace"]) == trace_digest(b_["trace"])):
+                raise SystemExit("oracle minimiser and the reference's AmoebaMinimizer disagree on %s (%s)" % (spec["panel"], label))
+        return dict(args=args, alpha_hex=float(a_["alpha"]).hex(), llk1_hex=float(a_["llk1"]).hex(),
+                    llk0_hex=float(a_["llk0"]).hex(), num_eval=a_["num_eval"], pc_hex=[float(x).hex() for x in a_["pc"]],
+                    pc2_hex=[float(x).hex() for x in a_["pc2"]], trace_sha256=trace_digest(a_["trace"]),
+                    trace_head_llk_hex=[float(x).hex() for x in a_["trace"]["llk"][:6]],
+                    cross_checked_with_reference_minimiser=have_ref)
+    if "within" in spec.get("extra_models", ()):
+        out["models"]["within"] = model_record(od, {"within_ancestry": True}, "within")
+    if "known_af" in spec.get("extra_models", ()):
+        afp = vb.synth.write_known_af(prefix, os.path.join(tmpdir, "real.af"), KNOWN_AF_SEED)
+        flat_k, _, _ = refio.load_flat(prefix, pile, k, sanity_disabled=False, known_af_path=afp)
+        if not flat_k.af_known:
+            raise SystemExit("the known-AF file was not taken up")
+        od_k = binding.OracleData(flat_k)
+        rec = model_record(od_k, {}, "known_af")
+        rec["known_af_seed"] = KNOWN_AF_SEED
+        rec["known_af_sha256"] = hashlib.sha256(open(afp, "rb").read()).hexdigest()
+        rec["llk_hex"] = [float(od_k.llk(pc1[i], pc2[i], alpha[i], num_thread=1)).hex() for i in range(B)]
+        out["models"]["known_af"] = rec
     return out
 
 

@@ -232,6 +232,19 @@ def test_real_panel_fixtures_reproduce_from_the_oracle(golden_dir, tmp_path, cas
         for key in ("alpha", "pc1", "pc2", "llk"):
             hh.update(np.ascontiguousarray(r["trace"][key]).tobytes())
         assert hh.hexdigest() == m["trace_sha256"]
+    if "known_af" in fx["models"]:
+        # --KnownAF at this size (round 4): the seeded AF file is the recorded one, the restated readers take it up,
+        # and the oracle gives the recorded +LLK bits and the recorded one-parameter search
+        mk = fx["models"]["known_af"]
+        afp = vb.synth.write_known_af(prefix, str(tmp_path / "real.af"), mk["known_af_seed"])
+        assert hashlib.sha256(open(afp, "rb").read()).hexdigest() == mk["known_af_sha256"]
+        flat_k, _, _ = refio.load_flat(prefix, pile, k, sanity_disabled=False, known_af_path=afp)
+        assert flat_k.af_known
+        od_k = binding.OracleData(flat_k)
+        for i in range(len(mk["llk_hex"])):
+            assert float(od_k.llk(P["pc1"][i], P["pc2"][i], P["alpha"][i], num_thread=1)).hex() == mk["llk_hex"][i], i
+        rk = od_k.optimize(num_thread=1)
+        assert float(rk["alpha"]).hex() == mk["alpha_hex"] and rk["num_eval"] == mk["num_eval"]
 
 
 # ---- the device's restatement of libm exp() (InvLogit, ContaminationEstimator.h:119-122) ----

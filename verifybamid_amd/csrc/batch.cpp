@@ -344,6 +344,13 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
         for (int s2 = 0; s2 < num_sample && plain; ++s2) plain = ctx_[s2]->L.known_af == nullptr;
         ml.ksel = plain ? num_pc : 0;
     }
+    // counts and rows as kernel arguments when they fit (saves every workgroup two trips to mapped host memory)
+    ml.inl.count = 0;
+    if (num_sample <= kMultiInlineSamples && (size_t)num_sample * NP * stride <= (size_t)kMultiInlineDoubles) {
+        ml.inl.count = num_sample * NP * stride;
+        for (int s2 = 0; s2 < num_sample; ++s2) ml.inl.nv[s2] = (unsigned char)h_nv_[s2];
+        std::memcpy(ml.inl.v, h_points_, sizeof(double) * (size_t)ml.inl.count);
+    }
     VB2_HIP(launch_llk_eval_multi(ml, stream_));
     ++num_launch;
     in_flight_ = true;

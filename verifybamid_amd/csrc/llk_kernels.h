@@ -112,6 +112,14 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
 void set_single_launch(bool on);
 void set_reduce_mode(int mode);     // 0 auto, 1 arrival ticket, 2 tagged sets (VB2_REDUCE)
 
+// A cohort step's point counts and parameter rows as kernel arguments (count = doubles valid in v; 0 = the kernel reads
+// d_num_valid / d_points): rows of sample s at v[s * np * (2k+1) ..)
+constexpr int kMultiInlineDoubles = 432, kMultiInlineSamples = 64;
+struct MultiInline {
+    int count;
+    unsigned char nv[kMultiInlineSamples];
+    double v[kMultiInlineDoubles];
+};
 // One launch over several samples (contexts on the same device): see llk_eval_multi_kernel.
 struct MultiLaunch {
     const DeviceLayout* d_layouts;   // [num_sample] in HBM
@@ -134,6 +142,7 @@ struct MultiLaunch {
     int ksel;                        // 2 or 4: every sample has --NumPC of that and no known-AF column (the kernels compiled
                                      // for it); 0: the general kernels
     size_t shmem;
+    MultiInline inl;                 // the step's counts and rows again, for the kernel-argument segment (count 0: not used)
 };
 // a launch of this geometry pulls its work items through the LDS queue (else: the static deal)
 bool eval_takes_the_queue(const DeviceLayout& L, int nblk, int nwave, int ngrp);

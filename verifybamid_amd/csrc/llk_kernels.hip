@@ -345,7 +345,7 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1,
           bool ONEGRP = (MODE >= 3), int KAF = -1, int KSEL = 0, bool LCACHE = false>
 __device__ __forceinline__ void
-eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restrict__ points, int num_valid,
+eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
           unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
           unsigned long long done_seq, const uint32_t blk, const uint32_t nblk,
@@ -416,7 +416,7 @@ eval_body(const DeviceLayout& L, const InlinePoints& ip, const double* __restric
         const double v = 0.01 * (double)(1 + idx % 7);
 #else
         const double v = lds_rows ? lds_rows[idx]
-                         : ip.count > 0 ? ip.v[idx]
+                         : ip_count > 0 ? ip_v[idx]
                          : coherent_points ? __hip_atomic_load(&points[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                            : points[idx];
 #endif
@@ -1165,7 +1165,7 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
                 unsigned long long done_seq, int ngrp, unsigned long long tag, const Schedule sch)
 {
-    eval_body<MODE, HWMAP, false, NoHook, false, QUEUE, (MODE >= 3), KAF, KSEL>(L, ip, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
+    eval_body<MODE, HWMAP, false, NoHook, false, QUEUE, (MODE >= 3), KAF, KSEL>(L, ip.v, ip.count, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
                            blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
 }
 
@@ -1181,21 +1181,23 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
                       const int* __restrict__ num_valid, double* __restrict__ partials,
                       double* __restrict__ llk_out, unsigned int* __restrict__ tickets, int bps,
                       unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
-                      unsigned int* __restrict__ batch_done, unsigned int batch_active, int use_ticket)
+                      unsigned int* __restrict__ batch_done, unsigned int batch_active, int use_ticket,
+                      const MultiInline mi)
 {
     constexpr int NP = ModeNp<MODE>::value;
     const int s = blockIdx.x / bps;
+    // (mi: the step's point counts and parameter rows as kernel arguments when they fit -- a step of 32 samples x 1 point
+    // or 16 x 2 --: otherwise every workgroup reads them from mapped host memory, two dependent trips over PCIe, ~2.4 us
+    // of the ~20 an empty step took in round 3)
 #ifdef VB2_ABL_NOMAP     // (ablation build: nothing is read from mapped host memory)
     const int nv = NP;
 #else
-    const int nv = num_valid[s];
+    const int nv = mi.count > 0 ? (int)mi.nv[s] : num_valid[s];
 #endif
     if (nv <= 0) return;                                   // uniform for the workgroup
     const DeviceLayout L = layouts[s];
     const int stride = 2 * L.num_pc + 1;
-    InlinePoints ip;
-    ip.count = 0;
-    eval_body<MODE, HWMAP, W16, NoHook, true, (STATIC ? 0 : -1), true, (KSEL > 0 ? 0 : -1), KSEL>(L, ip, points + (size_t)s * NP * stride, nv,
+    eval_body<MODE, HWMAP, W16, NoHook, true, (STATIC ? 0 : -1), true, (KSEL > 0 ? 0 : -1), KSEL>(L, mi.v + (size_t)s * NP * stride, mi.count, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1, use_ticket ? 0ull : done_seq,
@@ -1475,7 +1477,7 @@ static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream, i
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, grid, block, ml.shmem, stream, ml.d_layouts, ml.d_scheds, ml.d_points,
                            ml.d_num_valid, ml.d_partials, ml.d_out, ml.d_tickets, ml.bps, ml.done_flag, ml.done_seq,
-                           ml.d_batch_done, ml.batch_active, use_ticket);
+                           ml.d_batch_done, ml.batch_active, use_ticket, ml.inl);
         return hipGetLastError();
     };
     if (variant == 0) return go(&llk_eval_multi_kernel<MODE, false, false>, 0);

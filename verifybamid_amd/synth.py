@@ -173,3 +173,17 @@ def real_panel_sample(svd_prefix, pileup_path, mean_depth=30.0, alpha_true=0.05,
     mu = read_mu_column(svd_prefix + ".mu")
     off, b, q = reads_on_panel(mu, refs, alts, mean_depth, alpha_true, seed)
     return write_pileup_text(pileup_path, chrs, poss, refs, off, b, q)
+
+
+def write_known_af(svd_prefix, path, seed=1):
+    """A --KnownAF file for the panel behind `svd_prefix` (.bed/.mu): one `chr start end ref alt af` row per panel
+    row, af = clamp(mu / 2 + N(0, 0.02)) -- seeded, so a fixture recipe and its tests write the same file."""
+    chrs, poss, refs, alts = read_bed_rows(svd_prefix + ".bed")
+    mu = read_mu_column(svd_prefix + ".mu")
+    rng = np.random.default_rng(seed)
+    af = np.clip(mu / 2.0 + rng.normal(0.0, 0.02, size=mu.shape[0]), 0.001, 0.999)
+    with open(path, "w") as f:
+        for i in range(len(chrs)):
+            f.write("%s\t%d\t%d\t%s\t%s\t%r\n" % (chrs[i], int(poss[i]) - 1, int(poss[i]), chr(int(refs[i])),
+                                                  chr(int(alts[i])), float(af[i])))
+    return path
