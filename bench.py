@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--markers", type=int, default=100000)
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--num-pc", type=int, default=4)
+    ap.add_argument("--q-lo", type=int, default=20, help="base qualities of the synthetic reads: uniform in q-lo..q-hi "
+                    "(SURVEY 8d: 20..40; 2..60 = the BAQ-like alphabet of roofline_wide_alphabet, for its profile passes)")
+    ap.add_argument("--q-hi", type=int, default=40)
     ap.add_argument("--mode", choices=["sample", "marker"], default="sample")
     ap.add_argument("--cohort-samples", type=int, default=32, help="samples of the single-GPU cohort leg (0 = skip)")
     ap.add_argument("--cohort-files", type=int, default=256,
@@ -164,10 +167,11 @@ def main():
 
     k, B = args.num_pc, args.batch
     # ---- inputs (synthetic, seeded), flattened into HBM before timing ----
-    shared = vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.05, seed=2)   # the sample every rank knows
+    qkw = dict(q_lo=args.q_lo, q_hi=args.q_hi)
+    shared = vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.05, seed=2, **qkw)   # the sample every rank knows
     if args.mode == "sample":
         data = shared if rank == 0 else vb.synth.make_pileup(args.markers, args.depth, k, alpha_true=0.05,
-                                                             seed=2 + rank)
+                                                             seed=2 + rank, **qkw)
     else:
         data = shared
     # an explicit (non-null) stream: the kernels and the HIP events all go on it, so the events
@@ -256,8 +260,9 @@ def main():
         "higher_is_better": True, "scaling": "weak" if args.mode == "sample" else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": "synthetic pileup %d markers x depth %g, --NumPC %d (BASELINE.json configs[2] shape)"
-                        % (args.markers, args.depth, k),
+            "workload": "synthetic pileup %d markers x depth %g, --NumPC %d (BASELINE.json configs[2] shape)%s"
+                        % (args.markers, args.depth, k,
+                           "" if (args.q_lo, args.q_hi) == (20, 40) else ", base qualities %d..%d" % (args.q_lo, args.q_hi)),
             "batch_points_per_step": B, "prewarm_ms": args.prewarm_ms,
             "parallelism": ("1 GPU" if world == 1 else
                             ("sample-parallel x%d (one sample per GPU, no collective)" % world

@@ -32,7 +32,7 @@ class _Options(C.Structure):
     _fields_ = [
         ("is_heter", C.c_int32), ("is_pc_fixed", C.c_int32), ("is_alpha_fixed", C.c_int32),
         ("fix_alpha", C.c_double), ("fix_pc", C.c_void_p), ("epsilon", C.c_double),
-        ("num_thread", C.c_int32),
+        ("num_thread", C.c_int32), ("verbose", C.c_int32),
     ]
 
 
@@ -132,7 +132,7 @@ class OracleData:
                                            float(alpha), int(num_thread))
 
     def optimize(self, *, within_ancestry=False, fix_pc=None, fix_alpha=None, epsilon=1e-8,
-                 num_thread=1, minimizer="oracle", trace_capacity=0):
+                 num_thread=1, minimizer="oracle", trace_capacity=0, verbose=False):
         """Full OptimizeLLK.  minimizer: 'oracle' (C restatement) or 'reference'
         (oracle/_ref AmoebaMinimizer)."""
         k = self.flat.num_pc
@@ -140,7 +140,7 @@ class OracleData:
         opt = _Options(int(not within_ancestry), int(fix_pc is not None),
                        int(fix_pc is None and fix_alpha is not None),
                        float(fix_alpha if fix_alpha is not None else 0.0), _ptr(fpc),
-                       float(epsilon), int(num_thread))
+                       float(epsilon), int(num_thread), int(bool(verbose)))
         mini = None
         if minimizer == "reference":
             r = ref_lib()

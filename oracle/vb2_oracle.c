@@ -11,6 +11,7 @@
 #include <ctype.h>
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -288,6 +289,7 @@ typedef struct est_state {
     double llk1, llk0;
     int64_t num_eval;
     vb2o_trace *trace;
+    int verbose;
 } est_state;
 
 static double est_llk(est_state *e, const double *pc1, const double *pc2, double alpha)
@@ -378,6 +380,12 @@ static double est_evaluate(void *user, const double *v, int n)
             }
         }
     }
+    /* h:435-440: `notice(...)` of libStatGen (statgen/Error.cpp:70-79) = "NOTICE - " + the formatted text + '\n' on
+     * stderr; the reference indexes globalPC[0..1] whatever --NumPC is (k = 1 would read past the vector there: 0 here) */
+    if (e->verbose)
+        fprintf(stderr, "NOTICE - ContaminatingSamplePC1:%f\tContaminatingSamplePC2:%f\tIntendedSamplePC1:%f\t"
+                        "IntendedSamplePC2:%f\tFREEMIX(Alpha):%f\tllk:%f\n",
+                e->g_pc[0], k > 1 ? e->g_pc[1] : 0.0, e->g_pc2[0], k > 1 ? e->g_pc2[1] : 0.0, e->g_alpha, e->llk1);
     return sm;
 }
 
@@ -454,6 +462,7 @@ int vb2o_optimize_llk(const vb2o_data *d, const vb2o_options *opt,
     e->d = d;
     e->k = k;
     e->num_thread = opt->num_thread;
+    e->verbose = opt->verbose;
     e->trace = trace;
     if (trace) trace->count = 0;
     /* ctor, cpp:38-51 + main.cpp:287-319 */

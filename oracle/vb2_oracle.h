@@ -70,6 +70,7 @@ typedef struct vb2o_options {
     const double *fix_pc;    /* --FixPC values -> PC[1] (main.cpp:304-306), or NULL  */
     double  epsilon;         /* --Epsilon, default 1e-8 (main.cpp:76)                */
     int32_t num_thread;      /* --NumThread                                          */
+    int32_t verbose;         /* --Verbose: FullLLKFunc::Evaluate's notice per call (h:435-440) on stderr */
 } vb2o_options;
 
 /* One record per ComputeMixLLKs call, in call order. */

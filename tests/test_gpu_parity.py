@@ -165,6 +165,35 @@ def test_cli_reproduces_reference_ctest(golden_dir, kat, tmp_path, case):
     assert "FREEMIX(Alpha):" in p.stdout
 
 
+def test_cli_verbose_stream_is_the_references(golden_dir, tmp_path):
+    """`VerifyBamID --Verbose` on the GPU: one "NOTICE - ContaminatingSamplePC1:...\tllk:..." line per evaluation made
+    through FullLLKFunc::Evaluate (ContaminationEstimator.h:435-440), the same lines the oracle's restatement of that
+    statement prints for the same input -- number for number (the six decimals of %f; an LLK that differs in its
+    sixteenth digit may round the last printed one differently: 2e-6 allowed)."""
+    import re
+    import sys
+    from oracle import binding, refio
+    exe = os.path.join(ROOT, "verifybamid_amd", "bin", "VerifyBamID")
+    pile = os.path.join(golden_dir, "expected/result.Pileup")
+    p = subprocess.run([exe, "--DisableSanityCheck", "--PileupFile", pile, "--SVDPrefix", os.path.join(golden_dir, HAPMAP),
+                        "--Reference", "resource/test/chr20.fa.gz", "--NumPC", "2", "--Verbose", "--Output",
+                        str(tmp_path / "v")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    got = [ln for ln in p.stderr.split("\n") if ln.startswith("NOTICE - ContaminatingSamplePC1:")]
+    code = ("import sys; sys.path.insert(0, %r); from oracle import binding, refio; "
+            "flat, _, _ = refio.load_flat(%r, %r, 2); binding.OracleData(flat).optimize(verbose=True)"
+            % (ROOT, os.path.join(golden_dir, HAPMAP), pile))
+    q = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stderr
+    want = [ln for ln in q.stderr.split("\n") if ln.startswith("NOTICE - ContaminatingSamplePC1:")]
+    assert len(got) == len(want) == 604 - 2          # every evaluation but Initialize's and CalculateLLK0's direct calls
+    num = re.compile(r":(-?\d+\.\d{6})")
+    for a, b in zip(got, want):
+        va, vb_ = [float(x) for x in num.findall(a)], [float(x) for x in num.findall(b)]
+        assert len(va) == 6 and np.allclose(va, vb_, rtol=0, atol=2e-6), (a, b)
+        assert re.sub(num, ":#", a) == re.sub(num, ":#", b)
+
+
 def test_cli_optimiser_variants(golden_dir, tmp_path):
     """--NumStart / --Seed / --LineSearch (not in the reference; vb2_search_opts): one start is the
     plain run byte for byte; several starts report an LLK that is no worse; --LineSearch drives the --WithinAncestry --FixPC model through Brent."""

@@ -4,7 +4,7 @@
 #   WRITE_SIZE, SQ counters, GRBM_GUI_ACTIVE; each in its own run, with --kernel-trace only),
 #   kernel stats of the other wave shapes (4-point / 1-point launches, cohort steps) and of a search.
 # Usage: bash tools/collect_profiles.sh r02
-R=${1:-r03}
+R=${1:-r04}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
@@ -24,4 +24,23 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_modes -o m -- p
 # HBM-side bytes of the cohort steps (32 samples; 1, 2, 4 and 8 points per sample): FETCH_SIZE of llk_eval_multi_kernel<*>
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_modes_fetch -o m -- python $GRAFT_REPO_ROOT/tools/prof_modes.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_opt -o o -- python $GRAFT_REPO_ROOT/tools/opt_time.py > $O/trace_opt.log 2>&1
+# the cohort steps of a search (1 and 2 points per sample: llk_eval_multi_kernel<4,...>, <5,...>): kernel stats, SQ passes, FETCH_SIZE
+C="python $GRAFT_REPO_ROOT/tools/prof_cohort.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cohort -o c -- $C > $O/trace_cohort.log 2>&1
+VB2_STEPS=40 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_cohort_sq1 -o c -- $C > /dev/null 2>&1
+VB2_STEPS=40 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_cohort_sq2 -o c -- $C > /dev/null 2>&1
+VB2_STEPS=40 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_cohort_fetch -o c -- $C > /dev/null 2>&1
+VB2_STEPS=40 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_cohort_grbm -o c -- $C > /dev/null 2>&1
+# the headline launch on the BAQ-like quality alphabet (2..60: bench.py -> roofline_wide_alphabet): kernel stats + the SQ / GRBM passes
+W="$B --q-lo 2 --q-hi 60"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_wide -o w -- $W > $O/trace_wide.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_wide_sq1 -o w -- $W $P > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_wide_grbm -o w -- $W $P > /dev/null 2>&1
+# a search round's timeline (in-kernel stamps; the build with the stamps frozen at round 200 if it was made: make stamps_round)
+cd $GRAFT_REPO_ROOT
+python tools/stamps_resident.py > $O/search_round_stamps.txt 2>&1
+if [ -f verifybamid_amd/libvb2_stamps_r.so ]; then VB2_STAMPS_ROUND=1 VB2_STAMPS_DETAIL=1 python tools/stamps_resident.py > $O/search_round200_stamps.txt 2>&1; fi
+# the big raw tables stay on the box: only the per-kernel summaries travel (gpurun_out is capped at 64 MiB)
+for d in $O/pmc_* $O/trace*; do [ -d $d ] && find $d -name "*kernel_trace.csv" -size +2M -delete; done
+find $O -name "*.db" -delete
 ls $O

@@ -5,7 +5,7 @@ search), PMC summary, batch sweep, and the two derived files bench.py reads back
 instructions per marker x point).
 Usage: python tools/update_profiles.py r02"""
 import csv, json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles", R)
 os.makedirs(dst, exist_ok=True)
@@ -80,7 +80,7 @@ if os.path.isdir(cm):
     pth = [os.path.join(cm, f) for f in os.listdir(cm) if f.endswith("counter_collection.csv")][0]
     acc = {}
     for row in csv.DictReader(open(pth)):
-        mm = re.search(r"llk_eval_multi_kernel<(\d), (true|false)(?:, (true|false))?(?:, \d+)?>", row["Kernel_Name"])
+        mm = re.search(r"llk_eval_multi_kernel<(\d), (true|false)(?:, (true|false))?(?:, \d+)*>", row["Kernel_Name"])
         if mm and row["Counter_Name"] == "FETCH_SIZE":
             acc.setdefault((int(mm.group(1)), mm.group(3) == "true"), []).append(float(row["Counter_Value"]))
     np_of = {4: 1, 5: 2, 3: 4, 2: 8}
@@ -94,6 +94,82 @@ if os.path.isdir(cm):
         ct["kernels"][str(np_of[mode])] = "llk_eval_multi_kernel<%d, true, %s>, %d launches" % (mode, "true" if w16 else "false", len(vals))
     json.dump(ct, open(os.path.join(dst, "cohort_traffic.json"), "w"), indent=1)
     print("cohort step traffic (bytes):", ct["traffic_bytes_per_step"])
+
+# ---- round 4: the cohort steps of a search (1 / 2 points per sample), the wide alphabet, the round timeline ----
+def first_csv(d, suffix):
+    dd = os.path.join(src, d)
+    if not os.path.isdir(dd):
+        return None
+    c = [os.path.join(dd, f) for f in os.listdir(dd) if f.endswith(suffix)]
+    return c[0] if c else None
+
+
+def avg_of(path, kernel_sub, name):
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+            if kernel_sub in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return sum(vals) / len(vals) if vals else None
+
+
+ks = first_csv("trace_cohort", "kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(dst, "cohort_kernel_stats.csv"))
+    cp = {"_what": "the steps of a cohort search -- 32 C3-shaped samples, 1 and 2 points per sample: llk_eval_multi_kernel<4, true, true, 4, 1> "
+                   "and <5, ...> (16-bit run lists, --NumPC 4, static deal with the pipelined item loop) -- under rocprofv3 --pmc "
+                   "(tools/prof_cohort.py; one pass per counter group): VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles), "
+                   "cycles = GRBM_GUI_ACTIVE / 8; LDS busy = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles); parked = SQ_WAIT_ANY / "
+                   "SQ_WAVE_CYCLES (waves in s_waitcnt or at a barrier); traffic = FETCH_SIZE x 2 (gfx950 correction)",
+          "samples": 32, "markers": markers, "kernels": {}}
+    for mode, npnt in ((4, 1), (5, 2)):
+        sub = "llk_eval_multi_kernel<%d," % mode
+        sq1, sq2 = first_csv("pmc_cohort_sq1", "counter_collection.csv"), first_csv("pmc_cohort_sq2", "counter_collection.csv")
+        fe, gr = first_csv("pmc_cohort_fetch", "counter_collection.csv"), first_csv("pmc_cohort_grbm", "counter_collection.csv")
+        if not (sq1 and sq2 and fe and gr):
+            continue
+        cyc = avg_of(gr, sub, "GRBM_GUI_ACTIVE") / 8.0
+        iv, av = avg_of(sq1, sub, "SQ_INSTS_VALU"), avg_of(sq1, sub, "SQ_ACTIVE_INST_VALU")
+        cp["kernels"][str(npnt)] = {
+            "points_per_sample": npnt, "cycles_per_step_profiled": cyc,
+            "lane_instr_per_marker_point": round(iv * 64 / (32.0 * markers * npnt), 1),
+            "valu_busy_frac": round(av * 4 / (1024 * cyc), 3),
+            "lds_busy_frac": round(avg_of(sq1, sub, "SQ_LDS_IDX_ACTIVE") / (256 * cyc), 3),
+            "lds_bank_conflict_frac": round(avg_of(sq1, sub, "SQ_LDS_BANK_CONFLICT") / max(1.0, avg_of(sq1, sub, "SQ_LDS_IDX_ACTIVE")), 4),
+            "parked_frac": round(avg_of(sq2, sub, "SQ_WAIT_ANY") / avg_of(sq1, sub, "SQ_WAVE_CYCLES"), 3),
+            "issue_stall_frac": round(avg_of(sq2, sub, "SQ_WAIT_INST_ANY") / avg_of(sq1, sub, "SQ_WAVE_CYCLES"), 3),
+            "traffic_bytes_per_step": int(2 * 1024 * avg_of(fe, sub, "FETCH_SIZE"))}
+    json.dump(cp, open(os.path.join(dst, "cohort_pmc.json"), "w"), indent=1)
+    # bench.py reads cohort_traffic.json: refresh the 1- and 2-point entries from this pass
+    ctp = os.path.join(dst, "cohort_traffic.json")
+    ct2 = json.load(open(ctp)) if os.path.exists(ctp) else {"samples": 32, "markers": markers, "traffic_bytes_per_step": {}, "kernels": {}}
+    for npnt, kk in cp["kernels"].items():
+        ct2["traffic_bytes_per_step"][npnt] = kk["traffic_bytes_per_step"]
+    json.dump(ct2, open(ctp, "w"), indent=1)
+    print("cohort steps:", {n: (kk["valu_busy_frac"], kk["lds_busy_frac"], kk["parked_frac"], kk["traffic_bytes_per_step"]) for n, kk in cp["kernels"].items()})
+
+ws = first_csv("trace_wide", "kernel_stats.csv")
+if ws:
+    shutil.copy(ws, os.path.join(dst, "bench_b%d_wide_kernel_stats.csv" % B))
+    sq1, gr = first_csv("pmc_wide_sq1", "counter_collection.csv"), first_csv("pmc_wide_grbm", "counter_collection.csv")
+    if sq1 and gr:
+        sub = "llk_eval_kernel"
+        cyc = avg_of(gr, sub, "GRBM_GUI_ACTIVE") / 8.0
+        iv = avg_of(sq1, sub, "SQ_INSTS_VALU")
+        # (a %d-point call on this alphabet is several launches: per-launch counters, points per launch from the instruction count's
+        # ratio is not needed -- lane instructions are per marker x point of the launch's own points)
+        launches = len([1 for r in csv.DictReader(open(sq1)) if sub in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU"])
+        calls = 50 + 20
+        ppl = B / max(1.0, round(launches / float(calls)))
+        wv = {"_what": "the headline launch on base qualities 2..60 (118 dictionary codes: 16 points per launch fit the LDS, a "
+                       "48-point call is three launches): SQ / GRBM passes of `bench.py --q-lo 2 --q-hi 60 --no-extras`, per LAUNCH",
+              "markers": markers, "batch": B, "num_pc": k, "points_per_launch": ppl,
+              "lane_instr_per_marker_point": round(iv * 64 / (markers * ppl), 1),
+              "valu_busy_frac": round(avg_of(sq1, sub, "SQ_ACTIVE_INST_VALU") * 4 / (1024 * cyc), 3),
+              "lds_busy_frac": round(avg_of(sq1, sub, "SQ_LDS_IDX_ACTIVE") / (256 * cyc), 3),
+              "lds_bank_conflict_frac": round(avg_of(sq1, sub, "SQ_LDS_BANK_CONFLICT") / max(1.0, avg_of(sq1, sub, "SQ_LDS_IDX_ACTIVE")), 4)}
+        json.dump(wv, open(os.path.join(dst, "valu_b%d_wide.json" % B), "w"), indent=1)
+        print("wide alphabet:", wv["points_per_launch"], wv["lane_instr_per_marker_point"], wv["valu_busy_frac"], wv["lds_busy_frac"])
+for f in ("search_round_stamps.txt", "search_round200_stamps.txt"):
+    if os.path.exists(os.path.join(src, f)):
+        open(os.path.join(dst, f), "w").write("".join(l for l in open(os.path.join(src, f)) if "amdgpu.ids" not in l))
 
 print("value %.0f evals/s, %.2f us/launch, frac %.3f, optimize %.2f ms, traffic %d B/launch, %s lane instr per marker x point, "
       "VALU busy %s, LDS busy %s" % (bench["value"], bench["roofline"]["device_us_per_launch"], bench["roofline"]["frac"],
