@@ -215,7 +215,6 @@ def test_line_search_equals_the_references_scalar_minimizer(golden_dir):
             assert len(launched) == len(ref_x) + (1 if speculate else 0)   # the unused candidate for c
 
 
-@pytest.mark.parametrize("speculate", [4, 2])
 def _capture_stderr(fn):
     """fn() with file descriptor 2 redirected to a temporary file (C stdio of the libraries included)."""
     import ctypes
@@ -257,6 +256,7 @@ def test_verbose_notices_are_the_references_per_evaluation_lines(golden_dir, kw)
     assert len(lines_p) == got["num_eval"] - 2 and got["num_eval"] == want["num_eval"]
 
 
+@pytest.mark.parametrize("speculate", [4, 2])
 def test_lockstep_fibers_give_each_run_its_own_search(golden_dir, speculate):
     """lockstep.h -- what cohorts and multi-start searches run on: several OptimizeLLK searches as
     fibers of one thread, every step's requests answered by ONE evaluator call.  Here without a
