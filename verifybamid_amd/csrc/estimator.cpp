@@ -34,7 +34,7 @@ static void record(Estimator* e, const double* pc1, const double* pc2, double al
     if (!t) return;
     if (t->count < t->capacity) {
         const int64_t r = t->count;
-        const int k = e->numPC;
+        const int k = e->npc;
         t->alpha[r] = alpha;
         t->llk[r] = llk;
         std::memcpy(t->pc1 + r * k, pc1, sizeof(double) * k);
@@ -45,16 +45,16 @@ static void record(Estimator* e, const double* pc1, const double* pc2, double al
 
 int FullLLKFunc::Initialize()
 {
-    globalPC = fixPC = globalPC2 = fixPC2 = ptr->PC[1];   // h:317
-    globalAlpha = fixAlpha = ptr->alpha;                   // h:318
+    globalPC = fixPC = globalPC2 = fixPC2 = ptr->coord[1];   // h:317
+    globalAlpha = fixAlpha = ptr->mix;                   // h:318
     double v = 0;
     int rc = LLK(fixPC.data(), fixPC2.data(), fixAlpha, &v);
     if (rc) return rc;
     record(ptr, fixPC.data(), fixPC2.data(), fixAlpha, v);
     llk1 = (0 - v);                                        // h:319
-    for (int k = 0; k < ptr->numPC; ++k) ptr->PC[0][k] = 0.01;
-    for (int k = 0; k < ptr->numPC; ++k) ptr->PC[1][k] = 0.01;
-    ptr->alpha = 0.03;
+    for (int k = 0; k < ptr->npc; ++k) ptr->coord[0][k] = 0.01;
+    for (int k = 0; k < ptr->npc; ++k) ptr->coord[1][k] = 0.01;
+    ptr->mix = 0.03;
     return 0;
 }
 
@@ -71,7 +71,7 @@ int FullLLKFunc::CalculateLLK0()
 // The six packings of h:339-433 (table in SURVEY.md 3.2).
 void FullLLKFunc::Unpack(const double* v, int dim, double* pc1, double* pc2, double* a) const
 {
-    const int k = ptr->numPC;
+    const int k = ptr->npc;
     if (!ptr->isHeter) {
         if (ptr->isPCFixed) {                               // h:342-348
             std::memcpy(pc1, fixPC.data(), sizeof(double) * k);
@@ -112,7 +112,7 @@ void FullLLKFunc::Unpack(const double* v, int dim, double* pc1, double* pc2, dou
 
 int FullLLKFunc::EvaluateBatch(int n, const double* pts, int dim, double* y)
 {
-    const int k = ptr->numPC;
+    const int k = ptr->npc;
     std::vector<double> p1((size_t)n * k), p2((size_t)n * k), a(n), llk(n);
     for (int b = 0; b < n; ++b)
         Unpack(pts + (size_t)b * dim, dim, &p1[(size_t)b * k], &p2[(size_t)b * k], &a[b]);
@@ -125,7 +125,7 @@ int FullLLKFunc::EvaluateBatch(int n, const double* pts, int dim, double* y)
 
 void FullLLKFunc::Commit(const double* v, int dim, double smLLK)
 {
-    const int k = ptr->numPC;
+    const int k = ptr->npc;
     double p1[VB2_MAX_PC], p2[VB2_MAX_PC], a;
     Unpack(v, dim, p1, p2, &a);
     record(ptr, p1, p2, a, 0 - smLLK);
@@ -167,11 +167,11 @@ void FullLLKFunc::Commit(const double* v, int dim, double smLLK)
 }
 
 Estimator::Estimator(int nPC, vb2_eval_fn eval, void* user)
-    : numPC(nPC), PC(2, std::vector<double>(nPC, 0.)), eval_(eval), user_(user)
+    : npc(nPC), coord(2, std::vector<double>(nPC, 0.)), eval_(eval), user_(user)
 {
-    fn.ptr = this;
-    fn.fixPC.assign(nPC, 0.);
-    fn.fixPC2 = fn.globalPC = fn.globalPC2 = fn.fixPC;
+    objective.ptr = this;
+    objective.fixPC.assign(nPC, 0.);
+    objective.fixPC2 = objective.globalPC = objective.globalPC2 = objective.fixPC;
 }
 
 // The whole Minimize() on the device when the context offers it (resident_kernel.inc): same
@@ -185,13 +185,13 @@ static bool device_minimizer(Estimator* e, AmoebaMinimizer& m, int dim, const st
     rq.dim = dim;
     rq.kind = !e->isHeter ? (e->isPCFixed ? 0 : e->isAlphaFixed ? 1 : 2) : (e->isPCFixed ? 3 : e->isAlphaFixed ? 4 : 5);
     rq.start = start.data();
-    rq.fix_pc = e->fn.fixPC.data();
-    rq.fix_pc2 = e->fn.fixPC2.data();
-    rq.g_pc = e->fn.globalPC.data();
-    rq.g_pc2 = e->fn.globalPC2.data();
-    rq.fix_alpha = e->fn.fixAlpha;
-    rq.g_alpha = e->fn.globalAlpha;
-    rq.llk1 = e->fn.llk1;
+    rq.fix_pc = e->objective.fixPC.data();
+    rq.fix_pc2 = e->objective.fixPC2.data();
+    rq.g_pc = e->objective.globalPC.data();
+    rq.g_pc2 = e->objective.globalPC2.data();
+    rq.fix_alpha = e->objective.fixAlpha;
+    rq.g_alpha = e->objective.globalAlpha;
+    rq.llk1 = e->objective.llk1;
     rq.ftol = e->epsilon;
     rq.cycle_max = m.cycleMax;
     rq.trace = e->trace;
@@ -203,10 +203,10 @@ static bool device_minimizer(Estimator* e, AmoebaMinimizer& m, int dim, const st
     m.Reset(dim);
     m.point.assign(rq.status == 1 ? rq.point : start.data(), (rq.status == 1 ? rq.point : start.data()) + dim);
     m.cycleCount = rq.cycle_count;
-    e->fn.llk1 = rq.out_llk1;
-    e->fn.globalAlpha = rq.out_g_alpha;
-    e->fn.globalPC.assign(rq.out_g_pc, rq.out_g_pc + e->numPC);
-    e->fn.globalPC2.assign(rq.out_g_pc2, rq.out_g_pc2 + e->numPC);
+    e->objective.llk1 = rq.out_llk1;
+    e->objective.globalAlpha = rq.out_g_alpha;
+    e->objective.globalPC.assign(rq.out_g_pc, rq.out_g_pc + e->npc);
+    e->objective.globalPC2.assign(rq.out_g_pc2, rq.out_g_pc2 + e->npc);
     e->num_eval += rq.num_eval;
     e->num_launch_point += rq.num_point;
     ++e->num_device_minimize;
@@ -228,7 +228,7 @@ static bool run_minimizer(Estimator* e, AmoebaMinimizer& m, int dim,
         }
         return dev_ok;
     }
-    m.func = &e->fn;
+    m.func = &e->objective;
     m.speculate = e->speculate;
     if (const char* sp = std::getenv("VB2_SPECULATE")) m.speculate = std::atoi(sp);     // A/B and test knob: 1, 2, 4
     m.Reset(dim);
@@ -244,60 +244,39 @@ static bool run_minimizer(Estimator* e, AmoebaMinimizer& m, int dim,
     return ok;
 }
 
-bool Estimator::OptimizeHeter(AmoebaMinimizer& m)
+// One simplex search over the parts of (contaminant's PCs | intended sample's PCs | logit of the mixing fraction) that a
+// model leaves free -- the vector layout FullLLKFunc::Unpack expects for that model.  The reference has one hand-written
+// wrapper per model (ContaminationEstimator.cpp:192-332); what differs between them is only which parts are free and
+// whether a search that stopped at the cycle limit counts as a failure (its two --FixAlpha wrappers return true
+// regardless: cpp:258, 312).
+bool Estimator::Search(AmoebaMinimizer& m, const FreeParts& free_parts)
 {
-    std::vector<double> start(numPC * 2 + 1);
-    for (int i = 0; i < numPC * 2; ++i) start[i] = i < numPC ? PC[0][i] : PC[1][i - numPC];
-    start[numPC * 2] = FullLLKFunc::Logit(alpha);
+    std::vector<double> start;
+    if (free_parts.contaminant) start.insert(start.end(), coord[0].begin(), coord[0].end());
+    if (free_parts.intended) start.insert(start.end(), coord[1].begin(), coord[1].end());
+    if (free_parts.mixing) start.push_back(FullLLKFunc::Logit(mix));
+    const int dim = (int)start.size();
     double ret;
-    const bool ok = run_minimizer(this, m, numPC * 2 + 1, start, &ret);
-    alpha = FullLLKFunc::InvLogit(m.point[numPC * 2]);
-    for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
-    for (int i = numPC; i < numPC * 2; ++i) PC[1][i - numPC] = m.point[i];
-    return ok;
+    const bool converged = run_minimizer(this, m, dim, start, &ret);
+    int at = 0;
+    if (free_parts.contaminant) { std::copy(m.point.begin(), m.point.begin() + npc, coord[0].begin()); at = npc; }
+    if (free_parts.intended) { std::copy(m.point.begin() + at, m.point.begin() + at + npc, coord[1].begin()); at += npc; }
+    if (free_parts.mixing) mix = FullLLKFunc::InvLogit(m.point[at]);
+    return converged || free_parts.always_ok;
 }
 
-bool Estimator::OptimizeHeterFixedAlpha(AmoebaMinimizer& m)
-{
-    std::vector<double> start(numPC * 2);
-    for (int i = 0; i < numPC * 2; ++i) start[i] = i < numPC ? PC[0][i] : PC[1][i - numPC];
-    double ret;
-    (void)run_minimizer(this, m, numPC * 2, start, &ret);
-    for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
-    for (int i = numPC; i < numPC * 2; ++i) PC[1][i - numPC] = m.point[i];
-    return true;                                          // cpp:258 "fixAlpha usually converges well"
-}
-
-bool Estimator::OptimizeHeterFixedPC(AmoebaMinimizer& m) { return OptimizeHomo(m); }
-
-bool Estimator::OptimizeHomo(AmoebaMinimizer& m)
-{
-    std::vector<double> start(numPC + 1);
-    for (int i = 0; i < numPC; ++i) start[i] = PC[0][i];
-    start[numPC] = FullLLKFunc::Logit(alpha);
-    double ret;
-    const bool ok = run_minimizer(this, m, numPC + 1, start, &ret);
-    alpha = FullLLKFunc::InvLogit(m.point[numPC]);
-    for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
-    return ok;
-}
-
-bool Estimator::OptimizeHomoFixedAlpha(AmoebaMinimizer& m)
-{
-    std::vector<double> start(numPC);
-    for (int i = 0; i < numPC; ++i) start[i] = PC[0][i];
-    double ret;
-    (void)run_minimizer(this, m, numPC, start, &ret);
-    for (int i = 0; i < numPC; ++i) PC[0][i] = m.point[i];
-    return true;                                          // cpp:312
-}
+bool Estimator::OptimizeHeter(AmoebaMinimizer& m) { return Search(m, FreeParts{true, true, true, false}); }
+bool Estimator::OptimizeHeterFixedAlpha(AmoebaMinimizer& m) { return Search(m, FreeParts{true, true, false, true}); }
+bool Estimator::OptimizeHeterFixedPC(AmoebaMinimizer& m) { return OptimizeHomo(m); }       // (cpp:261-263)
+bool Estimator::OptimizeHomo(AmoebaMinimizer& m) { return Search(m, FreeParts{true, false, true, false}); }
+bool Estimator::OptimizeHomoFixedAlpha(AmoebaMinimizer& m) { return Search(m, FreeParts{true, false, false, true}); }
 
 namespace {
 // the one-parameter objective of the --FixPC models as a function of logit(alpha)
 struct AlphaObjective : ScalarObjective {
-    FullLLKFunc* fn;
-    int EvaluateBatch(int n, const double* x, double* y) override { return fn->EvaluateBatch(n, x, 1, y); }
-    void Commit(double x, double y) override { fn->Commit(&x, 1, y); }
+    FullLLKFunc* llk;
+    int EvaluateBatch(int n, const double* x, double* y) override { return llk->EvaluateBatch(n, x, 1, y); }
+    void Commit(double x, double y) override { llk->Commit(&x, 1, y); }
 };
 
 // splitmix64 -> uniform -> Box-Muller: a self-contained, reproducible N(0, 1) stream per (seed, run)
@@ -320,17 +299,17 @@ struct Gauss {
 bool Estimator::LineSearchAlpha()
 {
     AlphaObjective obj;
-    obj.fn = &fn;
+    obj.llk = &objective;
     BrentMinimizer bm;
     bm.func = &obj;
-    const double x0 = FullLLKFunc::Logit(alpha);
+    const double x0 = FullLLKFunc::Logit(mix);
     bm.Bracket(x0, x0 + 1.0);
     if (!bm.error) bm.Brent(epsilon);
     if (bm.error) {
         if (!error) error = bm.error;
         return false;
     }
-    alpha = FullLLKFunc::InvLogit(bm.min);
+    mix = FullLLKFunc::InvLogit(bm.min);
     if (bm.stuck) {
         hit_cycle_limit = true;
         if (notices) std::fprintf(stderr, "WARNING - ScalarMinimizer::Brent got stuck\n");
@@ -343,21 +322,16 @@ void Estimator::JitterStart()
     if (start_index <= 0) return;
     Gauss g{((uint64_t)start_seed << 32) ^ (0x5851f42d4c957f2dull * (uint64_t)start_index)};
     if (!isPCFixed) {
-        for (int k = 0; k < numPC; ++k) PC[0][k] += start_sd * g.normal();
-        for (int k = 0; k < numPC; ++k) PC[1][k] += start_sd * g.normal();
+        for (int k = 0; k < npc; ++k) coord[0][k] += start_sd * g.normal();
+        for (int k = 0; k < npc; ++k) coord[1][k] += start_sd * g.normal();
     }
-    if (!isAlphaFixed) alpha = FullLLKFunc::InvLogit(FullLLKFunc::Logit(alpha) + 50.0 * start_sd * g.normal());
+    if (!isAlphaFixed) mix = FullLLKFunc::InvLogit(FullLLKFunc::Logit(mix) + 50.0 * start_sd * g.normal());
 }
 
 bool Estimator::OptimizeHomoFixedPC(AmoebaMinimizer& m)
 {
     if (line_search) return LineSearchAlpha();
-    std::vector<double> start(1);
-    start[0] = FullLLKFunc::Logit(alpha);
-    double ret;
-    const bool ok = run_minimizer(this, m, 1, start, &ret);
-    alpha = FullLLKFunc::InvLogit(m.point[0]);
-    return ok;
+    return Search(m, FreeParts{false, false, true, false});
 }
 
 namespace {
@@ -385,7 +359,7 @@ int Estimator::OptimizeLLK()
     int rc;
     {
         PhaseTimer t("Initialize likelihood", notices);
-        rc = fn.Initialize();
+        rc = objective.Initialize();
     }
     if (rc) return rc;
     JitterStart();
@@ -405,8 +379,8 @@ int Estimator::OptimizeLLK()
                 PhaseTimer t("OptimizeHomoFixedAlpha (initial)", notices);
                 isHeter = false;
                 ok &= OptimizeHomoFixedAlpha(mini);
-                PC[1] = PC[0];
-                fn.globalPC2 = fn.globalPC;
+                coord[1] = coord[0];
+                objective.globalPC2 = objective.globalPC;
                 isHeter = true;
             }
             PhaseTimer t("OptimizeHeterFixedAlpha", notices);
@@ -416,23 +390,23 @@ int Estimator::OptimizeLLK()
                 PhaseTimer t("OptimizeHomo (initial)", notices);
                 isHeter = false;
                 ok &= OptimizeHomo(mini);
-                PC[1] = PC[0];
-                fn.globalPC2 = fn.globalPC;
+                coord[1] = coord[0];
+                objective.globalPC2 = objective.globalPC;
                 isHeter = true;
             }
             PhaseTimer t("OptimizeHeter", notices);
             ok &= OptimizeHeter(mini);
         }
-        if (fn.globalAlpha >= 0.5) {                      // cpp:146-149 (indices 0,1 hard-coded)
-            std::swap(fn.globalPC[0], fn.globalPC2[0]);
-            if (numPC >= 2) std::swap(fn.globalPC[1], fn.globalPC2[1]);
+        if (objective.globalAlpha >= 0.5) {                      // cpp:146-149 (indices 0,1 hard-coded)
+            std::swap(objective.globalPC[0], objective.globalPC2[0]);
+            if (npc >= 2) std::swap(objective.globalPC[1], objective.globalPC2[1]);
         }
     }
     if (error) return error;
     converged = !hit_cycle_limit;
     (void)ok;                                             // the reference ignores the wrappers' results
     PhaseTimer t("Calculate null-model LLK", notices);
-    return fn.CalculateLLK0();                            // cpp:152-155
+    return objective.CalculateLLK0();                            // cpp:152-155
 }
 
 void apply_model(Estimator& est, const vb2_model& model)
@@ -443,10 +417,10 @@ void apply_model(Estimator& est, const vb2_model& model)
     est.isHeter = model.is_heter != 0;
     if (model.epsilon > 0) est.epsilon = model.epsilon;
     if (model.is_pc_fixed && model.fix_pc) {
-        for (int i = 0; i < est.numPC; ++i) est.PC[1][i] = model.fix_pc[i];
+        for (int i = 0; i < est.npc; ++i) est.coord[1][i] = model.fix_pc[i];
         est.isPCFixed = true;
     } else if (model.is_alpha_fixed) {
-        est.alpha = model.fix_alpha;
+        est.mix = model.fix_alpha;
         est.isAlphaFixed = true;
     }
     if (model.is_af_known) {
@@ -469,12 +443,12 @@ void apply_model(Estimator& est, const vb2_model& model, bool data_has_known_af)
 void fill_estimate(const Estimator& est, vb2_estimate* out)
 {
     std::memset(out, 0, sizeof(*out));
-    out->alpha = est.fn.globalAlpha;
-    out->llk1 = est.fn.llk1;
-    out->llk0 = est.fn.llk0;
-    for (int i = 0; i < est.numPC; ++i) {
-        out->pc[i] = est.fn.globalPC[i];
-        out->pc2[i] = est.fn.globalPC2[i];
+    out->alpha = est.objective.globalAlpha;
+    out->llk1 = est.objective.llk1;
+    out->llk0 = est.objective.llk0;
+    for (int i = 0; i < est.npc; ++i) {
+        out->pc[i] = est.objective.globalPC[i];
+        out->pc2[i] = est.objective.globalPC2[i];
     }
     out->num_eval = est.num_eval;
     out->num_launch_point = est.num_launch_point;

@@ -46,11 +46,11 @@ public:
     // model flags, same names as the reference members (h:42-52)
     bool isPCFixed = false, isAlphaFixed = false, isAFknown = false, isHeter = true;
     bool verbose = false;
-    int numPC;
+    int npc;
     double epsilon = 1e-8;
-    double alpha = 0.5;                    // cpp:48
-    std::vector<std::vector<double>> PC;   // PC[0] contaminating, PC[1] intended (h:453)
-    FullLLKFunc fn;
+    double mix = 0.5;                      // the mixing fraction (the reference's `alpha`, cpp:48)
+    std::vector<std::vector<double>> coord;   // [0] the contaminating sample's PCs, [1] the intended sample's (the reference's PC, h:453)
+    FullLLKFunc objective;
     int speculate = 4;                  // AmoebaMinimizer::speculate
     // Optimiser variants (vb2_ctx_optimize_llk_ex), both off by default:
     //   line_search: a model with ONE free parameter (--FixPC / --KnownAF: alpha) is minimised by
@@ -80,6 +80,10 @@ public:
     int64_t num_device_minimize = 0;
 
 private:
+    // which parts of (contaminant's PCs | intended sample's PCs | logit of the mixing fraction) a search varies, and whether
+    // a search that ran into the cycle limit still counts as done (the reference's --FixAlpha wrappers: cpp:258, 312)
+    struct FreeParts { bool contaminant, intended, mixing, always_ok; };
+    bool Search(AmoebaMinimizer& m, const FreeParts& free_parts);
     bool OptimizeHomoFixedPC(AmoebaMinimizer& m);      // cpp:315-332
     bool LineSearchAlpha();                            // the same model through Brent's method
     void JitterStart();
