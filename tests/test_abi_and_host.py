@@ -529,6 +529,61 @@ def test_avx2_pileup_scanner_equals_the_scalar_one(tmp_path, monkeypatch):
     assert n_ok >= 8          # (mixed files are not all parse errors: the fallback transitions are exercised on successes)
 
 
+def _flatten_digest(d):
+    import ctypes
+    L = _abi.lib()
+    L.vb2_debug_flatten_digest.argtypes = [ctypes.POINTER(_abi.Input), ctypes.POINTER(ctypes.c_ulonglong)]
+    L.vb2_debug_flatten_digest.restype = ctypes.c_int
+    inp = d.as_input()
+    out = ctypes.c_ulonglong(0)
+    _abi.check(L.vb2_debug_flatten_digest(ctypes.byref(inp), ctypes.byref(out)), "vb2_debug_flatten_digest")
+    return out.value
+
+
+def test_flatten_is_the_same_bytes_whatever_the_thread_count():
+    """The host half of vb2_ctx_create (classification, run-length coding, marker sort, per-marker constants) gives the same
+    run words, tile records, constants and dictionary with one thread and with several (vb2_debug_flatten_digest: no device):
+    the bench shape in small, a wide quality alphabet (codes beyond the first 64), deep and ragged markers (depth 0 .. 200),
+    missing markers with the depth filter on, odd base characters, a known-AF input."""
+    import json
+    import subprocess
+    import sys
+    code = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import verifybamid_amd as vb
+sys.path.insert(0, %r)
+from test_abi_and_host import _flatten_digest
+out = []
+out.append(_flatten_digest(vb.synth.make_pileup(3000, 30, 4, seed=5)))
+out.append(_flatten_digest(vb.synth.make_pileup(3000, 30, 2, seed=6, q_lo=2, q_hi=93)))
+out.append(_flatten_digest(vb.synth.with_sanity_stats(vb.synth.make_pileup(2000, 33, 3, seed=7, missing_frac=0.2))))
+out.append(_flatten_digest(vb.synth.make_pileup(1500, 64, 2, seed=8, q_lo=0, q_hi=60)))
+rng = np.random.default_rng(9)
+M = 600
+depth = rng.choice([0, 1, 2, 31, 32, 33, 63, 64, 65, 100, 200], size=M)
+off = np.zeros(M + 1, dtype=np.int64); np.cumsum(depth, out=off[1:])
+R = int(off[-1])
+bases = rng.choice(np.frombuffer(b".,ACGTacgtNn*", dtype=np.uint8), size=R)
+quals = rng.integers(30, 130, size=R).astype(np.uint8)
+alt = rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=M)
+dd = vb.PileupData(2, rng.normal(size=(M, 2)), rng.uniform(0.1, 1.9, size=M), off, bases, quals, alt, None, 30.0, 0.0, True, {})
+out.append(_flatten_digest(dd))
+kaf = np.clip(rng.uniform(0, 1, size=M), 0.01, 0.99)
+out.append(_flatten_digest(vb.PileupData(2, dd.ud, dd.means, off, bases, quals, alt, kaf, 30.0, 0.0, True, {})))
+print(json.dumps(out))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for env_extra in ({"VB2_FLATTEN_THREADS": "1"}, {"VB2_FLATTEN_THREADS": "3"}, {"VB2_FLATTEN_THREADS": "8"}):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1] == res[2]
+    assert len(set(res[0])) == len(res[0])                 # (six different inputs, six different digests)
+
+
 def _tiny_panel(pre):
     open(pre + ".bed", "w").write("1\t0\t1\tA\tC\n1\t9\t10\tG\tT\n")
     open(pre + ".UD", "w").write("0.5 0.25\n-0.5 0.125\n")

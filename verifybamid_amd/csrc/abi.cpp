@@ -173,6 +173,18 @@ int vb2_llk_eval_batch_device(vb2_ctx* ctx, int32_t num_point, const double* d_p
 
 // Profiling aid (not part of the public header): per-workgroup wall-clock stamps of the
 // last launch when the context was created with VB2_STAMPS set.
+// (test hook, not in vb2_abi.h) the host half of vb2_ctx_create without a device: digest of the flattened data
+int vb2_debug_flatten_digest(const vb2_input* in, unsigned long long* digest)
+{
+    if (!in || !digest) return VB2_ERR_INVALID;
+    try {
+        return vb2::flatten_digest(in, digest);
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return VB2_ERR_INVALID;
+    }
+}
+
 int vb2_debug_read_stamps(vb2_ctx* ctx, unsigned long long* out, int max_blocks)
 {
     if (guard_ctx(ctx)) return 0;

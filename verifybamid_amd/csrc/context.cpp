@@ -224,6 +224,17 @@ bool recycle_pinned_slab(void* p, size_t bytes, int device) { return slab_cache(
 hipStream_t cached_stream(int device) { return slab_cache().take_stream(device); }
 bool recycle_stream(hipStream_t stream, int device) { return slab_cache().give_stream(stream, device); }
 
+static thread_local unsigned long long* t_digest_out = nullptr;
+
+int flatten_digest(const vb2_input* in, unsigned long long* digest)
+{
+    Context* none = nullptr;
+    t_digest_out = digest;
+    const int rc = Context::create_impl(in, nullptr, &none, true);
+    t_digest_out = nullptr;
+    return rc;
+}
+
 int flatten_dry_run(const vb2_input* in, double* ms)
 {
     Context* none = nullptr;
@@ -432,6 +443,11 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 uint64_t bm0 = 0, bm12[2] = {0, 0};
                 double c_other = 0.0;                 // class "other": same term for every genotype pair
                 const uint8_t* cls_of = class_table.row[alt_up];
+                // (Measured and dropped in round 4: the code bytes of 32 reads at a time with AVX2 -- compares for the class,
+                // six pshufb tables for the quality rank -- and a code's count as compare + movemask + popcount: same bytes out
+                // (digest-checked), classify 11.3 ms against 11.8 for this loop on a C3 sample: with four counter sets the loop
+                // already runs at ~4 cycles per read, and the rest of the pass -- per distinct code a histogram update, three
+                // dependent multiply-adds, a run word; per marker three exps -- is as long again.)
                 for (int64_t j = 0; j < depth; ++j) {
                     const unsigned char qv = qs[j];
                     const unsigned cls = cls_of[bs[j]];
@@ -725,6 +741,24 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     });
 
     const auto t_flat = tnow();
+    if (dry && t_digest_out) {
+        // digest of everything the flatten produced (the defined parts of the staging slab, not its alignment gaps)
+        uint64_t hsh = 1469598103934665603ull;
+        auto mix = [&](const void* ptr, size_t bytes) {
+            const unsigned char* q = static_cast<const unsigned char*>(ptr);
+            for (size_t i = 0; i < bytes; ++i) hsh = (hsh ^ q[i]) * 1099511628211ull;
+        };
+        mix(codes, n_codes * sizeof(uint32_t));
+        mix(mt_rec, (size_t)num_mt * sizeof(uint2));
+        if (in->known_af) mix(kaf_s, (size_t)m_pad * sizeof(double));
+        else { mix(ud_s, (size_t)k * m_pad * sizeof(double)); mix(mu_s, (size_t)m_pad * sizeof(double)); }
+        mix(cdiag, (size_t)4 * m_pad * sizeof(double));
+        mix(stage + o_dpe, dict_perr.size() * sizeof(double));
+        mix(stage + o_prim, prim.size() * sizeof(double2));
+        const int64_t counts[4] = {num_read, num_other, (int64_t)num_code, m_active};
+        mix(counts, sizeof(counts));
+        *t_digest_out = hsh;
+    }
     if (dry) {
         if (timing)
             std::fprintf(stderr, "flatten (dry): %.1f ms (classify %.1f, dictionary+sort %.1f, pack %.1f; %d threads)\n",

@@ -25,6 +25,9 @@ int usable_device_count();
 int usable_cpu_count();
 // The host half of vb2_ctx_create (flatten) without a device: timing aid for tools/ubench/host_pipeline.cpp.
 int flatten_dry_run(const vb2_input* in, double* ms);
+// ... and a digest of what it produced (run words, tile records, panel rows, per-marker constants, dictionary): lets a
+// test hold two ways of flattening -- the AVX2 classification and the scalar statements -- to the same bytes without a device.
+int flatten_digest(const vb2_input* in, unsigned long long* digest);
 // The process-wide recycling of device slabs, pinned device-mapped slabs and streams (context.cpp):
 // allocation and release calls cost milliseconds and serialise in the driver.  take: nullptr = none
 // cached, allocate yourself; give: false = cache full, release it yourself.
