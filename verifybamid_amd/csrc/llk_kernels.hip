@@ -342,8 +342,12 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // LCACHE (the resident search kernel): this workgroup's run lists and tile records were copied to LDS when the kernel
 // started (a workgroup owns the same micro-tiles in every round), so a round's read loops begin without the two dependent
 // trips to L2 (tile record, then its first rows) and never wait for a row again.
+// SWP (VERDICT r3 #3a, the 8-point shape on the work queue only): a software-pipelined item loop -- the twelve exponentials
+// of item i's epilogue ride in the first twelve row steps of item i+1, one per step, so that a wave's LDS-bound read loop and
+// its VALU-bound epilogue overlap inside the wave itself; the finished sums and constants of item i stay in registers
+// meanwhile (3 waves per SIMD, <= 168 VGPRs: the kernel is launched with 12-wave workgroups).  See the item loop.
 template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1,
-          bool ONEGRP = (MODE >= 3), int KAF = -1, int KSEL = 0, bool LCACHE = false>
+          bool ONEGRP = (MODE >= 3), int KAF = -1, int KSEL = 0, bool LCACHE = false, bool SWP = false>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -684,7 +688,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     };
     // ---- per-marker epilogue: a marker's likelihood as (mantissa, exponent) per point, from its six sums per point ----
     auto marker_lk = [&](const bool live, const size_t pos, const double* acc, const double e0, const double e1, const double e2,
-                         const double* udr, const double mur, const uint32_t my_ptq, double* lk_m, int* lk_e) {
+                         const double* udr, const double mur, const uint32_t my_ptq, double* lk_m, int* lk_e,
+                         const bool exps_taken = false /* acc holds exp(sum) already (SWP) */) {
 #pragma unroll
         for (int t = 0; t < BTL; ++t) { lk_m[t] = 1.0; lk_e[t] = 0; }
 #ifdef VB2_ABL_EPI       // (ablation build: the sums and the constants are consumed, nothing is computed from them)
@@ -740,9 +745,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 // of 27; the rounding differs from the reference's term-by-term sum at the 1e-16
                 // level, like the marker summation order does).  The three g1==g2 exponentials do
                 // not depend on (alpha, PC) and were taken at context creation.
-                const double x01 = exp_nonpos(a[0], etab_lane), x02 = exp_nonpos(a[1], etab_lane);
-                const double x10 = exp_nonpos(a[2], etab_lane), x12 = exp_nonpos(a[3], etab_lane);
-                const double x20 = exp_nonpos(a[4], etab_lane), x21 = exp_nonpos(a[5], etab_lane);
+                const double x01 = exps_taken ? a[0] : exp_nonpos(a[0], etab_lane), x02 = exps_taken ? a[1] : exp_nonpos(a[1], etab_lane);
+                const double x10 = exps_taken ? a[2] : exp_nonpos(a[2], etab_lane), x12 = exps_taken ? a[3] : exp_nonpos(a[3], etab_lane);
+                const double x20 = exps_taken ? a[4] : exp_nonpos(a[4], etab_lane), x21 = exps_taken ? a[5] : exp_nonpos(a[5], etab_lane);
                 const double s0 = fma(x02, gf2[2], fma(x01, gf2[1], e0 * gf2[0]));
                 const double s1 = fma(x12, gf2[2], fma(e1, gf2[1], x10 * gf2[0]));
                 const double s2 = fma(e2, gf2[2], fma(x21, gf2[1], x20 * gf2[0]));
@@ -791,6 +796,113 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         cst_nx = other_const(mt0, h0);
         issue_rows(rec_nx, h0);
     }
+    if constexpr (SWP) {
+        static_assert(MODE == 2 && QUEUE == 1 && !STREAM && !LCACHE && !W16, "the software-pipelined loop: 8-point shape on the work queue");
+        // state of the previous item, its epilogue still to be finished
+        double pa[BTL * 6];                               // its six sums per point; exp()'d in place, one per row step
+        double pe0 = 0.0, pe1 = 0.0, pe2 = 0.0, pud[4] = {0.0, 0.0, 0.0, 0.0}, pmu = 0.0;
+        size_t ppos = 0;
+        uint32_t pptq = ptq_addr, pslot = 0;
+        bool pvalid = false, plive = false;
+#pragma unroll
+        for (int i = 0; i < BTL * 6; ++i) pa[i] = 0.0;
+        auto finish_prev = [&]() {                        // (every exponential taken) priors, 9-term sums, tile product, slot
+            double lk_m[BTL];
+            int lk_e[BTL];
+            marker_lk(plive, ppos, pa, pe0, pe1, pe2, pud, pmu, pptq, lk_m, lk_e, true);
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                const int partner = lane_of<HWMAP>(m ^ off, g4);
+#pragma unroll
+                for (int t = 0; t < BTL; ++t) {
+                    lk_m[t] *= __shfl(lk_m[t], partner, 64);
+                    lk_e[t] += __shfl(lk_e[t], partner, 64);
+                }
+            }
+            if (m == 0 && pvalid) {
+#pragma unroll
+                for (int t = 0; t < BTL; ++t) {
+                    const size_t o = ((size_t)pslot * NP + g * BTL + t) * 2;
+                    tile_llk[o] = lk_m[t];
+                    tile_llk[o + 1] = (double)lk_e[t];
+                }
+            }
+        };
+        for (uint32_t idx = idx_first; idx < nitem;) {
+            uint32_t grp = ngrp == 1 ? 0u : (uint32_t)(((float)idx + 0.5f) * inv_nunit);
+            if (ngrp != 1) {
+                if (grp * nunit > idx) --grp;
+                else if ((grp + 1) * nunit <= idx) ++grp;
+            }
+            const uint32_t it = idx - grp * nunit;
+            const uint32_t mt = blk + it * nblk;
+            const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)row_bytes + (uint32_t)g * (6 * BTL * 8));
+            const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
+            const vuint2 rec = g_rec[mt];
+            const size_t pos = (size_t)mt * kMtMarkers + m;
+            const bool live = pos < (size_t)L.num_active;
+            const size_t posc = live ? pos : 0;
+            const double cst = g_ediag[posc];
+            const double e0 = g_ediag[mp + posc], e1 = g_ediag[2 * mp + posc], e2 = g_ediag[3 * mp + posc];
+            double udr[4], mur = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) udr[kk] = (!known_af_p && kk < k) ? g_ud[(size_t)kk * mp + posc] : 0.0;
+            if (!known_af_p) mur = g_mu[posc];
+            double acc[BTL * 6];
+#pragma unroll
+            for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
+            g_cuint2* cp = g_codes + (size_t)rec.x * kMtMarkers + m;
+            const int rows = (int)rec.y;
+#pragma unroll
+            for (int j = 0; j < kPf; ++j) w[j] = cp[(size_t)j * kMtMarkers];
+            // the first BTL * 6 row steps, straight-line: a row of this item's run words, then ONE exponential of the previous item
+            constexpr int kSteps = BTL * 6;
+            // (no branch per step: a step past the tile's last row walks a padding word -- the zero table row, count 0, an
+            // exact no-op -- so that the twelve steps are ONE basic block: with a branch per step every exponential sat in a
+            // block of its own behind the step's FMAs, a serial chain of 17 instructions, and the run-word ring was drained
+            // at every step by the copies the branches forced: 80 us per 48 points against 73 for the plain 12-wave geometry)
+            vuint2 padw;
+            padw.x = padw.y = (uint32_t)(L.num_code * row_bytes);
+#pragma unroll
+            for (int s_ = 0; s_ < kSteps; ++s_) {
+                {
+                    vuint2 w_cur = w[s_ % kPf];
+                    w[s_ % kPf] = cp[(size_t)(s_ + kPf) * kMtMarkers];
+                    if (s_ >= rows) w_cur = padw;
+                    walk_word(w_cur, acc, my_tab, 0u);
+                }
+                // (pinned here: left alone, the compiler sinks all twelve exponentials below the row steps, next to their uses
+                // in finish_prev -- i.e. rebuilds the un-pipelined loop)
+                pa[s_] = exp_nonpos(pa[s_], etab_lane);
+                asm volatile("" : "+v"(pa[s_]));
+            }
+            for (int s0 = kSteps; s0 < rows; s0 += kPf) {         // (kSteps is a multiple of kPf: the ring's phase carries over)
+#pragma unroll
+                for (int u = 0; u < kPf; ++u) {
+                    if (s0 + u >= rows) break;
+                    const vuint2 w_cur = w[u];
+                    w[u] = cp[(size_t)(s0 + u + kPf) * kMtMarkers];
+                    walk_word(w_cur, acc, my_tab, 0u);
+                }
+            }
+            finish_prev();
+            // this item becomes the previous one
+#pragma unroll
+            for (int i = 0; i < BTL * 6; ++i) pa[i] = acc[i];
+            pe0 = e0; pe1 = e1; pe2 = e2; pmu = mur;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) pud[kk] = udr[kk];
+            ppos = pos; plive = live; pptq = my_ptq; pvalid = true;
+            pslot = grp * ntile_blk + it;
+            uint32_t nxt = 0;
+            if (lane == 0) nxt = atomicAdd(queue, 1u);
+            idx = __builtin_amdgcn_readfirstlane(nxt);
+        }
+        // the last item's epilogue, un-overlapped
+#pragma unroll
+        for (int i = 0; i < BTL * 6; ++i) pa[i] = exp_nonpos(pa[i], etab_lane);
+        finish_prev();
+    } else
     for (uint32_t idx = idx_first; idx < nitem;) {
         // grp = idx / nunit without the ~25-instruction integer division: float estimate (exact for
         // these magnitudes up to one) and a correction step
@@ -1169,6 +1281,22 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
                            blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
 }
 
+// The software-pipelined form of the 8-point shape (eval_body: SWP): 12-wave workgroups, 3 waves per SIMD.  MEASURED AND
+// DROPPED in round 4: 80.5-83.3 us per 48-point launch against 70.4 (16 waves) and 73.1 (12 waves, plain loop) on
+// the same box, every variant bit-identical.  Compiled only with -DVB2_WITH_SWP (then VB2_SWP=1 selects it).
+#ifdef VB2_WITH_SWP
+template <int KSEL>
+__global__ void __launch_bounds__(768, 3)
+llk_eval_swp_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
+                    int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
+                    unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
+                    unsigned long long done_seq, int ngrp, unsigned long long tag, const Schedule sch)
+{
+    eval_body<2, true, false, NoHook, false, 1, false, 0, KSEL, false, true>(L, ip.v, ip.count, points, num_valid, partials, llk_out, ticket,
+                                                                              done_flag, done_seq, blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
+}
+#endif
+
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
 // w / bps as that sample's workgroup w % bps.  Every sample has its own layout, parameter rows,
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
@@ -1326,6 +1454,39 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
 {
     constexpr int NP = ModeNp<MODE>::value;     // points per group
     const LaunchGeom gm = launch_geom(L, MODE == 2 ? 2 : 1, ngrp);
+    // VB2_SWP=1 (experiment, VERDICT r3 #3a): the 8-point shape with the software-pipelined item loop -- 12-wave workgroups,
+    // work queue (its limit raised to 16 items per wave for this launch)
+#ifdef VB2_WITH_SWP
+    if constexpr (MODE == 2 && HWMAP) {
+        static const bool swp_on = std::getenv("VB2_SWP") && std::atoi(std::getenv("VB2_SWP")) != 0;
+        if (swp_on && L.known_af == nullptr && (L.num_pc == 4 || L.num_pc == 2) && gm.block_waves >= 12) {
+            DeviceLayout Ls = L;
+            Ls.dyn_limit = 16;
+            const int bw = 12;
+            if (eval_is_dynamic(Ls, (uint32_t)gm.grid, bw, ngrp)) {
+                const size_t shm = eval_shmem_np(Ls, NP, gm.grid, bw, ngrp);
+                if (shm > (size_t)kLdsLimitBytes) return hipErrorInvalidConfiguration;
+                const void* fns = L.num_pc == 4 ? reinterpret_cast<const void*>(&llk_eval_swp_kernel<4>)
+                                                : reinterpret_cast<const void*>(&llk_eval_swp_kernel<2>);
+                hipError_t e = raise_lds_limit(fns);
+                if (e != hipSuccess) return e;
+                InlinePoints ip;
+                ip.count = 0;
+                const int ndbl = num_valid * (2 * L.num_pc + 1);
+                if (h_points && ndbl <= kInlinePointDoubles) {
+                    ip.count = ndbl;
+                    for (int i = 0; i < ndbl; ++i) ip.v[i] = h_points[i];
+                }
+                const double* a_points = d_points;
+                int a_nv = num_valid, a_ngrp = ngrp;
+                unsigned long long a_seq = done_seq, a_tag = tag;
+                Schedule a_sch{nullptr, nullptr};
+                void* args[] = {&Ls, &ip, &a_points, &a_nv, &d_partials, &d_out, &d_ticket, &done_flag, &a_seq, &a_ngrp, &a_tag, &a_sch};
+                return hipLaunchKernel(fns, dim3(gm.grid), dim3(bw * 64), args, shm, stream);
+            }
+        }
+    }
+#endif
     const Schedule sch = sp ? sp->get(MODE, ngrp, gm.grid, gm.block_waves) : Schedule{nullptr, nullptr};
     const size_t shmem = eval_shmem_np(L, NP, gm.grid, gm.block_waves, ngrp);
     // (the group cap of launch_llk_eval is worked out on the geometry of a kMaxGroups launch; this launch's own
