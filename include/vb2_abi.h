@@ -353,11 +353,11 @@ typedef struct vb2_cohort_args {
     int32_t num_sample;
     const char *const *pileup_paths;     /* [num_sample]                                      */
     const char *const *output_prefixes;  /* [num_sample], or NULL = write nothing             */
-    int32_t group_size;                  /* samples searched together, at most; 0 = 64.  A device's
-                                          * first two groups are smaller (16, 32) so that it starts
+    int32_t group_size;                  /* samples searched together, at most (<= 64); 0 = 32.  A
+                                          * device's first group is smaller (16) so that it starts
                                           * early; < 0: plain equal groups of |group_size|        */
-    int32_t num_host_thread;             /* pileup readers/flatteners; 0 = half the host's cores,
-                                          * at least 4 and at most 64 per device               */
+    int32_t num_host_thread;             /* pileup readers/flatteners; 0 = the CPUs the process may
+                                          * use (cgroup quota / affinity), at most 64 per device  */
 } vb2_cohort_args;
 int vb2_cohort_run(const vb2_cohort_args *args, vb2_run_result *out /* [num_sample] */,
                    int32_t *status /* [num_sample] */);

@@ -1073,6 +1073,49 @@ def test_cohort_batch_lockstep_matches_individual_runs():
             c.close()
 
 
+def _batch_regroups(batch):
+    import ctypes
+    L = _abi.lib()
+    L.vb2_debug_batch_regroups.argtypes = [ctypes.c_void_p]
+    L.vb2_debug_batch_regroups.restype = ctypes.c_longlong
+    return int(L.vb2_debug_batch_regroups(batch._h))
+
+
+@pytest.mark.parametrize("S", [5, 20, 37])
+def test_lockstep_search_regroups_the_unfinished_samples(S, monkeypatch):
+    """Samples finish at different iterations; when half of a lane's samples are done the rest move to a batch of their own
+    with twice the workgroups per sample (Batch::optimize), and again at a quarter, an eighth ...  A sample's likelihood sums
+    then differ in the last bits (as they do between group sizes: the static deal multiplies a wave's items in the wave);
+    every estimate is the one the fixed batch (VB2_COHORT_REGROUP=0) gives and the one the sample's own single-context
+    search gives -- alpha to 1e-7, likelihoods to LLK_RTOL.  5 samples search in one lane, 20 and 37 in two (uneven) lanes;
+    sizes, depths and contamination differ so that the searches have different lengths; one sample has no reads."""
+    rng = np.random.default_rng(100 + S)
+    datas = []
+    for s in range(S):
+        M = int(rng.choice([300, 800, 1500, 2500, 4000]))
+        datas.append(vb.synth.make_pileup(M, float(rng.choice([6, 15, 30, 45])), 2, alpha_true=float(rng.choice([0.0, 0.01, 0.05, 0.2, 0.4])),
+                                          seed=500 + 41 * S + s))
+    datas[S // 2] = vb.synth.make_pileup(40, 10, 2, seed=77, missing_frac=1.0)
+    ctxs = [vb.LikelihoodContext(d) for d in datas]
+    try:
+        runs = {}
+        for knob in ("0", "1"):
+            monkeypatch.setenv("VB2_COHORT_REGROUP", knob)
+            with vb.CohortBatch(ctxs) as batch:
+                runs[knob] = batch.optimize()
+                n = _batch_regroups(batch)
+            assert (n == 0) if knob == "0" else (n >= 1), (knob, n)
+        for s in range(S):
+            a, b, one = runs["0"][s], runs["1"][s], ctxs[s].optimize()
+            for other in (a, one):
+                assert abs(other["alpha"] - b["alpha"]) <= 1e-7, (s, other["alpha"], b["alpha"])
+                assert rel_err([other["llk1"], other["llk0"]], [b["llk1"], b["llk0"]]) <= LLK_RTOL or (other["llk1"] == b["llk1"] == 0), s
+                assert np.allclose(other["pc"], b["pc"], rtol=0, atol=1e-6) and np.allclose(other["pc2"], b["pc2"], rtol=0, atol=1e-6), s
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_cohort_steps_on_16bit_run_lists_are_bit_identical():
     """The 1- and 2-point steps of a cohort stream a 16-bit copy of every sample's run lists
     (DeviceLayout::codes16: dictionary index | count << 8, re-coded on the device from the 32-bit run words;
@@ -1554,3 +1597,51 @@ def test_device_pointer_api_on_torch_stream(c2):
                 ctx.llk_device(pts.data_ptr(), out.data_ptr(), 8, stream.cuda_stream)
             stream.synchronize()
             assert np.array_equal(out.cpu().numpy(), host)
+
+
+def _layout_digest(ctx):
+    import ctypes
+    L = _abi.lib()
+    L.vb2_debug_layout_digest.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
+    L.vb2_debug_layout_digest.restype = ctypes.c_int
+    out = ctypes.c_ulonglong(0)
+    _abi.check(L.vb2_debug_layout_digest(ctx._h, ctypes.byref(out)), "vb2_debug_layout_digest")
+    return out.value
+
+
+@pytest.mark.gpu
+def test_data_arrays_on_the_device_are_the_host_flattens_bytes(monkeypatch):
+    """The device holds, byte for byte, what the host half of vb2_ctx_create produces without a device
+    (vb2_debug_flatten_digest, whose thread-count independence the CPU suite checks): run words in [tile][row][marker]
+    order, tile records, sorted panel rows and diagonal terms, dictionary and primitive records -- whether the pack step
+    ran as pack_layout_kernel on the GPU (default) or on the host (VB2_HOST_PACK=1).  Shapes: the bench shape in small, a wide
+    quality alphabet, missing markers with the depth filter, deep/ragged/empty markers with odd characters, a known-AF input,
+    one marker, and a sample with no reads at all."""
+    from test_abi_and_host import _flatten_digest
+    rng = np.random.default_rng(9)
+    M = 600
+    depth = rng.choice([0, 1, 2, 31, 32, 33, 63, 64, 65, 100, 200], size=M)
+    off = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(depth, out=off[1:])
+    R = int(off[-1])
+    bases = rng.choice(np.frombuffer(b".,ACGTacgtNn*", dtype=np.uint8), size=R)
+    quals = rng.integers(30, 130, size=R).astype(np.uint8)
+    alt = rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=M)
+    ragged = vb.PileupData(2, rng.normal(size=(M, 2)), rng.uniform(0.1, 1.9, size=M), off, bases, quals, alt, None, 30.0,
+                           0.0, True, {})
+    kaf = np.clip(rng.uniform(0, 1, size=M), 0.01, 0.99)
+    one = vb.synth.make_pileup(1, 30, 2, seed=3)
+    none = vb.synth.make_pileup(40, 0.0, 2, seed=4)
+    cases = [vb.synth.make_pileup(3000, 30, 4, seed=5),
+             vb.synth.make_pileup(3000, 30, 2, seed=6, q_lo=2, q_hi=93),
+             vb.synth.with_sanity_stats(vb.synth.make_pileup(2000, 33, 3, seed=7, missing_frac=0.2)),
+             ragged,
+             vb.PileupData(2, ragged.ud, ragged.means, off, bases, quals, alt, kaf, 30.0, 0.0, True, {}),
+             one, none,
+             vb.synth.make_pileup(20000, 30, 4, seed=11)]
+    for d in cases:
+        want = _flatten_digest(d)
+        for host in ("0", "1"):
+            monkeypatch.setenv("VB2_HOST_PACK", host)
+            with vb.LikelihoodContext(d, device=0) as ctx:
+                assert _layout_digest(ctx) == want, (d.num_marker, host)

@@ -185,6 +185,14 @@ int vb2_debug_flatten_digest(const vb2_input* in, unsigned long long* digest)
     }
 }
 
+// (test hook, not in vb2_abi.h) the same digest over the data arrays as they are on the device
+int vb2_debug_layout_digest(vb2_ctx* ctx, unsigned long long* digest)
+{
+    if (int rc = guard_ctx(ctx)) return rc;
+    if (!digest) return VB2_ERR_INVALID;
+    return ctx->impl->layout_digest(digest);
+}
+
 int vb2_debug_read_stamps(vb2_ctx* ctx, unsigned long long* out, int max_blocks)
 {
     if (guard_ctx(ctx)) return 0;
@@ -522,6 +530,12 @@ int vb2_batch_eval(vb2_batch* b, const int32_t* num_point, const double* pc1, co
         return VB2_ERR_INVALID;
     }
     return b->impl->eval(num_point, pc1, pc2, alpha, llk_out);
+}
+
+// Test aid (not part of the public header): batches the last vb2_batch_optimize_llk regrouped its unfinished samples into.
+long long vb2_debug_batch_regroups(vb2_batch* b)
+{
+    return b && b->impl ? (long long)b->impl->num_regroup : -1;
 }
 
 int vb2_batch_optimize_llk(vb2_batch* b, const vb2_model* models, int32_t num_model, vb2_estimate* out)

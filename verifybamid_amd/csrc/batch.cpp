@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -67,7 +68,54 @@ bool cohort_w16_enabled()
 }
 void set_cohort_w16(bool on) { g_cohort_w16.store(on ? 1 : 0); }
 
-int Batch::create(const std::vector<Context*>& ctxs, Batch** out)
+void Batch::geometry(int num_cu, int num_sample, int max_mt, int num_pc, int bps_in, int* bps, int* block_waves)
+{
+    // ~one workgroup per CU in total; the waves of a workgroup: one per tile it owns, 1024 threads at most, and enough
+    // of them to stage a step's parameter rows
+    *bps = bps_in > 0 ? bps_in : std::max(1, num_cu / std::max(1, num_sample));
+    const int tiles_per_block = (max_mt + *bps - 1) / *bps;
+    const int min_bw = std::max(4, (kSlot * (2 * num_pc + 1) + 127) / 128);
+    *block_waves = std::max(min_bw, std::min(kMaxBlockWaves, tiles_per_block));
+}
+
+int Batch::regroup_bps(int num_cu, int active)
+{
+    int b = 1;
+    while (2 * b * active <= num_cu) b *= 2;
+    return b;
+}
+
+namespace {
+constexpr int kSplitFrom = 16;               // a cohort of this many samples is searched as two half-cohorts taking turns
+}
+
+int Batch::prepare_for_cohort(Context* c, int group)
+{
+    if (group < 1 || c->L.num_mt == 0) return VB2_OK;
+    int lanes[2] = {group, 0};
+    if (group >= kSplitFrom) { lanes[0] = group / 2; lanes[1] = group - group / 2; }
+    Schedule sc[kShapes];
+    int first_bps = 0;
+    for (int l = 0; l < 2; ++l) {
+        if (lanes[l] <= 0) continue;
+        int bps, bw;
+        geometry(c->L.num_cu, lanes[l], c->L.num_mt, c->num_pc, 0, &bps, &bw);
+        if (bps == first_bps) continue;
+        if (!first_bps) first_bps = bps;
+        if (const int rc = c->cohort_schedules(bps, bw, sc)) return rc;
+    }
+    // the regrouped batches: powers of two above the lane's own (those that take the work queue need no schedule)
+    for (int b = 1; b <= c->L.num_cu; b *= 2) {
+        if (b <= first_bps) continue;
+        int bps, bw;
+        geometry(c->L.num_cu, 1, c->L.num_mt, c->num_pc, b, &bps, &bw);
+        if (eval_takes_the_queue(c->L, bps, bw, 1)) break;
+        if (const int rc = c->cohort_schedules(bps, bw, sc)) return rc;
+    }
+    return VB2_OK;
+}
+
+int Batch::create(const std::vector<Context*>& ctxs, Batch** out, int bps_in)
 {
     *out = nullptr;
     const int num_sample = (int)ctxs.size();
@@ -103,14 +151,9 @@ int Batch::create(const std::vector<Context*>& ctxs, Batch** out)
     }
     VB2_HIP(hipSetDevice(b->device));
 
-    // geometry: ~one workgroup per CU in total; more workgroups per sample when the per-tile
-    // result slots would not fit in LDS
-    const int bps = std::max(1, num_cu / num_sample);
+    int bps = 1;
+    geometry(num_cu, num_sample, max_mt, b->num_pc, bps_in, &bps, &b->block_waves_);
     b->bps_ = bps;
-    const int tiles_per_block = (max_mt + bps - 1) / bps;
-    const int k = b->num_pc;
-    const int min_bw = std::max(4, (kSlot * (2 * k + 1) + 127) / 128);
-    b->block_waves_ = std::max(min_bw, std::min(kMaxBlockWaves, tiles_per_block));
     // launch shapes of a step: 0 = up to 4 points per sample, 1 = 8 points, 2 = one point, 3 = two
     static const int kShapeNp[kShapes] = {4, 8, 1, 2};
     for (int sh = 0; sh < kShapes; ++sh) {
@@ -135,31 +178,18 @@ int Batch::ensure_resources()
     VB2_HIP(hipSetDevice(device));
     const int k = num_pc, bps = bps_;
     const size_t S = (size_t)num_sample, stride = 2 * (size_t)k + 1;
-    // static schedules (llk_kernels.h) of every sample for the wave shapes of a step: two micro-tiles
-    // per wave for <= 4 points (when paired), one for 8 points, four for one or two points
-    std::vector<char> blob;
-    std::vector<size_t> where[kShapes];
-    bool sched_ok = ctx_[0]->sched_enabled;
-    if (sched_ok) {
-        const int tpu[kShapes] = {paired_mode() ? 2 : 1, 1, paired_mode() ? 4 : 1, paired_mode() ? 4 : 1};
-        for (int sh = 0; sh < kShapes && sched_ok; ++sh)
-            for (int s = 0; s < num_sample && sched_ok; ++s) {
-                std::vector<uint32_t> off;
-                std::vector<uint16_t> item;
-                Context* c = ctx_[s];
-                if (c->L.num_mt == 0) { where[sh].push_back((size_t)-1); continue; }
-                sched_ok = build_schedule(c->h_mt_rows.data(), c->L.num_mt, bps, block_waves_, tpu[sh], 1, &off, &item);
-                if (!sched_ok) break;
-                blob.resize((blob.size() + 15) / 16 * 16);
-                where[sh].push_back(blob.size());
-                const size_t ob = (off.size() * sizeof(uint32_t) + 15) / 16 * 16;
-                blob.resize(blob.size() + ob + item.size() * sizeof(uint16_t));
-                std::memcpy(blob.data() + where[sh].back(), off.data(), off.size() * sizeof(uint32_t));
-                std::memcpy(blob.data() + where[sh].back() + ob, item.data(), item.size() * sizeof(uint16_t));
-            }
-        if (!sched_ok) blob.clear();
+    // static schedules (llk_kernels.h) of every sample for the wave shapes of a step: the contexts keep them
+    // (Context::cohort_schedules -- prepared by the reader threads in a vb2_cohort_run)
+    std::vector<Schedule> arr(kShapes * S, Schedule{nullptr, nullptr});
+    bool sched_ok = false;
+    for (int s = 0; s < num_sample; ++s) {
+        Schedule sc[kShapes];
+        if (const int rc = ctx_[s]->cohort_schedules(bps, block_waves_, sc)) return rc;
+        for (int sh = 0; sh < kShapes; ++sh) {
+            arr[sh * S + s] = sc[sh];
+            sched_ok |= sc[sh].off != nullptr;
+        }
     }
-    blob.resize((blob.size() + 15) / 16 * 16);
     // device slab
     size_t dtot = 0;
     auto carve = [&](size_t bytes) {
@@ -168,7 +198,6 @@ int Batch::ensure_resources()
         return off;
     };
     const size_t o_lay = carve(sizeof(DeviceLayout) * S);
-    const size_t o_blob = carve(blob.size());
     const size_t o_arr = carve(kShapes * S * sizeof(Schedule));
     const size_t o_zero = carve(0);
     const size_t o_part = carve(sizeof(double) * S * (kSlot + 1) * bps);
@@ -188,18 +217,6 @@ int Batch::ensure_resources()
     // host image of the read-only part, uploaded on the batch's stream (the launches follow on it)
     std::vector<char> image(o_zero, 0);
     std::memcpy(image.data() + o_lay, layouts_.data(), sizeof(DeviceLayout) * S);
-    if (!blob.empty()) std::memcpy(image.data() + o_blob, blob.data(), blob.size());
-    std::vector<Schedule> arr(kShapes * S, Schedule{nullptr, nullptr});
-    if (sched_ok) {
-        const size_t ob = (((size_t)bps * block_waves_ + 1) * sizeof(uint32_t) + 15) / 16 * 16;
-        for (int sh = 0; sh < kShapes; ++sh)
-            for (size_t s = 0; s < S; ++s) {
-                const size_t w = where[sh][s];
-                if (w == (size_t)-1) continue;
-                const uint32_t* o = reinterpret_cast<const uint32_t*>(dbase + o_blob + w);
-                arr[sh * S + s] = Schedule{o, reinterpret_cast<const uint16_t*>(dbase + o_blob + w + ob)};
-            }
-    }
     std::memcpy(image.data() + o_arr, arr.data(), kShapes * S * sizeof(Schedule));
     VB2_HIP(hipMemcpyAsync(dbase, image.data(), image.size(), hipMemcpyHostToDevice, stream_));
     VB2_HIP(hipMemsetAsync(dbase + o_zero, 0, dtot - o_zero, stream_));
@@ -406,12 +423,17 @@ int Batch::eval_end()
 namespace {
 
 struct Lane {
-    Batch* batch = nullptr;
+    Batch* batch = nullptr;                 // the lane's samples, all of them
     std::unique_ptr<FiberGang> gang;
     int base = 0, count = 0;                // samples [base, base + count) of the whole cohort
     std::vector<int32_t> npts;
     std::vector<double> pc1, pc2, alpha, llk;
     bool flying = false;
+    std::chrono::steady_clock::time_point t_launch;
+    // the samples still searching, regrouped (see Batch::optimize): slot j of `cur` is fiber slot_fiber[j]
+    Batch* cur = nullptr;
+    std::unique_ptr<Batch> regrouped;
+    std::vector<int> slot_fiber;
 };
 
 }  // namespace
@@ -429,7 +451,7 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     // measured: a 1-point step of 32 C3 samples takes 131 us against 236 us with 4 points) -- and
     // {R, C_R} is the better trade: 1.2 steps per iteration at about half the points.  Same
     // decisions, same trajectory either way.  VB2_COHORT_SPECULATE=1|2|4 forces one.
-    constexpr int kPairFrom = 8, kSplitFrom = 16;
+    constexpr int kPairFrom = 8;
     speculate_ = num_sample < kPairFrom ? 4 : 2;
     if (const char* e = std::getenv("VB2_COHORT_SPECULATE")) speculate_ = std::max(1, std::atoi(e));
     bool split = num_sample >= kSplitFrom;
@@ -453,9 +475,22 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     } else {
         lanes[0].batch = this; lanes[0].base = 0; lanes[0].count = S;
     }
+    // Samples finish at different iterations (C3-shaped cohort of 32: the shortest search is over after ~60 % of the
+    // longest's steps), and a step gives every sample of its batch 256 / num_sample workgroups whether it still takes part
+    // or not: in round 3 a third of all steps served one or two samples on an eighth of the device.  So when half of a
+    // lane's samples have finished, the rest are regrouped into a batch of their own -- twice the workgroups per sample; the
+    // sums move in their last bits, as they do between group sizes (the static deal multiplies a wave's items in the wave);
+    // what regroups when follows from the samples' own trajectories, so a run stays reproducible -- and again at a quarter,
+    // an eighth ...
+    // VB2_COHORT_REGROUP=0: the fixed batch to the end (A/B).
+    bool regroup = true;
+    if (const char* e = std::getenv("VB2_COHORT_REGROUP")) regroup = std::atoi(e) != 0;
     std::vector<int> rcs(S, 0);
     for (int l = 0; l < nlane; ++l) {
         Lane& L = lanes[l];
+        L.cur = L.batch;
+        L.slot_fiber.resize(L.count);
+        for (int i = 0; i < L.count; ++i) L.slot_fiber[i] = i;
         const size_t n = (size_t)L.count;
         L.gang.reset(new FiberGang(L.count, kSlot));
         L.npts.assign(n, 0);
@@ -482,6 +517,9 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
             }
         };
     };
+    const bool dbg = std::getenv("VB2_DEBUG_LOCKSTEP") != nullptr;
+    double dbg_regroup_s = 0, dbg_wall_by_slots[65] = {0}; long dbg_steps_by_slots[65] = {0};
+    long dbg_steps = 0, dbg_active = 0, dbg_points = 0, dbg_regroups = 0, dbg_hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int error = 0;
     auto fail = [&](int rc) {
         if (!error) error = rc;
@@ -491,29 +529,70 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     auto launch = [&](Lane& L) {
         if (error || !L.gang->pending()) return;
         std::vector<FiberGang::Request>& req = L.gang->requests();
-        for (int i = 0; i < L.count; ++i) {
-            const FiberGang::Request& r = req[i];
+        if (regroup) {
+            int act = 0;
+            for (int j : L.slot_fiber) act += req[j].n > 0;
+            if (act >= 1 && 2 * act <= (int)L.slot_fiber.size()) {
+                std::vector<int> keep;
+                std::vector<Context*> part;
+                for (int j : L.slot_fiber)
+                    if (req[j].n > 0) {
+                        keep.push_back(j);
+                        part.push_back(ctx_[L.base + j]);
+                    }
+                Batch* nb = nullptr;
+                const auto tr0 = std::chrono::steady_clock::now();
+                int rc = Batch::create(part, &nb, regroup_bps(ctx_[0]->L.num_cu, (int)part.size()));
+                if (!rc) rc = nb->ensure_resources();
+                if (rc) {
+                    delete nb;
+                    fail(rc);
+                    return;
+                }
+                dbg_regroup_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+                L.regrouped.reset(nb);             // (the batch it replaces has no step in flight: its slabs go back to the caches)
+                L.cur = nb;
+                L.slot_fiber.swap(keep);
+                ++dbg_regroups;
+            }
+        }
+        const int nslot = (int)L.slot_fiber.size();
+        for (int i = 0; i < nslot; ++i) {
+            const FiberGang::Request& r = req[L.slot_fiber[i]];
             L.npts[i] = r.n;
             if (r.n <= 0) continue;
             std::memcpy(&L.pc1[(size_t)i * kSlot * k], r.p1, sizeof(double) * r.n * k);
             std::memcpy(&L.pc2[(size_t)i * kSlot * k], r.p2, sizeof(double) * r.n * k);
             std::memcpy(&L.alpha[(size_t)i * kSlot], r.a, sizeof(double) * r.n);
         }
-        if (const int rc = L.batch->eval_begin(L.npts.data(), L.pc1.data(), L.pc2.data(), L.alpha.data(), L.llk.data())) {
+        if (dbg) {
+            int act = 0, pts = 0;
+            for (int i = 0; i < nslot; ++i) { act += L.npts[i] > 0; pts += std::max(0, L.npts[i]); }
+            ++dbg_steps; dbg_active += act; dbg_points += pts;
+            dbg_hist[std::min(8, (8 * act + nslot - 1) / nslot)]++;
+        }
+        if (const int rc = L.cur->eval_begin(L.npts.data(), L.pc1.data(), L.pc2.data(), L.alpha.data(), L.llk.data())) {
             fail(rc);
             return;
         }
         L.flying = true;
+        L.t_launch = std::chrono::steady_clock::now();
     };
     // wait for the lane's step, hand the values out, run its fibers up to their next requests
     auto land = [&](Lane& L) {
         if (L.flying) {
             L.flying = false;
-            if (const int rc = L.batch->eval_end()) fail(rc);
+            if (const int rc = L.cur->eval_end()) fail(rc);
+            if (dbg) {
+                const int ns = std::min(64, (int)L.slot_fiber.size());
+                dbg_wall_by_slots[ns] += std::chrono::duration<double>(std::chrono::steady_clock::now() - L.t_launch).count();
+                ++dbg_steps_by_slots[ns];
+            }
             if (!error) {
                 std::vector<FiberGang::Request>& req = L.gang->requests();
-                for (int i = 0; i < L.count; ++i)
-                    if (L.npts[i] > 0) std::memcpy(req[i].out, &L.llk[(size_t)i * kSlot], sizeof(double) * L.npts[i]);
+                for (int i = 0; i < (int)L.slot_fiber.size(); ++i)
+                    if (L.npts[i] > 0)
+                        std::memcpy(req[L.slot_fiber[i]].out, &L.llk[(size_t)i * kSlot], sizeof(double) * L.npts[i]);
             }
         }
         if (L.gang->pending()) L.gang->resume_parked();       // (after an error: the fibers unwind)
@@ -530,6 +609,7 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
             set_error("vb2_batch_optimize_llk: could not start the search fibers (mmap / getcontext failed)");
             return VB2_ERR_INVALID;
         }
+    const auto t_loop0 = std::chrono::steady_clock::now();
     launch(lanes[0]);
     for (;;) {
         bool busy = false;
@@ -545,6 +625,20 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
         }
         if (!busy) break;
     }
+    if (dbg) {
+        std::fprintf(stderr, "lock-step loop %.2f ms, of which regrouping %.2f ms\n",
+                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count(), 1e3 * dbg_regroup_s);
+        for (int n = 1; n <= 64; ++n)
+            if (dbg_steps_by_slots[n])
+                std::fprintf(stderr, "  batches of %d: %ld steps, %.1f us from launch to landing each\n", n, dbg_steps_by_slots[n],
+                             1e6 * dbg_wall_by_slots[n] / dbg_steps_by_slots[n]);
+    }
+    if (dbg)
+        std::fprintf(stderr, "lock-step search of %d samples in %d lane(s): %ld steps, %.1f active samples and %.1f points per step "
+                             "(a lane holds %d, %ld regroupings); steps by eighths of the batch active: %ld %ld %ld %ld %ld %ld %ld %ld\n",
+                     S, nlane, dbg_steps, (double)dbg_active / std::max(1L, dbg_steps), (double)dbg_points / std::max(1L, dbg_steps),
+                     lanes[0].count, dbg_regroups, dbg_hist[1], dbg_hist[2], dbg_hist[3], dbg_hist[4], dbg_hist[5], dbg_hist[6], dbg_hist[7], dbg_hist[8]);
+    num_regroup = dbg_regroups;
     if (error) return error;
     for (int s = 0; s < S; ++s)
         if (rcs[s]) return rcs[s];

@@ -19,7 +19,14 @@ class Batch {
 public:
     ~Batch();
     static int create(vb2_ctx* const* ctxs, int num_sample, Batch** out);
-    static int create(const std::vector<Context*>& ctxs, Batch** out);
+    static int create(const std::vector<Context*>& ctxs, Batch** out, int bps = 0);   // bps > 0: that many workgroups per sample
+    // launch geometry of a batch of num_sample samples whose biggest has max_mt micro-tiles: workgroups per sample and waves
+    // per workgroup (what create() uses -- and what a reader thread prepares a sample's schedules for: prepare_for_cohort)
+    static void geometry(int num_cu, int num_sample, int max_mt, int num_pc, int bps_in, int* bps, int* block_waves);
+    // the workgroups per sample of the batch a lane's remaining `active` samples are regrouped into (a power of two)
+    static int regroup_bps(int num_cu, int active);
+    // schedules of `c` for the lanes of a lock-step search of `group` samples (and for the regrouped ones that need any)
+    static int prepare_for_cohort(Context* c, int group);
     // num_point[s] in [0, 8]; pc1/pc2: [S][8][k]; alpha, llk_out: [S][8]
     int eval(const int32_t* num_point, const double* pc1, const double* pc2, const double* alpha,
              double* llk_out);
@@ -34,6 +41,7 @@ public:
     static constexpr int kShapes = 4;       // launch shapes of a step: <= 4, 8, 1, 2 points per sample
     int num_sample = 0, num_pc = 0, device = -1;
     int64_t num_launch = 0;
+    int64_t num_regroup = 0;                // batches the last optimize() regrouped its unfinished samples into
 
 private:
     std::vector<Context*> ctx_;

@@ -51,13 +51,16 @@ public:
         if (a->base.devices && a->base.num_device > 0) devices_.assign(a->base.devices, a->base.devices + a->base.num_device);
         else devices_.push_back(a->base.device);
         ndev_ = (int)devices_.size();
-        G_ = std::max(1, std::min(a->group_size != 0 ? std::abs(a->group_size) : 64, 64));
+        // (round 4: 32, not 64 -- with the finished samples regrouped (Batch::optimize) a group of 32 costs 1.55 ms per C3
+        // sample and one of 64 1.5, and the smaller group starts earlier and leaves a shorter tail nothing overlaps:
+        // 256 files 479 -> 546 samples/s)
+        G_ = std::max(1, std::min(a->group_size != 0 ? std::abs(a->group_size) : 32, 64));
         const int hw = vb2::usable_cpu_count();
-        // readers: text parsing + run packing is ~0.1 s of one core per C3-sized sample, the device
-        // needs ~4 ms per sample -> a device keeps ~25 readers busy.  The default leaves two CPUs of
-        // the process's allowance (cgroup quota / affinity, not the host's core count) to the
-        // lock-step search and the releaser; more runnable threads than CPUs only get the cgroup throttled
-        const int dflt = std::max(2, std::min(hw - 2, 64 * ndev_));
+        // readers: reading + flattening is ~17 ms of one CPU per C3-sized sample (round 4), the device needs ~1.55 ms per
+        // sample -> a device keeps ~11 readers busy.  The default is the process's allowance (cgroup quota / affinity, not
+        // the host's core count): the thread of the lock-step search mostly waits for the device, and a reader more is
+        // worth more than the CPU it shares (16 CPUs: 14 readers 530-548 samples/s, 16 readers 564-572)
+        const int dflt = std::max(2, std::min(hw, 64 * ndev_));
         T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, std::max(hw, 1) * 4, S_}));
         slots_.resize(S_);
         cnt_.assign(ndev_, 0);
@@ -68,7 +71,7 @@ public:
         // A remainder of up to half a group joins the last group instead of running alone.
         for (int begin = 0, gi = 0; begin < S_; ++gi) {
             const int nth = gi / ndev_;                       // this group's index on its device
-            int want = std::min(G_, nth == 0 ? 16 : nth == 1 ? 32 : G_);
+            int want = std::min(G_, nth == 0 ? 16 : nth == 1 ? 32 : G_);     // (G_ > 32: 16, 32, then full groups)
             if (a->group_size < 0) want = G_;                 // (negative group_size: plain equal groups of |group_size|)
             const int left = S_ - begin;
             if (left <= want + want / 2) want = left;
@@ -218,6 +221,12 @@ private:
         opt.device = devices_[device_of_group(group_of_[s])];
         opt.flags = VB2_OPT_COHORT_LAYOUT;       // the lock-step search streams the 16-bit run lists
         sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
+        if (sl.rc == VB2_OK && sl.ctx && sl.ctx->impl) {
+            // the static schedules of the sample's group (and of the batches its lane is regrouped into): here, on one of many
+            // reader threads, not on the one thread that feeds the device (a failure only means they are built there)
+            const int gi = group_of_[s];
+            (void)vb2::Batch::prepare_for_cohort(sl.ctx->impl, group_begin_[gi + 1] - group_begin_[gi]);
+        }
         // the context holds its own (flattened) copy: the sample's text-sized arrays go back now, on
         // this reader thread, instead of piling up in front of the single releaser (the writers need
         // only the viewer's counters and the panel)

@@ -214,6 +214,8 @@ Context::~Context()
     if (h_slab && !slab_cache().give(slab_cache().pin, h_slab, h_slab_bytes, device)) (void)hipHostFree(h_slab);
     if (h_trace_stage) (void)hipHostFree(h_trace_stage);
     if (d_codes16_own) (void)hipFree(d_codes16_own);
+    for (CohortSched& e : cohort_sched_)
+        if (e.d_mem && !slab_cache().give(slab_cache().dev, e.d_mem, e.bytes, device)) (void)hipFree(e.d_mem);
     if (own_stream && stream && !slab_cache().give_stream(stream, device)) (void)hipStreamDestroy(stream);
 }
 
@@ -654,13 +656,36 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
 
     // pinned staging slab (recycled through the cache like the other slabs: hipHostMalloc /
     // hipHostFree take milliseconds and synchronise)
+    // Pass B on the device (round 4; VB2_HOST_PACK=1: on the host, as before): the staging slab then carries, behind the
+    // (small) tables of the data block, the INPUTS of pack_layout_kernel as the host has them -- the run lists at their reads'
+    // positions, the per-marker constants and the panel rows in panel order, three words per sorted marker -- instead of
+    // the packed arrays; 7-8 ms of host CPU per C3 sample (scattered reads, 2 M table look-ups) become one more upload and
+    // a ~30 us kernel.
+    const bool host_pack_forced = std::getenv("VB2_HOST_PACK") && std::atoi(std::getenv("VB2_HOST_PACK")) != 0;
+    const bool device_pack = !dry && !host_pack_forced && m_active > 0 && total_reads < ((int64_t)1 << 32);
+    size_t in_total = 0;
+    auto icarve = [&](size_t bytes) {
+        const size_t off = (in_total + 255) & ~(size_t)255;
+        in_total = off + bytes;
+        return off;
+    };
+    const size_t i_runs = icarve((size_t)std::max<int64_t>(total_reads, 1) * sizeof(uint16_t));
+    const size_t i_src = icarve((size_t)m_active * sizeof(uint32_t));
+    const size_t i_eff = icarve((size_t)m_active * sizeof(uint32_t));
+    const size_t i_pidx = icarve((size_t)m_active * sizeof(int32_t));
+    const size_t i_cd = icarve((size_t)M * 4 * sizeof(double));
+    const size_t i_ud = icarve(in->known_af ? 0 : (size_t)M * k * sizeof(double));
+    const size_t i_mu = icarve(in->known_af ? 0 : (size_t)M * sizeof(double));
+    const size_t i_kaf = icarve(in->known_af ? (size_t)M * sizeof(double) : 0);
+    in_total = (in_total + 255) & ~(size_t)255;
+    const size_t stage_need = device_pack ? data_bytes + in_total : data_bytes;
     size_t stage_bytes = 0;
-    char* stage = dry ? static_cast<char*>(std::malloc(data_bytes))
-                      : static_cast<char*>(slab_cache().take(slab_cache().stage, data_bytes, dev, &stage_bytes));
+    char* stage = dry ? static_cast<char*>(std::malloc(stage_need))
+                      : static_cast<char*>(slab_cache().take(slab_cache().stage, stage_need, dev, &stage_bytes));
     if (!stage) {
         if (dry) { set_error("out of host memory"); return VB2_ERR_NOMEM; }
-        VB2_HIP(hipHostMalloc((void**)&stage, data_bytes, hipHostMallocDefault));
-        stage_bytes = data_bytes;
+        VB2_HIP(hipHostMalloc((void**)&stage, stage_need, hipHostMallocDefault));
+        stage_bytes = stage_need;
     }
     struct StageGuard {                       // back to the cache (or the driver) on every way out
         char* p; size_t bytes; int dev; bool dry;
@@ -681,8 +706,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     if (!prim.empty()) std::memcpy(stage + o_prim, prim.data(), prim.size() * sizeof(double2));
     if (want16) std::memcpy(stage + o_rec16, rec16.data(), rec16.size() * sizeof(uint2));
     // padding: the slack rows behind the last tile, and the (< 16) marker positions past the last active one
-    std::fill(codes + (size_t)total_rows * kMtMarkers * 2, codes + n_codes, pad4);
-    for (int64_t m = m_active; m < m_pad; ++m) {
+    if (!device_pack) std::fill(codes + (size_t)total_rows * kMtMarkers * 2, codes + n_codes, pad4);
+    for (int64_t m = device_pack ? m_pad : m_active; m < m_pad; ++m) {
         if (in->known_af) kaf_s[m] = 0.0;
         else {
             for (int kk = 0; kk < k; ++kk) ud_s[(size_t)kk * m_pad + m] = 0.0;
@@ -695,6 +720,27 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     }
     // ---- pass B (kernel order: markers sorted by run count, i.e. scattered reads of the panel
     // order arrays -- prefetched): run words, panel rows, diagonal terms into the staging slab ----
+    if (device_pack) {
+        char* const inp = stage + data_bytes;
+        std::memcpy(inp + i_runs, runs, (size_t)total_reads * sizeof(uint16_t));
+        std::memcpy(inp + i_cd, cd_tmp, (size_t)M * 4 * sizeof(double));
+        if (in->known_af) std::memcpy(inp + i_kaf, in->known_af, (size_t)M * sizeof(double));
+        else {
+            std::memcpy(inp + i_ud, in->ud, (size_t)M * k * sizeof(double));
+            std::memcpy(inp + i_mu, in->means, (size_t)M * sizeof(double));
+        }
+        uint32_t* const s_src = reinterpret_cast<uint32_t*>(inp + i_src);
+        uint32_t* const s_eff = reinterpret_cast<uint32_t*>(inp + i_eff);
+        int32_t* const s_pidx = reinterpret_cast<int32_t*>(inp + i_pidx);
+        parallel_for(m_active, [&](int, int64_t m0, int64_t m1) {
+            for (int64_t m = m0; m < m1; ++m) {
+                const int i = active[perm[m]];
+                s_src[m] = (uint32_t)(in->read_off[i] - read_base);
+                s_eff[m] = (uint32_t)eff_all[i];
+                s_pidx[m] = i;
+            }
+        });
+    } else
     parallel_for(m_active, [&](int, int64_t m0, int64_t m1) {
     constexpr int64_t kAhead = 12;
     for (int64_t m = m0; m < m1; ++m) {
@@ -772,7 +818,61 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     }
     char* const dbase = static_cast<char*>(c->d_slab);
     // the data arrays in ONE asynchronous copy; partial sums, ticket, relay, stamps and schedule space start as zeros
-    VB2_HIP(hipMemcpyAsync(dbase, stage, data_bytes, hipMemcpyHostToDevice, c->stream));
+    struct DevGuard {                          // the pack kernel's inputs on the device: back to the cache after the create's sync
+        void* p = nullptr; size_t bytes = 0; int dev = 0; hipStream_t st = nullptr;
+        ~DevGuard() {
+            if (!p) return;
+            (void)hipStreamSynchronize(st);    // (an early error return: the kernel may still be reading)
+            if (!slab_cache().give(slab_cache().dev, p, bytes, dev)) (void)hipFree(p);
+        }
+    } d_in;
+    d_in.dev = dev;
+    d_in.st = c->stream;
+    if (device_pack) {
+        d_in.p = slab_cache().take(slab_cache().dev, in_total, dev, &d_in.bytes);
+        if (!d_in.p) {
+            VB2_HIP(hipMalloc(&d_in.p, in_total));
+            d_in.bytes = in_total;
+        }
+        char* const din = static_cast<char*>(d_in.p);
+        VB2_HIP(hipMemcpyAsync(din, stage + data_bytes, in_total, hipMemcpyHostToDevice, c->stream));
+        // the small tables of the data block, each to its place
+        VB2_HIP(hipMemcpyAsync(dbase + o_rec, stage + o_rec, (size_t)num_mt * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+        if (!dict_perr.empty())
+            VB2_HIP(hipMemcpyAsync(dbase + o_dpe, stage + o_dpe, dict_perr.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (!prim.empty())
+            VB2_HIP(hipMemcpyAsync(dbase + o_prim, stage + o_prim, prim.size() * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+        if (want16)
+            VB2_HIP(hipMemcpyAsync(dbase + o_rec16, stage + o_rec16, rec16.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+        PackArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.runs = reinterpret_cast<const uint16_t*>(din + i_runs);
+        pa.src_off = reinterpret_cast<const uint32_t*>(din + i_src);
+        pa.eff = reinterpret_cast<const uint32_t*>(din + i_eff);
+        pa.pidx = reinterpret_cast<const int32_t*>(din + i_pidx);
+        pa.cd = reinterpret_cast<const double*>(din + i_cd);
+        pa.ud = in->known_af ? nullptr : reinterpret_cast<const double*>(din + i_ud);
+        pa.mu = in->known_af ? nullptr : reinterpret_cast<const double*>(din + i_mu);
+        pa.kaf = in->known_af ? reinterpret_cast<const double*>(din + i_kaf) : nullptr;
+        pa.mt_rec = reinterpret_cast<const uint2*>(dbase + o_rec);
+        pa.codes = reinterpret_cast<uint2*>(dbase + o_codes);
+        pa.ud_s = reinterpret_cast<double*>(dbase + o_ud);
+        pa.mu_s = reinterpret_cast<double*>(dbase + o_mu);
+        pa.kaf_s = in->known_af ? reinterpret_cast<double*>(dbase + o_kaf) : nullptr;
+        pa.cdiag = reinterpret_cast<double*>(dbase + o_cd);
+        pa.m_active = m_active;
+        pa.m_pad = m_pad;
+        pa.k = k;
+        pa.num_mt = num_mt;
+        pa.total_rows = (uint32_t)total_rows;
+        pa.slack_rows = (uint32_t)kCodeSlackRows;
+        pa.pad4 = pad4;
+        for (int idx = 0; idx < kMaxCode; ++idx) pa.row_of_idx[idx] = row_of_idx[idx];
+        for (int n = 0; n <= kMaxRunCount; ++n) pa.hi_of_count[n] = hi_of_count[n];
+        VB2_HIP(launch_pack_layout(pa, c->stream));
+    } else {
+        VB2_HIP(hipMemcpyAsync(dbase, stage, data_bytes, hipMemcpyHostToDevice, c->stream));
+    }
     VB2_HIP(hipMemsetAsync(dbase + o_part, 0, dev_total - o_part, c->stream));
     if (!in->known_af) {
         L.ud = reinterpret_cast<const double*>(dbase + o_ud);
@@ -797,6 +897,16 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         c->sched_[slot].bytes = sched_bytes[slot];
     }
     c->h_mt_rows.assign(mt_rows.begin(), mt_rows.end());
+    c->dbg_regions = {{o_codes, n_codes * sizeof(uint32_t)}, {o_rec, (size_t)num_mt * sizeof(uint2)}};
+    if (in->known_af) c->dbg_regions.push_back({o_kaf, (size_t)m_pad * sizeof(double)});
+    else {
+        c->dbg_regions.push_back({o_ud, (size_t)k * m_pad * sizeof(double)});
+        c->dbg_regions.push_back({o_mu, (size_t)m_pad * sizeof(double)});
+    }
+    c->dbg_regions.push_back({o_cd, (size_t)4 * m_pad * sizeof(double)});
+    c->dbg_regions.push_back({o_dpe, dict_perr.size() * sizeof(double)});
+    c->dbg_regions.push_back({o_prim, prim.size() * sizeof(double2)});
+    c->dbg_counts[0] = num_read; c->dbg_counts[1] = num_other; c->dbg_counts[2] = (int64_t)num_code; c->dbg_counts[3] = m_active;
     if (const char* sc = std::getenv("VB2_SCHED")) c->sched_enabled = std::atoi(sc) != 0;
     c->device_bytes = (int64_t)dev_total;
     L.num_prim = (int32_t)prim.size();
@@ -916,6 +1026,58 @@ Schedule Context::get(int mode, int ngrp, int grid, int block_waves)
     sl.s.off = reinterpret_cast<const uint32_t*>(sl.d_base);
     sl.s.item = reinterpret_cast<const uint16_t*>(sl.d_base + off_bytes);
     return sl.s;
+}
+
+int Context::cohort_schedules(int bps, int block_waves, Schedule out[4])
+{
+    for (int sh = 0; sh < 4; ++sh) out[sh] = Schedule{nullptr, nullptr};
+    if (!sched_enabled || L.num_mt == 0 || eval_takes_the_queue(L, bps, block_waves, 1)) return VB2_OK;
+    std::lock_guard<std::mutex> lk(cohort_mu_);
+    for (const CohortSched& e : cohort_sched_)
+        if (e.bps == bps && e.block_waves == block_waves) {
+            for (int sh = 0; sh < 4; ++sh) out[sh] = e.s[sh];
+            return VB2_OK;
+        }
+    // micro-tiles a wave takes per item: two for <= 4 points (when paired), one for 8 points, four for one or two points
+    const int tpu[4] = {paired_mode() ? 2 : 1, 1, paired_mode() ? 4 : 1, paired_mode() ? 4 : 1};
+    std::vector<char> blob;
+    size_t where[4];
+    const size_t ob = (((size_t)bps * block_waves + 1) * sizeof(uint32_t) + 15) / 16 * 16;
+    CohortSched e;
+    e.bps = bps;
+    e.block_waves = block_waves;
+    for (int sh = 0; sh < 4; ++sh) {
+        std::vector<uint32_t> off;
+        std::vector<uint16_t> item;
+        if (!build_schedule(h_mt_rows.data(), L.num_mt, bps, block_waves, tpu[sh], 1, &off, &item)) {
+            cohort_sched_.push_back(e);                     // (every shape: the snake deal)
+            return VB2_OK;
+        }
+        where[sh] = blob.size();
+        blob.resize(blob.size() + ob + (item.size() * sizeof(uint16_t) + 15) / 16 * 16);
+        std::memcpy(blob.data() + where[sh], off.data(), off.size() * sizeof(uint32_t));
+        std::memcpy(blob.data() + where[sh] + ob, item.data(), item.size() * sizeof(uint16_t));
+    }
+    VB2_HIP(hipSetDevice(device));
+    e.d_mem = slab_cache().take(slab_cache().dev, blob.size(), device, &e.bytes);
+    if (!e.d_mem) {
+        VB2_HIP(hipMalloc(&e.d_mem, blob.size()));
+        e.bytes = blob.size();
+    }
+    if (hipMemcpyAsync(e.d_mem, blob.data(), blob.size(), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {        // (a pageable source: staged before this returns)
+        (void)hipGetLastError();
+        if (!slab_cache().give(slab_cache().dev, e.d_mem, e.bytes, device)) (void)hipFree(e.d_mem);
+        set_error("cohort schedule upload failed");
+        return VB2_ERR_HIP;
+    }
+    for (int sh = 0; sh < 4; ++sh) {
+        const char* base = static_cast<const char*>(e.d_mem) + where[sh];
+        e.s[sh] = Schedule{reinterpret_cast<const uint32_t*>(base), reinterpret_cast<const uint16_t*>(base + ob)};
+        out[sh] = e.s[sh];
+    }
+    cohort_sched_.push_back(e);
+    return VB2_OK;
 }
 
 // One resident search per device at a time (all its workgroups must be on the CUs together).
@@ -1271,6 +1433,25 @@ int Context::ensure_codes16()
     for (int t = 0; t < L.num_mt; ++t) rows32 += h_mt_rows[t];
     cohort_bytes += ((int64_t)total16 - rows32) * kMtMarkers * 8;
     device_bytes += (int64_t)bytes;
+    return VB2_OK;
+}
+
+int Context::layout_digest(unsigned long long* digest)
+{
+    // the same regions, in the same order, as the dry flatten's digest (flatten_digest) -- read back from the device
+    VB2_HIP(hipSetDevice(device));
+    resident_end();
+    VB2_HIP(hipStreamSynchronize(stream));
+    uint64_t hsh = 1469598103934665603ull;
+    std::vector<unsigned char> buf;
+    for (const auto& r : dbg_regions) {
+        buf.resize(r.second);
+        if (r.second) VB2_HIP(hipMemcpy(buf.data(), static_cast<const char*>(d_slab) + r.first, r.second, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < r.second; ++i) hsh = (hsh ^ buf[i]) * 1099511628211ull;
+    }
+    const unsigned char* q = reinterpret_cast<const unsigned char*>(dbg_counts);
+    for (size_t i = 0; i < sizeof(dbg_counts); ++i) hsh = (hsh ^ q[i]) * 1099511628211ull;
+    *digest = hsh;
     return VB2_OK;
 }
 

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <memory>
 #include <string>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/vb2_abi.h"
@@ -55,6 +57,20 @@ public:
     };
     SchedSlot sched_[9];
     bool sched_enabled = true;               // VB2_SCHED=0: in-kernel snake deal
+    // Static schedules of a cohort step's four wave shapes (batch.h: <= 4, 8, 1, 2 points per sample) for this sample served
+    // by `bps` workgroups of `block_waves` waves: built and uploaded on first use, kept for the context's lifetime (a
+    // reader thread of vb2_cohort_run prepares them; Batch::ensure_resources then only collects pointers: building them there
+    // cost 0.35 ms per C3 sample on the thread that feeds the device).  {nullptr, nullptr} where the launch takes the work
+    // queue (no schedule needed) or none could be built (-> the in-kernel snake deal).  Thread-safe.
+    int cohort_schedules(int bps, int block_waves, Schedule out[4]);
+    struct CohortSched {
+        int bps = 0, block_waves = 0;
+        Schedule s[4];
+        void* d_mem = nullptr;
+        size_t bytes = 0;
+    };
+    std::vector<CohortSched> cohort_sched_;
+    std::mutex cohort_mu_;
     std::vector<uint32_t> h_mt_rows;         // rows per micro-tile (host copy: the schedules are built from it)
     static int create(const vb2_input* in, const vb2_options* opt, Context** out);
     static int create_impl(const vb2_input* in, const vb2_options* opt, Context** out, bool dry);
@@ -104,6 +120,9 @@ public:
     int64_t trace_stage_rows = 0;
     void fill_info(vb2_info* info) const;
     int read_stamps(unsigned long long* out, int max_blocks);
+    int layout_digest(unsigned long long* digest);     // (test hook) the flatten_digest of what is ON THE DEVICE
+    std::vector<std::pair<size_t, size_t>> dbg_regions;   // (offset, bytes) of the defined data regions, in digest order
+    int64_t dbg_counts[4] = {0, 0, 0, 0};
     // The cohort-step copy of the run lists (DeviceLayout::codes16): built on the device from `codes`, in the
     // slab when the context was created with VB2_OPT_COHORT_LAYOUT, else in an allocation of its own here.
     int ensure_codes16();

@@ -155,6 +155,31 @@ hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 // rows16_total + kCodeSlackRows rows are written, the slack as padding words)
 hipError_t launch_pack_codes16(const DeviceLayout& L, uint2* codes16, const uint2* mt_rec16, uint32_t rows16_total,
                                hipStream_t stream);
+// Pass B of the flatten on the device (round 4): the host classifies, run-length codes and sorts; this kernel writes the
+// kernel-order arrays -- run words [tile][row][marker], panel rows, per-marker constants -- from the panel-order inputs the
+// host uploaded as they were.  Pure data movement: the same bytes as the host's pass B (tested).
+struct PackArgs {
+    const uint16_t* runs;          // a marker's runs (dictionary index | count << 8), at src_off[m]
+    const uint32_t* src_off;       // [m_active] sorted marker m -> offset of its runs
+    const uint32_t* eff;           // [m_active] its number of runs
+    const int32_t* pidx;           // [m_active] its panel row
+    const double* cd;              // [M][4] panel order: c_other, exp(c_other + D[g])
+    const double* ud;              // [M][k] panel order (nullptr with known_af)
+    const double* mu;              // [M]
+    const double* kaf;             // [M] or nullptr
+    const uint2* mt_rec;           // [num_mt] {first row, rows}
+    uint2* codes;                  // out: [rows + slack][16]
+    double* ud_s;                  // out: [k][m_pad]
+    double* mu_s;                  // out: [m_pad]
+    double* kaf_s;                 // out: [m_pad] or nullptr
+    double* cdiag;                 // out: [4][m_pad]
+    int64_t m_active, m_pad;
+    int32_t k, num_mt;
+    uint32_t total_rows, slack_rows, pad4;
+    uint32_t row_of_idx[kMaxCode];
+    uint32_t hi_of_count[kMaxRunCount + 1];
+};
+hipError_t launch_pack_layout(const PackArgs& a, hipStream_t stream);
 // n doubles from device memory to mapped host memory, then done_seq to the mapped flag (stream-ordered
 // hand-off to a spinning host: see publish_kernel)
 hipError_t launch_publish(const double* d_src, double* d_dst_mapped, int n, unsigned long long* done_flag,

@@ -1726,6 +1726,47 @@ hipError_t launch_pack_codes16(const DeviceLayout& L, uint2* codes16, const uint
     return hipGetLastError();
 }
 
+// One thread per position of the padded, sorted marker list (see PackArgs): 16 consecutive threads = one micro-tile, so a
+// row of run words leaves as one 128-byte store per tile.
+__global__ void __launch_bounds__(256)
+pack_layout_kernel(const PackArgs a)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < a.m_pad) {
+        const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
+        const uint2 rec = a.mt_rec[t];
+        const bool have = m < a.m_active;
+        const uint32_t eff = have ? a.eff[m] : 0u;
+        const uint16_t* src = a.runs + (have ? a.src_off[m] : 0u);
+        uint2* out = a.codes + (size_t)rec.x * kMtMarkers + lane;
+        for (uint32_t r = 0; r < rec.y; ++r) {
+            uint32_t w0 = a.pad4, w1 = a.pad4;
+            if (2 * r < eff) { const uint32_t rw = src[2 * r]; w0 = a.row_of_idx[rw & 0xffu] | a.hi_of_count[rw >> 8]; }
+            if (2 * r + 1 < eff) { const uint32_t rw = src[2 * r + 1]; w1 = a.row_of_idx[rw & 0xffu] | a.hi_of_count[rw >> 8]; }
+            out[(size_t)r * kMtMarkers] = make_uint2(w0, w1);
+        }
+        const int64_t i = have ? (int64_t)a.pidx[m] : 0;
+        if (a.kaf_s) a.kaf_s[m] = have ? a.kaf[i] : 0.0;
+        else {
+            for (int kk = 0; kk < a.k; ++kk) a.ud_s[(size_t)kk * a.m_pad + m] = have ? a.ud[(size_t)i * a.k + kk] : 0.0;
+            a.mu_s[m] = have ? a.mu[i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.cdiag[(size_t)q * a.m_pad + m] = have ? a.cd[(size_t)i * 4 + q] : 0.0;
+    }
+    // the slack rows behind the last tile (the read loops request past a tile's rows): padding words
+    const int64_t nslack = (int64_t)a.slack_rows * kMtMarkers;
+    for (int64_t e = m; e < nslack; e += (int64_t)gridDim.x * blockDim.x)
+        a.codes[(size_t)a.total_rows * kMtMarkers + e] = make_uint2(a.pad4, a.pad4);
+}
+
+hipError_t launch_pack_layout(const PackArgs& a, hipStream_t stream)
+{
+    const int64_t n = std::max<int64_t>(a.m_pad, (int64_t)a.slack_rows * kMtMarkers);
+    hipLaunchKernelGGL(pack_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int tpu, int ngrp,
                     std::vector<uint32_t>* off, std::vector<uint16_t>* item)
 {
