@@ -1242,6 +1242,40 @@ def test_wide_quality_alphabet_at_100k_markers():
         assert abs(est["alpha"] - 0.04) <= 5e-3
 
 
+@pytest.mark.parametrize("shape", [(100000, 4, 2, 60), (20000, 2, 2, 93), (3000, 3, 2, 60)])
+def test_passes_of_one_launch_equal_the_separate_launches_bit_for_bit(shape):
+    """A call of more points than the LDS holds tables for (wide quality alphabets) runs as the passes of ONE launch
+    (llk_eval_passes_kernel: own points, partial sums and arrival ticket per pass, a compact exp table so that a third point
+    group fits) -- every value bit for bit what separate launches give (vb2_debug_set_eval_passes(0)), whatever the number of
+    points (9 .. 48 and beyond one call's 48), and the oracle's to LLK_RTOL; repeated calls give the same bits (the tickets
+    go back to zero)."""
+    import ctypes
+    M, k, q_lo, q_hi = shape
+    lib = _abi.lib()
+    lib.vb2_debug_set_eval_passes.argtypes = [ctypes.c_int]
+    lib.vb2_debug_set_eval_passes.restype = None
+    d = vb.synth.make_pileup(M, 30, k, alpha_true=0.04, seed=131, q_lo=q_lo, q_hi=q_hi)
+    od = oracle_data(d)
+    rng = np.random.default_rng(118)
+    try:
+        with vb.LikelihoodContext(d) as ctx:
+            assert ctx.info()["num_code"] >= 100
+            for B in (9, 17, 24, 25, 33, 40, 48, 50, 97):
+                pc1, pc2, al = rng.normal(0, 0.03, (B, k)), rng.normal(0, 0.03, (B, k)), rng.uniform(0, 0.4, B)
+                lib.vb2_debug_set_eval_passes(0)
+                want = ctx.llk(pc1, pc2, al)
+                lib.vb2_debug_set_eval_passes(1)
+                got = ctx.llk(pc1, pc2, al)
+                assert np.array_equal(got, want), B
+                assert np.array_equal(ctx.llk(pc1, pc2, al), want), B
+                if B in (25, 48):
+                    idx = [0, 8, 16, 23, 24, B - 1]
+                    ref = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=os.cpu_count() or 1) for i in idx])
+                    assert rel_err(got[idx], ref) <= LLK_RTOL
+    finally:
+        lib.vb2_debug_set_eval_passes(1)
+
+
 def test_value_of_a_point_does_not_depend_on_the_wave_shape(c2, c3):
     """A point evaluated alone (four micro-tiles per wave), among four (two tiles x two slots) or in
     a group of eight (one tile x four slots x two points) gets the same bits: every micro-tile's

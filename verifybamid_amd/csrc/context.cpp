@@ -127,6 +127,7 @@ static void init_process_knobs()
         if (const char* rm = std::getenv("VB2_REDUCE"))
             set_reduce_mode(!std::strcmp(rm, "ticket") ? 1 : !std::strcmp(rm, "tagged") ? 2 : 0);
         if (const char* co = std::getenv("VB2_COOP")) set_coop_launch(std::atoi(co) != 0);
+        if (const char* ps = std::getenv("VB2_PASSES")) set_eval_passes(std::atoi(ps) != 0);
         if (const char* pm = std::getenv("VB2_PAIRED")) set_paired_mode(std::atoi(pm) != 0);
         for (int btl = 1; btl <= 2; ++btl) {
             const char* gv = std::getenv(btl == 1 ? "VB2_GEOM1" : "VB2_GEOM2");
@@ -641,7 +642,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     const size_t data_bytes = (dev_total + 255) & ~(size_t)255;
     const size_t o_codes16 = carve(want16 ? (size_t)(total_rows16 + kCodeSlackRows) * kMtMarkers * sizeof(uint2) : 0);
     const size_t o_part = carve(sizeof(double) * (size_t)(kMaxPointsPerLaunch + 1) * nb);
-    const size_t o_ticket = carve(sizeof(unsigned int));
+    const size_t o_ticket = carve(sizeof(unsigned int) * kTicketWords);
     const size_t o_relay = carve(sizeof(unsigned long long) * relay_words);
     const size_t o_stamps = carve(want_stamps ? sizeof(unsigned long long) * 8 * nb : 0);
     // room for the static schedules of the nine launch shapes (filled on first use)
@@ -1199,7 +1200,7 @@ bool Context::resident_collect(int n, double* out)
         resident_active = false;
         resident_enabled = false;
         g_resident_busy[device].store(0);
-        (void)hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream);
+        (void)hipMemsetAsync(d_ticket, 0, sizeof(unsigned int) * kTicketWords, stream);
         return false;
     }
     std::memcpy(out, h_out, sizeof(double) * n);
@@ -1273,7 +1274,7 @@ int Context::device_minimize(MinimizeRequest* req)
         resident_active = false;
         resident_enabled = false;
         g_resident_busy[device].store(0);
-        (void)hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream);
+        (void)hipMemsetAsync(d_ticket, 0, sizeof(unsigned int) * kTicketWords, stream);
         rc = VB2_ERR_HIP;
     } else {
         req->status = (int)h_result[0];

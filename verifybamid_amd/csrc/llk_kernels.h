@@ -22,6 +22,9 @@ constexpr int kRowBytesWide = 400;         // 8 points x 6 doubles + 2 doubles o
 constexpr int kRowBytesNarrow = 208;       // 4 points x 6 doubles + 2 (13 slots)
 constexpr int kMaxWideCodes = 65535 / kRowBytesWide - 1;   // run words hold 16-bit byte offsets (pad row included)
 constexpr int kMaxRunCount = 31;           // the 16-bit prefix of a double holds integers up to 31 exactly
+// d_ticket of launch_llk_eval: kTicketWords zero-initialised unsigned ints -- [0, kTicketScratchWord) the arrival tickets of a
+// launch's passes (llk_eval_passes_kernel; a plain launch uses [0]), two words from kTicketScratchWord on a scratch flag
+constexpr int kTicketScratchWord = 8, kTicketWords = 16;
 constexpr int kInlinePointDoubles = 96;    // parameter rows that travel as kernel arguments (768 B)
 
 // Everything the kernels read, in HBM.  "Sorted order" = active markers sorted by
@@ -97,7 +100,7 @@ inline int max_grid(const DeviceLayout& L) { return kMaxGridPerCU * L.num_cu; }
 // Enqueue evaluation of num_point candidate rows (pc1 | pc2 | alpha) on stream.
 // d_partials: >= (kMaxPointsPerLaunch + 1) * kMaxGridPerCU * L.num_cu doubles of scratch.
 // tag_counter: incremented per kernel launch; tags must never repeat on one partials buffer.
-// d_ticket: one zero-initialised unsigned int (arrival counter of the single-launch mode).
+// d_ticket: kTicketWords zero-initialised unsigned ints (arrival counters of the single-launch mode: see kTicketScratchWord).
 // done_flag: optional word in mapped host memory that receives done_seq after the results of
 // the LAST launch are written (lets the host wait without hipStreamSynchronize).
 // h_points: the same rows readable by the host (or nullptr): small batches then travel as
@@ -110,6 +113,7 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            int reduce_override = 0,      // 1 ticket / 2 tagged for this call only
                            ScheduleProvider* sched = nullptr);
 void set_single_launch(bool on);
+void set_eval_passes(bool on);     // llk_eval_passes_kernel for calls of more points than one launch's tables hold (default on)
 void set_reduce_mode(int mode);     // 0 auto, 1 arrival ticket, 2 tagged sets (VB2_REDUCE)
 
 // A cohort step's point counts and parameter rows as kernel arguments (count = doubles valid in v; 0 = the kernel reads
@@ -147,7 +151,7 @@ struct MultiLaunch {
 // a launch of this geometry pulls its work items through the LDS queue (else: the static deal)
 bool eval_takes_the_queue(const DeviceLayout& L, int nblk, int nwave, int ngrp);
 size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);   // groups of 4*btl points
-size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp);
+size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp, int exp_tab_doubles = 0 /* the 16-KiB table */);
 int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves);
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);

@@ -108,6 +108,10 @@ __device__ __forceinline__ uint32_t lds_byte_addr(const void* p)      // generic
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
+// ESH: log2 of the byte stride between two entries of the table -- 8: 32 copies of every entry, the conflict-free layout
+// above (16 KiB); 6: eight copies (4 KiB; lookups of different entries in one column collide) for the one kernel that needs
+// the 12 KiB for a third point group's table (llk_eval_passes_kernel).
+template <int ESH = 8>
 __device__ __forceinline__ double exp_nonpos(double x, uint32_t etab_lane)
 {
     const double kInvStep = 0x1.71547652b82fep+6;        // 64/ln2
@@ -126,7 +130,7 @@ __device__ __forceinline__ double exp_nonpos(double x, uint32_t etab_lane)
     r = fma(-kd, kStepLo, r);
     // (the table sits at LDS address 0 and etab_lane < 256, so the index bits are OR-ed in:
     // one v_lshlrev + one v_and_or)
-    const double t = *reinterpret_cast<lds_cdouble*>((((uint32_t)k << 8) & 0x3f00u) | etab_lane);
+    const double t = *reinterpret_cast<lds_cdouble*>((((uint32_t)k << ESH) & (63u << ESH)) | etab_lane);
     double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
     p = fma(p, r, 1.0 / 24.0);
     p = fma(p, r, 1.0 / 6.0);
@@ -347,7 +351,7 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // its VALU-bound epilogue overlap inside the wave itself; the finished sums and constants of item i stay in registers
 // meanwhile (3 waves per SIMD, <= 168 VGPRs: the kernel is launched with 12-wave workgroups).  See the item loop.
 template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1,
-          bool ONEGRP = (MODE >= 3), int KAF = -1, int KSEL = 0, bool LCACHE = false, bool SWP = false>
+          bool ONEGRP = (MODE >= 3), int KAF = -1, int KSEL = 0, bool LCACHE = false, bool SWP = false, int ESH = 8>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -376,8 +380,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     const int ngrp = ONEGRP ? 1 : ngrp_in;
     const double* const known_af_p = KAF == 0 ? nullptr : L.known_af;
     const int NPT = NP * ngrp;                  // points of this launch
+    constexpr int kEtabCopies = (1 << ESH) / 8, kEtabDoubles = 64 * kEtabCopies;
     double* etab = lds;                         // [64][32] exp_nonpos's 2^(j/64), bank-replicated; at LDS address 0
-    double* tab = lds + kExpTabDoubles;         // [ngrp][nrow][RS]
+    double* tab = lds + kEtabDoubles;           // [ngrp][nrow][RS]
     double* red = tab + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
     unsigned int* queue = reinterpret_cast<unsigned int*>(red + NPT);
     double* pts = red + NPT + 2;                // [NPT][2k+1] this launch's parameter rows
@@ -434,7 +439,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     if (!hook.keep_etab())
         for (int jb = 2 * wave; jb < 64; jb += 2 * nwave) {
             const double t0 = kExp2Tab[jb], t1 = kExp2Tab[jb + 1];
-            etab[jb * 32 + lane] = lane < 32 ? t0 : t1;
+            if constexpr (ESH == 8) etab[jb * 32 + lane] = lane < 32 ? t0 : t1;
+            else if ((lane & 31) < kEtabCopies) etab[(jb + (lane >> 5)) * kEtabCopies + (lane & 31)] = lane < 32 ? t0 : t1;
         }
     // With several groups a thread builds several table entries: the primary-code records (a
     // few dozen) go to LDS first so that the loop below does not wait on a global load per
@@ -585,7 +591,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
         for (int t = 0; t < BTL; ++t) wave_prod[t] = LaneProd{1.0, 0};
     };
-    const uint32_t etab_lane = (uint32_t)(lane & 31) * 8u;     // etab is at LDS address 0 (no static LDS in this file)
+    const uint32_t etab_lane = (uint32_t)(lane & (kEtabCopies - 1)) * 8u;     // etab is at LDS address 0 (no static LDS in this file)
     const uint32_t tab_addr = lds_byte_addr(tab);
     const uint32_t ptq_addr = lds_byte_addr(ptq);
     if (L.stagger > 0 && wave >= (nwave >> 1))
@@ -745,9 +751,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 // of 27; the rounding differs from the reference's term-by-term sum at the 1e-16
                 // level, like the marker summation order does).  The three g1==g2 exponentials do
                 // not depend on (alpha, PC) and were taken at context creation.
-                const double x01 = exps_taken ? a[0] : exp_nonpos(a[0], etab_lane), x02 = exps_taken ? a[1] : exp_nonpos(a[1], etab_lane);
-                const double x10 = exps_taken ? a[2] : exp_nonpos(a[2], etab_lane), x12 = exps_taken ? a[3] : exp_nonpos(a[3], etab_lane);
-                const double x20 = exps_taken ? a[4] : exp_nonpos(a[4], etab_lane), x21 = exps_taken ? a[5] : exp_nonpos(a[5], etab_lane);
+                const double x01 = exps_taken ? a[0] : exp_nonpos<ESH>(a[0], etab_lane), x02 = exps_taken ? a[1] : exp_nonpos<ESH>(a[1], etab_lane);
+                const double x10 = exps_taken ? a[2] : exp_nonpos<ESH>(a[2], etab_lane), x12 = exps_taken ? a[3] : exp_nonpos<ESH>(a[3], etab_lane);
+                const double x20 = exps_taken ? a[4] : exp_nonpos<ESH>(a[4], etab_lane), x21 = exps_taken ? a[5] : exp_nonpos<ESH>(a[5], etab_lane);
                 const double s0 = fma(x02, gf2[2], fma(x01, gf2[1], e0 * gf2[0]));
                 const double s1 = fma(x12, gf2[2], fma(e1, gf2[1], x10 * gf2[0]));
                 const double s2 = fma(e2, gf2[2], fma(x21, gf2[1], x20 * gf2[0]));
@@ -873,7 +879,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 }
                 // (pinned here: left alone, the compiler sinks all twelve exponentials below the row steps, next to their uses
                 // in finish_prev -- i.e. rebuilds the un-pipelined loop)
-                pa[s_] = exp_nonpos(pa[s_], etab_lane);
+                pa[s_] = exp_nonpos<ESH>(pa[s_], etab_lane);
                 asm volatile("" : "+v"(pa[s_]));
             }
             for (int s0 = kSteps; s0 < rows; s0 += kPf) {         // (kSteps is a multiple of kPf: the ring's phase carries over)
@@ -900,7 +906,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         }
         // the last item's epilogue, un-overlapped
 #pragma unroll
-        for (int i = 0; i < BTL * 6; ++i) pa[i] = exp_nonpos(pa[i], etab_lane);
+        for (int i = 0; i < BTL * 6; ++i) pa[i] = exp_nonpos<ESH>(pa[i], etab_lane);
         finish_prev();
     } else
     for (uint32_t idx = idx_first; idx < nitem;) {
@@ -919,7 +925,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
         // (one slot, one group: the table's address is the constant behind the exp table -- this file has no static LDS --
         // and the compiler folds it into the reads' immediate offsets)
-        const uint32_t my_tab_w16 = (SLOTS == 1 && ONEGRP) ? (uint32_t)(kExpTabDoubles * sizeof(double)) : my_tab;
+        const uint32_t my_tab_w16 = (SLOTS == 1 && ONEGRP) ? (uint32_t)(kEtabDoubles * sizeof(double)) : my_tab;
         while (!dyn && grp_wave < grp) {                     // wave-uniform
             flush_wave(grp_wave);
             ++grp_wave;
@@ -1281,6 +1287,36 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
                            blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
 }
 
+// A call of more points than the LDS holds tables for -- wide quality alphabets: 118 codes x 8 points are 48.5 KB per point
+// group, two groups per workgroup -- as ONE launch of several passes (round 4; before: one launch per 16 points, each with
+// its own start-up, table build, tail and hand-off, ~10 us of a 41.6 us launch).  A pass is eval_body on its own points,
+// its own stretch of the partial sums and its own arrival ticket; a workgroup that has delivered a pass's sums starts on the
+// next pass at once -- only the workgroup that arrives last at a pass adds that pass up -- so the hand-offs of all passes but
+// the last hide behind the other workgroups' work.  Same grid, same groups, same order as the separate launches: the same
+// bits.  The results of the earlier passes are stored through the caches like the last one's (eval_body does that when it
+// is given a flag to raise: theirs is a scratch word on the device), and acknowledged before the storing workgroup draws
+// its next ticket, so the flag the host waits for is behind every pass's results.
+template <int KSEL>
+__global__ void __launch_bounds__(Geom<2>::kMaxWaves * 64, Geom<2>::kWavesPerSimd)
+llk_eval_passes_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid, int points_per_pass,
+                       double* __restrict__ partials, double* __restrict__ llk_out, unsigned int* __restrict__ tickets,
+                       unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
+                       unsigned long long* __restrict__ scratch_flag)
+{
+    const int stride = 2 * L.num_pc + 1;
+    int pass = 0;
+    for (int first = 0; first < num_valid; first += points_per_pass, ++pass) {
+        const int left = num_valid - first;
+        const int nv = left < points_per_pass ? left : points_per_pass;
+        const bool last = left <= points_per_pass;
+        if (pass > 0) __syncthreads();                      // the pass before is done with the workgroup's LDS
+        eval_body<2, true, false, NoHook, false, 1, false, (KSEL > 0 ? 0 : -1), KSEL, false, false, 6>(
+            L, nullptr, 0, points + (size_t)first * stride, nv, partials + (size_t)first * gridDim.x, llk_out + first,
+            tickets + pass, (last || !done_flag) ? done_flag : scratch_flag, done_seq, blockIdx.x, gridDim.x, nullptr, 0u,
+            (nv + 7) / 8, 0ull, Schedule{nullptr, nullptr});
+    }
+}
+
 // The software-pipelined form of the 8-point shape (eval_body: SWP): 12-wave workgroups, 3 waves per SIMD.  MEASURED AND
 // DROPPED in round 4: 80.5-83.3 us per 48-point launch against 70.4 (16 waves) and 73.1 (12 waves, plain loop) on
 // the same box, every variant bit-identical.  Compiled only with -DVB2_WITH_SWP (then VB2_SWP=1 selects it).
@@ -1530,6 +1566,51 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
     }
 }
 
+// see llk_eval_passes_kernel.  Needs the work queue (a slot per item: the launches it replaces take it too at these sizes).
+static hipError_t launch_passes(const DeviceLayout& L, const double* d_points, int num_valid, int groups_per_launch,
+                                double* d_partials, double* d_out, unsigned int* d_tickets,
+                                unsigned long long* done_flag, unsigned long long done_seq, hipStream_t stream, bool* taken)
+{
+    *taken = false;
+    if (L.known_af != nullptr) return hipSuccess;
+    // point groups per pass: what fits beside the compact exp table (4 KiB instead of 16: see exp_nonpos) -- 118 codes: three
+    // groups instead of two, i.e. 75 work items for a workgroup's 16 waves instead of 50 (5 rounds at 94 % instead of 4 at
+    // 78 %) and two passes per 48 points instead of three
+    constexpr int kCompactExpTabDoubles = 64 * 8;
+    int g = kMaxGroups;
+    LaunchGeom gm = launch_geom(L, 2, g);
+    while (g > 1 && eval_shmem_np(L, 8, gm.grid, gm.block_waves, g, kCompactExpTabDoubles) > (size_t)kLdsLimitBytes) {
+        --g;
+        gm = launch_geom(L, 2, g);
+    }
+    const int ngroup = (num_valid + 7) / 8;
+    const int npass = (ngroup + g - 1) / g;
+    // only where the passes are fewer than the launches they replace (118 codes: 2 for 3, 125 -> 120 us per 48 points; 72
+    // codes: 2 for 2 -- measured equal, 92.3 / 93.4 us, and the launches keep the conflict-free exp table)
+    if (npass >= (ngroup + groups_per_launch - 1) / groups_per_launch) return hipSuccess;
+    const int gpp = (ngroup + npass - 1) / npass;            // balanced: 6 groups at 4 per pass -> 3 + 3, not 4 + 2
+    if (npass > kTicketScratchWord) return hipSuccess;
+    gm = launch_geom(L, 2, gpp);
+    if (!eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, gpp)) return hipSuccess;
+    const size_t shmem = eval_shmem_np(L, 8, gm.grid, gm.block_waves, gpp, kCompactExpTabDoubles);
+    if (shmem > (size_t)kLdsLimitBytes) return hipSuccess;
+    const void* fn = L.num_pc == 4 ? reinterpret_cast<const void*>(&llk_eval_passes_kernel<4>)
+                     : L.num_pc == 2 ? reinterpret_cast<const void*>(&llk_eval_passes_kernel<2>)
+                                     : reinterpret_cast<const void*>(&llk_eval_passes_kernel<0>);
+    hipError_t e = raise_lds_limit(fn);
+    if (e != hipSuccess) return e;
+    DeviceLayout Lc = L;
+    const double* a_points = d_points;
+    int a_nv = num_valid, a_ppp = 8 * gpp;
+    unsigned long long a_seq = done_seq;
+    unsigned long long* a_scratch = reinterpret_cast<unsigned long long*>(d_tickets + kTicketScratchWord);
+    void* args[] = {&Lc, &a_points, &a_nv, &a_ppp, &d_partials, &d_out, &d_tickets, &done_flag, &a_seq, &a_scratch};
+    *taken = true;
+    return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
+}
+
+static bool g_eval_passes = true;      // VB2_PASSES=0 / vb2_debug_set_eval_passes(0): a launch per table-load of points
+void set_eval_passes(bool on) { g_eval_passes = on; }
 static int g_reduce_mode = 0;          // 0 auto, 1 ticket, 2 tagged
 void set_reduce_mode(int m) { g_reduce_mode = m; }
 static bool g_single_launch = true;
@@ -1560,6 +1641,18 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         const bool m1 = one_point > 0 && L.row_bytes != kRowBytesWide;
         const int cap = m1 ? 4 * std::min(one_point, max_groups(L, 1, gm2.grid, gm2.block_waves))
                            : L.row_bytes == kRowBytesWide ? 8 * max_groups(L, 2, gm2.grid, gm2.block_waves) : 4;
+        // more points than one launch's tables hold: the passes of ONE launch (VB2_PASSES=0: a launch per `cap` points)
+        if (g_eval_passes && tk && g_hwmap && !m1 && reduce_mode != 2 && L.row_bytes == kRowBytesWide && cap >= 8 && left > cap) {
+            const int take = left < kMaxPointsPerLaunch ? left : kMaxPointsPerLaunch;
+            bool taken = false;
+            unsigned long long* dfp = (done + take >= num_point) ? done_flag : nullptr;
+            hipError_t ep = launch_passes(L, p, take, cap / 8, d_partials, d_out + done, tk, dfp, done_seq, stream, &taken);
+            if (ep != hipSuccess) return ep;
+            if (taken) {
+                done += take;
+                continue;
+            }
+        }
         const int step = left < cap ? left : cap;
         const int ngrp = step > 4 ? (m1 ? (step + 3) / 4 : (step + 7) / 8) : 1;
         unsigned long long* df = (done + step >= num_point) ? done_flag : nullptr;   // last launch signals
@@ -1594,15 +1687,16 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
     return hipSuccess;
 }
 
-size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp)
+size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp, int exp_tab_doubles)
 {
+    if (exp_tab_doubles <= 0) exp_tab_doubles = kExpTabDoubles;
     const size_t NP = (size_t)np, G = (size_t)ngrp;
     const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;      // (one slot per micro-tile and group)
     const size_t slots = items <= (size_t)L.dyn_limit * block_waves ? items : (size_t)block_waves * G;
     const size_t bytes = sizeof(double) * (G * (L.num_code + 1) * (size_t)(L.row_bytes / 8) + G * NP + 2 +
                                            G * NP * (2 * L.num_pc + 1) + 1 + G * NP * 2 * L.num_pc +
                                            1 + 2 * (size_t)L.num_prim +
-                                           kExpTabDoubles + 2 * slots * NP);
+                                           (size_t)exp_tab_doubles + 2 * slots * NP);
     // workgroup 0 stages every workgroup's partial sums ([points][workgroups]) over the dead table
     const size_t stage = sizeof(double) * G * NP * (size_t)nblk;
     return bytes > stage ? bytes : stage;
