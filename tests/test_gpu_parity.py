@@ -722,6 +722,87 @@ def test_cohort_run_group_schedule_does_not_change_results(tmp_path):
             assert open(out_a[s] + ext).read() == open(out_b[s] + ext).read(), (s, ext)
 
 
+def test_strict_batch_values_do_not_depend_on_the_neighbours_requests(c3):
+    """Under the static deal (16 samples of 100 000 markers on one device: 390 micro-tiles per workgroup) a step's wave
+    shape decides which tiles a wave multiplies together, and the shape follows from the largest request of the step.  A
+    strict batch (what the streaming cohort search uses) evaluates the requests of 1-2, 3-4 and 5-8 points as separate
+    launches: sample 0's values for its own 1, 2, 4 and 7 points are bit for bit the same whatever the other samples ask for
+    at the same step."""
+    import ctypes
+    lib = _abi.lib()
+    lib.vb2_debug_batch_set_strict.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.vb2_debug_batch_set_strict.restype = None
+    k = c3.num_pc
+    rng = np.random.default_rng(77)
+    S = 16
+    with vb.LikelihoodContext(c3) as ctx:
+        with vb.CohortBatch([ctx] * S) as batch:
+            lib.vb2_debug_batch_set_strict(batch._h, 1)
+            pc1 = rng.normal(0, 0.03, size=(S, 8, k))
+            pc2 = rng.normal(0, 0.03, size=(S, 8, k))
+            al = rng.uniform(0, 0.5, size=(S, 8))
+            for own in (1, 2, 4, 7):
+                seen = None
+                for others in ([0] * 15, [1] * 15, [2] * 15, [1, 2, 4, 8, 0, 3, 6] * 2 + [5], [8] * 15, [4] * 15, [2, 8] * 7 + [1]):
+                    npt = np.array([own] + list(others), dtype=np.int32)
+                    got = batch.eval(npt, pc1, pc2, al)
+                    if seen is None:
+                        seen = got[0, :own].copy()
+                        want = ctx.llk(pc1[0, :own], pc2[0, :own], al[0, :own])
+                        assert rel_err(seen, want) <= LLK_RTOL
+                    assert np.array_equal(got[0, :own], seen), (own, others)
+                    for s in range(1, S):                      # (and everybody else got an answer)
+                        n = int(npt[s])
+                        if n:
+                            assert rel_err(got[s, :n], ctx.llk(pc1[s, :n], pc2[s, :n], al[s, :n])) <= LLK_RTOL
+
+
+def test_cohort_run_streams_samples_through_slots_reproducibly(tmp_path, monkeypatch):
+    """vb2_cohort_run keeps `group_size` slots per device and hands a converged sample's slot to the next ready sample
+    (stream_search.h).  Which samples share the device, and when, depends on the readers' timing; a sample's workgroups and
+    waves do not -- so two runs with different reader counts give every sample the SAME bits (alpha, likelihoods,
+    evaluation count) and byte-identical output files, also for a sample that appears 8 times in the list.  Against the
+    group-at-a-time pipeline (VB2_COHORT_STREAM=0) the estimates agree to the tolerance group sizes always had.  45 samples
+    of four sizes through 12 slots (one lane) and through 20 (two lanes), one unreadable file in the middle."""
+    k = 2
+    base = vb.synth.with_sanity_stats(vb.synth.make_pileup(2500, 14, k, alpha_true=0.03, seed=170))
+    pre = vb.synth.write_files(base, str(tmp_path / "panel"))
+    piles = []
+    for s in range(6):
+        d = vb.synth.make_pileup(2500, 8 + 5 * s, k, alpha_true=0.02 * (s + 1), seed=180 + s)
+        d = vb.PileupData(k, base.ud, base.means, d.read_off, d.bases, d.quals, base.alt_base, None,
+                          d.avg_depth, d.sd_depth, True, dict(base.meta))
+        piles.append(vb.synth.write_files(d, str(tmp_path / ("s%d" % s))) + ".pileup")
+    S = 45
+    paths = [piles[(s * s + s // 3) % 6] for s in range(S)]
+    paths[17] = str(tmp_path / "missing.pileup")
+    keys = ("alpha", "llk1", "llk0", "num_eval")
+
+    def run(tag, **kw):
+        outs = [str(tmp_path / ("%s%d" % (tag, s))) for s in range(S)]
+        return vb.run_cohort_files(pre, paths, outs, num_pc=k, **kw), outs
+
+    for slots in (12, 20):
+        a, out_a = run("a%d_" % slots, group_size=slots, num_host_thread=2)
+        b, out_b = run("b%d_" % slots, group_size=slots, num_host_thread=9)
+        monkeypatch.setenv("VB2_COHORT_STREAM", "0")
+        g, _ = run("g%d_" % slots, group_size=slots, num_host_thread=4)
+        monkeypatch.delenv("VB2_COHORT_STREAM")
+        for s in range(S):
+            if s == 17:
+                assert a[s]["status"] != 0 and b[s]["status"] != 0 and g[s]["status"] != 0
+                continue
+            assert a[s]["status"] == 0 and b[s]["status"] == 0 and g[s]["status"] == 0, s
+            for key in keys:
+                assert a[s][key] == b[s][key], (slots, s, key)
+            for ext in (".Ancestry", ".selfSM"):
+                assert open(out_a[s] + ext, "rb").read() == open(out_b[s] + ext, "rb").read(), (s, ext)
+            assert abs(a[s]["alpha"] - g[s]["alpha"]) <= 1e-7, s
+            assert rel_err([a[s]["llk1"], a[s]["llk0"]], [g[s]["llk1"], g[s]["llk0"]]) <= LLK_RTOL
+        same = [s for s in range(S) if paths[s] == paths[0] and s != 17]
+        assert len(same) >= 4 and all(a[s]["alpha"] == a[0]["alpha"] and a[s]["num_eval"] == a[0]["num_eval"] for s in same)
+
+
 def test_cohort_run_reports_bad_samples_and_finishes_the_rest(tmp_path):
     """A cohort with a pileup that does not exist, one whose bases column is malformed (an indel
     marker without a length: the reference dies on it) and one that is empty: the first two get

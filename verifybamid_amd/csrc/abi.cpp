@@ -536,6 +536,13 @@ int vb2_batch_eval(vb2_batch* b, const int32_t* num_point, const double* pc1, co
     return b->impl->eval(num_point, pc1, pc2, alpha, llk_out);
 }
 
+// Test aid: the batch evaluates the request classes of a step as separate launches (Batch::strict_shapes: what the
+// streaming cohort search's batches do)
+void vb2_debug_batch_set_strict(vb2_batch* b, int on)
+{
+    if (b && b->impl) b->impl->strict_shapes = on != 0;
+}
+
 // Test aid (not part of the public header): batches the last vb2_batch_optimize_llk regrouped its unfinished samples into.
 long long vb2_debug_batch_regroups(vb2_batch* b)
 {

@@ -12,6 +12,7 @@
 
 #include "estimator.h"
 #include "lockstep.h"
+#include "stream_search.h"
 
 namespace vb2 {
 
@@ -172,6 +173,88 @@ int Batch::create(const std::vector<Context*>& ctxs, Batch** out, int bps_in)
     return VB2_OK;
 }
 
+int Batch::create_slots(int capacity, int device, int num_pc, int num_cu, Batch** out)
+{
+    *out = nullptr;
+    if (capacity < 1 || capacity > 64 || num_pc < 1 || num_pc > VB2_MAX_PC) {
+        set_error("streaming batch: invalid argument");
+        return VB2_ERR_INVALID;
+    }
+    std::unique_ptr<Batch> b(new Batch());
+    b->num_sample = capacity;
+    b->device = device;
+    b->num_pc = num_pc;
+    b->slots_ = true;
+    b->strict_shapes = true;
+    b->ctx_.assign(capacity, nullptr);
+    DeviceLayout none;
+    std::memset(&none, 0, sizeof(none));
+    none.num_pc = num_pc;
+    none.row_bytes = kRowBytesWide;
+    none.num_cu = num_cu;
+    b->layouts_.assign(capacity, none);
+    b->bps_ = std::max(1, num_cu / capacity);
+    b->block_waves_ = kMaxBlockWaves;         // whatever the samples: a sample's sums must not depend on its neighbours
+    *out = b.release();
+    return VB2_OK;
+}
+
+int Batch::set_slot(int i, Context* c)
+{
+    if (!slots_ || i < 0 || i >= num_sample || in_flight_) {
+        set_error("streaming batch: set_slot out of place");
+        return VB2_ERR_INVALID;
+    }
+    DeviceLayout lay = layouts_[i];
+    Schedule sc[kShapes];
+    for (int sh = 0; sh < kShapes; ++sh) sc[sh] = Schedule{nullptr, nullptr};
+    if (c) {
+        if (c->device != device || c->num_pc != num_pc) {
+            set_error("streaming batch: contexts must share the device and --NumPC");
+            return VB2_ERR_INVALID;
+        }
+        if (cohort_w16_enabled() && c->L.num_mt > 0)
+            if (const int rc16 = c->ensure_codes16()) return rc16;
+        lay = c->L;
+        lay.stamps = nullptr;
+        static const int kShapeNp[kShapes] = {4, 8, 1, 2};
+        size_t need[kShapes];
+        for (int sh = 0; sh < kShapes; ++sh) need[sh] = std::max(shmem_[sh], eval_shmem_np(lay, kShapeNp[sh], bps_, block_waves_, 1));
+        if (need[1] > (size_t)kLdsLimitBytes) {
+            set_error("streaming batch: per-workgroup LDS need exceeds 160 KiB");
+            return VB2_ERR_INVALID;
+        }
+        for (int sh = 0; sh < kShapes; ++sh) shmem_[sh] = need[sh];
+        if (const int rc = c->cohort_schedules(bps_, block_waves_, sc)) return rc;
+    } else {
+        std::memset(&lay, 0, sizeof(lay));
+        lay.num_pc = num_pc;
+        lay.row_bytes = kRowBytesWide;
+        lay.num_cu = layouts_[i].num_cu;
+    }
+    ctx_[i] = c;
+    layouts_[i] = lay;
+    w16_ = cohort_w16_enabled();
+    wide_rows_ = true;
+    for (int s = 0; s < num_sample; ++s) {
+        if (!ctx_[s]) continue;
+        if (ctx_[s]->L.num_mt > 0 && !ctx_[s]->L.codes16) w16_ = false;
+        if (ctx_[s]->L.row_bytes != kRowBytesWide) wide_rows_ = false;
+    }
+    if (!ready_) return VB2_OK;                 // (ensure_resources uploads everything at the first step)
+    VB2_HIP(hipSetDevice(device));
+    // slot i's layout and schedules through the slot's own stretch of pinned staging: stream-ordered before the next step;
+    // the stretch is not written again before that step is over (the slot cannot change hands sooner)
+    char* st = h_slot_stage_ + (size_t)i * kSlotStageBytes;
+    std::memcpy(st, &lay, sizeof(lay));
+    std::memcpy(st + sizeof(DeviceLayout), sc, sizeof(sc));
+    VB2_HIP(hipMemcpyAsync(d_layouts_ + i, st, sizeof(DeviceLayout), hipMemcpyHostToDevice, stream_));
+    for (int sh = 0; sh < kShapes; ++sh)
+        VB2_HIP(hipMemcpyAsync(const_cast<Schedule*>(d_sched_arr_) + (size_t)sh * num_sample + i,
+                               st + sizeof(DeviceLayout) + sh * sizeof(Schedule), sizeof(Schedule), hipMemcpyHostToDevice, stream_));
+    return VB2_OK;
+}
+
 int Batch::ensure_resources()
 {
     if (ready_) return VB2_OK;
@@ -184,6 +267,7 @@ int Batch::ensure_resources()
     bool sched_ok = false;
     for (int s = 0; s < num_sample; ++s) {
         Schedule sc[kShapes];
+        if (!ctx_[s]) continue;                              // (an empty slot: create_slots)
         if (const int rc = ctx_[s]->cohort_schedules(bps, block_waves_, sc)) return rc;
         for (int sh = 0; sh < kShapes; ++sh) {
             arr[sh * S + s] = sc[sh];
@@ -222,8 +306,9 @@ int Batch::ensure_resources()
     VB2_HIP(hipMemsetAsync(dbase + o_zero, 0, dtot - o_zero, stream_));
     VB2_HIP(hipStreamSynchronize(stream_));                       // (image is a pageable temporary)
     d_layouts_ = reinterpret_cast<DeviceLayout*>(dbase + o_lay);
+    d_sched_arr_ = reinterpret_cast<const Schedule*>(dbase + o_arr);
     for (int sh = 0; sh < kShapes; ++sh)
-        d_scheds_[sh] = sched_ok ? reinterpret_cast<const Schedule*>(dbase + o_arr) + sh * S : nullptr;
+        d_scheds_[sh] = (sched_ok || slots_) ? d_sched_arr_ + sh * S : nullptr;
     d_partials_ = reinterpret_cast<double*>(dbase + o_part);
     d_tickets_ = reinterpret_cast<unsigned int*>(dbase + o_tick);
     d_batch_done_ = reinterpret_cast<unsigned int*>(dbase + o_done);
@@ -238,6 +323,7 @@ int Batch::ensure_resources()
     const size_t p_out = hcarve(sizeof(double) * S * kSlot);
     const size_t p_nv = hcarve(sizeof(int) * S);
     const size_t p_done = hcarve(sizeof(unsigned long long) * 8);
+    const size_t p_stage = hcarve(slots_ ? S * kSlotStageBytes : 0);
     h_slab_ = cached_pinned_slab(htot, device, &h_slab_bytes_);
     if (!h_slab_) {
         VB2_HIP(hipHostMalloc(&h_slab_, htot, hipHostMallocMapped));
@@ -255,6 +341,7 @@ int Batch::ensure_resources()
     d_nv_ = reinterpret_cast<int*>(hdev + p_nv);
     h_done_ = reinterpret_cast<unsigned long long*>(hbase + p_done);
     d_done_ = reinterpret_cast<unsigned long long*>(hdev + p_done);
+    h_slot_stage_ = hbase + p_stage;
     seq_ = 0;
     ready_ = true;
     return VB2_OK;
@@ -287,6 +374,35 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     }
     if (max_n == 0) return VB2_OK;
     if (const int rc = ensure_resources()) return rc;
+    if (strict_shapes && !in_split_) {
+        // A step's wave shape follows from the LARGEST request in it, and under the static deal the shape decides which tiles a
+        // wave multiplies together -- so a sample's sums would move in their last bits with what its neighbours happen to ask
+        // for (a new sample's initial simplex, a shrink).  Strict: the requests of 1-2, of 3-4 and of 5-8 points are evaluated
+        // as separate launches (the one- and two-point shapes deal and multiply alike: bit-identical, tested), so a sample's
+        // values depend on its own requests only.  Mixed steps are rare (a sample starts or shrinks in 1-2 % of them): all
+        // classes but the most populous are evaluated synchronously first.
+        auto cls = [](int n) { return n <= 0 ? -1 : n <= 2 ? 0 : n <= 4 ? 1 : 2; };
+        int pop[3] = {0, 0, 0};
+        for (int s = 0; s < num_sample; ++s)
+            if (num_point[s] > 0) ++pop[cls(num_point[s])];
+        if ((pop[0] > 0) + (pop[1] > 0) + (pop[2] > 0) > 1) {
+            const int keep = pop[0] >= pop[1] && pop[0] >= pop[2] ? 0 : pop[1] >= pop[2] ? 1 : 2;
+            std::vector<int32_t> np((size_t)num_sample);
+            in_split_ = true;
+            int rc = VB2_OK;
+            for (int c = 0; c < 3 && !rc; ++c) {
+                if (c == keep || pop[c] == 0) continue;
+                for (int s = 0; s < num_sample; ++s) np[s] = cls(num_point[s]) == c ? num_point[s] : 0;
+                rc = eval(np.data(), pc1, pc2, alpha, llk_out);
+            }
+            if (!rc) {
+                for (int s = 0; s < num_sample; ++s) np[s] = cls(num_point[s]) == keep ? num_point[s] : 0;
+                rc = eval_begin(np.data(), pc1, pc2, alpha, llk_out);
+            }
+            in_split_ = false;
+            return rc;
+        }
+    }
     if (max_n > 4 && !wide_rows_) {
         // a sample with a very wide dictionary has narrow table rows: 4 points per launch at most
         const size_t S = (size_t)num_sample;
@@ -316,7 +432,7 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     for (int s = 0; s < num_sample; ++s) {
         int n = num_point[s];
         // a sample without active markers has LLK 0 for every point: answer it here
-        if (n > 0 && ctx_[s]->L.num_mt == 0) {
+        if (n > 0 && (!ctx_[s] || ctx_[s]->L.num_mt == 0)) {
             for (int j = 0; j < n; ++j) llk_out[(size_t)s * kSlot + j] = 0.0;
             n = 0;
         }
@@ -353,12 +469,12 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     {   // (the pipelined item loop is compiled for the static deal: every sample of the cohort must run it)
         bool st = true;
         for (int s2 = 0; s2 < num_sample && st; ++s2)
-            st = ctx_[s2]->L.num_mt == 0 || !eval_takes_the_queue(ctx_[s2]->L, bps_, block_waves_, 1);
+            st = !ctx_[s2] || ctx_[s2]->L.num_mt == 0 || !eval_takes_the_queue(ctx_[s2]->L, bps_, block_waves_, 1);
         ml.all_static = st;
     }
     {   // (the cohort kernels compiled for --NumPC 2 / 4 without a known-AF column)
         bool plain = num_pc == 2 || num_pc == 4;
-        for (int s2 = 0; s2 < num_sample && plain; ++s2) plain = ctx_[s2]->L.known_af == nullptr;
+        for (int s2 = 0; s2 < num_sample && plain; ++s2) plain = !ctx_[s2] || ctx_[s2]->L.known_af == nullptr;
         ml.ksel = plain ? num_pc : 0;
     }
     // counts and rows as kernel arguments when they fit (saves every workgroup two trips to mapped host memory)
@@ -643,6 +759,214 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     for (int s = 0; s < S; ++s)
         if (rcs[s]) return rcs[s];
     return VB2_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stream_search.h: slots that change hands
+// ---------------------------------------------------------------------------
+namespace {
+
+struct StreamLane {
+    std::unique_ptr<Batch> batch;
+    std::unique_ptr<FiberGang> gang;
+    int count = 0;
+    std::vector<int> id;                    // [slot] the sample in it, or -1
+    std::vector<int> rc;
+    std::vector<vb2_estimate> est;
+    std::vector<double> t0;
+    std::vector<int32_t> npts;
+    std::vector<double> pc1, pc2, alpha, llk;
+    bool flying = false;
+};
+
+double wall_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void stream_lanes(int capacity, int* n0, int* n1)
+{
+    *n0 = capacity;
+    *n1 = 0;
+    if (capacity >= kSplitFrom) {
+        *n0 = capacity / 2;
+        *n1 = capacity - capacity / 2;
+    }
+}
+
+}  // namespace
+
+int prepare_for_stream(Context* c, int capacity)
+{
+    if (!c || c->L.num_mt == 0) return VB2_OK;
+    int n[2];
+    stream_lanes(capacity, &n[0], &n[1]);
+    Schedule sc[Batch::kShapes];
+    for (int l = 0; l < 2; ++l) {
+        if (n[l] <= 0 || (l == 1 && n[1] == n[0])) continue;
+        if (const int rc = c->cohort_schedules(std::max(1, c->L.num_cu / n[l]), kMaxBlockWaves, sc)) return rc;
+    }
+    return VB2_OK;
+}
+
+int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource& src)
+{
+    capacity = std::max(1, std::min(capacity, 128));
+    const int k = num_pc;
+    int speculate = capacity < 8 ? 4 : 2;                      // (Batch::optimize: kPairFrom)
+    if (const char* e = std::getenv("VB2_COHORT_SPECULATE")) speculate = std::max(1, std::atoi(e));
+    StreamLane lanes[2];
+    int cnt[2];
+    stream_lanes(capacity, &cnt[0], &cnt[1]);
+    const int nlane = cnt[1] > 0 ? 2 : 1;
+    int error = 0;
+    for (int l = 0; l < nlane; ++l) {
+        StreamLane& L = lanes[l];
+        L.count = cnt[l];
+        Batch* b = nullptr;
+        if (const int rc = Batch::create_slots(L.count, device, k, num_cu, &b)) return rc;
+        L.batch.reset(b);
+        L.gang.reset(new FiberGang(L.count, kSlot));
+        const size_t n = (size_t)L.count;
+        L.id.assign(n, -1);
+        L.rc.assign(n, 0);
+        L.est.resize(n);
+        L.t0.assign(n, 0.0);
+        L.npts.assign(n, 0);
+        L.pc1.resize(n * kSlot * k); L.pc2.resize(n * kSlot * k); L.alpha.resize(n * kSlot); L.llk.resize(n * kSlot);
+    }
+    for (int l = 0; l < nlane; ++l) {
+        StreamLane& L = lanes[l];
+        L.gang->open(k, [&L, &src, k, speculate](int i) {
+            try {
+                Estimator est(k, FiberGang::eval_cb, L.gang->user(i));
+                apply_model(est, src.model(L.id[i]), L.batch->slot(i)->L.known_af != nullptr);
+                est.speculate = speculate;
+                L.rc[i] = est.OptimizeLLK();
+                fill_estimate(est, &L.est[i]);
+            } catch (const std::bad_alloc&) {
+                L.rc[i] = VB2_ERR_NOMEM;
+            } catch (const std::exception& e) {
+                set_error(e.what());
+                L.rc[i] = VB2_ERR_INVALID;
+            } catch (...) {                      // nothing may unwind past the fiber's entry frame
+                set_error("stream_search: unknown exception in a sample's search");
+                L.rc[i] = VB2_ERR_INVALID;
+            }
+        });
+    }
+    bool ended = false;
+    const bool dbg = std::getenv("VB2_DEBUG_LOCKSTEP") != nullptr;
+    long dbg_steps = 0, dbg_active = 0, dbg_points = 0, dbg_samples = 0;
+    double dbg_blocked = 0, dbg_refill = 0;
+    const double dbg_t0 = wall_s();
+    auto fail = [&](int rc) {
+        if (!error) error = rc;
+        for (int l = 0; l < nlane; ++l) lanes[l].gang->fail(rc);
+    };
+    auto retire = [&](StreamLane& L, int i) {
+        const int rc = error ? error : L.rc[i];
+        src.done(L.id[i], rc, L.est[i], wall_s() - L.t0[i]);
+        L.id[i] = -1;
+        (void)L.batch->set_slot(i, nullptr);
+    };
+    // free slots of a lane <- samples that are ready; block: wait for the first one (nothing is running anywhere)
+    auto refill = [&](StreamLane& L, bool block) {
+        if (error) return;
+        for (int i = 0; i < L.count && !ended; ++i) {
+            if (L.id[i] >= 0) continue;
+            Context* c = nullptr;
+            const double tb = dbg ? wall_s() : 0.0;
+            const int id = src.next(block, &c);
+            if (dbg && block) dbg_blocked += wall_s() - tb;
+            block = false;
+            if (id == StreamSource::kEnd) ended = true;
+            if (id < 0) break;
+            L.id[i] = id;
+            L.rc[i] = 0;
+            std::memset(&L.est[i], 0, sizeof(vb2_estimate));
+            L.t0[i] = wall_s();
+            ++dbg_samples;
+            if (const int rc = L.batch->set_slot(i, c)) {      // this sample cannot be searched here: the others can
+                L.rc[i] = rc;
+                retire(L, i);
+                --i;
+                continue;
+            }
+            if (L.gang->spawn(i) < 0) {
+                set_error("stream_search: could not start a search fiber (mmap / getcontext failed)");
+                L.rc[i] = VB2_ERR_INVALID;
+                retire(L, i);
+                continue;
+            }
+            if (L.gang->idle(i)) {                              // over before its first request
+                retire(L, i);
+                --i;
+            }
+            if (dbg) dbg_refill += wall_s() - L.t0[i < 0 ? 0 : i];
+        }
+    };
+    auto launch = [&](StreamLane& L) {
+        if (error || !L.gang->pending()) return;
+        std::vector<FiberGang::Request>& req = L.gang->requests();
+        for (int i = 0; i < L.count; ++i) {
+            const FiberGang::Request& r = req[i];
+            L.npts[i] = (L.id[i] >= 0 && !L.gang->idle(i)) ? r.n : 0;
+            if (L.npts[i] <= 0) continue;
+            std::memcpy(&L.pc1[(size_t)i * kSlot * k], r.p1, sizeof(double) * r.n * k);
+            std::memcpy(&L.pc2[(size_t)i * kSlot * k], r.p2, sizeof(double) * r.n * k);
+            std::memcpy(&L.alpha[(size_t)i * kSlot], r.a, sizeof(double) * r.n);
+        }
+        if (dbg) {
+            ++dbg_steps;
+            for (int i = 0; i < L.count; ++i) { dbg_active += L.npts[i] > 0; dbg_points += std::max(0, L.npts[i]); }
+        }
+        if (const int rc = L.batch->eval_begin(L.npts.data(), L.pc1.data(), L.pc2.data(), L.alpha.data(), L.llk.data())) {
+            fail(rc);
+            return;
+        }
+        L.flying = true;
+    };
+    auto land = [&](StreamLane& L) {
+        if (L.flying) {
+            L.flying = false;
+            if (const int rc = L.batch->eval_end()) fail(rc);
+            if (!error) {
+                std::vector<FiberGang::Request>& req = L.gang->requests();
+                for (int i = 0; i < L.count; ++i)
+                    if (L.npts[i] > 0) std::memcpy(req[i].out, &L.llk[(size_t)i * kSlot], sizeof(double) * L.npts[i]);
+            }
+        }
+        if (L.gang->pending()) L.gang->resume_parked();       // (after an error: the fibers unwind)
+        for (int i = 0; i < L.count; ++i)
+            if (L.id[i] >= 0 && L.gang->idle(i)) retire(L, i);
+    };
+    for (;;) {
+        bool busy = false;
+        for (int l = 0; l < nlane; ++l) {
+            StreamLane& next = lanes[(l + 1) % nlane];
+            if (nlane > 1 && !next.flying) {                   // queued behind the step in flight
+                refill(next, false);
+                launch(next);
+            }
+            StreamLane& cur = lanes[l];
+            if (cur.flying || cur.gang->pending()) land(cur);
+            refill(cur, false);
+            launch(cur);
+            busy |= cur.flying || cur.gang->pending();
+        }
+        if (busy) continue;
+        if (error || ended) break;
+        refill(lanes[0], true);                                 // nothing in flight, nothing ready: wait for a sample
+        launch(lanes[0]);
+        if (!lanes[0].flying && !lanes[0].gang->pending() && ended) break;
+    }
+    if (dbg)
+        std::fprintf(stderr, "stream search: %ld samples through %d slots in %.1f ms: %ld steps, %.1f active samples and %.1f points "
+                             "per step (a lane holds %d); waited %.1f ms with nothing to do, %.1f ms taking samples in\n",
+                     dbg_samples, capacity, 1e3 * (wall_s() - dbg_t0), dbg_steps, (double)dbg_active / std::max(1L, dbg_steps),
+                     (double)dbg_points / std::max(1L, dbg_steps), lanes[0].count, 1e3 * dbg_blocked, 1e3 * dbg_refill);
+    return error;
 }
 
 }  // namespace vb2

@@ -20,6 +20,13 @@ public:
     ~Batch();
     static int create(vb2_ctx* const* ctxs, int num_sample, Batch** out);
     static int create(const std::vector<Context*>& ctxs, Batch** out, int bps = 0);   // bps > 0: that many workgroups per sample
+    // A batch of `capacity` slots whose samples come and go (the streaming cohort search, stream_search.h): created empty;
+    // set_slot(i, c) puts context c -- or nothing (nullptr) -- into slot i, between two steps.  Every slot has
+    // num_cu / capacity workgroups of 16 waves whatever the other slots hold: a sample's sums do not depend on its
+    // neighbours, nor on when it arrived.
+    static int create_slots(int capacity, int device, int num_pc, int num_cu, Batch** out);
+    int set_slot(int i, Context* c);
+    Context* slot(int i) const { return ctx_[i]; }
     // launch geometry of a batch of num_sample samples whose biggest has max_mt micro-tiles: workgroups per sample and waves
     // per workgroup (what create() uses -- and what a reader thread prepares a sample's schedules for: prepare_for_cohort)
     static void geometry(int num_cu, int num_sample, int max_mt, int num_pc, int bps_in, int* bps, int* block_waves);
@@ -41,6 +48,7 @@ public:
     static constexpr int kShapes = 4;       // launch shapes of a step: <= 4, 8, 1, 2 points per sample
     int num_sample = 0, num_pc = 0, device = -1;
     int64_t num_launch = 0;
+    bool strict_shapes = false;             // requests of 1-2, 3-4 and 5-8 points leave as separate launches (see eval_begin)
     int64_t num_regroup = 0;                // batches the last optimize() regrouped its unfinished samples into
 
 private:
@@ -60,6 +68,10 @@ private:
     size_t h_slab_bytes_ = 0;
     DeviceLayout* d_layouts_ = nullptr;
     const Schedule* d_scheds_[kShapes] = {nullptr, nullptr, nullptr, nullptr};    // [shape]
+    const Schedule* d_sched_arr_ = nullptr;                                       // [shape][sample]: what d_scheds_ points into
+    bool slots_ = false;                    // create_slots: ctx_ entries may be null, set_slot changes them
+    static constexpr size_t kSlotStageBytes = (sizeof(DeviceLayout) + kShapes * sizeof(Schedule) + 63) / 64 * 64;
+    char* h_slot_stage_ = nullptr;          // pinned: [sample] layout + schedules on their way to the device
     double* d_partials_ = nullptr;
     unsigned int* d_tickets_ = nullptr;
     unsigned int* d_batch_done_ = nullptr;
@@ -75,6 +87,7 @@ private:
     int speculate_ = 4;                     // points a lock-step search evaluates per iteration (amoeba.h)
     // the step in flight (eval_begin .. eval_end)
     bool in_flight_ = false;
+    bool in_split_ = false;                 // eval_begin is evaluating one request class of a mixed step
     MultiLaunch ml_{};
     int flight_np_ = 0;
     double* flight_out_ = nullptr;

@@ -2,11 +2,13 @@
 //
 // The reference runs one process per sample (main.cpp:56-414).  Here the panel is read once, a
 // pool of host threads reads + flattens + uploads pileups, and every DEVICE of the run has its
-// own pipeline thread that takes the next ready group of samples and searches it in lock-step
-// (vb2_batch_*: one kernel launch per Nelder-Mead step for the whole group).  Samples are
-// independent, so several devices need no collective: groups are dealt round-robin
-// (--Devices a,b,...: group g runs on devices[g % n]), which is the sample-parallel sharding
-// of SURVEY.md 8e(2) inside one process.
+// own pipeline thread that searches the samples in lock-step (one kernel launch per Nelder-Mead
+// step for all the samples on the device).  Round 4: the device keeps `group_size` slots and a
+// sample that has converged hands its slot to the next one that is ready (stream_search.h) --
+// before, a device took the next ready GROUP of samples and searched it to its last sample
+// (vb2_batch_*; still there as VB2_COHORT_STREAM=0).  Samples are independent, so several devices
+// need no collective: sample s runs on devices[s % n] (--Devices a,b,...; groups: group g on
+// devices[g % n]), which is the sample-parallel sharding of SURVEY.md 8e(2) inside one process.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -26,6 +28,7 @@
 #include "context.h"
 #include "estimator.h"
 #include "hostio.h"
+#include "stream_search.h"
 
 using vb2::set_error;
 
@@ -64,6 +67,11 @@ public:
         T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, std::max(hw, 1) * 4, S_}));
         slots_.resize(S_);
         cnt_.assign(ndev_, 0);
+        stream_ = !(std::getenv("VB2_COHORT_STREAM") && std::atoi(std::getenv("VB2_COHORT_STREAM")) == 0);
+        inflight_.assign(ndev_, 0);
+        remaining_.assign(ndev_, 0);
+        for (int s = 0; s < S_; ++s) ++remaining_[s % ndev_];
+        ready_q_.resize(ndev_);
         // Group boundaries, a function of (S, G, devices) only -- never of timing, so a run is
         // reproducible.  A device's first groups are small (16, then 32 samples): it starts searching
         // after a fraction of the reading a full group needs; the later ones have the full size (a
@@ -120,7 +128,7 @@ public:
 
         releaser_ = std::thread([this] { release_loop(); });
         for (int t = 0; t < T_; ++t) pool_.emplace_back([this] { reader_loop(); });
-        for (int d = 0; d < ndev_; ++d) dev_threads_.emplace_back([this, d] { device_loop(d); });
+        for (int d = 0; d < ndev_; ++d) dev_threads_.emplace_back([this, d] { if (stream_) stream_loop(d); else device_loop(d); });
         for (auto& t : dev_threads_) t.join();
         dev_threads_.clear();
         const double t_dev = now_s();
@@ -165,7 +173,16 @@ private:
     double rel_s_[2] = {0, 0};             // releaser thread: vb2_ctx_destroy, freeing the host arrays
     double phase_s_[3] = {0, 0, 0};        // reader threads' wall-clock: read_pileup, sanity + resolve, vb2_ctx_create
 
+    // streaming (stream_search.h): sample s belongs to device s % ndev_
+    bool stream_ = true;
+    std::vector<int> inflight_;            // [device] samples handed to a reader and not yet done
+    std::vector<int> remaining_;           // [device] samples not yet delivered to the search (or failed before it)
+    std::vector<std::deque<int>> ready_q_; // [device] prepared samples, in the order they became ready
+    struct Done { int s; vb2_ctx* ctx; std::unique_ptr<vb2_flat> flat; bool write; vb2_estimate est; };
+    std::deque<Done> done_queue_;          // (rel_mu_) searched samples: outputs to write, context and arrays to free
+
     int device_of_group(int gi) const { return gi % ndev_; }
+    int device_of_sample(int s) const { return stream_ ? s % ndev_ : device_of_group(group_of_[s]); }
 
     // every way out (normal end, error, exception in run()) stops and joins all threads and
     // gives back the contexts that were never handed to a device pipeline
@@ -218,14 +235,15 @@ private:
             return;
         }
         vb2_options opt{};
-        opt.device = devices_[device_of_group(group_of_[s])];
+        opt.device = devices_[device_of_sample(s)];
         opt.flags = VB2_OPT_COHORT_LAYOUT;       // the lock-step search streams the 16-bit run lists
         sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
         if (sl.rc == VB2_OK && sl.ctx && sl.ctx->impl) {
             // the static schedules of the sample's group (and of the batches its lane is regrouped into): here, on one of many
             // reader threads, not on the one thread that feeds the device (a failure only means they are built there)
             const int gi = group_of_[s];
-            (void)vb2::Batch::prepare_for_cohort(sl.ctx->impl, group_begin_[gi + 1] - group_begin_[gi]);
+            if (stream_) (void)vb2::prepare_for_stream(sl.ctx->impl, G_);
+            else (void)vb2::Batch::prepare_for_cohort(sl.ctx->impl, group_begin_[gi + 1] - group_begin_[gi]);
         }
         // the context holds its own (flattened) copy: the sample's text-sized arrays go back now, on
         // this reader thread, instead of piling up in front of the single releaser (the writers need
@@ -255,11 +273,13 @@ private:
                 // stay at most two groups ahead of the group's device (bounds host and device memory)
                 cv_.wait(lk, [&] {
                     if (stop_ || next_ >= S_) return true;
+                    if (stream_) return inflight_[next_ % ndev_] < 2 * G_ + T_;       // (two slot sets ahead of the device)
                     const int gi = group_of_[next_];
                     return gi / ndev_ < cnt_[device_of_group(gi)] + 2;
                 });
                 if (stop_ || next_ >= S_) return;
                 s = next_++;
+                if (stream_) ++inflight_[s % ndev_];
             }
             try {
                 prepare(s);
@@ -268,12 +288,109 @@ private:
             } catch (const std::exception&) {
                 slots_[s].rc = VB2_ERR_INVALID;
             }
+            if (stream_ && !(slots_[s].rc == VB2_OK && slots_[s].ctx)) {
+                // never reaches the search: reported here (the pipeline thread may be waiting for this device's last sample)
+                status_[s] = slots_[s].rc ? slots_[s].rc : VB2_ERR_INVALID;
+                finish_sample(s, false, nullptr);
+                continue;
+            }
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 slots_[s].ready = true;
+                if (stream_) ready_q_[s % ndev_].push_back(s);
             }
             cv_.notify_all();
         }
+    }
+
+    // sample s leaves the pipeline: outputs (write) + context + host arrays go to the releaser thread, its place in the
+    // readers' window is free again
+    void finish_sample(int s, bool write, const vb2_estimate* est)
+    {
+        {
+            std::lock_guard<std::mutex> lk(rel_mu_);
+            Done d{s, slots_[s].ctx, std::move(slots_[s].flat), write, vb2_estimate{}};
+            if (est) d.est = *est;
+            slots_[s].ctx = nullptr;
+            done_queue_.push_back(std::move(d));
+        }
+        rel_cv_.notify_one();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            const int d = s % ndev_;
+            --inflight_[d];
+            if (!write) --remaining_[d];       // (a searched sample was counted when the search took it)
+        }
+        cv_.notify_all();
+    }
+
+    // the pipeline thread's view of its device's samples (stream_search.h)
+    struct DeviceSource : vb2::StreamSource {
+        CohortRunner* r;
+        int d;
+        DeviceSource(CohortRunner* runner, int dev) : r(runner), d(dev) {}
+        int next(bool block, vb2::Context** ctx) override
+        {
+            std::unique_lock<std::mutex> lk(r->mu_);
+            for (;;) {
+                if (r->stop_) return kEnd;
+                if (!r->ready_q_[d].empty()) {
+                    const int s = r->ready_q_[d].front();
+                    r->ready_q_[d].pop_front();
+                    --r->remaining_[d];
+                    *ctx = r->slots_[s].ctx->impl;
+                    return s;
+                }
+                if (r->remaining_[d] <= 0) return kEnd;
+                if (!block) return kNone;
+                r->cv_.wait(lk);
+            }
+        }
+        const vb2_model& model(int) override { return r->model_; }
+        void done(int s, int rc, const vb2_estimate& est, double seconds) override
+        {
+            r->status_[s] = rc;
+            if (!rc) {
+                r->out_[s].est = est;
+                r->out_[s].seconds_optimize = seconds;
+            }
+            r->finish_sample(s, rc == VB2_OK, &est);
+        }
+    };
+
+    void stream_loop(int d)
+    {
+        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+        const double t0 = now_s();
+        DeviceSource src(this, d);
+        int rc = VB2_OK;
+        int num_cu = 256;
+        {
+            hipDeviceProp_t prop;
+            const int dev = devices_[d];
+            int cur = dev;
+            if (dev < 0) (void)hipGetDevice(&cur);
+            if (hipGetDeviceProperties(&prop, cur) == hipSuccess && prop.multiProcessorCount > 0) num_cu = prop.multiProcessorCount;
+        }
+        try {
+            int dev = devices_[d];
+            if (dev < 0) (void)hipGetDevice(&dev);
+            rc = vb2::stream_search(dev, a_->base.num_pc, num_cu, G_, src);
+        } catch (const std::exception& e) {
+            set_error(e.what());
+            rc = VB2_ERR_INVALID;
+        }
+        if (timing)
+            std::fprintf(stderr, "vb2_cohort_run: device %d: %d slots, stream over after %.1f ms\n", devices_[d], G_, 1e3 * (now_s() - t0));
+        if (rc) {                                // device-level failure: concerns every sample
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!rc_all_) {
+                rc_all_ = rc;
+                err_all_ = vb2::g_last_error;
+            }
+            stop_ = true;
+        }
+        cv_.notify_all();
     }
 
     void release_loop()
@@ -282,10 +399,25 @@ private:
             std::pair<vb2_ctx*, std::unique_ptr<vb2_flat>> item;
             {
                 std::unique_lock<std::mutex> lk(rel_mu_);
-                rel_cv_.wait(lk, [&] { return rel_stop_ || !rel_queue_.empty(); });
-                if (rel_queue_.empty()) return;
-                item = std::move(rel_queue_.front());
-                rel_queue_.pop_front();
+                rel_cv_.wait(lk, [&] { return rel_stop_ || !rel_queue_.empty() || !done_queue_.empty(); });
+                if (!done_queue_.empty()) {
+                    Done d = std::move(done_queue_.front());
+                    done_queue_.pop_front();
+                    lk.unlock();
+                    // a searched sample: its output files first (they need the flattened sample's counters)
+                    const char* prefix = a_->output_prefixes ? a_->output_prefixes[d.s] : nullptr;
+                    if (d.write && prefix && d.flat) {
+                        int rw = vb2::write_ancestry(prefix, a_->base.num_pc, d.est.pc, d.est.pc2);
+                        if (!rw) rw = vb2::write_selfsm(prefix, *d.flat, d.est, true);   // (cohort input is text pileups: #READS = NA)
+                        if (rw) status_[d.s] = rw;
+                    }
+                    item.first = d.ctx;
+                    item.second = std::move(d.flat);
+                } else {
+                    if (rel_queue_.empty()) return;
+                    item = std::move(rel_queue_.front());
+                    rel_queue_.pop_front();
+                }
             }
             const double t0 = now_s();
             if (item.first) vb2_ctx_destroy(item.first);

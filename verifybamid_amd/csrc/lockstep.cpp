@@ -56,35 +56,62 @@ int FiberGang::eval_cb(void* user, int32_t n, const double* p1, const double* p2
     return 0;
 }
 
+int FiberGang::prepare(int i)
+{
+    Fiber& f = fibers_[i];
+    if (!f.map) {
+        // stacks grow downwards: an overflow hits the PROT_NONE page and faults instead of
+        // scribbling over the heap
+        void* m = mmap(nullptr, kFiberStack + page_size(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) return -1;
+        (void)mprotect(m, page_size(), PROT_NONE);
+        f.map = m;
+    }
+    f.done = false;
+    req_[i] = Request{};
+    if (getcontext(&f.ctx) != 0) return -1;
+    f.ctx.uc_stack.ss_sp = static_cast<char*>(f.map) + page_size();
+    f.ctx.uc_stack.ss_size = kFiberStack;
+    f.ctx.uc_link = &main_;
+    const uintptr_t p = reinterpret_cast<uintptr_t>(this);
+    makecontext(&f.ctx, reinterpret_cast<void (*)()>(entry), 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+    return 0;
+}
+
 int FiberGang::start(int num_pc, const std::function<void(int)>& body)
 {
     num_pc_ = num_pc;
     body_ = body;
     error_ = 0;
     const int n = (int)fibers_.size();
-    for (int i = 0; i < n; ++i) {
-        Fiber& f = fibers_[i];
-        if (!f.map) {
-            // stacks grow downwards: an overflow hits the PROT_NONE page and faults instead of
-            // scribbling over the heap
-            void* m = mmap(nullptr, kFiberStack + page_size(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-            if (m == MAP_FAILED) return -1;
-            (void)mprotect(m, page_size(), PROT_NONE);
-            f.map = m;
-        }
-        f.done = false;
-        req_[i] = Request{};
-        if (getcontext(&f.ctx) != 0) return -1;
-        f.ctx.uc_stack.ss_sp = static_cast<char*>(f.map) + page_size();
-        f.ctx.uc_stack.ss_size = kFiberStack;
-        f.ctx.uc_link = &main_;
-        const uintptr_t p = reinterpret_cast<uintptr_t>(this);
-        makecontext(&f.ctx, reinterpret_cast<void (*)()>(entry), 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
-    }
+    for (int i = 0; i < n; ++i)
+        if (prepare(i) < 0) return -1;
     for (int i = 0; i < n; ++i) {                                  // up to everybody's first request
         cur_ = i;
         swapcontext(&main_, &fibers_[i].ctx);
     }
+    return 0;
+}
+
+void FiberGang::open(int num_pc, const std::function<void(int)>& body)
+{
+    num_pc_ = num_pc;
+    body_ = body;
+    error_ = 0;
+    for (size_t i = 0; i < fibers_.size(); ++i) {
+        fibers_[i].done = true;
+        req_[i] = Request{};
+    }
+}
+
+int FiberGang::spawn(int i)
+{
+    if (prepare(i) < 0) {
+        fibers_[i].done = true;
+        return -1;
+    }
+    cur_ = i;
+    swapcontext(&main_, &fibers_[i].ctx);                          // up to its first request, or to the end
     return 0;
 }
 

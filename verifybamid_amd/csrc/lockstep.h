@@ -49,6 +49,13 @@ public:
     void fail(int rc) { if (!error_) error_ = rc; }                 // the fibers see it at resume and unwind
     int error() const { return error_; }
     void resume_parked();                                           // values delivered: every parked fiber runs on
+    // A gang whose fibers come and go (the streaming cohort search: a finished sample's fiber is given the next sample):
+    // open() starts with every fiber idle; spawn(i) runs body(i) as fiber i up to its first request (or to its end);
+    // idle(i): fiber i is not running anything (never spawned, or its body has returned).
+    void open(int num_pc, const std::function<void(int)>& body);
+    int spawn(int i);                                               // < 0: no context / stack
+    bool idle(int i) const { return fibers_[i].done; }
+    int size() const { return (int)fibers_.size(); }
 
 private:
     struct Fiber {
@@ -67,6 +74,7 @@ private:
     std::vector<Request> req_;
     std::function<void(int)> body_;
     int cur_ = -1, num_pc_ = 0, max_points_, error_ = 0;
+    int prepare(int i);                  // fiber i's stack and context, ready to enter body(i)
 };
 
 }  // namespace vb2
