@@ -353,11 +353,13 @@ typedef struct vb2_cohort_args {
     int32_t num_sample;
     const char *const *pileup_paths;     /* [num_sample]                                      */
     const char *const *output_prefixes;  /* [num_sample], or NULL = write nothing             */
-    int32_t group_size;                  /* samples searched together, at most (<= 64); 0 = 32.  A
-                                          * device's first group is smaller (16) so that it starts
-                                          * early; < 0: plain equal groups of |group_size|        */
+    int32_t group_size;                  /* samples on a device at a time (<= 64); 0 = 32: slots
+                                          * that a converged sample hands to the next ready one;
+                                          * < 0: |group_size|.  (VB2_COHORT_STREAM=0: groups of that
+                                          * size searched one after the other, the first of 16)   */
     int32_t num_host_thread;             /* pileup readers/flatteners; 0 = the CPUs the process may
-                                          * use (cgroup quota / affinity), at most 64 per device  */
+                                          * use (cgroup quota / affinity) less one, at most 64 per
+                                          * device                                                */
 } vb2_cohort_args;
 int vb2_cohort_run(const vb2_cohort_args *args, vb2_run_result *out /* [num_sample] */,
                    int32_t *status /* [num_sample] */);

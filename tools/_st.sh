@@ -1,10 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.txt 2>&1; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" gpurun_out/pytest_gpu.txt | tail -4 | cut -c1-250
-for st in 0 1; do
-VB2_COHORT_STREAM=$st python bench.py --no-cpu-baseline --no-optimize --steps 200 2>/dev/null | tail -1 | python -c "
-import sys,json
-c=json.loads(sys.stdin.read())['cohort']; print('stream $st bench from_text', c['from_text']['samples_per_s'], 'search only', c['samples_per_s_search_only'])"
+export VB2_S=256 VB2_DISTINCT=8 VB2_GROUPS=32,32,32,32
+for t in 10 12 14 15 16; do
+VB2_THREADS=$t timeout 600 python tools/cohort_run_time.py 2>&1 | grep -E "host threads" | awk '{print $3, $4, $5, $13, $14}' | tr '\n' ' '; echo
 done
-VB2_CPUS=8 python bench.py --no-cpu-baseline --no-optimize --steps 200 2>/dev/null | tail -1 | python -c "
-import sys,json
-c=json.loads(sys.stdin.read())['cohort']; print('VB2_CPUS=8 bench from_text', c['from_text']['samples_per_s'])"

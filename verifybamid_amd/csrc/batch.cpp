@@ -225,7 +225,7 @@ int Batch::set_slot(int i, Context* c)
             return VB2_ERR_INVALID;
         }
         for (int sh = 0; sh < kShapes; ++sh) shmem_[sh] = need[sh];
-        if (const int rc = c->cohort_schedules(bps_, block_waves_, sc)) return rc;
+        if (const int rc = c->cohort_schedules(bps_, block_waves_, sc, false)) return rc;
     } else {
         std::memset(&lay, 0, sizeof(lay));
         lay.num_pc = num_pc;
@@ -268,7 +268,7 @@ int Batch::ensure_resources()
     for (int s = 0; s < num_sample; ++s) {
         Schedule sc[kShapes];
         if (!ctx_[s]) continue;                              // (an empty slot: create_slots)
-        if (const int rc = ctx_[s]->cohort_schedules(bps, block_waves_, sc)) return rc;
+        if (const int rc = ctx_[s]->cohort_schedules(bps, block_waves_, sc, !slots_)) return rc;
         for (int sh = 0; sh < kShapes; ++sh) {
             arr[sh * S + s] = sc[sh];
             sched_ok |= sc[sh].off != nullptr;
@@ -804,7 +804,7 @@ int prepare_for_stream(Context* c, int capacity)
     Schedule sc[Batch::kShapes];
     for (int l = 0; l < 2; ++l) {
         if (n[l] <= 0 || (l == 1 && n[1] == n[0])) continue;
-        if (const int rc = c->cohort_schedules(std::max(1, c->L.num_cu / n[l]), kMaxBlockWaves, sc)) return rc;
+        if (const int rc = c->cohort_schedules(std::max(1, c->L.num_cu / n[l]), kMaxBlockWaves, sc, false)) return rc;
     }
     return VB2_OK;
 }

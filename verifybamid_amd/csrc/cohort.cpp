@@ -59,11 +59,12 @@ public:
         // 256 files 479 -> 546 samples/s)
         G_ = std::max(1, std::min(a->group_size != 0 ? std::abs(a->group_size) : 32, 64));
         const int hw = vb2::usable_cpu_count();
-        // readers: reading + flattening is ~17 ms of one CPU per C3-sized sample (round 4), the device needs ~1.55 ms per
-        // sample -> a device keeps ~11 readers busy.  The default is the process's allowance (cgroup quota / affinity, not
-        // the host's core count): the thread of the lock-step search mostly waits for the device, and a reader more is
-        // worth more than the CPU it shares (16 CPUs: 14 readers 530-548 samples/s, 16 readers 564-572)
-        const int dflt = std::max(2, std::min(hw, 64 * ndev_));
+        // readers: reading + flattening is ~15 ms of one CPU per C3-sized sample (round 4), the device needs ~1.6 ms per
+        // sample -> a device keeps ~10 readers busy (16 CPUs: 10 to 16 readers all give 550-590 samples/s).  The default is
+        // the process's allowance (cgroup quota / affinity, not the host's core count) less one: the thread of the lock-step
+        // search spins on the device's flag between steps, and when it has to queue for a CPU the device idles (one run in
+        // four at 16 readers on 16 CPUs: 330 samples/s instead of 480)
+        const int dflt = std::max(2, std::min(hw - 1, 64 * ndev_));
         T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, std::max(hw, 1) * 4, S_}));
         slots_.resize(S_);
         cnt_.assign(ndev_, 0);

@@ -278,7 +278,18 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             set_error("vb2_ctx_create: device ordinal out of range");
             return VB2_ERR_INVALID;
         }
-        VB2_HIP(hipGetDeviceProperties(&prop, dev));
+        {   // (asked once per device and process: the query takes a fraction of a millisecond, per context, on a reader thread)
+            static std::mutex prop_mu;
+            static std::vector<std::pair<int, hipDeviceProp_t>> known;
+            std::lock_guard<std::mutex> lk(prop_mu);
+            bool have = false;
+            for (const auto& e : known)
+                if (e.first == dev) { prop = e.second; have = true; break; }
+            if (!have) {
+                VB2_HIP(hipGetDeviceProperties(&prop, dev));
+                known.emplace_back(dev, prop);
+            }
+        }
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
             set_error(std::string("vb2_ctx_create: device is ") + prop.gcnArchName +
                       ", kernels are built for gfx950 only");
@@ -396,17 +407,54 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         size_t runs_cap = 0, cd_cap = 0;
     };
     static thread_local Scratch scratch;
+    // Pass B on the device (round 4; VB2_HOST_PACK=1: on the host, as before): the host uploads the INPUTS of
+    // pack_layout_kernel as it has them -- the run lists at their reads' positions, the per-marker constants and the panel
+    // rows in panel order, three words per sorted marker -- instead of the packed arrays; 2-3 ms of host CPU per C3 sample
+    // (scattered reads, 2 M table look-ups) become a ~30 us kernel.  The run lists and the constants are WRITTEN into the
+    // pinned slab the upload leaves from (no scratch arrays, no copy).
+    const bool host_pack_forced = std::getenv("VB2_HOST_PACK") && std::atoi(std::getenv("VB2_HOST_PACK")) != 0;
+    const bool device_pack_wanted = !dry && !host_pack_forced && M > 0 && total_reads > 0 && total_reads < ((int64_t)1 << 32);
+    size_t in_total = 0;
+    auto icarve = [&](size_t bytes) {
+        const size_t off = (in_total + 255) & ~(size_t)255;
+        in_total = off + bytes;
+        return off;
+    };
+    const size_t i_runs = icarve((size_t)std::max<int64_t>(total_reads, 1) * sizeof(uint16_t));
+    const size_t i_src = icarve((size_t)M * sizeof(uint32_t));           // (sized for every marker: how many are active is not known yet)
+    const size_t i_eff = icarve((size_t)M * sizeof(uint32_t));
+    const size_t i_pidx = icarve((size_t)M * sizeof(int32_t));
+    const size_t i_cd = icarve((size_t)M * 4 * sizeof(double));
+    const size_t i_ud = icarve(in->known_af ? 0 : (size_t)M * k * sizeof(double));
+    const size_t i_mu = icarve(in->known_af ? 0 : (size_t)M * sizeof(double));
+    const size_t i_kaf = icarve(in->known_af ? (size_t)M * sizeof(double) : 0);
+    in_total = (in_total + 255) & ~(size_t)255;
+    struct InGuard {                          // the pinned slab of the pack kernel's inputs: back to the cache on every way out
+        char* p = nullptr; size_t bytes = 0; int dev = 0;
+        ~InGuard() { if (p && !slab_cache().give(slab_cache().stage, p, bytes, dev)) (void)hipHostFree(p); }
+    } in_stage;
+    in_stage.dev = dev;
+    if (device_pack_wanted) {
+        in_stage.p = static_cast<char*>(slab_cache().take(slab_cache().stage, in_total, dev, &in_stage.bytes));
+        if (!in_stage.p) {
+            VB2_HIP(hipHostMalloc((void**)&in_stage.p, in_total, hipHostMallocDefault));
+            in_stage.bytes = in_total;
+        }
+    }
     const size_t runs_need = (size_t)std::max<int64_t>(total_reads, 1), cd_need = (size_t)std::max(M, 1) * 4;
-    if (scratch.runs_cap < runs_need || scratch.runs_cap > 4 * runs_need + (1u << 20)) {
-        scratch.runs.reset(new uint16_t[runs_need]);
-        scratch.runs_cap = runs_need;
+    if (!device_pack_wanted) {
+        if (scratch.runs_cap < runs_need || scratch.runs_cap > 4 * runs_need + (1u << 20)) {
+            scratch.runs.reset(new uint16_t[runs_need]);
+            scratch.runs_cap = runs_need;
+        }
+        if (scratch.cd_cap < cd_need || scratch.cd_cap > 4 * cd_need + (1u << 20)) {
+            scratch.cd.reset(new double[cd_need]);
+            scratch.cd_cap = cd_need;
+        }
     }
-    if (scratch.cd_cap < cd_need || scratch.cd_cap > 4 * cd_need + (1u << 20)) {
-        scratch.cd.reset(new double[cd_need]);
-        scratch.cd_cap = cd_need;
-    }
-    uint16_t* const runs = scratch.runs.get();
-    double* const cd_tmp = scratch.cd.get();                  // c_other, exp(c_other + D[g]) in panel order
+    uint16_t* const runs = device_pack_wanted ? reinterpret_cast<uint16_t*>(in_stage.p + i_runs) : scratch.runs.get();
+    // c_other, exp(c_other + D[g]) in panel order
+    double* const cd_tmp = device_pack_wanted ? reinterpret_cast<double*>(in_stage.p + i_cd) : scratch.cd.get();
     std::vector<int64_t> code_hist(kMaxCode, 0);
     {
         std::vector<std::vector<int64_t>> hist_t(nthr, std::vector<int64_t>(kMaxCode, 0));
@@ -657,29 +705,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
 
     // pinned staging slab (recycled through the cache like the other slabs: hipHostMalloc /
     // hipHostFree take milliseconds and synchronise)
-    // Pass B on the device (round 4; VB2_HOST_PACK=1: on the host, as before): the staging slab then carries, behind the
-    // (small) tables of the data block, the INPUTS of pack_layout_kernel as the host has them -- the run lists at their reads'
-    // positions, the per-marker constants and the panel rows in panel order, three words per sorted marker -- instead of
-    // the packed arrays; 7-8 ms of host CPU per C3 sample (scattered reads, 2 M table look-ups) become one more upload and
-    // a ~30 us kernel.
-    const bool host_pack_forced = std::getenv("VB2_HOST_PACK") && std::atoi(std::getenv("VB2_HOST_PACK")) != 0;
-    const bool device_pack = !dry && !host_pack_forced && m_active > 0 && total_reads < ((int64_t)1 << 32);
-    size_t in_total = 0;
-    auto icarve = [&](size_t bytes) {
-        const size_t off = (in_total + 255) & ~(size_t)255;
-        in_total = off + bytes;
-        return off;
-    };
-    const size_t i_runs = icarve((size_t)std::max<int64_t>(total_reads, 1) * sizeof(uint16_t));
-    const size_t i_src = icarve((size_t)m_active * sizeof(uint32_t));
-    const size_t i_eff = icarve((size_t)m_active * sizeof(uint32_t));
-    const size_t i_pidx = icarve((size_t)m_active * sizeof(int32_t));
-    const size_t i_cd = icarve((size_t)M * 4 * sizeof(double));
-    const size_t i_ud = icarve(in->known_af ? 0 : (size_t)M * k * sizeof(double));
-    const size_t i_mu = icarve(in->known_af ? 0 : (size_t)M * sizeof(double));
-    const size_t i_kaf = icarve(in->known_af ? (size_t)M * sizeof(double) : 0);
-    in_total = (in_total + 255) & ~(size_t)255;
-    const size_t stage_need = device_pack ? data_bytes + in_total : data_bytes;
+    const bool device_pack = device_pack_wanted && m_active > 0;
+    const size_t stage_need = data_bytes;
     size_t stage_bytes = 0;
     char* stage = dry ? static_cast<char*>(std::malloc(stage_need))
                       : static_cast<char*>(slab_cache().take(slab_cache().stage, stage_need, dev, &stage_bytes));
@@ -722,9 +749,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // ---- pass B (kernel order: markers sorted by run count, i.e. scattered reads of the panel
     // order arrays -- prefetched): run words, panel rows, diagonal terms into the staging slab ----
     if (device_pack) {
-        char* const inp = stage + data_bytes;
-        std::memcpy(inp + i_runs, runs, (size_t)total_reads * sizeof(uint16_t));
-        std::memcpy(inp + i_cd, cd_tmp, (size_t)M * 4 * sizeof(double));
+        char* const inp = in_stage.p;            // (run lists and constants are there already)
         if (in->known_af) std::memcpy(inp + i_kaf, in->known_af, (size_t)M * sizeof(double));
         else {
             std::memcpy(inp + i_ud, in->ud, (size_t)M * k * sizeof(double));
@@ -836,7 +861,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             d_in.bytes = in_total;
         }
         char* const din = static_cast<char*>(d_in.p);
-        VB2_HIP(hipMemcpyAsync(din, stage + data_bytes, in_total, hipMemcpyHostToDevice, c->stream));
+        VB2_HIP(hipMemcpyAsync(din, in_stage.p, in_total, hipMemcpyHostToDevice, c->stream));
         // the small tables of the data block, each to its place
         VB2_HIP(hipMemcpyAsync(dbase + o_rec, stage + o_rec, (size_t)num_mt * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
         if (!dict_perr.empty())
@@ -1029,32 +1054,47 @@ Schedule Context::get(int mode, int ngrp, int grid, int block_waves)
     return sl.s;
 }
 
-int Context::cohort_schedules(int bps, int block_waves, Schedule out[4])
+int Context::cohort_schedules(int bps, int block_waves, Schedule out[4], bool full)
 {
     for (int sh = 0; sh < 4; ++sh) out[sh] = Schedule{nullptr, nullptr};
     if (!sched_enabled || L.num_mt == 0 || eval_takes_the_queue(L, bps, block_waves, 1)) return VB2_OK;
     std::lock_guard<std::mutex> lk(cohort_mu_);
     for (const CohortSched& e : cohort_sched_)
-        if (e.bps == bps && e.block_waves == block_waves) {
-            for (int sh = 0; sh < 4; ++sh) out[sh] = e.s[sh];
+        if (e.bps == bps && e.block_waves == block_waves && (e.full || !full)) {
+            for (int sh = full ? 0 : 2; sh < 4; ++sh) out[sh] = e.s[sh];      // (!full: never the other two, whoever built them)
             return VB2_OK;
         }
-    // micro-tiles a wave takes per item: two for <= 4 points (when paired), one for 8 points, four for one or two points
+    // micro-tiles a wave takes per item: two for <= 4 points (when paired), one for 8 points, four for one or two points.
+    // Shapes with the same number share ONE schedule; !full: only the one- and two-point shapes (a search's steps but for
+    // its first and its shrinks, which then take the in-kernel snake deal).
     const int tpu[4] = {paired_mode() ? 2 : 1, 1, paired_mode() ? 4 : 1, paired_mode() ? 4 : 1};
     std::vector<char> blob;
-    size_t where[4];
+    size_t where[4] = {0, 0, 0, 0};
+    bool built[4] = {false, false, false, false};
     const size_t ob = (((size_t)bps * block_waves + 1) * sizeof(uint32_t) + 15) / 16 * 16;
     CohortSched e;
     e.bps = bps;
     e.block_waves = block_waves;
+    e.full = full;
     for (int sh = 0; sh < 4; ++sh) {
+        if (!full && sh < 2) continue;
+        int same = -1;
+        for (int prev = 0; prev < sh; ++prev)
+            if (built[prev] && tpu[prev] == tpu[sh]) same = prev;
+        if (same >= 0) {
+            where[sh] = where[same];
+            built[sh] = true;
+            continue;
+        }
         std::vector<uint32_t> off;
         std::vector<uint16_t> item;
         if (!build_schedule(h_mt_rows.data(), L.num_mt, bps, block_waves, tpu[sh], 1, &off, &item)) {
+            e.full = true;                                  // (nothing more to be had for this geometry)
             cohort_sched_.push_back(e);                     // (every shape: the snake deal)
             return VB2_OK;
         }
         where[sh] = blob.size();
+        built[sh] = true;
         blob.resize(blob.size() + ob + (item.size() * sizeof(uint16_t) + 15) / 16 * 16);
         std::memcpy(blob.data() + where[sh], off.data(), off.size() * sizeof(uint32_t));
         std::memcpy(blob.data() + where[sh] + ob, item.data(), item.size() * sizeof(uint16_t));
@@ -1073,6 +1113,7 @@ int Context::cohort_schedules(int bps, int block_waves, Schedule out[4])
         return VB2_ERR_HIP;
     }
     for (int sh = 0; sh < 4; ++sh) {
+        if (!built[sh]) continue;
         const char* base = static_cast<const char*>(e.d_mem) + where[sh];
         e.s[sh] = Schedule{reinterpret_cast<const uint32_t*>(base), reinterpret_cast<const uint16_t*>(base + ob)};
         out[sh] = e.s[sh];

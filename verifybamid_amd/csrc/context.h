@@ -62,10 +62,11 @@ public:
     // reader thread of vb2_cohort_run prepares them; Batch::ensure_resources then only collects pointers: building them there
     // cost 0.35 ms per C3 sample on the thread that feeds the device).  {nullptr, nullptr} where the launch takes the work
     // queue (no schedule needed) or none could be built (-> the in-kernel snake deal).  Thread-safe.
-    int cohort_schedules(int bps, int block_waves, Schedule out[4]);
+    int cohort_schedules(int bps, int block_waves, Schedule out[4], bool full = true);   // !full: the 1- and 2-point shapes only
     struct CohortSched {
         int bps = 0, block_waves = 0;
-        Schedule s[4];
+        bool full = true;
+        Schedule s[4] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
         void* d_mem = nullptr;
         size_t bytes = 0;
     };
