@@ -444,6 +444,8 @@ def main():
                 "valu_busy_frac": wj.get("valu_busy_frac") if wj else None,
                 "lds_busy_frac": wj.get("lds_busy_frac") if wj else None, "pmc_source": wsrc,
                 "optimize": wopt,
+                "launch": "one launch of two passes of 24 points (llk_eval_passes_kernel: three point groups' tables fit in "
+                          "LDS beside a compact exp table) when the dictionary is this wide; VB2_PASSES=0: three launches of 16",
             }
         if world == 1 and not args.no_optimize:
             # second half of the metric: wall-clock of OptimizeLLK (Initialize + Homo + Heter +
@@ -528,6 +530,8 @@ def main():
                 "num_eval_first": ests[0]["num_eval"], "points_launched_first": ests[0]["num_launch_point"],
                 "optimize_ms_per_sample": 1e3 * dto / S, "samples_per_s_search_only": S / dto,
                 "alpha_first": ests[0]["alpha"],
+                "search_note": "two half-cohorts take turns on the device; when half of a lane's samples have converged the "
+                               "rest are regrouped with twice the workgroups each (VB2_COHORT_REGROUP=0: not)",
             }
         if world == 1 and not args.no_extras and args.cohort_samples > 0 and args.cohort_files > 0:
             # the same cohort from TEXT files (vb2_cohort_run: the panel read once, pileups parsed and
@@ -566,7 +570,9 @@ def main():
                 ok = sum(1 for r in res if r["status"] == 0)
                 result["cohort"]["from_text"] = {
                     "what": "vb2_cohort_run on %d C3-shaped text pileups (7.6 MB each) + one panel, outputs written; "
-                            "wall-clock of the call" % nf,
+                            "wall-clock of the call.  32 slots on the device: a converged sample hands its slot to the next "
+                            "one the reader threads have ready (VB2_COHORT_STREAM=0: groups of 32 one after the other)" % nf,
+                    "host_cpus_by_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                     "samples": nf, "samples_ok": ok, "seconds": dtf, "samples_per_s": nf / dtf,
                     "alpha_first": res[0]["alpha"], "alpha_true_first": 0.01,
                     "alpha_by_distinct_sample": [res[i]["alpha"] for i in range(min(nf, 8))],

@@ -150,7 +150,9 @@ if ws:
     shutil.copy(ws, os.path.join(dst, "bench_b%d_wide_kernel_stats.csv" % B))
     sq1, gr = first_csv("pmc_wide_sq1", "counter_collection.csv"), first_csv("pmc_wide_grbm", "counter_collection.csv")
     if sq1 and gr:
-        sub = "llk_eval_kernel"
+        sub = "llk_eval_passes_kernel"          # (one launch of two passes of 24 points since round 4; VB2_PASSES=0: llk_eval_kernel x 3)
+        if avg_of(gr, sub, "GRBM_GUI_ACTIVE") is None:
+            sub = "llk_eval_kernel"
         cyc = avg_of(gr, sub, "GRBM_GUI_ACTIVE") / 8.0
         iv = avg_of(sq1, sub, "SQ_INSTS_VALU")
         # (a %d-point call on this alphabet is several launches: per-launch counters, points per launch from the instruction count's
@@ -158,8 +160,9 @@ if ws:
         launches = len([1 for r in csv.DictReader(open(sq1)) if sub in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU"])
         calls = 50 + 20
         ppl = B / max(1.0, round(launches / float(calls)))
-        wv = {"_what": "the headline launch on base qualities 2..60 (118 dictionary codes: 16 points per launch fit the LDS, a "
-                       "48-point call is three launches): SQ / GRBM passes of `bench.py --q-lo 2 --q-hi 60 --no-extras`, per LAUNCH",
+        wv = {"_what": "the headline call on base qualities 2..60 (118 dictionary codes: three point groups' tables fit the LDS "
+                       "beside a compact exp table, a 48-point call is ONE launch of two passes -- llk_eval_passes_kernel): SQ / "
+                       "GRBM passes of `bench.py --q-lo 2 --q-hi 60 --no-extras`, per LAUNCH", "kernel": sub,
               "markers": markers, "batch": B, "num_pc": k, "points_per_launch": ppl,
               "lane_instr_per_marker_point": round(iv * 64 / (markers * ppl), 1),
               "valu_busy_frac": round(avg_of(sq1, sub, "SQ_ACTIVE_INST_VALU") * 4 / (1024 * cyc), 3),
