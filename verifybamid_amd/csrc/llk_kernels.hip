@@ -996,6 +996,50 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
             for (int j = 0; j < kPf; ++j) w[j] = load_row(j);
         }
+        // AHEAD (-DVB2_RUN_AHEAD=1, the 8-point shape on the 32-bit lists): a ring of kRing table reads in flight ACROSS runs and
+        // rows -- read q of a row is requested kRing reads before its two multiply-adds, also past the per-row exit test (a
+        // row that does not exist is read from whatever run word the ring holds there and never consumed) -- where the
+        // compiler's own schedule keeps 3-4 in flight and drains them at every row's end.  Same multiply-adds, same order.
+#ifndef VB2_RUN_AHEAD
+#define VB2_RUN_AHEAD 0
+#endif
+        constexpr bool AHEAD = VB2_RUN_AHEAD != 0 && MODE == 2 && !W16 && !LCACHE && !SWP && !PIPE;
+        constexpr int kRp = 3 * BTL, kRing = 8;              // 16-byte reads per run; reads in flight
+        static_assert(!AHEAD || (16 * 2 * kRp) % kRing == 0, "the ring's phase must carry over a block of rows");
+        vdouble2 ring[AHEAD ? kRing : 1];
+        auto tab_read = [&](const vuint2 w_, const int q) -> vdouble2 {        // read q (0 .. 2 kRp - 1) of a row's two runs
+            const uint32_t rw = q < kRp ? w_.x : w_.y;
+            return reinterpret_cast<lds_cdouble2*>(my_tab + (rw & 0xffffu))[q % kRp];
+        };
+        if constexpr (AHEAD) {
+            if (rows > 0) {
+#pragma unroll
+                for (int q = 0; q < kRing; ++q) ring[q] = tab_read(w[0], q);
+            }
+        }
+        // (kAheadRows rows of straight-line code: the ring lives in registers that change name from read to read, and a loop's
+        // back edge would pin them -- copies of registers that are being loaded, i.e. a drain of all reads per trip)
+        constexpr int kAheadRows = 16;
+        auto walk_ahead = [&](const int s0) {
+#pragma unroll
+            for (int u = 0; u < kAheadRows; ++u) {
+                if (s0 + u >= rows) break;
+                const vuint2 w_cur = w[u % kPf];
+                w[u % kPf] = load_row(s0 + u + kPf);
+                const vuint2 w_nxt = w[(u + 1) % kPf];                 // the next row's word
+                const double n0 = __hiloint2double((int)(w_cur.x & 0xffff0000u), 0);
+                const double n1 = __hiloint2double((int)(w_cur.y & 0xffff0000u), 0);
+#pragma unroll
+                for (int q = 0; q < 2 * kRp; ++q) {
+                    const int slot = (u * 2 * kRp + q) % kRing;
+                    const double n = q < kRp ? n0 : n1;
+                    const int i = q % kRp;
+                    acc[2 * i] = fma(n, ring[slot].x, acc[2 * i]);
+                    acc[2 * i + 1] = fma(n, ring[slot].y, acc[2 * i + 1]);
+                    ring[slot] = q + kRing < 2 * kRp ? tab_read(w_cur, q + kRing) : tab_read(w_nxt, q + kRing - 2 * kRp);
+                }
+            }
+        };
         auto walk_block = [&](const int s0, const bool refill) {     // rows s0 .. s0 + kPf - 1 of the tile
 #pragma unroll
             for (int u = 0; u < kPf; ++u) {
@@ -1020,6 +1064,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             } else {
                 for (int s0 = 0; s0 < rows; s0 += kPf) walk_block(s0, true);
             }
+        } else if constexpr (AHEAD) {
+            for (int s0 = 0; s0 < rows; s0 += kAheadRows) walk_ahead(s0);
         } else {
             for (int s0 = 0; s0 < rows; s0 += kPf) walk_block(s0, true);
         }
