@@ -627,8 +627,21 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // (compiled for the static deal only -- QUEUE == 0 --: with the way of dealing decided at run time the carried
     // registers of the two ways meet in copies after every item, and a copy of a register that is being loaded drains the
     // loads: the 4-point cohort step, whose kernel decides at run time, went 199 -> 228 us that way)
-    constexpr bool PIPE = VB2_PIPE && STREAM && ONEGRP && !LCACHE && QUEUE == 0;
-    const bool pipe = PIPE && !dyn;
+    constexpr bool PIPES = VB2_PIPE && STREAM && ONEGRP && !LCACHE && QUEUE == 0;
+    // PIPEQ (round 4, second half; MEASURED AND DROPPED, compiled only with -DVB2_PIPEQ=1): the same for the 8-point shape on
+    // the work queue.  Ablation of the 48-point launch: 73.5 us; without the epilogue's arithmetic 55.5; without the table
+    // reads 42.3; with NEITHER 40.2 -- a launch's skeleton alone (a wave draws an item, loads its tile record, then its first
+    // rows, nine to ten times) takes more than half a launch.  So: a wave draws its NEXT item at the top of the current one,
+    // requests that item's record at once and its first rows when the current item's rows are walked, under the epilogue.
+    // Bit-identical, 69.5 -> 70.8 us per 48-point launch (8 / 16 / 32 points: 18.55 -> 18.77, 27.98 -> 28.97, 48.26 -> 49.65):
+    // with arithmetic in the loop the other three waves of the SIMD already cover those trips; the skeleton's 40 us is not
+    // additive.  (Round 3's version of this lost 4 %.)
+#ifndef VB2_PIPEQ
+#define VB2_PIPEQ 0
+#endif
+    constexpr bool PIPEQ = VB2_PIPEQ && MODE == 2 && QUEUE == 1 && !STREAM && !LCACHE && !SWP && !W16;
+    constexpr bool PIPE = PIPES || PIPEQ;
+    const bool pipe = PIPEQ || (PIPES && !dyn);
     // the item after position (s_pos, rnd) of this wave's static deal
     auto static_item = [&](uint32_t s_pos, uint32_t rnd) -> uint32_t {
         if (have_sched) return s_pos < s_end ? (uint32_t)sch.item[s_pos] : nitem;
@@ -639,6 +652,21 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const uint32_t it_ = TPW * idx_ + (uint32_t)half;
         have_ = idx_ < nitem && (TPW == 1 || it_ < ntile_blk);
         return have_ ? blk + it_ * nblk : blk;
+    };
+    // (several groups, one tile per item: the work queue's items) item -> this lane's micro-tile
+    auto tile_of_q = [&](uint32_t idx_, bool& have_) -> uint32_t {
+        uint32_t grp_ = ngrp == 1 ? 0u : (uint32_t)(((float)idx_ + 0.5f) * inv_nunit);
+        if (ngrp != 1) {
+            if (grp_ * nunit > idx_) --grp_;
+            else if ((grp_ + 1) * nunit <= idx_) ++grp_;
+        }
+        have_ = idx_ < nitem;
+        return have_ ? blk + (idx_ - grp_ * nunit) * nblk : blk;
+    };
+    auto draw_item = [&]() -> uint32_t {                             // the workgroup's next item, whichever wave asks first
+        uint32_t nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane(nxt);
     };
     auto issue_rows = [&](const vuint2 rec_, bool have_) {           // the first kPf rows of a tile (clamped to its own)
         g_cuint2* cp_ = g_codes + (size_t)rec_.x * kMtMarkers + m;
@@ -797,7 +825,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                                             : (uint32_t)(wave - (hook_blk ? 1 : 0));
     if (pipe && idx_first < nitem) {
         bool h0;
-        const uint32_t mt0 = tile_of(idx_first, h0);
+        const uint32_t mt0 = PIPEQ ? tile_of_q(idx_first, h0) : tile_of(idx_first, h0);
         rec_nx = g_rec[mt0];
         cst_nx = other_const(mt0, h0);
         issue_rows(rec_nx, h0);
@@ -942,8 +970,13 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         vuint2 rec_n2;
         rec_n2.x = rec_n2.y = 0u;
         if (pipe) {
-            idx_next = static_item(s_i + 1, round + 1);
-            mt_next = tile_of(idx_next, have_next);
+            if constexpr (PIPEQ) {
+                idx_next = draw_item();
+                mt_next = tile_of_q(idx_next, have_next);
+            } else {
+                idx_next = static_item(s_i + 1, round + 1);
+                mt_next = tile_of(idx_next, have_next);
+            }
             rec_n2 = g_rec[mt_next];
         }
         // per-marker constants: issued now, consumed after the read loop
@@ -1116,10 +1149,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 tile_llk[o + 1] = (double)lk_e[t];
             }
         }
-        // next work item of this workgroup, whichever wave gets there first
-        uint32_t nxt = 0;
-        if (lane == 0) nxt = atomicAdd(queue, 1u);
-        idx = __builtin_amdgcn_readfirstlane(nxt);
+        // next work item of this workgroup, whichever wave gets there first (PIPEQ: drawn at this item's top)
+        if constexpr (PIPEQ) idx = idx_next;
+        else idx = draw_item();
     }
     if (!dyn) {                                           // slots (wave, group): factor 1 if idle
         for (uint32_t grp = grp_wave; grp < (uint32_t)ngrp; ++grp) flush_wave(grp);
