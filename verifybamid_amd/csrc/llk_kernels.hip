@@ -410,7 +410,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #define VB2_STAMP_ROUND 0
 #endif
     const bool stamp_this = VB2_STAMP_ROUND == 0 || (unsigned)(tag & 0xffffffffull) == (unsigned)VB2_STAMP_ROUND;
+#ifdef VB2_ITEM_PROF
+    unsigned long long* stamps = nullptr;                 // (the per-workgroup slots hold the item profile's sums in this build)
+#else
     unsigned long long* stamps = (VB2_STAMPS_OF(L) && stamp_this) ? VB2_STAMPS_OF(L) + (size_t)blk * 8 : nullptr;
+#endif
     if (stamps && tid == 0) { stamps[0] = wall_clock64(); stamps[4] = 0; }
 
     const bool hook_blk = hook.on_block(), hook_mine = hook.mine();
@@ -936,8 +940,17 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
         for (int i = 0; i < BTL * 6; ++i) pa[i] = exp_nonpos<ESH>(pa[i], etab_lane);
         finish_prev();
-    } else
+    } else {
+#ifdef VB2_ITEM_PROF     // (profiling build, with VB2_WITH_STAMPS: where a wave's time per work item goes -- tools/item_prof.py)
+    unsigned long long ip_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define VB2_IP_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define VB2_IP_USE(x) asm volatile("" :: "v"(x))
+#else
+#define VB2_IP_T(var)
+#define VB2_IP_USE(x)
+#endif
     for (uint32_t idx = idx_first; idx < nitem;) {
+        VB2_IP_T(ip_t0);
         // grp = idx / nunit without the ~25-instruction integer division: float estimate (exact for
         // these magnitudes up to one) and a correction step
         uint32_t grp = ngrp == 1 ? 0u : (uint32_t)(((float)idx + 0.5f) * inv_nunit);
@@ -963,6 +976,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         if constexpr (LCACHE) rec = *reinterpret_cast<lds_cuint2v*>(hook.cache_rec() + (have_tile ? it : 0u) * 8u);
         else if (pipe) rec = rec_nx;
         else rec = g_rec[mt];
+        VB2_IP_USE(rec.x);
+        VB2_IP_T(ip_t1);
         // PIPE: the next item's record, requested now, needed when this item's rows have been walked
         uint32_t idx_next = nitem;
         bool have_next = false;
@@ -1082,6 +1097,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 walk_word(w_cur, acc, my_tab, my_tab_w16);
             }
         };
+        VB2_IP_USE(w[0].x);
+        VB2_IP_T(ip_t2);
         if constexpr (PIPE) {
             if (pipe) {
                 // the first kPf rows outside any loop (loads in flight are counted, not drained); an item with more
@@ -1105,10 +1122,16 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 
         __builtin_amdgcn_s_setprio(0);
         if (stamps && lane == 0 && wave == 1) stamps[3] = wall_clock64();      // wave 1: out of its (first) read loop
+        VB2_IP_USE(acc[0]); VB2_IP_USE(acc[BTL * 6 - 1]);
+        VB2_IP_T(ip_t3);
+        VB2_IP_USE(e0); VB2_IP_USE(e1); VB2_IP_USE(e2); VB2_IP_USE(mur); VB2_IP_USE(udr[0]); VB2_IP_USE(udr[3]);
+        VB2_IP_T(ip_t4);
         // ---- per-marker epilogue: this marker's likelihood as (mantissa, exponent) per point ----
         double lk_m[BTL];
         int lk_e[BTL];
         marker_lk(live, pos, acc, e0, e1, e2, udr, mur, my_ptq, lk_m, lk_e);
+        VB2_IP_USE(lk_m[0]); VB2_IP_USE(lk_m[BTL - 1]);
+        VB2_IP_T(ip_t5);
         if (!dyn) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {               // running product, renormalised lazily
@@ -1149,9 +1172,22 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 tile_llk[o + 1] = (double)lk_e[t];
             }
         }
+        VB2_IP_T(ip_t6);
         // next work item of this workgroup, whichever wave gets there first (PIPEQ: drawn at this item's top)
         if constexpr (PIPEQ) idx = idx_next;
         else idx = draw_item();
+#ifdef VB2_ITEM_PROF
+        {
+            const unsigned long long ip_t7 = __builtin_readcyclecounter();
+            ip_sum[0] += ip_t1 - ip_t0; ip_sum[1] += ip_t2 - ip_t1; ip_sum[2] += ip_t3 - ip_t2; ip_sum[3] += ip_t4 - ip_t3;
+            ip_sum[4] += ip_t5 - ip_t4; ip_sum[5] += ip_t6 - ip_t5; ip_sum[6] += ip_t7 - ip_t6; ip_sum[7] += 1;
+        }
+#endif
+    }
+#ifdef VB2_ITEM_PROF
+    if (VB2_STAMPS_OF(L) && lane == 0 && dyn)
+        for (int i = 0; i < 8; ++i) atomicAdd(&VB2_STAMPS_OF(L)[(size_t)blk * 8 + i], ip_sum[i]);
+#endif
     }
     if (!dyn) {                                           // slots (wave, group): factor 1 if idle
         for (uint32_t grp = grp_wave; grp < (uint32_t)ngrp; ++grp) flush_wave(grp);
