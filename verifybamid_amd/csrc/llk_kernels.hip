@@ -262,6 +262,39 @@ __device__ __forceinline__ void lane_map(int lane, int& m, int& g)
     }
 }
 
+// The value of lane `partner` = the lane whose marker index differs in bit `off` (same slot).  Both lane maps keep the low
+// two marker bits in the low two lane bits, so the exchanges over off = 1 and 2 stay inside a quad: DPP quad permutes -- VALU
+// moves, no trip through the LDS crossbar (a ds_bpermute per dword and ~100 cycles before the dependent multiply); the
+// exchange over 4 crosses quads inside a 16-lane row (HW4 below), the one over 8 crosses rows and stays a ds_bpermute.
+// Measured (48-point launch, same box): every exchange a ds_bpermute (-DVB2_DPP_XCHG=0) 70.1 us; off = 1, 2 as quad permutes
+// (=1) 68.4 us; off = 4 as two masked row rotations too (=2, the default) 68.0 us; OptimizeLLK 6.41 -> 6.32 ms; cohort steps
+// unchanged (the static deal exchanges once per wave, not per item).  Multiplication commutes: the same bits.
+#ifndef VB2_DPP_XCHG
+#define VB2_DPP_XCHG 2
+#endif
+// HW4 (the hardware lane map, off = 4; -DVB2_DPP_XCHG=2): marker bit 2 selects between the quads {0,3}, {1,2} of a 16-lane
+// row (lane_of: ranks 0,1,2,3 of slot-parity 0 sit in quads 0,3,5,6, of parity 1 in 1,2,4,7), i.e. quad j <-> 3 - j with
+// the lane in the quad kept: a row rotation by 4 for the quads 0 and 2, by 12 for 1 and 3 (tools/ubench/dpp_map.hip:
+// row_ror:n gives lane i the value of lane i - n of its row) -- two DPP moves with bank masks.
+template <bool HW4 = false>
+__device__ __forceinline__ int lane_xchg_i32(int x, int off, int partner)
+{
+    if (VB2_DPP_XCHG && off == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    if (VB2_DPP_XCHG && off == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    if (VB2_DPP_XCHG >= 2 && HW4 && off == 4) {
+        const int a = __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0x5, false);       // row_ror:4  -> quads 0 and 2 of every row
+        return __builtin_amdgcn_update_dpp(a, x, 0x12C, 0xf, 0xa, false);              // row_ror:12 -> quads 1 and 3
+    }
+    return __shfl(x, partner, 64);
+}
+template <bool HW4 = false>
+__device__ __forceinline__ double lane_xchg_f64(double x, int off, int partner)
+{
+    if (VB2_DPP_XCHG && (off == 1 || off == 2 || (VB2_DPP_XCHG >= 2 && HW4 && off == 4)))
+        return __hiloint2double(lane_xchg_i32<HW4>(__double2hiint(x), off, partner), lane_xchg_i32<HW4>(__double2loint(x), off, partner));
+    return __shfl(x, partner, 64);
+}
+
 template <bool HWMAP>
 __device__ __forceinline__ int lane_of(int m, int g)
 {
@@ -550,8 +583,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             const int partner = lane_of<HWMAP>(m ^ off, g4);
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
-                p[t].m *= __shfl(p[t].m, partner, 64);    // 16 factors in [0.5,1): no underflow
-                p[t].e += __shfl(p[t].e, partner, 64);
+                p[t].m *= lane_xchg_f64<HWMAP>(p[t].m, off, partner);    // 16 factors in [0.5,1): no underflow
+                p[t].e += lane_xchg_f64<HWMAP>(p[t].e, off, partner);
             }
         }
         if (!cross) return;
@@ -1160,8 +1193,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             const int partner = lane_of<HWMAP>(m ^ off, g4);
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
-                lk_m[t] *= __shfl(lk_m[t], partner, 64);
-                lk_e[t] += __shfl(lk_e[t], partner, 64);
+                lk_m[t] *= lane_xchg_f64<HWMAP>(lk_m[t], off, partner);
+                lk_e[t] += lane_xchg_i32<HWMAP>(lk_e[t], off, partner);
             }
         }
         if (m == 0 && have_tile) {
