@@ -241,7 +241,8 @@ int Batch::set_slot(int i, Context* c)
         if (ctx_[s]->L.num_mt > 0 && !ctx_[s]->L.codes16) w16_ = false;
         if (ctx_[s]->L.row_bytes != kRowBytesWide) wide_rows_ = false;
     }
-    if (!ready_) return VB2_OK;                 // (ensure_resources uploads everything at the first step)
+    if (!ready_ || !c) return VB2_OK;           // (ensure_resources uploads everything at the first step; an empty slot's
+                                                //  workgroups leave before they read its layout)
     VB2_HIP(hipSetDevice(device));
     // slot i's layout and schedules through the slot's own stretch of pinned staging: stream-ordered before the next step;
     // the stretch is not written again before that step is over (the slot cannot change hands sooner)
