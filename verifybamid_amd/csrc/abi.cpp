@@ -335,6 +335,7 @@ void vb2_debug_set_cohort_w16(int on) { vb2::set_cohort_w16(on != 0); }
 // Test aid: calls of more points than one launch's tables hold as the passes of one launch (1, the default) or as separate
 // launches (0)
 void vb2_debug_set_eval_passes(int on) { vb2::set_eval_passes(on != 0); }
+void vb2_debug_set_eval_split(int on) { vb2::set_eval_split(on); }
 
 // Test aid: turn the resident search mode off/on for one context (VB2_RESIDENT does it globally).
 void vb2_debug_set_resident(vb2_ctx* ctx, int on)

@@ -128,6 +128,7 @@ static void init_process_knobs()
             set_reduce_mode(!std::strcmp(rm, "ticket") ? 1 : !std::strcmp(rm, "tagged") ? 2 : 0);
         if (const char* co = std::getenv("VB2_COOP")) set_coop_launch(std::atoi(co) != 0);
         if (const char* ps = std::getenv("VB2_PASSES")) set_eval_passes(std::atoi(ps) != 0);
+        if (const char* sp = std::getenv("VB2_SPLIT")) set_eval_split(std::atoi(sp));
         if (const char* pm = std::getenv("VB2_PAIRED")) set_paired_mode(std::atoi(pm) != 0);
         for (int btl = 1; btl <= 2; ++btl) {
             const char* gv = std::getenv(btl == 1 ? "VB2_GEOM1" : "VB2_GEOM2");
@@ -609,6 +610,26 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     }
     const int num_mt = (int)((m_active + kMtMarkers - 1) / kMtMarkers);
     const int64_t m_pad = (int64_t)num_mt * kMtMarkers;
+    // Workgroup b of a launch owns the micro-tiles b, b + grid, b + 2 grid, ...: in a plainly descending list it would get
+    // the deepest tile of EVERY stripe of `grid` tiles and the last workgroup the shallowest -- at C3 workgroup 0 walks ~4 %
+    // more rows than workgroup 255, and a launch (a search round, a cohort step) ends with its slowest workgroup
+    // (tools/stamps.py: the workgroups of a 48-point launch finished their tiles between 61.4 and 68.1 us).  So every other
+    // complete stripe of num_cu tiles is laid out in ASCENDING order (a snake): every workgroup's share then differs by
+    // less than one stripe's spread, whatever grid divides num_cu (a cohort's 16 workgroups per sample: residue b of an
+    // even stripe is residue 15 - b of an odd one).  A workgroup's own tiles still come deepest first, and a tile keeps
+    // its 16 markers; the last, incomplete stripe stays as it is (the positions past the last active marker must be the
+    // array's last).  VB2_TILE_ORDER=plain: the descending list.
+    {
+        static const bool plain_order = std::getenv("VB2_TILE_ORDER") && !std::strcmp(std::getenv("VB2_TILE_ORDER"), "plain");
+        const int64_t stripe = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const int64_t full_stripes = (m_active / kMtMarkers) / stripe;      // stripes of complete tiles
+        if (!plain_order)
+            for (int64_t s = 1; s < full_stripes; s += 2) {
+                int64_t* base = perm.data() + s * stripe * kMtMarkers;
+                for (int64_t a = 0, b = stripe - 1; a < b; ++a, --b)
+                    std::swap_ranges(base + a * kMtMarkers, base + (a + 1) * kMtMarkers, base + b * kMtMarkers);
+            }
+    }
 
     std::vector<uint32_t> mt_row_off(num_mt), mt_rows(num_mt);
     uint64_t total_rows = 0;

@@ -24,7 +24,7 @@ constexpr int kMaxWideCodes = 65535 / kRowBytesWide - 1;   // run words hold 16-
 constexpr int kMaxRunCount = 31;           // the 16-bit prefix of a double holds integers up to 31 exactly
 // d_ticket of launch_llk_eval: kTicketWords zero-initialised unsigned ints -- [0, kTicketScratchWord) the arrival tickets of a
 // launch's passes (llk_eval_passes_kernel; a plain launch uses [0]), two words from kTicketScratchWord on a scratch flag
-constexpr int kTicketScratchWord = 8, kTicketWords = 16;
+constexpr int kTicketScratchWord = 8, kTicketSplitWord = 12, kTicketWords = 16;   // [12]: llk_eval_split_kernel's count of finished halves
 constexpr int kInlinePointDoubles = 96;    // parameter rows that travel as kernel arguments (768 B)
 
 // Everything the kernels read, in HBM.  "Sorted order" = active markers sorted by
@@ -113,6 +113,7 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            int reduce_override = 0,      // 1 ticket / 2 tagged for this call only
                            ScheduleProvider* sched = nullptr);
 void set_single_launch(bool on);
+void set_eval_split(int on);       // llk_eval_split_kernel (two workgroups per CU, half the point groups each) for calls of >= 2 point groups (default on)
 void set_eval_passes(bool on);     // llk_eval_passes_kernel for calls of more points than one launch's tables hold (default on)
 void set_reduce_mode(int mode);     // 0 auto, 1 arrival ticket, 2 tagged sets (VB2_REDUCE)
 

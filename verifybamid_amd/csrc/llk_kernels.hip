@@ -316,7 +316,14 @@ template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU =
 #else
 template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 #endif
-template <> struct Geom<2> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
+#ifndef VB2_G2_WAVES      // (experiment: the 8-point shape in smaller workgroups at a smaller register budget, two per CU)
+#define VB2_G2_WAVES 16
+#define VB2_G2_WPS 4
+#endif
+#ifndef VB2_SPLIT_WAVES   // waves of a workgroup of llk_eval_split_kernel (two workgroups per CU)
+#define VB2_SPLIT_WAVES 8
+#endif
+template <> struct Geom<2> { static constexpr int kMaxWaves = VB2_G2_WAVES, kBlocksPerCU = 1, kWavesPerSimd = VB2_G2_WPS; };
 template <> struct Geom<3> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<4> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 template <> struct Geom<5> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
@@ -1229,26 +1236,45 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     if (stamps && lane == 0 && !hook_mine) atomicMax(&stamps[4], wall_clock64());   // the wave that is done with its tiles last
     // ---- deterministic block reduction -> one partial per (point, block) ----
     const uint32_t nres = dyn ? ntile_blk : (uint32_t)nwave;   // result slots per group
-    auto reduce_point = [&](int b) {                  // slots in index order, then a butterfly
-        const int grp = b / NP, bb = b - grp * NP;
-        ScaledProd p{1.0, 0.0};
-        for (uint32_t i = lane; i < nres; i += 64) {
-            const size_t o = (((size_t)grp * nres + i) * NP + bb) * 2;
-            p.m *= tile_llk[o];
-            p.e += tile_llk[o + 1];
-            sp_renorm(p);                              // a slot can be as small as 2^-16
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            p.m *= __shfl_xor(p.m, off, 64);
-            p.e += __shfl_xor(p.e, off, 64);
-            sp_renorm(p);
-        }
-        // the only logarithm of this (workgroup, point): log(prod lk) = log(m) + e*ln2
-        if (lane == 0) red[b] = log_nonneg(p.m) + p.e * 6.93147180559945286227e-01;
-    };
+    // Every point at once, SIXTEEN lanes (one DPP row) per point: lane j of the row multiplies the slots j, j + 16, ... in index
+    // order, then the row's sixteen products meet through four DPP moves -- mirror of the row, mirror of its halves, quad
+    // permutes over distance 1 and 2: VALU moves, no trip through the LDS crossbar -- and the row's lane 0 takes the point's
+    // only logarithm.  (Until round 4's second session a WAVE reduced a point, and a wave's three points of a 48-point launch
+    // one after the other: 64-lane butterflies of ds_bpermutes with a renormalisation per step, 4.9 us between "last wave
+    // done with its tiles" and "block reduced" in the launch's timeline -- tools/stamps.py.)  The order of the products is a
+    // function of the slot count alone, the same for every wave shape and kernel, so a point's value still does not depend
+    // on how it was evaluated.  Sixteen factors >= 2^-64 cannot underflow: one renormalisation after the butterfly.
     __syncthreads();
-    for (int b = wave; b < NPT; b += nwave) reduce_point(b);
+    {
+        const uint32_t j16 = (uint32_t)lane & 15u;
+        for (int b = tid >> 4; b < NPT; b += nthread >> 4) {          // (uniform over a row of 16 lanes)
+            const int grp = b / NP, bb = b - grp * NP;
+            ScaledProd p{1.0, 0.0};
+            for (uint32_t i = j16; i < nres; i += 16) {
+                const size_t o = (((size_t)grp * nres + i) * NP + bb) * 2;
+                p.m *= tile_llk[o];
+                p.e += tile_llk[o + 1];
+                sp_renorm(p);                              // a slot can be as small as 2^-64
+            }
+            auto row_move = [&](double x, auto ctrl) -> double {
+                constexpr int kCtrl = decltype(ctrl)::value;
+                return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), kCtrl, 0xf, 0xf, false),
+                                        __builtin_amdgcn_update_dpp(0, __double2loint(x), kCtrl, 0xf, 0xf, false));
+            };
+            auto row_step = [&](auto ctrl) {
+                const double om = row_move(p.m, ctrl), oe = row_move(p.e, ctrl);
+                p.m *= om;
+                p.e += oe;
+            };
+            row_step(std::integral_constant<int, 0x140>());     // row_mirror:      lane j <- lane 15 - j
+            row_step(std::integral_constant<int, 0x141>());     // row_half_mirror: lane j <- lane 7 - j of its half
+            row_step(std::integral_constant<int, 0xB1>());      // quad_perm [1,0,3,2]
+            row_step(std::integral_constant<int, 0x4E>());      // quad_perm [2,3,0,1]
+            sp_renorm(p);
+            // the only logarithm of this (workgroup, point): log(prod lk) = log(m) + e*ln2
+            if (j16 == 0) red[b] = log_nonneg(p.m) + p.e * 6.93147180559945286227e-01;
+        }
+    }
     __syncthreads();
     if (VB2_STAMPS_OF(L) && tid == 0) {
         const unsigned long long t5 = wall_clock64();
@@ -1286,22 +1312,37 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         if (*last_flag == 0u) return;
         // same summation order as llk_finalize_kernel: lane-strided, then a wave butterfly
         const int nbt = (int)nblk;
-        for (int b = wave; b < num_valid; b += nwave) {
-            const double* p = partials + (size_t)b * nbt;
-            double s = 0;
-            for (int base = 0; base < nbt; base += 8 * 64) {
-                double x[8];
+        // (a wave's points side by side -- three of a 48-point launch: their loads, each a trip to memory, are in flight
+        // together, and so are their butterflies; every point's sum in the order it always had)
+        constexpr int kSide = 3;
+        for (int b0 = wave; b0 < num_valid; b0 += kSide * nwave) {
+            double s[kSide];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int i = base + q * 64 + lane;
-                    x[q] = i < nbt ? __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : 0.0;
+            for (int u = 0; u < kSide; ++u) s[u] = 0;
+            for (int base = 0; base < nbt; base += 8 * 64) {
+                double x[kSide][8];
+#pragma unroll
+                for (int u = 0; u < kSide; ++u) {
+                    const int b = b0 + u * nwave;
+                    const double* p = partials + (size_t)(b < num_valid ? b : b0) * nbt;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = base + q * 64 + lane;
+                        x[u][q] = i < nbt ? __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : 0.0;
+                    }
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) s += x[q];
+                for (int u = 0; u < kSide; ++u)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s[u] += x[u][q];
             }
-            s = wave_sum(s);
-            if (lane == 0) put_result(b, s);
+#pragma unroll
+            for (int u = 0; u < kSide; ++u) {
+                const int b = b0 + u * nwave;
+                const double t = wave_sum(s[u]);
+                if (lane == 0 && b < num_valid) put_result(b, t);
+            }
         }
         if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -1462,6 +1503,32 @@ llk_eval_passes_kernel(const DeviceLayout L, const double* __restrict__ points, 
             tickets + pass, (last || !done_flag) ? done_flag : scratch_flag, done_seq, blockIdx.x, gridDim.x, nullptr, 0u,
             (nv + 7) / 8, 0ull, Schedule{nullptr, nullptr});
     }
+}
+
+// A many-point call as TWO workgroups per CU (round 4, second session): workgroup (b, h) owns the micro-tiles of workgroup b
+// of the plain launch and the h-th half of the call's point groups -- so it builds only its own three tables (80 KB of LDS:
+// two such workgroups share a CU), has eight waves and a work queue, result slots, block reduction and arrival ticket of its
+// own.  The same tiles, the same slots, the same order of every product and sum as the plain launch: the same bits.  What
+// it buys: the phases in which a workgroup's waves mostly wait -- table build behind its barrier, the queue running dry,
+// block reduction, hand-off -- overlap with the other workgroup's tile work instead of leaving the CU idle.
+// blockIdx = h * (gridDim / 2) + b: both halves of b sit on the XCD b mod 8 (the same slice of the pileup in that L2), and
+// the dispatcher hands out every h = 0 workgroup before the first h = 1 one.
+template <int KSEL>
+__global__ void __launch_bounds__(VB2_SPLIT_WAVES * 64, 4)
+llk_eval_split_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid, int points_first_half,
+                      double* __restrict__ partials, double* __restrict__ llk_out, unsigned int* __restrict__ tickets,
+                      unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
+                      unsigned int* __restrict__ halves_done)
+{
+    const uint32_t nblk = gridDim.x >> 1;
+    const uint32_t h = blockIdx.x >= nblk ? 1u : 0u;
+    const uint32_t blk = blockIdx.x - h * nblk;
+    const int stride = 2 * L.num_pc + 1;
+    const int first = h ? points_first_half : 0;
+    const int nv = h ? num_valid - points_first_half : points_first_half;       // (the host splits so that both are > 0)
+    eval_body<2, true, false, NoHook, false, 1, false, (KSEL > 0 ? 0 : -1), KSEL>(
+        L, nullptr, 0, points + (size_t)first * stride, nv, partials + (size_t)first * nblk, llk_out + first, tickets + h,
+        done_flag, done_seq, blk, nblk, halves_done, 2u, (nv + 7) / 8, 0ull, Schedule{nullptr, nullptr});
 }
 
 // The software-pipelined form of the 8-point shape (eval_body: SWP): 12-wave workgroups, 3 waves per SIMD.  MEASURED AND
@@ -1756,6 +1823,36 @@ static hipError_t launch_passes(const DeviceLayout& L, const double* d_points, i
     return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
 }
 
+// see llk_eval_split_kernel.  Taken for a call of two or more point groups on a sample big enough for a full grid.
+static int g_split = 0;                // VB2_SPLIT=1 / vb2_debug_set_eval_split(1): taken; default: the plain launch (measured equal to slower: DESIGN 3.3e)
+void set_eval_split(int on) { g_split = on; }
+static hipError_t launch_split(const DeviceLayout& L, const double* d_points, int num_valid, int ngrp,
+                               double* d_partials, double* d_out, unsigned int* d_tickets,
+                               unsigned long long* done_flag, unsigned long long done_seq, hipStream_t stream, bool* taken)
+{
+    *taken = false;
+    if (L.known_af != nullptr || ngrp < 2) return hipSuccess;
+    const LaunchGeom gm = launch_geom(L, 2, ngrp);
+    if (gm.grid != Geom<2>::kBlocksPerCU * L.num_cu || gm.block_waves != Geom<2>::kMaxWaves) return hipSuccess;   // a full grid only
+    const int g0 = (ngrp + 1) / 2, bw = VB2_SPLIT_WAVES;
+    if (!eval_is_dynamic(L, (uint32_t)gm.grid, bw, g0)) return hipSuccess;
+    const size_t shmem = eval_shmem_np(L, 8, gm.grid, bw, g0);
+    if (2 * shmem > (size_t)kLdsLimitBytes) return hipSuccess;                    // two workgroups per CU
+    const void* fn = L.num_pc == 4 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<4>)
+                     : L.num_pc == 2 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<2>)
+                                     : reinterpret_cast<const void*>(&llk_eval_split_kernel<0>);
+    hipError_t e = raise_lds_limit(fn);
+    if (e != hipSuccess) return e;
+    DeviceLayout Lc = L;
+    const double* a_points = d_points;
+    int a_nv = num_valid, a_first = 8 * g0;
+    unsigned long long a_seq = done_seq;
+    unsigned int* a_halves = d_tickets + kTicketSplitWord;
+    void* args[] = {&Lc, &a_points, &a_nv, &a_first, &d_partials, &d_out, &d_tickets, &done_flag, &a_seq, &a_halves};
+    *taken = true;
+    return hipLaunchKernel(fn, dim3(2 * gm.grid), dim3(bw * 64), args, shmem, stream);
+}
+
 static bool g_eval_passes = true;      // VB2_PASSES=0 / vb2_debug_set_eval_passes(0): a launch per table-load of points
 void set_eval_passes(bool on) { g_eval_passes = on; }
 static int g_reduce_mode = 0;          // 0 auto, 1 ticket, 2 tagged
@@ -1809,6 +1906,15 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         // matters), arrival ticket for bigger batches (cheaper per point); VB2_REDUCE overrides
         const bool tagged = reduce_mode == 2 || (reduce_mode == 0 && step <= 4);
         const unsigned long long tag = tagged ? ++*tag_counter : 0ull;   // unique per launch on this buffer
+        if (g_split && step > 8 && !m1 && tk && g_hwmap && !tagged && L.row_bytes == kRowBytesWide) {
+            bool taken = false;
+            e = launch_split(L, p, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream, &taken);
+            if (e != hipSuccess) return e;
+            if (taken) {
+                done += step;
+                continue;
+            }
+        }
         if (step > 4 && m1)
             e = launch_btl<1, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
         else if (step > 4)
