@@ -49,6 +49,9 @@ for i, n in enumerate(names):
     col = us[:, i][s[:, i] > 0]
     if len(col): print("%-24s min %6.2f  median %6.2f  max %6.2f us" % (n, col.min(), np.median(col), col.max()))
 if os.environ.get("VB2_STAMPS_DETAIL"):
+    print("workgroup 0's own stamps (us): " + ", ".join("%s %.2f" % (nm, us[0, i]) for i, nm in enumerate(names)))
+    print("workgroup 1's:                 " + ", ".join("%s %.2f" % (nm, us[1, i]) for i, nm in enumerate(names)))
+    print("workgroup 200's:               " + ", ".join("%s %.2f" % (nm, us[200, i]) for i, nm in enumerate(names)))
     br = us[:, 5]
     order = np.argsort(-br)
     print("slowest workgroups by 'block reduced' (us): " + ", ".join("%d: %.2f" % (i, br[i]) for i in order[:12]))

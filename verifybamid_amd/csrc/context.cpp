@@ -610,26 +610,15 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     }
     const int num_mt = (int)((m_active + kMtMarkers - 1) / kMtMarkers);
     const int64_t m_pad = (int64_t)num_mt * kMtMarkers;
-    // Workgroup b of a launch owns the micro-tiles b, b + grid, b + 2 grid, ...: in a plainly descending list it would get
-    // the deepest tile of EVERY stripe of `grid` tiles and the last workgroup the shallowest -- at C3 workgroup 0 walks ~4 %
-    // more rows than workgroup 255, and a launch (a search round, a cohort step) ends with its slowest workgroup
-    // (tools/stamps.py: the workgroups of a 48-point launch finished their tiles between 61.4 and 68.1 us).  So every other
-    // complete stripe of num_cu tiles is laid out in ASCENDING order (a snake): every workgroup's share then differs by
-    // less than one stripe's spread, whatever grid divides num_cu (a cohort's 16 workgroups per sample: residue b of an
-    // even stripe is residue 15 - b of an odd one).  A workgroup's own tiles still come deepest first, and a tile keeps
-    // its 16 markers; the last, incomplete stripe stays as it is (the positions past the last active marker must be the
-    // array's last).  VB2_TILE_ORDER=plain: the descending list.
-    {
-        static const bool plain_order = std::getenv("VB2_TILE_ORDER") && !std::strcmp(std::getenv("VB2_TILE_ORDER"), "plain");
-        const int64_t stripe = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        const int64_t full_stripes = (m_active / kMtMarkers) / stripe;      // stripes of complete tiles
-        if (!plain_order)
-            for (int64_t s = 1; s < full_stripes; s += 2) {
-                int64_t* base = perm.data() + s * stripe * kMtMarkers;
-                for (int64_t a = 0, b = stripe - 1; a < b; ++a, --b)
-                    std::swap_ranges(base + a * kMtMarkers, base + (a + 1) * kMtMarkers, base + b * kMtMarkers);
-            }
-    }
+    // (Measured and dropped, round 4.  Workgroup b owns the micro-tiles b, b + grid, ...: in this plainly descending list it gets
+    // the deepest tile of every stripe of `grid` tiles and the last workgroup the shallowest, ~4 % more rows at C3.  (a) Every
+    // other stripe of num_cu tiles in ASCENDING order, a snake that evens the workgroups out: 48-point launch 65.17 / 65.47 us
+    // plain, 65.30 / 65.27 us snaked on the same box, OptimizeLLK 6.12 / 6.10 ms either way -- the 61-67 us over which the
+    // workgroups of a launch finish their tiles follow the CUs (two or three XCDs of a box run slower), not the tile list.
+    // (b) The snake plus position 0 of every stripe = the stripe's SHALLOWEST tile, so that workgroup 0 -- it hosts the wave
+    // that runs the simplex and is the last to have its block sums in a search round, 9.6 us against a median of 8.3 -- has
+    // the least tile work: its block sums were as late as before (its lateness is not tile work) and OptimizeLLK went
+    // 6.12 -> 6.22-6.28 ms.)
 
     std::vector<uint32_t> mt_row_off(num_mt), mt_rows(num_mt);
     uint64_t total_rows = 0;

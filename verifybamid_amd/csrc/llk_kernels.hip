@@ -1902,9 +1902,13 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         unsigned long long* df = (done + step >= num_point) ? done_flag : nullptr;   // last launch signals
         unsigned long long* df_eval = tk ? df : nullptr;
         hipError_t e;
-        // hand-off protocol: tagged sets for <= 4 points (one fabric round trip less, latency
+        // hand-off protocol: tagged sets for <= 16 points (one fabric round trip less, latency
         // matters), arrival ticket for bigger batches (cheaper per point); VB2_REDUCE overrides
-        const bool tagged = reduce_mode == 2 || (reduce_mode == 0 && step <= 4);
+        // (round 4, second session: the tagged sets up to 16 points -- 8 points 18.6 -> 16.4 us, 16 points 27.7 -> 26.6 us on the
+        // same box; 32 points 45.5 -> 47.6 us, 48 points 64.3 -> 68.5 us: there workgroup 0's polling passes cost more than the
+        // ticket's third trip.  VB2_TAGGED_MAX=n moves the limit.)
+        static const int tagged_max = std::getenv("VB2_TAGGED_MAX") ? std::atoi(std::getenv("VB2_TAGGED_MAX")) : 16;
+        const bool tagged = reduce_mode == 2 || (reduce_mode == 0 && step <= tagged_max);
         const unsigned long long tag = tagged ? ++*tag_counter : 0ull;   // unique per launch on this buffer
         if (g_split && step > 8 && !m1 && tk && g_hwmap && !tagged && L.row_bytes == kRowBytesWide) {
             bool taken = false;
