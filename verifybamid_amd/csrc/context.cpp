@@ -9,6 +9,7 @@
 // Everything that does not depend on (alpha, PC) is hoisted out of the
 // per-evaluation path: see DESIGN.md "What is computed once".
 #include "context.h"
+#include "tile_sched.h"
 
 #include <sched.h>
 
@@ -655,6 +656,10 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     uint32_t row_of_idx[kMaxCode], hi_of_count[kMaxRunCount + 1];     // the two halves of a run word, by table
     for (int idx = 0; idx < kMaxCode; ++idx) row_of_idx[idx] = dict_of[idx] == kPadCode ? 0u : (uint32_t)(dict_of[idx] * row_bytes);
     for (int n = 0; n <= kMaxRunCount; ++n) hi_of_count[n] = run_word(0, (uint32_t)n);
+    // wide quality alphabets: a tile's runs are placed by schedule_tile (tile_sched.h) instead of in plain dictionary order
+    // (VB2_RUN_SCHED=0: plain order always; =1: scheduled whatever the dictionary's size)
+    static const int run_sched_knob = std::getenv("VB2_RUN_SCHED") ? std::atoi(std::getenv("VB2_RUN_SCHED")) : -1;
+    const bool run_sched = run_sched_knob < 0 ? num_code > kSchedMinCodes : run_sched_knob != 0;
 
     // ---- device memory: ONE allocation per context, carved into 256-byte aligned pieces.
     // (A cohort creates contexts from many host threads; allocation calls go through driver
@@ -802,7 +807,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
         uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
         const size_t slots = (size_t)mt_rows[t] * 2;
-        size_t j = 0;
+        size_t j = run_sched ? slots : 0;                  // (scheduled: the tiles' run words are written below)
         for (; j < eff; ++j) {
             const uint32_t rw = src[j];
             row0[((j >> 1) * kMtMarkers + lane) * 2 + (j & 1)] = row_of_idx[rw & 0xffu] | hi_of_count[rw >> 8];
@@ -821,6 +826,29 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         cdiag[3 * m_pad + m] = cd[3];
     }
     });
+
+    if (!device_pack && run_sched)
+        parallel_for(num_mt, [&](int, int64_t t0, int64_t t1) {
+            TileSched S;
+            for (int64_t t = t0; t < t1; ++t) {
+                uint32_t eff16[kMtMarkers];
+                const uint16_t* src16[kMtMarkers];
+                for (int l = 0; l < kMtMarkers; ++l) {
+                    const int64_t m = t * kMtMarkers + l;
+                    const bool have = m < m_active;
+                    const int i = have ? active[perm[m]] : 0;
+                    eff16[l] = have ? (uint32_t)eff_all[i] : 0u;
+                    src16[l] = have ? runs + (in->read_off[i] - read_base) : runs;
+                }
+                uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
+                schedule_tile(S, eff16, (int)(2u * mt_rows[t]), num_code, dict_of.data(),
+                              [&](int l, int j) -> uint32_t { return src16[l][j]; },
+                              [&](int l, int c, uint32_t rw) {
+                                  row0[((size_t)(c >> 1) * kMtMarkers + l) * 2 + (c & 1)] = row_of_idx[rw & 0xffu] | hi_of_count[rw >> 8];
+                              },
+                              [&](int l, int c) { row0[((size_t)(c >> 1) * kMtMarkers + l) * 2 + (c & 1)] = pad4; });
+            }
+        });
 
     const auto t_flat = tnow();
     if (dry && t_digest_out) {
@@ -905,6 +933,9 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         pa.pad4 = pad4;
         for (int idx = 0; idx < kMaxCode; ++idx) pa.row_of_idx[idx] = row_of_idx[idx];
         for (int n = 0; n <= kMaxRunCount; ++n) pa.hi_of_count[n] = hi_of_count[n];
+        pa.sched = run_sched ? 1 : 0;
+        pa.num_code = num_code;
+        for (int idx = 0; idx < kMaxCode; ++idx) pa.dict_of[idx] = dict_of[idx];
         VB2_HIP(launch_pack_layout(pa, c->stream));
     } else {
         VB2_HIP(hipMemcpyAsync(dbase, stage, data_bytes, hipMemcpyHostToDevice, c->stream));

@@ -183,6 +183,9 @@ struct PackArgs {
     uint32_t total_rows, slack_rows, pad4;
     uint32_t row_of_idx[kMaxCode];
     uint32_t hi_of_count[kMaxRunCount + 1];
+    int32_t sched;                 // 1: the run words of a tile are placed by schedule_tile (tile_sched.h: wide alphabets)
+    int32_t num_code;
+    uint8_t dict_of[kMaxCode];     // dictionary index -> dictionary position (the scheduler's bank groups)
 };
 hipError_t launch_pack_layout(const PackArgs& a, hipStream_t stream);
 // n doubles from device memory to mapped host memory, then done_seq to the mapped flag (stream-ordered

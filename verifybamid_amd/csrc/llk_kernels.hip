@@ -33,6 +33,7 @@
 #include "llk_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include "tile_sched.h"
 
 #include <algorithm>
 #include <atomic>
@@ -649,6 +650,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     }
     uint32_t round = 0;
     if (hook_mine) hook.run();                            // (this wave takes no work items; the others cover for it)
+#ifdef VB2_STAMP_CTRL     // (profiling build: workgroup 0's slot 3 = the control wave is back from its tile-phase work)
+    if (stamps && hook_mine && lane == 0) stamps[3] = wall_clock64();
+#endif
 #ifndef VB2_PF_M2
 #define VB2_PF_M2 4
 #endif
@@ -1161,7 +1165,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         }
 
         __builtin_amdgcn_s_setprio(0);
+#ifdef VB2_STAMP_CTRL
+        if (stamps && lane == 0 && wave == 1 && !hook_blk) stamps[3] = wall_clock64();
+#else
         if (stamps && lane == 0 && wave == 1) stamps[3] = wall_clock64();      // wave 1: out of its (first) read loop
+#endif
         VB2_IP_USE(acc[0]); VB2_IP_USE(acc[BTL * 6 - 1]);
         VB2_IP_T(ip_t3);
         VB2_IP_USE(e0); VB2_IP_USE(e1); VB2_IP_USE(e2); VB2_IP_USE(mur); VB2_IP_USE(udr[0]); VB2_IP_USE(udr[3]);
@@ -2090,7 +2098,7 @@ pack_layout_kernel(const PackArgs a)
         const uint32_t eff = have ? a.eff[m] : 0u;
         const uint16_t* src = a.runs + (have ? a.src_off[m] : 0u);
         uint2* out = a.codes + (size_t)rec.x * kMtMarkers + lane;
-        for (uint32_t r = 0; r < rec.y; ++r) {
+        for (uint32_t r = 0; r < (a.sched ? 0u : rec.y); ++r) {         // (sched: pack_sched_kernel writes the run words)
             uint32_t w0 = a.pad4, w1 = a.pad4;
             if (2 * r < eff) { const uint32_t rw = src[2 * r]; w0 = a.row_of_idx[rw & 0xffu] | a.hi_of_count[rw >> 8]; }
             if (2 * r + 1 < eff) { const uint32_t rw = src[2 * r + 1]; w1 = a.row_of_idx[rw & 0xffu] | a.hi_of_count[rw >> 8]; }
@@ -2111,10 +2119,40 @@ pack_layout_kernel(const PackArgs a)
         a.codes[(size_t)a.total_rows * kMtMarkers + e] = make_uint2(a.pad4, a.pad4);
 }
 
+// Wide quality alphabets: one THREAD per micro-tile places the tile's run words (schedule_tile, tile_sched.h -- the very
+// function the host pack calls, so the two write the same bytes); ~1 KB of scratch per thread, a few thousand integer
+// operations per tile.
+__global__ void __launch_bounds__(64)
+pack_sched_kernel(const PackArgs a)
+{
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= a.num_mt) return;
+    const uint2 rec = a.mt_rec[t];
+    uint32_t eff[kMtMarkers];
+    const uint16_t* src[kMtMarkers];
+    for (int l = 0; l < kMtMarkers; ++l) {
+        const int64_t m = (int64_t)t * kMtMarkers + l;
+        const bool have = m < a.m_active;
+        eff[l] = have ? a.eff[m] : 0u;
+        src[l] = a.runs + (have ? a.src_off[m] : 0u);
+    }
+    uint32_t* const out = reinterpret_cast<uint32_t*>(a.codes + (size_t)rec.x * kMtMarkers);
+    TileSched S;
+    schedule_tile(S, eff, (int)(2u * rec.y), a.num_code, a.dict_of,
+                  [&](int l, int j) -> uint32_t { return src[l][j]; },
+                  [&](int l, int c, uint32_t rw) {
+                      out[((size_t)(c >> 1) * kMtMarkers + l) * 2 + (c & 1)] = a.row_of_idx[rw & 0xffu] | a.hi_of_count[rw >> 8];
+                  },
+                  [&](int l, int c) { out[((size_t)(c >> 1) * kMtMarkers + l) * 2 + (c & 1)] = a.pad4; });
+}
+
 hipError_t launch_pack_layout(const PackArgs& a, hipStream_t stream)
 {
     const int64_t n = std::max<int64_t>(a.m_pad, (int64_t)a.slack_rows * kMtMarkers);
     hipLaunchKernelGGL(pack_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !a.sched || a.num_mt <= 0) return e;
+    hipLaunchKernelGGL(pack_sched_kernel, dim3((unsigned)((a.num_mt + 63) / 64)), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
