@@ -284,3 +284,40 @@ def test_device_exp_restatement_equals_libm_bit_for_bit():
         pytest.skip(p.stdout.strip())
     assert p.returncode == 0, p.stdout + p.stderr
     assert " 0 mismatches" in p.stdout and "checked 150" in p.stdout, p.stdout
+
+
+# ---- the kernels' table-driven logarithm (the per-alpha table's entries, ContaminationEstimator.h:223-225) ----
+def test_device_log_table_is_the_mathematical_one():
+    """log_table.inc (included by llk_kernels.hip and by oracle/check_log_table.c): entry i = {inv, logc} with
+    logc = -log(inv) to within 0.1 ulp (the generator picks reciprocals whose logarithm is nearly a double), inv within
+    1e-7 of 1 / the interval's midpoint, the interval around 1 exactly {1, 0} -- recomputed here with 50-digit arithmetic."""
+    import re
+    import struct
+    mpmath = pytest.importorskip("mpmath")
+    mpmath.mp.dps = 50
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "verifybamid_amd", "csrc", "log_table.inc")).read()
+    rows = [(float.fromhex(a), float.fromhex(b)) for a, b in re.findall(r"\{(\S+), (\S+)\}", text)]
+    assert len(rows) == 128
+    hi2d = lambda hi: struct.unpack("<d", struct.pack("<Q", hi << 32))[0]
+    for i, (inv, logc) in enumerate(rows):
+        lo, up = hi2d(0x3FE5F000 + i * 0x2000), hi2d(0x3FE5F000 + (i + 1) * 0x2000)
+        if lo < 1.0 < up:
+            assert (inv, logc) == (1.0, 0.0)
+            continue
+        assert abs(inv * (lo + up) / 2 - 1.0) < 1e-7, i
+        exact = -mpmath.log(mpmath.mpf(inv))
+        assert abs((mpmath.mpf(logc) - exact) / exact) < 0.1 * 2.0 ** -52, i
+        assert max(abs(lo * inv - 1.0), abs(up * inv - 1.0)) <= 2.0 ** -8 * (1 + 1e-5), i
+
+
+def test_device_log_restatement_is_within_an_ulp_and_a_half_of_libm():
+    """oracle/check_log_table.c: the statement sequence of the kernels' log_tab on the host against the C library's
+    long-double logarithm: (0, 1) uniformly, 1 - p for p down to 2^-34, every binade down to 2^-41, the intervals next to 1."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_check_log.bin")
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "check_log"], stdout=subprocess.DEVNULL)
+    p = subprocess.run([exe, "2000000"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "log_tab(1) = 0x0p+0" in p.stdout and "log_tab(0) = -inf" in p.stdout, p.stdout

@@ -177,6 +177,44 @@ __device__ __forceinline__ double log_nonneg(double x)
     return x == 0.0 ? -__builtin_huge_val() : res;
 }
 
+// log(x) for 0 <= x <= 1 and normal (the per-alpha table's entries: logarithms of probabilities), table-driven -- round 4,
+// second session: the six tables of a 48-point launch were 3.9 us of its 65 (the launch with the table build compiled out),
+// nearly all of it the fdlibm-style logarithm above: ~40 dependent instructions, with a reciprocal and two Newton steps.
+// Here: x = 2^k z, the interval i of z (seven mantissa bits after an offset that puts 1 INSIDE an interval) gives
+// {1 / c_i, log c_i} from a 2 KiB table in LDS; r = fma(z, 1/c, -1) is exact and |r| <= 2^-8;
+// log x = k ln2 + log c + (r + r^2 P(r)), P of degree 4.  ~22 instructions, none of them a transcendental.
+// The table and the polynomial: log_table.inc, generated with 60-digit arithmetic by tools/gen_log_table.py (the interval
+// around 1 has c = 1 exactly: log(1) = 0, and log(1 - p_err) -- most entries of a pileup's table -- keeps full relative
+// accuracy; the other reciprocals are chosen so that log c is a double to within 0.001 ulp).  oracle/check_log_table.c is
+// this routine statement for statement on the host, held to <= 1.6 ulp against the C library's long-double logarithm
+// (tests/test_oracle_golden.py; typical < 0.8, the 1.5 where k ln2 + log c sits a binade above the result).
+#include "log_table.inc"
+constexpr int kLogTabDoubles = 256;
+__device__ const double2 kLogTabRows[128] = {VB2_LOG_TAB_ROWS};
+__device__ __forceinline__ double log_tab(double x, uint32_t ltab_addr /* LDS byte address of the table's copy */)
+{
+    const double kLn2Hi = 0x1.62e42fefa3800p-1, kLn2Lo = 0x1.ef35793c76730p-45;
+    constexpr double kP[5] = {VB2_LOG_POLY};
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    const uint32_t tmp = hi - 0x3FE5F000u;
+    const uint32_t i = (tmp >> 13) & 127u;
+    const int k = (int)tmp >> 20;
+    const double z = __hiloint2double((int)(hi - (tmp & 0xFFF00000u)), __double2loint(x));
+    const vdouble2 t = *reinterpret_cast<lds_cdouble2*>(ltab_addr + i * 16u);
+    const double r = fma(z, t.x, -1.0);
+    const double kd = (double)k;
+    const double w = fma(kd, kLn2Hi, t.y);
+    const double r2 = r * r;
+    // (the polynomial in two halves and k ln2's low part next to r: five dependent steps behind r instead of seven)
+    const double q0 = fma(r, kP[1], kP[0]);
+    double q1 = fma(r, kP[3], kP[2]);
+    q1 = fma(r2, kP[4], q1);
+    const double p = fma(r2, q1, q0);
+    const double rl = fma(kd, kLn2Lo, r);
+    const double y = fma(r2, p, rl);
+    return x == 0.0 ? -__builtin_huge_val() : w + y;
+}
+
 // A positive value as (mantissa in [0.5,1), binary exponent): products of likelihoods are
 // kept in this form so that a marker's log is never taken -- one log per (workgroup, point)
 // replaces one per (marker, point).
@@ -201,7 +239,7 @@ constexpr int kLazyRenorm = 256;
 // One table entry, with the reference's expression order (h:223-225).
 // perr_signed = +pErr(q) for class ref, -pErr(q) for class alt (one load per code;
 // the alt class is the ref class with genotypes mirrored, g -> 2-g: h:164-177).
-__device__ __forceinline__ double table_entry(double alpha, double perr_signed, int g1, int g2)
+__device__ __forceinline__ double table_entry(double alpha, double perr_signed, int g1, int g2, uint32_t ltab_addr)
 {
     const bool alt = perr_signed < 0.0;
     const double p_err = fabs(perr_signed);
@@ -215,7 +253,11 @@ __device__ __forceinline__ double table_entry(double alpha, double perr_signed, 
     const double one_minus_alpha = 1.0 - alpha;
     const double val = (alpha * e1 + one_minus_alpha * e2) * p_err +
                        (alpha * n1 + one_minus_alpha * n2) * p_ok;
+#ifdef VB2_OLD_LOG        // (A/B: the fdlibm-style logarithm)
     return log_nonneg(val);
+#else
+    return log_tab(val, ltab_addr);
+#endif
 }
 
 __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
@@ -423,7 +465,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     const int NPT = NP * ngrp;                  // points of this launch
     constexpr int kEtabCopies = (1 << ESH) / 8, kEtabDoubles = 64 * kEtabCopies;
     double* etab = lds;                         // [64][32] exp_nonpos's 2^(j/64), bank-replicated; at LDS address 0
-    double* tab = lds + kEtabDoubles;           // [ngrp][nrow][RS]
+    double* ltab = lds + kEtabDoubles;          // [128] {1 / c, log c} of log_tab
+    double* tab = ltab + kLogTabDoubles;        // [ngrp][nrow][RS]
     double* red = tab + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
     unsigned int* queue = reinterpret_cast<unsigned int*>(red + NPT);
     double* pts = red + NPT + 2;                // [NPT][2k+1] this launch's parameter rows
@@ -481,6 +524,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // 2^(j/64) table of exp_nonpos, one copy per pair of LDS banks (see there)
     // (entry j = e / 32 is the same for a half-wave: two SCALAR loads per step, no vector-memory
     // round trip before the first barrier)
+    if (!hook.keep_etab() && tid < kLogTabDoubles / 2)
+        reinterpret_cast<double2*>(ltab)[tid] = kLogTabRows[tid];
     if (!hook.keep_etab())
         for (int jb = 2 * wave; jb < 64; jb += 2 * nwave) {
             const double t0 = kExp2Tab[jb], t1 = kExp2Tab[jb + 1];
@@ -510,6 +555,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // it into the alt twin's row: half the logarithms, and no barrier in between.
     // (a thread's entries for the different groups are independent: computed side by side so
     // that their long dependent logarithm chains overlap)
+    const uint32_t ltab_addr = lds_byte_addr(ltab);
 #ifdef VB2_ABL_NOTABLE   // (ablation build)
     for (int e = tid; e < 0; e += nthread) {
 #else
@@ -528,7 +574,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         for (int grp_e = 0; grp_e < kMaxGroups; ++grp_e)
             if (grp_e < ngrp)
                 v[grp_e] = table_entry(early_table ? lds_rows[(bb < num_valid ? bb : num_valid - 1) * stride + 2 * k]
-                                                   : pts[(grp_e * NP + bb) * stride + 2 * k], rec.x, g1, g2);
+                                                   : pts[(grp_e * NP + bb) * stride + 2 * k], rec.x, g1, g2, ltab_addr);
         // W16 (cohort steps on the 16-bit run lists): the run word's count field decodes to the double 2 * n with ONE
         // byte permute (see the read loop), so the table holds T / 2 -- both scalings are exact (powers of two), and
         // fma(2n, T/2, acc) rounds the same real number as fma(n, T, acc): bit-identical to the 32-bit lists.
@@ -1010,7 +1056,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
         // (one slot, one group: the table's address is the constant behind the exp table -- this file has no static LDS --
         // and the compiler folds it into the reads' immediate offsets)
-        const uint32_t my_tab_w16 = (SLOTS == 1 && ONEGRP) ? (uint32_t)(kEtabDoubles * sizeof(double)) : my_tab;
+        const uint32_t my_tab_w16 = (SLOTS == 1 && ONEGRP) ? (uint32_t)((kEtabDoubles + kLogTabDoubles) * sizeof(double)) : my_tab;
         while (!dyn && grp_wave < grp) {                     // wave-uniform
             flush_wave(grp_wave);
             ++grp_wave;
@@ -1961,7 +2007,7 @@ size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, i
     const size_t bytes = sizeof(double) * (G * (L.num_code + 1) * (size_t)(L.row_bytes / 8) + G * NP + 2 +
                                            G * NP * (2 * L.num_pc + 1) + 1 + G * NP * 2 * L.num_pc +
                                            1 + 2 * (size_t)L.num_prim +
-                                           (size_t)exp_tab_doubles + 2 * slots * NP);
+                                           (size_t)exp_tab_doubles + (size_t)kLogTabDoubles + 2 * slots * NP);
     // workgroup 0 stages every workgroup's partial sums ([points][workgroups]) over the dead table
     const size_t stage = sizeof(double) * G * NP * (size_t)nblk;
     return bytes > stage ? bytes : stage;
