@@ -132,10 +132,12 @@ __device__ __forceinline__ double exp_nonpos(double x, uint32_t etab_lane)
     // (the table sits at LDS address 0 and etab_lane < 256, so the index bits are OR-ed in:
     // one v_lshlrev + one v_and_or)
     const double t = *reinterpret_cast<lds_cdouble*>((((uint32_t)k << ESH) & (63u << ESH)) | etab_lane);
-    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
+    // exp(r) - 1 = r + r^2 q(r), q of degree 3 through the Chebyshev nodes of |r| <= ln2/128 (60-digit arithmetic; relative error
+    // of exp 4.4e-18): one multiply-add less than the degree-6 Taylor form of rounds 1-3, worst error against expl over
+    // [-700, 0] 1.02 ulp (Taylor: 1.00) -- six of a marker x point's ~370 instructions
+    double p = fma(r, 0x1.11111d8fbe766p-7, 0x1.55556b3304ec0p-5);
+    p = fma(p, r, 0x1.5555555555255p-3);
+    p = fma(p, r, 0x1.ffffffffff57fp-2);
     p = fma(p, r * r, r);
     return ldexp(fma(t, p, t), k >> 6);
 }
