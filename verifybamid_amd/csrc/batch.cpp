@@ -69,14 +69,31 @@ bool cohort_w16_enabled()
 }
 void set_cohort_w16(bool on) { g_cohort_w16.store(on ? 1 : 0); }
 
+// Waves per workgroup of a cohort step (round 4, third part): EIGHT, and twice as many workgroups per sample, instead of
+// sixteen.  A search runs its samples as two lanes whose steps take turns; with 1 024-thread workgroups a lane's launch fills
+// the CUs' wave slots by itself and the other lane's launch overlaps only with its tail, with 512-thread workgroups two
+// workgroups of DIFFERENT launches share a CU and one lane's table builds, barriers and hand-off run under the other's
+// streaming: search only 1.356 -> 1.243 ms per sample (737 -> 801 samples/s) on the same box; a synchronous step alone
+// takes what it took (75.5 / 105 us).  VB2_COHORT_BW=16 restores the big workgroups (4 and 8 are the other values).
+int cohort_waves()
+{
+    static const int v = [] {
+        const int k = std::getenv("VB2_COHORT_BW") ? std::atoi(std::getenv("VB2_COHORT_BW")) : 8;
+        return (k == 4 || k == 8 || k == 16) ? k : 8;
+    }();
+    return v;
+}
+
 void Batch::geometry(int num_cu, int num_sample, int max_mt, int num_pc, int bps_in, int* bps, int* block_waves)
 {
     // ~one workgroup per CU in total; the waves of a workgroup: one per tile it owns, 1024 threads at most, and enough
     // of them to stage a step's parameter rows
-    *bps = bps_in > 0 ? bps_in : std::max(1, num_cu / std::max(1, num_sample));
+    const int max_bw = cohort_waves();
+    const int wg_total = num_cu * kMaxBlockWaves / max_bw;
+    *bps = bps_in > 0 ? bps_in * (kMaxBlockWaves / max_bw) : std::max(1, wg_total / std::max(1, num_sample));
     const int tiles_per_block = (max_mt + *bps - 1) / *bps;
     const int min_bw = std::max(4, (kSlot * (2 * num_pc + 1) + 127) / 128);
-    *block_waves = std::max(min_bw, std::min(kMaxBlockWaves, tiles_per_block));
+    *block_waves = std::max(min_bw, std::min(max_bw, tiles_per_block));
 }
 
 int Batch::regroup_bps(int num_cu, int active)
@@ -193,8 +210,8 @@ int Batch::create_slots(int capacity, int device, int num_pc, int num_cu, Batch*
     none.row_bytes = kRowBytesWide;
     none.num_cu = num_cu;
     b->layouts_.assign(capacity, none);
-    b->bps_ = std::max(1, num_cu / capacity);
-    b->block_waves_ = kMaxBlockWaves;         // whatever the samples: a sample's sums must not depend on its neighbours
+    b->bps_ = std::max(1, num_cu * (kMaxBlockWaves / cohort_waves()) / capacity);
+    b->block_waves_ = cohort_waves();         // whatever the samples: a sample's sums must not depend on its neighbours
     *out = b.release();
     return VB2_OK;
 }
@@ -805,7 +822,7 @@ int prepare_for_stream(Context* c, int capacity)
     Schedule sc[Batch::kShapes];
     for (int l = 0; l < 2; ++l) {
         if (n[l] <= 0 || (l == 1 && n[1] == n[0])) continue;
-        if (const int rc = c->cohort_schedules(std::max(1, c->L.num_cu / n[l]), kMaxBlockWaves, sc, false)) return rc;
+        if (const int rc = c->cohort_schedules(std::max(1, c->L.num_cu * (kMaxBlockWaves / cohort_waves()) / n[l]), cohort_waves(), sc, false)) return rc;
     }
     return VB2_OK;
 }

@@ -12,6 +12,7 @@
 
 namespace vb2 {
 
+int cohort_waves();                   // waves per workgroup of a cohort step: 8 (VB2_COHORT_BW=16|8|4)
 bool cohort_w16_enabled();            // cohort steps stream the 16-bit run lists (default; VB2_COHORT_W16=0 turns it off)
 void set_cohort_w16(bool on);
 
