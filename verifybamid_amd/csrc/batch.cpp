@@ -592,20 +592,22 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     if (const char* e = std::getenv("VB2_COHORT_SPLIT")) split = std::atoi(e) != 0 && num_sample >= 2;
 
     const int S = num_sample, k = num_pc;
-    Lane lanes[2];
+    Lane lanes[kMaxLanes];
     int nlane = 1;
     if (split) {
-        const int cut = S / 2;
-        for (int h = 0; h < 2; ++h)
-            if (!half_[h]) {
-                std::vector<Context*> part(ctx_.begin() + (h ? cut : 0), h ? ctx_.end() : ctx_.begin() + cut);
+        // (VB2_COHORT_LANES=n, an experiment knob: n lanes taking turns instead of two)
+        static const int lanes_knob = std::getenv("VB2_COHORT_LANES") ? std::atoi(std::getenv("VB2_COHORT_LANES")) : 2;
+        nlane = std::max(2, std::min(std::min(kMaxLanes, lanes_knob), S));
+        for (int h = 0; h < nlane; ++h) {
+            const int lo = (int)((long)S * h / nlane), hi = (int)((long)S * (h + 1) / nlane);
+            if (!half_[h] || half_[h]->num_sample != hi - lo) {
+                std::vector<Context*> part(ctx_.begin() + lo, ctx_.begin() + hi);
                 Batch* hb = nullptr;
                 if (const int rc = Batch::create(part, &hb)) return rc;
                 half_[h].reset(hb);
             }
-        nlane = 2;
-        lanes[0].batch = half_[0].get(); lanes[0].base = 0;   lanes[0].count = cut;
-        lanes[1].batch = half_[1].get(); lanes[1].base = cut; lanes[1].count = S - cut;
+            lanes[h].batch = half_[h].get(); lanes[h].base = lo; lanes[h].count = hi - lo;
+        }
     } else {
         lanes[0].batch = this; lanes[0].base = 0; lanes[0].count = S;
     }

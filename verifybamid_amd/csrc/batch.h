@@ -93,7 +93,8 @@ private:
     int flight_np_ = 0;
     double* flight_out_ = nullptr;
     // optimize() of a big cohort: two half-cohorts taking turns on the device (see batch.cpp)
-    std::unique_ptr<Batch> half_[2];
+    static constexpr int kMaxLanes = 4;
+    std::unique_ptr<Batch> half_[kMaxLanes];
     int optimize_range(const vb2_model* models, int num_model, vb2_estimate* out);
 };
 
