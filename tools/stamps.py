@@ -27,4 +27,12 @@ print("blocks with stamps:", len(s), "B =", B)
 for i, n in enumerate(names):
     col = us[:, i][s[:, i] > 0]
     if len(col): print("%-24s min %6.2f  median %6.2f  max %6.2f us" % (n, col.min(), np.median(col), col.max()))
+if os.environ.get("VB2_STAMPS_DETAIL"):
+    t4 = us[:, 4]
+    print("last wave done, median by workgroup index mod 8 (XCD): " + " ".join("%.2f" % np.median(t4[x::8]) for x in range(8)))
+    print("   by index mod 16: " + " ".join("%.1f" % np.median(t4[x::16]) for x in range(16)))
+    print("   by index // 32:  " + " ".join("%.2f" % np.median(t4[32 * x:32 * x + 32]) for x in range(8)))
+    order = np.argsort(-t4)
+    print("   slowest: " + ", ".join("%d: %.1f" % (i, t4[i]) for i in order[:16]))
+    print("   fastest: " + ", ".join("%d: %.1f" % (i, t4[i]) for i in order[-16:]))
 ctx.close()
