@@ -584,6 +584,41 @@ print(json.dumps(out))
     assert len(set(res[0])) == len(res[0])                 # (six different inputs, six different digests)
 
 
+def test_run_scheduling_only_reorders_the_runs_of_a_marker():
+    """Wide quality alphabets: a tile's runs are placed by schedule_tile (tile_sched.h) instead of in dictionary order.  The
+    flatten's digest with the run words taken as a per-marker multiset (VB2_DIGEST_CODES=multiset) is the same with the
+    scheduling on and off -- every run of every marker is still there, once, next to the same padding -- while the plain digest
+    differs (the order did change); a narrow alphabet is left alone either way."""
+    import json
+    import subprocess
+    import sys
+    code = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import verifybamid_amd as vb
+sys.path.insert(0, %r)
+from test_abi_and_host import _flatten_digest
+print(json.dumps([_flatten_digest(vb.synth.make_pileup(3000, 30, 2, seed=6, q_lo=2, q_hi=93)),
+                  _flatten_digest(vb.synth.make_pileup(2000, 30, 4, seed=12, q_lo=2, q_hi=60)),
+                  _flatten_digest(vb.synth.make_pileup(1500, 80, 2, seed=13, q_lo=5, q_hi=70)),
+                  _flatten_digest(vb.synth.make_pileup(3000, 30, 4, seed=5))]))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for sched in ("0", "1"):
+        for mode in ("bytes", "multiset"):
+            env = dict(os.environ, VB2_RUN_SCHED=sched, VB2_DIGEST_CODES=mode)
+            if sched == "1":
+                del env["VB2_RUN_SCHED"]                   # (the default: scheduled above 48 codes)
+            p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-2000:]
+            res[sched, mode] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["0", "multiset"] == res["1", "multiset"]
+    for i in range(3):
+        assert res["0", "bytes"][i] != res["1", "bytes"][i], i     # wide alphabets: the order changed
+    assert res["0", "bytes"][3] == res["1", "bytes"][3]            # 42 codes: plain order either way
+
+
 def _tiny_panel(pre):
     open(pre + ".bed", "w").write("1\t0\t1\tA\tC\n1\t9\t10\tG\tT\n")
     open(pre + ".UD", "w").write("0.5 0.25\n-0.5 0.125\n")

@@ -858,7 +858,23 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             const unsigned char* q = static_cast<const unsigned char*>(ptr);
             for (size_t i = 0; i < bytes; ++i) hsh = (hsh ^ q[i]) * 1099511628211ull;
         };
-        mix(codes, n_codes * sizeof(uint32_t));
+        // (VB2_DIGEST_CODES=multiset, a test aid: the run words enter as a SUM of word hashes per micro-tile -- the same for
+        // any order of a tile's words: what schedule_tile may change and nothing else)
+        static const bool codes_as_multiset = std::getenv("VB2_DIGEST_CODES") && !std::strcmp(std::getenv("VB2_DIGEST_CODES"), "multiset");
+        if (codes_as_multiset) {
+            for (int t = 0; t < num_mt; ++t) {
+                uint64_t sum = 0;
+                const uint32_t* w = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
+                for (size_t j = 0; j < (size_t)mt_rows[t] * kMtMarkers * 2; ++j) {
+                    // (per lane: the lane index enters, so words may move between steps but not between markers)
+                    const uint64_t x = ((uint64_t)((j >> 1) % kMtMarkers) << 32 | w[j]) * 0x9E3779B97F4A7C15ull;
+                    sum += x ^ (x >> 29);
+                }
+                mix(&sum, sizeof(sum));
+            }
+        } else {
+            mix(codes, n_codes * sizeof(uint32_t));
+        }
         mix(mt_rec, (size_t)num_mt * sizeof(uint2));
         if (in->known_af) mix(kaf_s, (size_t)m_pad * sizeof(double));
         else { mix(ud_s, (size_t)k * m_pad * sizeof(double)); mix(mu_s, (size_t)m_pad * sizeof(double)); }
