@@ -1412,12 +1412,16 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     unsigned long long* pw = reinterpret_cast<unsigned long long*>(partials);
     if (wave == 0) {
         const unsigned long long bits = lane < NPT ? (unsigned long long)__double_as_longlong(red[lane]) : 0ull;
-        unsigned long long x = lane < NPT ? word_hash(bits, (unsigned)lane) : 0ull;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off, 64);
+        // (the sums first: they do not wait for the check word; then the check word from lane 0, which has the XOR of the
+        // NPT word hashes after log2(NPT) exchange steps -- a search round's four words: two quad permutes -- instead of a
+        // 64-lane butterfly of six: the check word is what workgroup 0 waits for)
         if (lane < NPT)
             __hip_atomic_store(&pw[(size_t)lane * nblk + blk], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == NPT)
+        unsigned long long x = lane < NPT ? word_hash(bits, (unsigned)lane) : 0ull;
+        int top = 1;
+        while (top < NPT) top <<= 1;
+        for (int off = top >> 1; off >= 1; off >>= 1) x ^= __shfl_xor(x, off, 64);
+        if (lane == 0)
             __hip_atomic_store(&pw[(size_t)NPT * nblk + blk], x ^ resident_mix(tag), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
