@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include <vector>
 
 namespace vb2 {
@@ -50,11 +51,46 @@ __device__ __forceinline__ void pair_of(int p, int& g1, int& g2)
     g2 = lo + (lo >= g1 ? 1 : 0);
 }
 
+// v[i] + v[i ^ 32], then ^ 16, 8, 4, 2, 1: the butterfly every final sum of partial LLKs goes through (the order is part of the
+// result's bits).  Round 4: without ds_bpermute -- gfx950's v_permlane32_swap / v_permlane16_swap bring the other half / the
+// other row next to a lane's own value (x + y = y + x: which of the two registers holds the lane's own does not matter), the
+// distances 8 .. 1 are DPP moves inside a row.  The same additions in the same order: the same bits; a search round waits for
+// this once (workgroup 0's four sums), a cross-lane LDS round trip per step before.
 __device__ __forceinline__ double wave_sum(double v)
 {
+#ifdef VB2_OLD_WAVE_SUM
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+#else
+    {
+        const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    {
+        const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    auto dpp = [](double x, auto ctrl) -> double {
+        constexpr int kCtrl = decltype(ctrl)::value;
+        return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), kCtrl, 0xf, 0xf, false),
+                                __builtin_amdgcn_update_dpp(0, __double2loint(x), kCtrl, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0x128>());                       // row_ror:8   -> lane i ^ 8
+    {                                                                        // lane i ^ 4: quads 1, 3 <- i - 4, quads 0, 2 <- i + 4
+        const int hi = __double2hiint(v), lo = __double2loint(v);
+        const int h1 = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xa, false), l1 = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xa, false);
+        const int h2 = __builtin_amdgcn_update_dpp(h1, hi, 0x12C, 0xf, 0x5, false), l2 = __builtin_amdgcn_update_dpp(l1, lo, 0x12C, 0xf, 0x5, false);
+        v += __hiloint2double(h2, l2);
+    }
+    v += dpp(v, std::integral_constant<int, 0x4E>());                        // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0xB1>());                        // quad_perm [1,0,3,2]
+    return v;
+#endif
 }
 
 // 2^(j/64), j = 0..63, correctly rounded (generated with 60-digit decimal arithmetic).
