@@ -366,12 +366,24 @@ __device__ __forceinline__ int lane_xchg_i32(int x, int off, int partner)
         const int a = __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0x5, false);       // row_ror:4  -> quads 0 and 2 of every row
         return __builtin_amdgcn_update_dpp(a, x, 0x12C, 0xf, 0xa, false);              // row_ror:12 -> quads 1 and 3
     }
+    // HW8 (-DVB2_DPP_XCHG=3; the hardware lane map, off = 8): marker bit 3 selects between the two 16-lane rows of a 32-lane half,
+    // quad position p of row 0 <-> position p ^ 1 of row 1 (ranks 0,1 sit in row 0, ranks 2,3 in row 1).  The exchange over
+    // 8 is the FIRST of the four and only the lanes of markers 0..7 -- row 0 -- are read afterwards (the product ends in
+    // marker 0's lane), so a one-way move is enough: lane ^ 4 by two masked row rotations, then gfx950's v_permlane16_swap
+    // brings row 1 down to row 0.  Three VALU moves per dword instead of a ds_bpermute.  Rows 1 and 3 hold no product after it.
+    // MEASURED AND DROPPED (bit-identical): 48-point launch 62.27 -> 62.62 us, OptimizeLLK 5.89 -> 6.06 ms -- eighteen VALU moves
+    // per item cost more than the six ds_bpermutes they replace; the default stays 2.
+    if (VB2_DPP_XCHG >= 3 && HW4 && off == 8) {
+        const int a = __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xa, false);       // row_ror:4  -> quads 1 and 3 <- lane - 4
+        const int y = __builtin_amdgcn_update_dpp(a, x, 0x12C, 0xf, 0x5, false);       // row_ror:12 -> quads 0 and 2 <- lane + 4
+        return (int)__builtin_amdgcn_permlane16_swap((unsigned)y, (unsigned)y, false, false)[1];
+    }
     return __shfl(x, partner, 64);
 }
 template <bool HW4 = false>
 __device__ __forceinline__ double lane_xchg_f64(double x, int off, int partner)
 {
-    if (VB2_DPP_XCHG && (off == 1 || off == 2 || (VB2_DPP_XCHG >= 2 && HW4 && off == 4)))
+    if (VB2_DPP_XCHG && (off == 1 || off == 2 || (VB2_DPP_XCHG >= 2 && HW4 && off == 4) || (VB2_DPP_XCHG >= 3 && HW4 && off == 8)))
         return __hiloint2double(lane_xchg_i32<HW4>(__double2hiint(x), off, partner), lane_xchg_i32<HW4>(__double2loint(x), off, partner));
     return __shfl(x, partner, 64);
 }
