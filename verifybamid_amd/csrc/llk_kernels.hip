@@ -25,7 +25,7 @@
 //     same depth mix, and pulled by the waves of a workgroup through an LDS work queue;
 //   * deterministic reduction: 16-lane butterfly -> work-item slots -> per-workgroup partial;
 //     the partials cross workgroups inside the launch, either collected by workgroup 0 from
-//     tagged, self-validating sets (<= 4 points, cohorts, resident search) or summed by the last
+//     tagged, self-validating sets (<= 16 points, cohorts, resident search) or summed by the last
 //     workgroup to arrive at an agent-scope ticket (bigger batches), always in the same fixed
 //     order (or, two-kernel mode, by llk_finalize_kernel);
 //   * llk_resident_kernel keeps the same body on the CUs for a whole Nelder-Mead search and
