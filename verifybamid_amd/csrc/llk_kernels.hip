@@ -750,7 +750,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     if (stamps && hook_mine && lane == 0) stamps[3] = wall_clock64();
 #endif
 #ifndef VB2_PF_M2
-#define VB2_PF_M2 4
+#define VB2_PF_M2 2
 #endif
 #ifndef VB2_PF_SEARCH
 #define VB2_PF_SEARCH 2
