@@ -314,6 +314,10 @@ def main():
             "hbm_actual_GBps": (traffic / (step_us * 1e-6) / 1e9) if traffic else None,
             "binding_ceiling": "FP64 VALU issue (see valu), not HBM: the 10 MB pileup is read once per launch "
                                "and re-used from L2/LDS by every point",
+            "frac_note": "frac is quoted against the NOMINAL roofline of SURVEY 8d (algorithmic bytes per evaluation x points / "
+                         "time / 8 TB/s) and can pass 1: the 48 points of a launch are served by one L2/LDS-resident copy of the "
+                         "pileup; the HBM side moves `traffic` bytes per launch (`hbm_actual_GBps`); valu_frac is the fraction "
+                         "of the ceiling that binds",
             "valu": valu, "mfma_util": 0.0,
             "mfma_note": "no MFMA instruction on the path: FP64 MFMA and FP64 VALU share the unit on gfx950 "
                          "(profiles/r01/ubench_mfma_overlap.txt), and the UD x PC projection is 2k FMAs per marker",
