@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VB2_ABI_VERSION 5
+#define VB2_ABI_VERSION 6
 
 typedef enum vb2_status {
     VB2_OK = 0,
@@ -300,6 +300,17 @@ void vb2_shard_group_destroy(vb2_shard_group *g);
  *    (main.cpp:283-411): panel + pileup readers, sanity check, OptimizeLLK,
  *    <out>.Ancestry and <out>.selfSM writers.
  * ------------------------------------------------------------------------- */
+typedef struct vb2_mpileup_opts {
+    int32_t given;             /* 0: every field below is ignored, the defaults of main.cpp:81-96 apply */
+    int32_t min_bq;            /* --min-BQ      skip bases with baseQ/BAQ below it         (13)   */
+    int32_t min_mq;            /* --min-MQ      skip alignments with mapQ below it         (2)    */
+    int32_t adjust_mq;         /* --adjust-MQ   mapQ cap coefficient, 0 disables           (40)   */
+    int32_t max_depth;         /* --max-depth   per-file depth cap                         (8000) */
+    int32_t no_orphans;        /* --no-orphans  drop anomalous read pairs                  (0)    */
+    int32_t incl_flags;        /* --incl-flags  the reference stores this in mplp.flag     (REALN | SMART_OVERLAPS) */
+    int32_t excl_flags;        /* --excl-flags  skip reads with any of these bits set      (UNMAP|SECONDARY|QCFAIL|DUP) */
+} vb2_mpileup_opts;
+
 typedef struct vb2_run_args {
     const char *ud_path;       /* <SVDPrefix>.UD   (main.cpp:229)                  */
     const char *mean_path;     /* <SVDPrefix>.mu                                   */
@@ -325,6 +336,10 @@ typedef struct vb2_run_args {
     /* --NumStart / --Seed / --LineSearch: optimiser variants (vb2_search_opts); all zero = the
      * reference's single Nelder-Mead run.  One sample on one device only. */
     vb2_search_opts search;
+    /* (ABI 6) The reference's "Pileup Options" (main.cpp:176-187; defaults main.cpp:81-96): they shape what
+     * --BamFile input turns into pileup columns (SimplePileupViewer.cpp:172-237, 457-476) and have no effect on
+     * --PileupFile input, exactly as in the reference.  given == 0: the defaults. */
+    vb2_mpileup_opts mpileup;
 } vb2_run_args;
 
 typedef struct vb2_run_result {

@@ -34,7 +34,7 @@ def test_header_symbols_exported():
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vb2_abi_version() == 5
+    assert lib.vb2_abi_version() == 6
 
 
 def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
@@ -43,7 +43,8 @@ def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
     import subprocess
     src = tmp_path / "abi_check.c"
     names = ["vb2_input", "vb2_options", "vb2_info", "vb2_model", "vb2_estimate", "vb2_trace",
-             "vb2_run_args", "vb2_run_result", "vb2_cohort_args", "vb2_shard_info", "vb2_search_opts"]
+             "vb2_run_args", "vb2_run_result", "vb2_cohort_args", "vb2_shard_info", "vb2_search_opts",
+             "vb2_mpileup_opts"]
     src.write_text('#include <stdio.h>\n#include "vb2_abi.h"\nint main(void) {\n' +
                    "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) +
                    "  return 0;\n}\n")
@@ -55,7 +56,7 @@ def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
     binding = dict(vb2_input=_abi.Input, vb2_options=_abi.Options, vb2_info=_abi.Info, vb2_model=_abi.Model,
                    vb2_estimate=_abi.Estimate, vb2_trace=_abi.Trace, vb2_run_args=_abi.RunArgs,
                    vb2_run_result=_abi.RunResult, vb2_cohort_args=_abi.CohortArgs, vb2_shard_info=_abi.ShardInfo,
-                   vb2_search_opts=_abi.SearchOpts)
+                   vb2_search_opts=_abi.SearchOpts, vb2_mpileup_opts=_abi.MpileupOpts)
     for n, cls in binding.items():
         assert int(sizes[n]) == C.sizeof(cls), (n, sizes[n], C.sizeof(cls))
 
@@ -90,6 +91,26 @@ def test_bam_input_without_htslib_fails_loudly(tmp_path):
     rc = _abi.lib().vb2_flat_load(C.byref(args), C.byref(h))
     assert rc == _abi.VB2_ERR_IO
     assert b"htslib" in _abi.lib().vb2_last_error()
+
+
+def test_cli_knows_the_references_pileup_options(tmp_path):
+    """The reference's seven "Pileup Options" (main.cpp:176-187: --min-BQ --min-MQ --adjust-MQ --max-depth
+    --no-orphans --incl-flags --excl-flags) are flags of the command line: a drop-in --BamFile command line
+    fails with the htslib explanation (this build has no BAM reader), never with "unknown option ... ignored";
+    a repeated one is the reference's "specified more than once" error."""
+    import subprocess
+    exe = os.path.join(ROOT, "verifybamid_amd", "bin", "VerifyBamID")
+    pre = str(tmp_path / "q")
+    _tiny_panel(pre)
+    cmd = [exe, "--SVDPrefix", pre, "--BamFile", "/nonexistent/sample.bam", "--Reference", "/nonexistent/ref.fa",
+           "--min-BQ", "20", "--min-MQ", "10", "--adjust-MQ", "50", "--max-depth", "500", "--no-orphans",
+           "--incl-flags", "16", "--excl-flags", "1796", "--Output", str(tmp_path / "out")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "htslib" in r.stderr, r.stderr
+    assert "unknown option" not in r.stderr, r.stderr
+    r2 = subprocess.run(cmd + ["--min-BQ", "3"], capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "specified more than once" in r2.stderr, r2.stderr
 
 
 def test_no_device_fails_loudly():

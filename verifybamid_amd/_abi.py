@@ -74,6 +74,11 @@ class Trace(C.Structure):
     ]
 
 
+class MpileupOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("given", "min_bq", "min_mq", "adjust_mq", "max_depth", "no_orphans",
+                                          "incl_flags", "excl_flags")]
+
+
 class RunArgs(C.Structure):
     _fields_ = [
         ("ud_path", C.c_char_p), ("mean_path", C.c_char_p), ("bed_path", C.c_char_p),
@@ -82,6 +87,7 @@ class RunArgs(C.Structure):
         ("device", C.c_int32), ("model", Model),
         ("devices", C.POINTER(C.c_int32)), ("num_device", C.c_int32), ("reserved", C.c_int32),
         ("bam_path", C.c_char_p), ("reference_path", C.c_char_p), ("search", SearchOpts),
+        ("mpileup", MpileupOpts),
     ]
 
 

@@ -712,7 +712,7 @@ int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
         if (!rc) {
             rc_pile = a->pileup_path ? vb2::read_pileup(a->pileup_path, f->panel, &f->viewer)
                                      : vb2::read_bam(a->bam_path, a->reference_path ? a->reference_path : "",
-                                                     f->panel, &f->viewer);
+                                                     f->panel, &f->viewer, &a->mpileup);
             if (rc_pile) err_pile = vb2::g_last_error;
         }
         tl_pile = now_s();

@@ -47,10 +47,27 @@
 namespace vb2 {
 namespace {
 
+// the reference's mode bits of mplp.flag (SimplePileupViewer.h:14-24) -- `--incl-flags` stores its value THERE
+// (main.cpp:185-186), not in a required-read-flags mask: kept
+constexpr int kMplpNoOrphan = 1 << 3, kMplpRealn = 1 << 4, kMplpIllumina13 = 1 << 7, kMplpRedoBaq = 1 << 6,
+              kMplpSmartOverlaps = 1 << 10;
+
 struct MplpConf {                      // main.cpp:81-96
     int min_mq = 2, min_baseQ = 13, capQ_thres = 40, max_depth = 8000;
-    bool realn = true, smart_overlaps = true;
+    int flag = kMplpRealn | kMplpSmartOverlaps;
     uint32_t rflag_filter = BAM_FUNMAP | BAM_FSECONDARY | BAM_FQCFAIL | BAM_FDUP;
+    void apply(const vb2_mpileup_opts* mp)      // main.cpp:176-187, 208-211
+    {
+        if (!mp || !mp->given) return;
+        min_baseQ = mp->min_bq;
+        min_mq = mp->min_mq;
+        capQ_thres = mp->adjust_mq;
+        max_depth = mp->max_depth;
+        flag = mp->incl_flags;
+        if (mp->no_orphans) flag |= kMplpNoOrphan;
+        else flag &= ~kMplpNoOrphan;
+        rflag_filter = (uint32_t)mp->excl_flags;
+    }
 };
 
 struct Aux {
@@ -87,15 +104,21 @@ int next_read(void* data, bam1_t* b)
         if (ret < 0) break;
         if (b->core.tid < 0 || (b->core.flag & BAM_FUNMAP)) continue;
         if (a->conf.rflag_filter & b->core.flag) continue;
+        if (a->conf.flag & kMplpIllumina13) {                          // SimplePileupViewer.cpp:203-208
+            uint8_t* qual = bam_get_qual(b);
+            for (int i = 0; i < b->core.l_qseq; ++i) qual[i] = qual[i] > 31 ? qual[i] - 31 : 0;
+        }
         const bool has_ref = fetch_ref(a, b->core.tid);
         if (has_ref && a->ref_len <= b->core.pos) continue;            // read outside the reference sequence
-        if (has_ref && a->conf.realn) sam_prob_realn(b, a->ref, a->ref_len, 3);     // BAQ
+        if (has_ref && (a->conf.flag & kMplpRealn))                    // BAQ
+            sam_prob_realn(b, a->ref, a->ref_len, (a->conf.flag & kMplpRedoBaq) ? 7 : 3);
         if (has_ref && a->conf.capQ_thres > 10) {
             const int q = sam_cap_mapq(b, a->ref, a->ref_len, a->conf.capQ_thres);
             if (q < 0) continue;
             if (b->core.qual > q) b->core.qual = (uint8_t)q;
         }
         if (b->core.qual < a->conf.min_mq) continue;
+        if ((a->conf.flag & kMplpNoOrphan) && (b->core.flag & BAM_FPAIRED) && !(b->core.flag & BAM_FPROPER_PAIR)) continue;
         break;
     }
     return ret;
@@ -121,9 +144,11 @@ std::string sample_name(sam_hdr_t* hdr)     // @RG SM: (SimplePileupViewer.cpp:2
 
 }  // namespace
 
-int read_bam(const std::string& bam_path, const std::string& ref_path, const Panel& panel, PileupViewer* v)
+int read_bam(const std::string& bam_path, const std::string& ref_path, const Panel& panel, PileupViewer* v,
+             const vb2_mpileup_opts* mp)
 {
     Aux a;
+    a.conf.apply(mp);
     hts_idx_t* idx = nullptr;
     struct Cleanup {                       // every exit path releases what was opened so far
         Aux& a;
@@ -170,7 +195,7 @@ int read_bam(const std::string& bam_path, const std::string& ref_path, const Pan
         if (a.iter) {
             bam_plp_t plp = bam_plp_init(next_read, &a);
             bam_plp_set_maxcnt(plp, a.conf.max_depth);
-            if (a.conf.smart_overlaps) bam_plp_init_overlaps(plp);
+            if (a.conf.flag & kMplpSmartOverlaps) bam_plp_init_overlaps(plp);
             int ptid, ppos, n;
             const bam_pileup1_t* pl;
             while ((pl = bam_plp_auto(plp, &ptid, &ppos, &n)) != nullptr) {
@@ -220,7 +245,7 @@ bool bam_support() { return true; }
 
 namespace vb2 {
 
-int read_bam(const std::string&, const std::string&, const Panel&, PileupViewer*)
+int read_bam(const std::string&, const std::string&, const Panel&, PileupViewer*, const vb2_mpileup_opts*)
 {
     set_error("--BamFile needs htslib, which this build does not have (configure with CMake where libhts is "
               "installed); run the reference once with --OutputPileup and pass the result with --PileupFile");

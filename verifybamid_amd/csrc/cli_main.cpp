@@ -5,6 +5,8 @@
 //               [--WithinAncestry] [--FixPC a:b:..] [--FixAlpha x] [--KnownAF f]
 //               [--Epsilon e] [--DisableSanityCheck] [--OutputPileup] [--Verbose]
 //               [--NumThread n] [--Seed s]      (+ deprecated --UDPath/--MeanPath/--BedPath)
+//               [--min-BQ n] [--min-MQ n] [--adjust-MQ n] [--max-depth n] [--no-orphans]
+//               [--incl-flags n] [--excl-flags n]      (the reference's "Pileup Options", main.cpp:176-187: --BamFile only)
 //
 // --BamFile needs a build with htslib (CMake finds it: bam_flatten.cpp); a build without it --
 // this image's -- reports that and suggests the reference's own --OutputPileup file with --PileupFile.
@@ -54,6 +56,10 @@ int main(int argc, char** argv)
     bool withinAncestry = false, outputPileup = false, verbose = false, disableSanityCheck = false;
     int seed = 12345, nPC = 2, nthread = 4, device = -1, numStart = 1;
     bool lineSearch = false;
+    // "Pileup Options" (main.cpp:176-187), defaults main.cpp:81-96 (MPLP_REALN | MPLP_SMART_OVERLAPS; UNMAP | SECONDARY |
+    // QCFAIL | DUP): they shape what --BamFile input becomes and, as in the reference, do nothing to --PileupFile input
+    int minBQ = 13, minMQ = 2, adjustMQ = 40, maxDepth = 8000, inclFlags = (1 << 4) | (1 << 10), exclFlags = 0x4 | 0x100 | 0x200 | 0x400;
+    bool noOrphans = false;
 
     std::map<std::string, Flag> flags = {
         {"BamFile", {Flag::kString, &BamFile, false}},
@@ -75,6 +81,13 @@ int main(int argc, char** argv)
         {"UDPath", {Flag::kString, &UDPath, false}},
         {"MeanPath", {Flag::kString, &MeanPath, false}},
         {"BedPath", {Flag::kString, &BedPath, false}},
+        {"min-BQ", {Flag::kInt, &minBQ, false}},
+        {"min-MQ", {Flag::kInt, &minMQ, false}},
+        {"adjust-MQ", {Flag::kInt, &adjustMQ, false}},
+        {"max-depth", {Flag::kInt, &maxDepth, false}},
+        {"no-orphans", {Flag::kBool, &noOrphans, false}},
+        {"incl-flags", {Flag::kInt, &inclFlags, false}},
+        {"excl-flags", {Flag::kInt, &exclFlags, false}},
         {"Device", {Flag::kInt, &device, false}},
         {"Devices", {Flag::kString, &Devices, false}},
         // not in the reference: a cohort against one panel.  File of lines "<pileup>\t<output prefix>";
@@ -165,6 +178,18 @@ int main(int argc, char** argv)
         args.num_device = (int32_t)devs.size();
         args.device = devs[0];
     }
+    static const char* const kPileupOpts[] = {"min-BQ", "min-MQ", "adjust-MQ", "max-depth", "no-orphans", "incl-flags", "excl-flags"};
+    for (const char* name : kPileupOpts) args.mpileup.given |= flags[name].seen ? 1 : 0;
+    args.mpileup.min_bq = minBQ;
+    args.mpileup.min_mq = minMQ;
+    args.mpileup.adjust_mq = adjustMQ;
+    args.mpileup.max_depth = maxDepth;
+    args.mpileup.no_orphans = noOrphans ? 1 : 0;
+    args.mpileup.incl_flags = inclFlags;
+    args.mpileup.excl_flags = exclFlags;
+    if (args.mpileup.given && BamFile == "Empty")
+        std::fprintf(stderr, "NOTICE - pileup options (--min-BQ, --min-MQ, ...) apply to --BamFile input only; "
+                             "the text pileup is taken as it is (as in the reference)\n");
     args.model.is_heter = !withinAncestry;
     args.model.epsilon = epsilon;
     args.model.verbose = verbose;

@@ -292,7 +292,7 @@ private:
             if (stream_ && !(slots_[s].rc == VB2_OK && slots_[s].ctx)) {
                 // never reaches the search: reported here (the pipeline thread may be waiting for this device's last sample)
                 status_[s] = slots_[s].rc ? slots_[s].rc : VB2_ERR_INVALID;
-                finish_sample(s, false, nullptr);
+                finish_sample(s, false, nullptr, /*delivered=*/false);
                 continue;
             }
             {
@@ -305,8 +305,10 @@ private:
     }
 
     // sample s leaves the pipeline: outputs (write) + context + host arrays go to the releaser thread, its place in the
-    // readers' window is free again
-    void finish_sample(int s, bool write, const vb2_estimate* est)
+    // readers' window is free again.  delivered: the search took the sample (DeviceSource::next counted it out of
+    // remaining_ then) -- whether or not the search then succeeded; a sample that fails on a reader thread never
+    // gets that far and is counted out here.
+    void finish_sample(int s, bool write, const vb2_estimate* est, bool delivered)
     {
         {
             std::lock_guard<std::mutex> lk(rel_mu_);
@@ -320,7 +322,7 @@ private:
             std::lock_guard<std::mutex> lk(mu_);
             const int d = s % ndev_;
             --inflight_[d];
-            if (!write) --remaining_[d];       // (a searched sample was counted when the search took it)
+            if (!delivered) --remaining_[d];
         }
         cv_.notify_all();
     }
@@ -355,7 +357,7 @@ private:
                 r->out_[s].est = est;
                 r->out_[s].seconds_optimize = seconds;
             }
-            r->finish_sample(s, rc == VB2_OK, &est);
+            r->finish_sample(s, rc == VB2_OK, &est, /*delivered=*/true);
         }
     };
 

@@ -95,7 +95,9 @@ int read_known_af(const std::string& path, Panel* p);
 int read_pileup(const std::string& path, const Panel& panel, PileupViewer* v);
 // BAM/CRAM input through htslib (bam_flatten.cpp; VB2_ERR_IO with an explanation when the library was
 // built without htslib).  SimplePileupViewer.cpp:172-557 with main.cpp:81-96's defaults.
-int read_bam(const std::string& bam_path, const std::string& ref_path, const Panel& panel, PileupViewer* v);
+// mp: the reference's "Pileup Options" (main.cpp:176-187), nullptr or given == 0 = its defaults (main.cpp:81-96)
+int read_bam(const std::string& bam_path, const std::string& ref_path, const Panel& panel, PileupViewer* v,
+             const vb2_mpileup_opts* mp = nullptr);
 bool bam_support();
 bool sanity_check(const Panel& p, PileupViewer* v);
 
