@@ -81,6 +81,12 @@ typedef struct vb2_options {
 #define VB2_OPT_COHORT_LAYOUT 1   /* also keep the 16-bit run lists that vb2_batch_* steps stream (half the bytes
                                    * per sample and step; +28 % device memory).  Without it vb2_batch_create
                                    * builds them on first use. */
+/* (ABI 6) how vb2_ctx_optimize_llk runs on this context -- the defaults are the fast way; results are the same bits:   */
+#define VB2_OPT_PLAIN_LAUNCH 2    /* the resident search kernel goes up with a plain launch instead of a cooperative one (the
+                                   * library does this by itself under rocprofv3, whose exit handler does not survive a
+                                   * cooperative launch in ROCm 7.2)                                                     */
+#define VB2_OPT_HOST_SEARCH 4     /* the simplex decisions stay on the host (the resident kernel only evaluates)        */
+#define VB2_OPT_LAUNCH_PER_STEP 8 /* no resident kernel at all: one launch per search step                               */
     void *stream;              /* hipStream_t to run on; NULL = context-owned      */
 } vb2_options;
 

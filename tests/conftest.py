@@ -45,6 +45,21 @@ def golden_dir():
     return GOLDEN
 
 
+@pytest.fixture
+def tunable():
+    """tunable(name, value) sets a run-time switch of the library (csrc/tunables.h) for the rest of the test."""
+    from verifybamid_amd import _abi
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = _abi.get_tunable(name)
+        _abi.set_tunable(name, value)
+    yield set_
+    for name, value in saved.items():
+        _abi.set_tunable(name, value)
+
+
 def fixture_input_must_match(got_sha, want_sha, what):
     """A committed fixture is only evidence if the seeded generator reproduces the input it was made from.
     A mismatch (another numpy drawing other samples) FAILS -- a silent skip would let the at-size

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import numpy as np          # noqa: E402
 import verifybamid_amd as vb  # noqa: E402
+from verifybamid_amd import _abi  # noqa: E402
 
 
 def fixture(size):
@@ -48,12 +49,12 @@ def main():
             out["allreduces_after_eval"] = g.info()["num_allreduce"]
             est = g.optimize()
             out["allreduces_after_search"] = g.info()["num_allreduce"]
-        os.environ["VB2_SHARD_REDUCE"] = "host"                  # the same shards, summed on the host in shard order
+        _abi.set_tunable("shard_reduce_host", 1)                 # the same shards, summed on the host in shard order
         with vb.ShardGroup(d, devices=[0] * n) as gh:
             assert not gh.info()["uses_rccl"]
             host = gh.llk(pc1, pc2, al)
             est_h = gh.optimize()
-        del os.environ["VB2_SHARD_REDUCE"]
+        _abi.set_tunable("shard_reduce_host", 0)
         out.update(rel_vs_fixture=rel(got, want), equals_host_sum=bool(np.array_equal(got, host)),
                    big_equals_tiled=bool(np.array_equal(big, np.tile(got, 7))), est=est_summary(est),
                    est_host=est_summary(est_h))
@@ -84,7 +85,7 @@ def main():
                                  rel_vs_fixture=rel(r["got"], want)) for r in res]
             out["all_ranks_equal"] = bool(all(np.array_equal(res[0]["got"], r["got"]) for r in res[1:]))
             # the shards of a rank-mode group are the shards of the one-process group: same partial sums, same order
-            os.environ["VB2_SHARD_REDUCE"] = "host"
+            _abi.set_tunable("shard_reduce_host", 1)
             with vb.ShardGroup(d, devices=[0] * n) as gh:
                 host = gh.llk(pc1, pc2, al)
             out["equals_host_sum"] = bool(np.array_equal(res[0]["got"], host))

@@ -169,14 +169,14 @@ def test_cpp_optimiser_trace_equals_oracle(golden_dir, pileup, kw):
 @pytest.mark.parametrize("level", [1, 2, 4])
 @pytest.mark.parametrize("kw", [{}, {"within_ancestry": True}, {"fix_alpha": 0.1},
                                 {"within_ancestry": True, "fix_pc": [0.034756, 0.0193]}])
-def test_speculation_level_does_not_change_the_trajectory(golden_dir, level, kw, monkeypatch):
+def test_speculation_level_does_not_change_the_trajectory(golden_dir, level, kw, tunable):
     """amoeba.h: 4 = {R, E, C_A, C_R} per iteration, 2 = {R, C_R}, 1 = one point at a time.  The
     committed evaluations (the trace) are the reference's in every case; only the number of points
     launched differs."""
     flat, _, _ = refio.load_flat(os.path.join(golden_dir, HAPMAP), os.path.join(golden_dir, "test.LongRead.pileup"), 2)
     od = binding.OracleData(flat)
     want = od.optimize(trace_capacity=4096, **kw)
-    monkeypatch.setenv("VB2_SPECULATE", str(level))
+    tunable("speculate", level)
     got = vb.optimize_with_evaluator(_oracle_evaluator(od), 2, trace_capacity=4096, **kw)
     assert got["num_eval"] == want["num_eval"]
     for key in ("alpha", "pc1", "pc2", "llk"):
@@ -406,7 +406,7 @@ def _load_arrays(pre, k, **kw):
                 nb=d.meta["num_bases"])
 
 
-def test_fast_scanner_equals_stringstream_statements(tmp_path, monkeypatch):
+def test_fast_scanner_equals_stringstream_statements(tmp_path, tunable):
     """The readers parse plainly formatted lines with a hand-written scanner and everything else
     with the original `stringstream >> field` statements.  Differential test on deliberately
     odd files (CRLF, blank and short lines, signs, exponents, junk after numbers, hex, nan,
@@ -451,20 +451,19 @@ def test_fast_scanner_equals_stringstream_statements(tmp_path, monkeypatch):
             with open(pre + ext, "w", newline="") as f:
                 f.write("".join(rows))
         out = []
-        for slow in ("0", "1"):
-            monkeypatch.setenv("VB2_SLOW_PARSE", slow)
+        for slow in (0, 1):
+            tunable("slow_parse", slow)
             try:
                 out.append(_load_arrays(pre, 2, disable_sanity=True))
             except Exception as exc:             # both paths must fail alike, too
                 out.append(("error", str(exc)))
         assert out[0] == out[1], trial
-    monkeypatch.delenv("VB2_SLOW_PARSE")
 
 
-def test_avx2_pileup_scanner_equals_the_scalar_one(tmp_path, monkeypatch):
+def test_avx2_pileup_scanner_equals_the_scalar_one(tmp_path, tunable):
     """read_pileup classifies the bases column 32 characters at a time (AVX2) and copies runs of kept
     characters with their qualities as blocks.  Differential test against the scalar scanner
-    (VB2_SCALAR_PARSE=1) and the stringstream statements (VB2_SLOW_PARSE=1): long columns (runs that
+    (tunable scalar_parse) and the stringstream statements (tunable slow_parse): long columns (runs that
     cross block boundaries), read-start / read-end marks, indels with one- and two-digit lengths, '*' / '#'
     placeholders, fewer qualities than bases, a last line without a newline, lines outside the panel."""
     rng = np.random.default_rng(4242)
@@ -534,15 +533,15 @@ def test_avx2_pileup_scanner_equals_the_scalar_one(tmp_path, monkeypatch):
         with open(pre + ".pileup", "w", newline="") as f:
             f.write("".join(lines))
         out = []
-        for var in (None, "VB2_SCALAR_PARSE", "VB2_SLOW_PARSE"):
+        for var in (None, "scalar_parse", "slow_parse"):
             if var:
-                monkeypatch.setenv(var, "1")
+                tunable(var, 1)
             try:
                 out.append(_load_arrays(pre, 2, disable_sanity=True))
             except Exception as exc:             # the three paths must fail alike, too
                 out.append(("error", str(exc)))
             if var:
-                monkeypatch.delenv(var)
+                tunable(var, 0)
         assert out[0] == out[1] == out[2], trial
         if trial < 3:
             assert out[0]["nb"] > 0
@@ -607,7 +606,7 @@ print(json.dumps(out))
 
 def test_run_scheduling_only_reorders_the_runs_of_a_marker():
     """Wide quality alphabets: a tile's runs are placed by schedule_tile (tile_sched.h) instead of in dictionary order.  The
-    flatten's digest with the run words taken as a per-marker multiset (VB2_DIGEST_CODES=multiset) is the same with the
+    flatten's digest with the run words taken as a per-marker multiset (tunable digest_multiset) is the same with the
     scheduling on and off -- every run of every marker is still there, once, next to the same padding -- while the plain digest
     differs (the order did change); a narrow alphabet is left alone either way."""
     import json
@@ -628,7 +627,7 @@ print(json.dumps([_flatten_digest(vb.synth.make_pileup(3000, 30, 2, seed=6, q_lo
     res = {}
     for sched in ("0", "1"):
         for mode in ("bytes", "multiset"):
-            env = dict(os.environ, VB2_RUN_SCHED=sched, VB2_DIGEST_CODES=mode)
+            env = dict(os.environ, VB2_RUN_SCHED=sched, VB2_DIGEST_MULTISET="1" if mode == "multiset" else "0")
             if sched == "1":
                 del env["VB2_RUN_SCHED"]                   # (the default: scheduled above 48 codes)
             p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)

@@ -481,6 +481,33 @@ def test_quality_clamping_and_base_classes():
     assert info["num_read_other"] > 0 and np.all(np.isfinite(got))
 
 
+def test_parameters_at_the_edges_of_the_double_range_follow_the_reference():
+    """ADVICE r4.  alpha so small that table entries are SUBNORMAL (InvLogit of a logit under -708: 1e-310 and the
+    smallest double) -- the table's logarithm scales them into its domain, the LLK matches the oracle's libm to the
+    usual tolerance; alpha exactly 0 and 1 (entries exactly 0: log = -inf); NaN parameters: in the reference every
+    marker's likelihood is NaN, fails `markerLK > 0` (ContaminationEstimator.h:310) and is left out -- LLK 0 -- with a
+    NaN alpha, and with NaN PCs unless the allele frequencies are known (then the PCs are never read)."""
+    d = vb.synth.make_pileup(700, 25, 2, alpha_true=0.05, seed=77, q_lo=0, q_hi=45)       # (q = 0 codes: entries alpha * const)
+    od = oracle_data(d)
+    pcs = np.array([0.01, -0.02])
+    with vb.LikelihoodContext(d) as ctx:
+        for a in (1e-310, 5e-324, 2.3e-308, 0.0, 1.0, 1.0 - 2.0 ** -53):
+            got = ctx.llk(pcs[None, :], pcs[None, :] * 0.5, np.array([a]))[0]
+            want = od.llk(pcs, pcs * 0.5, a)
+            assert np.isfinite(want) and rel_err([got], [want]) <= LLK_RTOL, (a, got, want)
+        nan = float("nan")
+        got = ctx.llk(np.tile(pcs, (3, 1)), np.array([pcs, [nan, 0.0], pcs]), np.array([nan, 0.05, 0.05]))
+        want = [od.llk(pcs, pcs, nan), od.llk(pcs, np.array([nan, 0.0]), 0.05), od.llk(pcs, pcs, 0.05)]
+        assert want[0] == 0.0 and want[1] == 0.0 and got[0] == 0.0 and got[1] == 0.0
+        assert rel_err(got[2:], want[2:]) <= LLK_RTOL
+    kaf = vb.PileupData(2, d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base, np.clip(d.means / 2, 0.01, 0.99),
+                        d.avg_depth, d.sd_depth, True, {})
+    okaf = oracle_data(kaf)
+    with vb.LikelihoodContext(kaf) as ctx:
+        got = ctx.llk(np.array([[nan, nan]]), np.array([[nan, 0.0]]), np.array([0.07]))[0]
+        assert rel_err([got], [okaf.llk(np.array([nan, nan]), np.array([nan, 0.0]), 0.07)]) <= LLK_RTOL
+
+
 def test_ragged_depths_and_many_codes():
     rng = np.random.default_rng(5)
     markers = []
@@ -757,12 +784,12 @@ def test_strict_batch_values_do_not_depend_on_the_neighbours_requests(c3):
                             assert rel_err(got[s, :n], ctx.llk(pc1[s, :n], pc2[s, :n], al[s, :n])) <= LLK_RTOL
 
 
-def test_cohort_run_streams_samples_through_slots_reproducibly(tmp_path, monkeypatch):
+def test_cohort_run_streams_samples_through_slots_reproducibly(tmp_path, tunable):
     """vb2_cohort_run keeps `group_size` slots per device and hands a converged sample's slot to the next ready sample
     (stream_search.h).  Which samples share the device, and when, depends on the readers' timing; a sample's workgroups and
     waves do not -- so two runs with different reader counts give every sample the SAME bits (alpha, likelihoods,
     evaluation count) and byte-identical output files, also for a sample that appears 8 times in the list.  Against the
-    group-at-a-time pipeline (VB2_COHORT_STREAM=0) the estimates agree to the tolerance group sizes always had.  45 samples
+    group-at-a-time pipeline (tunable cohort_stream = 0) the estimates agree to the tolerance group sizes always had.  45 samples
     of four sizes through 12 slots (one lane) and through 20 (two lanes), one unreadable file in the middle."""
     k = 2
     base = vb.synth.with_sanity_stats(vb.synth.make_pileup(2500, 14, k, alpha_true=0.03, seed=170))
@@ -785,9 +812,9 @@ def test_cohort_run_streams_samples_through_slots_reproducibly(tmp_path, monkeyp
     for slots in (12, 20):
         a, out_a = run("a%d_" % slots, group_size=slots, num_host_thread=2)
         b, out_b = run("b%d_" % slots, group_size=slots, num_host_thread=9)
-        monkeypatch.setenv("VB2_COHORT_STREAM", "0")
+        tunable("cohort_stream", 0)
         g, _ = run("g%d_" % slots, group_size=slots, num_host_thread=4)
-        monkeypatch.delenv("VB2_COHORT_STREAM")
+        tunable("cohort_stream", 1)
         for s in range(S):
             if s == 17:
                 assert a[s]["status"] != 0 and b[s]["status"] != 0 and g[s]["status"] != 0
@@ -842,7 +869,41 @@ def test_cohort_run_reports_bad_samples_and_finishes_the_rest(tmp_path):
             assert abs(res[i]["alpha"] - alone[good.index(p)]["alpha"]) <= 1e-9, i
 
 
-def test_cohort_run_over_several_device_pipelines(tmp_path, monkeypatch):
+@pytest.mark.parametrize("fail_at", [0, 3, 11])
+def test_streamed_cohort_survives_a_sample_that_fails_at_its_slot(tmp_path, tunable, fail_at):
+    """a sample the streamed search takes and then cannot search (its slot refuses it: LDS need, a fiber that
+    does not start, OptimizeLLK's own error) was counted out of the device's remaining samples twice -- the search ended
+    early and the samples still with the readers were never searched (status VB2_ERR_INVALID, no error text, the call
+    itself VB2_OK).  One sample of 24 is refused at its slot (a test hook: tunable cohort_fail_sample), early, in the
+    middle and late in the stream, with few slots and slow readers (one thread): every other sample must come out, with the
+    estimate its own run gives."""
+    k, M = 2, 1200
+    base = vb.synth.with_sanity_stats(vb.synth.make_pileup(M, 12, k, alpha_true=0.03, seed=370))
+    pre = vb.synth.write_files(base, str(tmp_path / "panel"))
+    good = []
+    for s in range(3):
+        d = vb.synth.make_pileup(M, 9 + 4 * s, k, alpha_true=0.04 * (s + 1), seed=380 + s)
+        d = vb.PileupData(k, base.ud, base.means, d.read_off, d.bases, d.quals, base.alt_base, None,
+                          d.avg_depth, d.sd_depth, True, dict(base.meta))
+        good.append(vb.synth.write_files(d, str(tmp_path / ("s%d" % s))) + ".pileup")
+    S = 24
+    paths = [good[s % 3] for s in range(S)]
+    outs = [str(tmp_path / ("o%d" % s)) for s in range(S)]
+    tunable("cohort_fail_sample", fail_at)
+    res = vb.run_cohort_files(pre, paths, outs, num_pc=k, group_size=4, num_host_thread=1, disable_sanity=True)
+    tunable("cohort_fail_sample", -1)
+    alone = [vb.run_files(pre, g, str(tmp_path / ("alone%d" % i)), num_pc=k, disable_sanity=True) for i, g in enumerate(good)]
+    for s in range(S):
+        if s == fail_at:
+            assert res[s]["status"] == _abi.VB2_ERR_INVALID
+            assert not os.path.exists(outs[s] + ".Ancestry")
+            continue
+        assert res[s]["status"] == 0, (s, res[s]["status"])
+        assert abs(res[s]["alpha"] - alone[s % 3]["alpha"]) <= 1e-9, s
+        assert os.path.exists(outs[s] + ".Ancestry")
+
+
+def test_cohort_run_over_several_device_pipelines(tmp_path, tunable):
     """vb2_cohort_run with a device list: one pipeline thread per entry, groups dealt round-robin,
     each device with its own small first groups, the readers looking two groups ahead per device.
     A machine with one GPU lists it three times (allowed by a test switch only): 70 samples, every
@@ -863,7 +924,7 @@ def test_cohort_run_over_several_device_pipelines(tmp_path, monkeypatch):
     one = vb.run_cohort_files(pre, paths, out_a, num_pc=k, group_size=8)
     with pytest.raises(_abi.Vb2Error):
         vb.run_cohort_files(pre, paths, out_b, num_pc=k, group_size=8, devices=[0, 0, 0])
-    monkeypatch.setenv("VB2_COHORT_DUP_DEVICES", "1")
+    tunable("cohort_dup_devices", 1)
     three = vb.run_cohort_files(pre, paths, out_b, num_pc=k, group_size=8, devices=[0, 0, 0])
     assert all(r["status"] == 0 for r in one) and all(r["status"] == 0 for r in three)
     for s in range(S):
@@ -1019,7 +1080,7 @@ def _stub_case(*args, timeout=900):
     # (more hardware queues than shard streams: two streams of one queue would run a rank's all-reduce kernel
     # BEHIND the one that waits for it)
     env = dict(os.environ, VB2_RCCL_LIB=STUB_RCCL, GPU_MAX_HW_QUEUES="8")
-    env.pop("VB2_SHARD_REDUCE", None)
+    env.pop("VB2_SHARD_REDUCE_HOST", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stub_rccl", "run_case.py")] + [str(a) for a in args],
                        env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
@@ -1163,11 +1224,11 @@ def _batch_regroups(batch):
 
 
 @pytest.mark.parametrize("S", [5, 20, 37])
-def test_lockstep_search_regroups_the_unfinished_samples(S, monkeypatch):
+def test_lockstep_search_regroups_the_unfinished_samples(S, tunable):
     """Samples finish at different iterations; when half of a lane's samples are done the rest move to a batch of their own
     with twice the workgroups per sample (Batch::optimize), and again at a quarter, an eighth ...  A sample's likelihood sums
     then differ in the last bits (as they do between group sizes: the static deal multiplies a wave's items in the wave);
-    every estimate is the one the fixed batch (VB2_COHORT_REGROUP=0) gives and the one the sample's own single-context
+    every estimate is the one the fixed batch (tunable cohort_regroup = 0) gives and the one the sample's own single-context
     search gives -- alpha to 1e-7, likelihoods to LLK_RTOL.  5 samples search in one lane, 20 and 37 in two (uneven) lanes;
     sizes, depths and contamination differ so that the searches have different lengths; one sample has no reads."""
     rng = np.random.default_rng(100 + S)
@@ -1181,7 +1242,7 @@ def test_lockstep_search_regroups_the_unfinished_samples(S, monkeypatch):
     try:
         runs = {}
         for knob in ("0", "1"):
-            monkeypatch.setenv("VB2_COHORT_REGROUP", knob)
+            tunable("cohort_regroup", int(knob))
             with vb.CohortBatch(ctxs) as batch:
                 runs[knob] = batch.optimize()
                 n = _batch_regroups(batch)
@@ -1725,11 +1786,11 @@ def _layout_digest(ctx):
 
 
 @pytest.mark.gpu
-def test_data_arrays_on_the_device_are_the_host_flattens_bytes(monkeypatch):
+def test_data_arrays_on_the_device_are_the_host_flattens_bytes(tunable):
     """The device holds, byte for byte, what the host half of vb2_ctx_create produces without a device
     (vb2_debug_flatten_digest, whose thread-count independence the CPU suite checks): run words in [tile][row][marker]
     order, tile records, sorted panel rows and diagonal terms, dictionary and primitive records -- whether the pack step
-    ran as pack_layout_kernel on the GPU (default) or on the host (VB2_HOST_PACK=1).  Shapes: the bench shape in small, a wide
+    ran as pack_layout_kernel on the GPU (default) or on the host (tunable host_pack).  Shapes: the bench shape in small, a wide
     quality alphabet, missing markers with the depth filter, deep/ragged/empty markers with odd characters, a known-AF input,
     one marker, and a sample with no reads at all."""
     from test_abi_and_host import _flatten_digest
@@ -1757,6 +1818,6 @@ def test_data_arrays_on_the_device_are_the_host_flattens_bytes(monkeypatch):
     for d in cases:
         want = _flatten_digest(d)
         for host in ("0", "1"):
-            monkeypatch.setenv("VB2_HOST_PACK", host)
+            tunable("host_pack", int(host))
             with vb.LikelihoodContext(d, device=0) as ctx:
                 assert _layout_digest(ctx) == want, (d.num_marker, host)

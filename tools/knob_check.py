@@ -1,6 +1,6 @@
 """Every A/B knob still gives the same results: LLKs against the oracle, wave-shape independence, one search.
-for kv in NONE=1 VB2_LANE_MAP=plain VB2_PAIRED=0 VB2_SINGLE_LAUNCH=0 VB2_REDUCE=1 VB2_REDUCE=2 VB2_DYN_TILES=0 VB2_RESIDENT=0 \
-          VB2_DEVICE_SIMPLEX=0 VB2_OWN_ROWS=0 VB2_RELAY_REPS=1; do env KNOB=$kv $kv python tools/knob_check.py; done"""
+for kv in NONE=1 VB2_SINGLE_LAUNCH=0 VB2_REDUCE=1 VB2_REDUCE=2 VB2_DYN_TILES=0 VB2_RESIDENT=0 VB2_SCHED=0 VB2_COOP=0 \
+          VB2_DEVICE_SIMPLEX=0 VB2_LDS_CACHE=0 VB2_PASSES=0; do env KNOB=$kv $kv python tools/knob_check.py; done"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

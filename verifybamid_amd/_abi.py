@@ -194,8 +194,23 @@ def lib():
     L.vb2_shard_range.argtypes = [C.POINTER(Input), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.vb2_shard_group_destroy.argtypes = [C.c_void_p]
     L.vb2_shard_group_destroy.restype = None
+    L.vb2_debug_set_tunable.argtypes = [C.c_char_p, C.c_int]
+    L.vb2_debug_get_tunable.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
     _lib = L
     return L
+
+
+def set_tunable(name, value):
+    """A run-time switch of the library by name (csrc/tunables.h): tests and measurement scripts only."""
+    if lib().vb2_debug_set_tunable(name.encode(), int(value)) != VB2_OK:
+        raise KeyError("libvb2 has no tunable %r" % name)
+
+
+def get_tunable(name):
+    v = C.c_int(0)
+    if lib().vb2_debug_get_tunable(name.encode(), C.byref(v)) != VB2_OK:
+        raise KeyError("libvb2 has no tunable %r" % name)
+    return v.value
 
 
 class Vb2Error(RuntimeError):

@@ -17,6 +17,7 @@
 #include <memory>
 #include <new>
 
+#include "tunables.h"
 #include "batch.h"
 #include "context.h"
 #include "estimator.h"
@@ -330,12 +331,15 @@ int vb2_debug_resident_active(vb2_ctx* ctx)
 
 // Test aid (not part of the public header): batches created from now on stream the 16-bit (1) or the 32-bit (0)
 // run lists in their 1- and 2-point steps.
-void vb2_debug_set_cohort_w16(int on) { vb2::set_cohort_w16(on != 0); }
+void vb2_debug_set_cohort_w16(int on) { vb2::tunables().cohort_w16 = on != 0; }
 
 // Test aid: calls of more points than one launch's tables hold as the passes of one launch (1, the default) or as separate
 // launches (0)
-void vb2_debug_set_eval_passes(int on) { vb2::set_eval_passes(on != 0); }
-void vb2_debug_set_eval_split(int on) { vb2::set_eval_split(on); }
+void vb2_debug_set_eval_passes(int on) { vb2::tunables().passes = on != 0; }
+
+// Test / tool aid: the library's run-time switches by name (tunables.h).  0 on success, VB2_ERR_INVALID for an unknown name.
+int vb2_debug_set_tunable(const char* name, int value) { return vb2::set_tunable(name, value) ? VB2_OK : VB2_ERR_INVALID; }
+int vb2_debug_get_tunable(const char* name, int* value) { return vb2::get_tunable(name, value) ? VB2_OK : VB2_ERR_INVALID; }
 
 // Test aid: turn the resident search mode off/on for one context (VB2_RESIDENT does it globally).
 void vb2_debug_set_resident(vb2_ctx* ctx, int on)
@@ -689,7 +693,7 @@ int vb2_flat_load(const vb2_run_args* a, vb2_flat** out)
         // The four files are independent until the markers are resolved: .UD and .mu are parsed
         // on two helper threads while this one reads the .bed (the pileup reader needs it) and
         // the pileup.  Errors are reported in the reference's reading order (.bed, AF, .UD, .mu).
-        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+        const bool timing = vb2::tunables().debug_timing != 0;
         const double tl0 = now_s();
         double tl_bed = 0, tl_pile = 0, tl_join = 0;
         int rc_ud = VB2_OK, rc_mu = VB2_OK;

@@ -8,11 +8,13 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <memory>
 
 #include "estimator.h"
 #include "lockstep.h"
 #include "stream_search.h"
+#include "tunables.h"
 
 namespace vb2 {
 
@@ -56,32 +58,19 @@ int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
     return create(list, out);
 }
 
-// VB2_COHORT_W16=0 (or vb2_debug_set_cohort_w16(0), a test aid): cohort steps stream the 32-bit run lists
-static std::atomic<int> g_cohort_w16{-1};
-bool cohort_w16_enabled()
-{
-    int v = g_cohort_w16.load();
-    if (v < 0) {
-        v = (std::getenv("VB2_COHORT_W16") && std::atoi(std::getenv("VB2_COHORT_W16")) == 0) ? 0 : 1;
-        g_cohort_w16.store(v);
-    }
-    return v != 0;
-}
-void set_cohort_w16(bool on) { g_cohort_w16.store(on ? 1 : 0); }
+// Tunables::cohort_w16 = 0 (a test aid): cohort steps stream the 32-bit run lists
+bool cohort_w16_enabled() { return tunables().cohort_w16 != 0; }
 
 // Waves per workgroup of a cohort step (round 4, third part): EIGHT, and twice as many workgroups per sample, instead of
 // sixteen.  A search runs its samples as two lanes whose steps take turns; with 1 024-thread workgroups a lane's launch fills
 // the CUs' wave slots by itself and the other lane's launch overlaps only with its tail, with 512-thread workgroups two
 // workgroups of DIFFERENT launches share a CU and one lane's table builds, barriers and hand-off run under the other's
 // streaming: search only 1.356 -> 1.243 ms per sample (737 -> 801 samples/s) on the same box; a synchronous step alone
-// takes what it took (75.5 / 105 us).  VB2_COHORT_BW=16 restores the big workgroups (4 and 8 are the other values).
+// takes what it took (75.5 / 105 us).  Tunables::cohort_bw = 16 restores the big workgroups (4 and 8 are the other values).
 int cohort_waves()
 {
-    static const int v = [] {
-        const int k = std::getenv("VB2_COHORT_BW") ? std::atoi(std::getenv("VB2_COHORT_BW")) : 8;
-        return (k == 4 || k == 8 || k == 16) ? k : 8;
-    }();
-    return v;
+    const int k = tunables().cohort_bw;
+    return (k == 4 || k == 8 || k == 16) ? k : 8;
 }
 
 void Batch::geometry(int num_cu, int num_sample, int max_mt, int num_pc, int bps_in, int* bps, int* block_waves)
@@ -124,9 +113,9 @@ int Batch::prepare_for_cohort(Context* c, int group)
     }
     // the regrouped batches: powers of two above the lane's own (those that take the work queue need no schedule)
     for (int b = 1; b <= c->L.num_cu; b *= 2) {
-        if (b <= first_bps) continue;
         int bps, bw;
-        geometry(c->L.num_cu, 1, c->L.num_mt, c->num_pc, b, &bps, &bw);
+        geometry(c->L.num_cu, 1, c->L.num_mt, c->num_pc, b, &bps, &bw);      // (bps: b times the workgroups-per-CU factor)
+        if (bps <= first_bps) continue;                                       // like with like
         if (eval_takes_the_queue(c->L, bps, bw, 1)) break;
         if (const int rc = c->cohort_schedules(bps, bw, sc)) return rc;
     }
@@ -399,29 +388,42 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
         // as separate launches (the one- and two-point shapes deal and multiply alike: bit-identical, tested), so a sample's
         // values depend on its own requests only.  Mixed steps are rare (a sample starts or shrinks in 1-2 % of them): all
         // classes but the most populous are evaluated synchronously first.
-        auto cls = [](int n) { return n <= 0 ? -1 : n <= 2 ? 0 : n <= 4 ? 1 : 2; };
-        int pop[3] = {0, 0, 0};
+        // (a 5-8 point request of a sample with narrow table rows -- more than kMaxWideCodes codes -- is evaluated as two
+        // 4-point launches, below: a class of its own, or one such neighbour would change everybody's wave shape: ADVICE r4)
+        auto cls = [&](int s) {
+            const int n = num_point[s];
+            if (n <= 0) return -1;
+            if (n <= 2) return 0;
+            if (n <= 4) return 1;
+            return (ctx_[s] && ctx_[s]->L.row_bytes != kRowBytesWide) ? 3 : 2;
+        };
+        int pop[4] = {0, 0, 0, 0};
         for (int s = 0; s < num_sample; ++s)
-            if (num_point[s] > 0) ++pop[cls(num_point[s])];
-        if ((pop[0] > 0) + (pop[1] > 0) + (pop[2] > 0) > 1) {
-            const int keep = pop[0] >= pop[1] && pop[0] >= pop[2] ? 0 : pop[1] >= pop[2] ? 1 : 2;
+            if (num_point[s] > 0) ++pop[cls(s)];
+        if ((pop[0] > 0) + (pop[1] > 0) + (pop[2] > 0) + (pop[3] > 0) > 1) {
+            int keep = 0;
+            for (int c = 1; c < 4; ++c)
+                if (pop[c] > pop[keep]) keep = c;
             std::vector<int32_t> np((size_t)num_sample);
             in_split_ = true;
             int rc = VB2_OK;
-            for (int c = 0; c < 3 && !rc; ++c) {
+            for (int c = 0; c < 4 && !rc; ++c) {
                 if (c == keep || pop[c] == 0) continue;
-                for (int s = 0; s < num_sample; ++s) np[s] = cls(num_point[s]) == c ? num_point[s] : 0;
+                for (int s = 0; s < num_sample; ++s) np[s] = cls(s) == c ? num_point[s] : 0;
                 rc = eval(np.data(), pc1, pc2, alpha, llk_out);
             }
             if (!rc) {
-                for (int s = 0; s < num_sample; ++s) np[s] = cls(num_point[s]) == keep ? num_point[s] : 0;
+                for (int s = 0; s < num_sample; ++s) np[s] = cls(s) == keep ? num_point[s] : 0;
                 rc = eval_begin(np.data(), pc1, pc2, alpha, llk_out);
             }
             in_split_ = false;
             return rc;
         }
     }
-    if (max_n > 4 && !wide_rows_) {
+    bool narrow_in_step = false;               // (of the samples that take part in THIS step)
+    for (int s = 0; s < num_sample && !wide_rows_; ++s)
+        narrow_in_step |= num_point[s] > 0 && ctx_[s] && ctx_[s]->L.row_bytes != kRowBytesWide;
+    if (max_n > 4 && narrow_in_step) {
         // a sample with a very wide dictionary has narrow table rows: 4 points per launch at most
         const size_t S = (size_t)num_sample;
         std::vector<int32_t> np(S);
@@ -445,7 +447,7 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     // one or two points per sample (a search that speculates little or not at all): the wave takes
     // four micro-tiles, and the step costs a quarter / half of a 4-point step whose other slots
     // would replicate the last point
-    const bool small = max_n <= 2 && paired_mode();
+    const bool small = max_n <= 2;
     const int NP = max_n > 4 ? 8 : small ? max_n : 4, shape = max_n > 4 ? 1 : small ? (max_n == 1 ? 2 : 3) : 0;
     for (int s = 0; s < num_sample; ++s) {
         int n = num_point[s];
@@ -502,6 +504,10 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
         for (int s2 = 0; s2 < num_sample; ++s2) ml.inl.nv[s2] = (unsigned char)h_nv_[s2];
         std::memcpy(ml.inl.v, h_points_, sizeof(double) * (size_t)ml.inl.count);
     }
+    // (results come back as relaxed stores behind a relaxed flag: NaN first, so that a store still on its way when the
+    // flag is seen is noticed -- Context::eval_host, settle_results)
+    for (int s = 0; s < num_sample; ++s)
+        for (int j = 0; j < h_nv_[s]; ++j) h_out_[(size_t)s * NP + j] = std::numeric_limits<double>::quiet_NaN();
     VB2_HIP(launch_llk_eval_multi(ml, stream_));
     ++num_launch;
     in_flight_ = true;
@@ -523,6 +529,8 @@ int Batch::eval_end()
         if (attempt > 0) {
             ml.force_ticket = true;
             ml.done_seq = ++seq_;
+            for (int s = 0; s < num_sample; ++s)
+                for (int j = 0; j < h_nv_[s]; ++j) h_out_[(size_t)s * NP + j] = std::numeric_limits<double>::quiet_NaN();
             VB2_HIP(launch_llk_eval_multi(ml, stream_));
             ++num_launch;
         }
@@ -534,9 +542,15 @@ int Batch::eval_end()
             __builtin_ia32_pause();
         }
         if (!seen) VB2_HIP(hipStreamSynchronize(stream_));
-        bool any_nan = false;
-        for (int s = 0; s < num_sample && !any_nan; ++s)
-            for (int j = 0; j < h_nv_[s]; ++j) any_nan |= std::isnan(h_out_[(size_t)s * NP + j]);
+        bool any_nan = true;
+        const auto ts = std::chrono::steady_clock::now();
+        while (any_nan) {                         // (a store still on its way: a few microseconds; then the kernels' own marker)
+            any_nan = false;
+            for (int s = 0; s < num_sample && !any_nan; ++s)
+                for (int j = 0; j < h_nv_[s]; ++j)
+                    any_nan |= std::isnan(reinterpret_cast<volatile double*>(h_out_)[(size_t)s * NP + j]);
+            if (std::chrono::steady_clock::now() - ts > std::chrono::microseconds(50)) break;
+        }
         if (!any_nan) break;
     }
     for (int s = 0; s < num_sample; ++s)
@@ -584,20 +598,19 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     // it, down to the floor of streaming every sample's pileup from HBM once per step (5.7 TB/s
     // measured: a 1-point step of 32 C3 samples takes 131 us against 236 us with 4 points) -- and
     // {R, C_R} is the better trade: 1.2 steps per iteration at about half the points.  Same
-    // decisions, same trajectory either way.  VB2_COHORT_SPECULATE=1|2|4 forces one.
+    // decisions, same trajectory either way.  Tunables::cohort_speculate = 1|2|4 forces one.
+    const Tunables& tn = tunables();
     constexpr int kPairFrom = 8;
     speculate_ = num_sample < kPairFrom ? 4 : 2;
-    if (const char* e = std::getenv("VB2_COHORT_SPECULATE")) speculate_ = std::max(1, std::atoi(e));
+    if (tn.cohort_speculate > 0) speculate_ = tn.cohort_speculate;
     bool split = num_sample >= kSplitFrom;
-    if (const char* e = std::getenv("VB2_COHORT_SPLIT")) split = std::atoi(e) != 0 && num_sample >= 2;
+    if (tn.cohort_split >= 0) split = tn.cohort_split != 0 && num_sample >= 2;
 
     const int S = num_sample, k = num_pc;
     Lane lanes[kMaxLanes];
     int nlane = 1;
     if (split) {
-        // (VB2_COHORT_LANES=n, an experiment knob: n lanes taking turns instead of two)
-        static const int lanes_knob = std::getenv("VB2_COHORT_LANES") ? std::atoi(std::getenv("VB2_COHORT_LANES")) : 2;
-        nlane = std::max(2, std::min(std::min(kMaxLanes, lanes_knob), S));
+        nlane = std::max(2, std::min(std::min(kMaxLanes, tn.cohort_lanes), S));
         for (int h = 0; h < nlane; ++h) {
             const int lo = (int)((long)S * h / nlane), hi = (int)((long)S * (h + 1) / nlane);
             if (!half_[h] || half_[h]->num_sample != hi - lo) {
@@ -618,9 +631,8 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     // sums move in their last bits, as they do between group sizes (the static deal multiplies a wave's items in the wave);
     // what regroups when follows from the samples' own trajectories, so a run stays reproducible -- and again at a quarter,
     // an eighth ...
-    // VB2_COHORT_REGROUP=0: the fixed batch to the end (A/B).
-    bool regroup = true;
-    if (const char* e = std::getenv("VB2_COHORT_REGROUP")) regroup = std::atoi(e) != 0;
+    // Tunables::cohort_regroup = 0: the fixed batch to the end (A/B).
+    const bool regroup = tn.cohort_regroup != 0;
     std::vector<int> rcs(S, 0);
     for (int l = 0; l < nlane; ++l) {
         Lane& L = lanes[l];
@@ -653,7 +665,7 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
             }
         };
     };
-    const bool dbg = std::getenv("VB2_DEBUG_LOCKSTEP") != nullptr;
+    const bool dbg = tn.debug_lockstep != 0;
     double dbg_regroup_s = 0, dbg_wall_by_slots[65] = {0}; long dbg_steps_by_slots[65] = {0};
     long dbg_steps = 0, dbg_active = 0, dbg_points = 0, dbg_regroups = 0, dbg_hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int error = 0;
@@ -834,7 +846,7 @@ int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource
     capacity = std::max(1, std::min(capacity, 128));
     const int k = num_pc;
     int speculate = capacity < 8 ? 4 : 2;                      // (Batch::optimize: kPairFrom)
-    if (const char* e = std::getenv("VB2_COHORT_SPECULATE")) speculate = std::max(1, std::atoi(e));
+    if (tunables().cohort_speculate > 0) speculate = tunables().cohort_speculate;
     StreamLane lanes[2];
     int cnt[2];
     stream_lanes(capacity, &cnt[0], &cnt[1]);
@@ -876,7 +888,7 @@ int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource
         });
     }
     bool ended = false;
-    const bool dbg = std::getenv("VB2_DEBUG_LOCKSTEP") != nullptr;
+    const bool dbg = tunables().debug_lockstep != 0;
     long dbg_steps = 0, dbg_active = 0, dbg_points = 0, dbg_samples = 0;
     double dbg_blocked = 0, dbg_refill = 0;
     const double dbg_t0 = wall_s();
@@ -907,7 +919,10 @@ int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource
             std::memset(&L.est[i], 0, sizeof(vb2_estimate));
             L.t0[i] = wall_s();
             ++dbg_samples;
-            if (const int rc = L.batch->set_slot(i, c)) {      // this sample cannot be searched here: the others can
+            // (Tunables::cohort_fail_sample: a test's way to send one sample down this error path)
+            const int rc_slot = id == tunables().cohort_fail_sample ? (set_error("streaming batch: sample refused (test hook)"), VB2_ERR_INVALID)
+                                                                   : L.batch->set_slot(i, c);
+            if (const int rc = rc_slot) {                       // this sample cannot be searched here: the others can
                 L.rc[i] = rc;
                 retire(L, i);
                 --i;

@@ -14,7 +14,6 @@ namespace vb2 {
 
 int cohort_waves();                   // waves per workgroup of a cohort step: 8 (VB2_COHORT_BW=16|8|4)
 bool cohort_w16_enabled();            // cohort steps stream the 16-bit run lists (default; VB2_COHORT_W16=0 turns it off)
-void set_cohort_w16(bool on);
 
 class Batch {
 public:
@@ -23,7 +22,7 @@ public:
     static int create(const std::vector<Context*>& ctxs, Batch** out, int bps = 0);   // bps > 0: that many workgroups per sample
     // A batch of `capacity` slots whose samples come and go (the streaming cohort search, stream_search.h): created empty;
     // set_slot(i, c) puts context c -- or nothing (nullptr) -- into slot i, between two steps.  Every slot has
-    // num_cu / capacity workgroups of 16 waves whatever the other slots hold: a sample's sums do not depend on its
+    // 2 x num_cu / capacity workgroups of cohort_waves() = 8 waves whatever the other slots hold: a sample's sums do not depend on its
     // neighbours, nor on when it arrived.
     static int create_slots(int capacity, int device, int num_pc, int num_cu, Batch** out);
     int set_slot(int i, Context* c);

@@ -29,6 +29,7 @@
 #include "estimator.h"
 #include "hostio.h"
 #include "stream_search.h"
+#include "tunables.h"
 
 using vb2::set_error;
 
@@ -68,7 +69,7 @@ public:
         T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, std::max(hw, 1) * 4, S_}));
         slots_.resize(S_);
         cnt_.assign(ndev_, 0);
-        stream_ = !(std::getenv("VB2_COHORT_STREAM") && std::atoi(std::getenv("VB2_COHORT_STREAM")) == 0);
+        stream_ = vb2::tunables().cohort_stream != 0;
         inflight_.assign(ndev_, 0);
         remaining_.assign(ndev_, 0);
         for (int s = 0; s < S_; ++s) ++remaining_[s % ndev_];
@@ -100,7 +101,7 @@ public:
             std::memset(&out_[s], 0, sizeof(out_[s]));
             status_[s] = VB2_ERR_INVALID;
         }
-        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+        const bool timing = vb2::tunables().debug_timing != 0;
         const double t_run0 = now_s();
         // HIP runtime start-up (per device) behind the panel reading
         std::vector<std::thread> warm;
@@ -363,7 +364,7 @@ private:
 
     void stream_loop(int d)
     {
-        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+        const bool timing = vb2::tunables().debug_timing != 0;
         const double t0 = now_s();
         DeviceSource src(this, d);
         int rc = VB2_OK;
@@ -433,7 +434,7 @@ private:
 
     void device_loop(int d)
     {
-        const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+        const bool timing = vb2::tunables().debug_timing != 0;
         for (int gi = d; gi < ngroup_; gi += ndev_) {
             const int g0 = group_begin_[gi], g1 = group_begin_[gi + 1];
             const double tg0 = now_s();
@@ -532,9 +533,9 @@ extern "C" int vb2_cohort_run(const vb2_cohort_args* a, vb2_run_result* out, int
         set_error("vb2_cohort_run: invalid argument");
         return VB2_ERR_INVALID;
     }
-    // (VB2_COHORT_DUP_DEVICES=1: a test switch -- the pipelines of a several-device run, their group
+    // (Tunables::cohort_dup_devices: a test switch -- the pipelines of a several-device run, their group
     // schedule and the readers' per-device look-ahead exercised on a machine with one GPU)
-    const bool dup_ok = std::getenv("VB2_COHORT_DUP_DEVICES") != nullptr;
+    const bool dup_ok = vb2::tunables().cohort_dup_devices != 0;
     for (int i = 0; i < a->base.num_device && !dup_ok; ++i)
         for (int j = 0; j < i; ++j)
             if (a->base.devices && a->base.devices[i] == a->base.devices[j]) {

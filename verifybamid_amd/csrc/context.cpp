@@ -10,6 +10,7 @@
 // per-evaluation path: see DESIGN.md "What is computed once".
 #include "context.h"
 #include "tile_sched.h"
+#include "tunables.h"
 
 #include <sched.h>
 
@@ -24,6 +25,7 @@
 #include <numeric>
 #include <queue>
 #include <functional>
+#include <limits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -51,13 +53,13 @@ namespace {
 // each (a cohort run creates and destroys a context per sample: 5 ms per sample went there).
 // Bounded: at most kMaxCached slabs and kMaxCachedBytes per kind (a cohort run has up to three
 // groups of 64 contexts alive), and a slab is only reused for a request of at least half its
-// size.  VB2_SLAB_CACHE=0 turns the cache off.
+// size.  Tunables::slab_cache = 0 turns the cache off.
 struct SlabCache {
     struct Entry { void* p; size_t bytes; int device; };
     static constexpr size_t kMaxCached = 256, kMaxCachedBytes = (size_t)8 << 30;
     std::mutex mu;
     std::vector<Entry> dev, pin, stage;      // device slabs, small pinned slabs, big pinned upload staging
-    bool enabled() { static const bool on = !(std::getenv("VB2_SLAB_CACHE") && std::getenv("VB2_SLAB_CACHE")[0] == '0'); return on; }
+    bool enabled() { return tunables().slab_cache != 0; }
     void* take(std::vector<Entry>& v, size_t bytes, int device, size_t* got)
     {
         if (!enabled()) return nullptr;
@@ -118,29 +120,6 @@ SlabCache& slab_cache()
 }
 }  // namespace
 
-// The A/B switches of llk_kernels.hip are process-wide: read the environment once, not from every
-// (possibly concurrent) context creation.
-static void init_process_knobs()
-{
-    static std::once_flag once;
-    std::call_once(once, [] {
-        if (const char* sl = std::getenv("VB2_SINGLE_LAUNCH")) set_single_launch(std::atoi(sl) != 0);
-        if (const char* rm = std::getenv("VB2_REDUCE"))
-            set_reduce_mode(!std::strcmp(rm, "ticket") ? 1 : !std::strcmp(rm, "tagged") ? 2 : 0);
-        if (const char* co = std::getenv("VB2_COOP")) set_coop_launch(std::atoi(co) != 0);
-        if (const char* ps = std::getenv("VB2_PASSES")) set_eval_passes(std::atoi(ps) != 0);
-        if (const char* sp = std::getenv("VB2_SPLIT")) set_eval_split(std::atoi(sp));
-        if (const char* pm = std::getenv("VB2_PAIRED")) set_paired_mode(std::atoi(pm) != 0);
-        for (int btl = 1; btl <= 2; ++btl) {
-            const char* gv = std::getenv(btl == 1 ? "VB2_GEOM1" : "VB2_GEOM2");
-            int mw = 0, bpc = 0;
-            if (gv && std::sscanf(gv, "%d,%d", &mw, &bpc) == 2 && mw > 0 && bpc > 0 && bpc <= kMaxGridPerCU)
-                set_geom_override(btl, mw, bpc);
-        }
-        if (const char* lm = std::getenv("VB2_LANE_MAP")) set_lane_mapping(std::strcmp(lm, "plain") != 0);
-    });
-}
-
 int usable_cpu_count()
 {
     static const int cached = [] {
@@ -163,7 +142,7 @@ int usable_cpu_count()
             }
         }
         if (quota > 0 && period > 0) n = std::min(n, std::max(1L, (quota + period / 2) / period));
-        if (const char* e = std::getenv("VB2_CPUS")) n = std::max(1, std::atoi(e));
+        if (tunables().cpus > 0) n = tunables().cpus;
         return (int)n;
     }();
     return cached;
@@ -315,7 +294,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     c->num_pc = in->num_pc;
 
     const int M = in->num_marker, k = in->num_pc;
-    const bool timing = std::getenv("VB2_DEBUG_TIMING") != nullptr;
+    const Tunables& tn = tunables();
+    const bool timing = tn.debug_timing != 0;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -354,7 +334,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     int nthr = std::min(usable_cpu_count(), 16);
     nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, total_reads / 200000));
     if (const int cap = g_flatten_thread_cap.load()) nthr = std::min(nthr, cap);     // cohort runner: many creates at once
-    if (const char* ft = std::getenv("VB2_FLATTEN_THREADS")) nthr = std::max(1, std::atoi(ft));
+    if (tn.flatten_threads > 0) nthr = tn.flatten_threads;
     auto parallel_for = [&](int64_t n, const std::function<void(int, int64_t, int64_t)>& fn) {
         if (nthr == 1 || n < nthr) { fn(0, 0, n); return; }
         std::vector<std::thread> th;
@@ -369,15 +349,13 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // no bank conflict.  The frequency ranking comes from a strided sample of the reads (any order
     // is correct; this one only has to be known BEFORE the reads are walked, so that pass A can
     // emit every marker's runs already sorted).  `idx` = 2 * rank(quality) + class below.
-    // VB2_DICT_ORDER=plain ranks the qualities by ascending value instead (A/B).
     int qrank[kNumQual], qof[kNumQual];
     {
         int64_t qh[kNumQual];
         std::fill(qh, qh + kNumQual, 0);
-        static const bool plain = std::getenv("VB2_DICT_ORDER") && !std::strcmp(std::getenv("VB2_DICT_ORDER"), "plain");
         const int64_t nsample = std::min<int64_t>(total_reads, 1 << 16);
         const int64_t step = nsample > 0 ? total_reads / nsample : 1;
-        if (!plain && in->quals)
+        if (in->quals)
             for (int64_t j = 0; j < nsample; ++j) ++qh[clamp_qual(in->quals[read_base + j * step])];
         for (int q = 0; q < kNumQual; ++q) qof[q] = q;
         std::stable_sort(qof, qof + kNumQual, [&](int x, int y) { return qh[x] > qh[y]; });
@@ -414,7 +392,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // rows in panel order, three words per sorted marker -- instead of the packed arrays; 2-3 ms of host CPU per C3 sample
     // (scattered reads, 2 M table look-ups) become a ~30 us kernel.  The run lists and the constants are WRITTEN into the
     // pinned slab the upload leaves from (no scratch arrays, no copy).
-    const bool host_pack_forced = std::getenv("VB2_HOST_PACK") && std::atoi(std::getenv("VB2_HOST_PACK")) != 0;
+    const bool host_pack_forced = tn.host_pack != 0;
     const bool device_pack_wanted = !dry && !host_pack_forced && M > 0 && total_reads > 0 && total_reads < ((int64_t)1 << 32);
     size_t in_total = 0;
     auto icarve = [&](size_t bytes) {
@@ -643,8 +621,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // word of a double whose low word is 0).  Unused slots: the padding row (zeros) with count +0.0.
     // Two runs per (row, marker) entry.  16-bit offsets reach 163 wide rows; a bigger dictionary
     // gets the narrow rows (and 4-point launches only).
-    // (VB2_FORCE_NARROW=1: an experiment knob -- narrow table rows although the dictionary would fit wide ones)
-    static const bool force_narrow = std::getenv("VB2_FORCE_NARROW") && std::getenv("VB2_FORCE_NARROW")[0] == '1';
+    const bool force_narrow = tn.force_narrow != 0;
     const int row_bytes = (num_code <= kMaxWideCodes && !force_narrow) ? kRowBytesWide : kRowBytesNarrow;
     auto run_word = [&](int d, uint32_t n) {
         const double nd = (double)n;
@@ -657,9 +634,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     for (int idx = 0; idx < kMaxCode; ++idx) row_of_idx[idx] = dict_of[idx] == kPadCode ? 0u : (uint32_t)(dict_of[idx] * row_bytes);
     for (int n = 0; n <= kMaxRunCount; ++n) hi_of_count[n] = run_word(0, (uint32_t)n);
     // wide quality alphabets: a tile's runs are placed by schedule_tile (tile_sched.h) instead of in plain dictionary order
-    // (VB2_RUN_SCHED=0: plain order always; =1: scheduled whatever the dictionary's size)
-    static const int run_sched_knob = std::getenv("VB2_RUN_SCHED") ? std::atoi(std::getenv("VB2_RUN_SCHED")) : -1;
-    const bool run_sched = run_sched_knob < 0 ? num_code > kSchedMinCodes : run_sched_knob != 0;
+    // (Tunables::run_sched 0: plain order always; 1: scheduled whatever the dictionary's size)
+    const bool run_sched = tn.run_sched < 0 ? num_code > kSchedMinCodes : tn.run_sched != 0;
 
     // ---- device memory: ONE allocation per context, carved into 256-byte aligned pieces.
     // (A cohort creates contexts from many host threads; allocation calls go through driver
@@ -672,7 +648,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     std::memset(&L, 0, sizeof(L));
     const int nb = kMaxGridPerCU * num_cu;
     const size_t relay_words = (size_t)resident_relay_words(k);
-    const bool want_stamps = std::getenv("VB2_STAMPS") != nullptr;
+    const bool want_stamps = tn.stamps != 0;
     size_t dev_total = 0;
     auto carve = [&](size_t bytes) {
         const size_t off = (dev_total + 255) & ~(size_t)255;
@@ -858,10 +834,9 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             const unsigned char* q = static_cast<const unsigned char*>(ptr);
             for (size_t i = 0; i < bytes; ++i) hsh = (hsh ^ q[i]) * 1099511628211ull;
         };
-        // (VB2_DIGEST_CODES=multiset, a test aid: the run words enter as a SUM of word hashes per micro-tile -- the same for
+        // (Tunables::digest_multiset, a test aid: the run words enter as a SUM of word hashes per micro-tile -- the same for
         // any order of a tile's words: what schedule_tile may change and nothing else)
-        static const bool codes_as_multiset = std::getenv("VB2_DIGEST_CODES") && !std::strcmp(std::getenv("VB2_DIGEST_CODES"), "multiset");
-        if (codes_as_multiset) {
+        if (tn.digest_multiset) {
             for (int t = 0; t < num_mt; ++t) {
                 uint64_t sum = 0;
                 const uint32_t* w = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
@@ -990,15 +965,15 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     c->dbg_regions.push_back({o_dpe, dict_perr.size() * sizeof(double)});
     c->dbg_regions.push_back({o_prim, prim.size() * sizeof(double2)});
     c->dbg_counts[0] = num_read; c->dbg_counts[1] = num_other; c->dbg_counts[2] = (int64_t)num_code; c->dbg_counts[3] = m_active;
-    if (const char* sc = std::getenv("VB2_SCHED")) c->sched_enabled = std::atoi(sc) != 0;
+    c->sched_enabled = tn.sched != 0;
     c->device_bytes = (int64_t)dev_total;
     L.num_prim = (int32_t)prim.size();
     L.num_code = num_code;
     L.row_bytes = row_bytes;
     L.num_mt = num_mt;
     L.num_cu = num_cu;
-    L.dyn_limit = std::getenv("VB2_DYN_TILES") ? std::atoi(std::getenv("VB2_DYN_TILES")) : 10;
-    L.stagger = std::getenv("VB2_STAGGER") ? std::atoi(std::getenv("VB2_STAGGER")) : 0;
+    L.dyn_limit = tn.dyn_tiles;
+    L.stagger = tn.stagger;
     L.num_pc = k;
     L.num_active = m_active;
     L.m_pad = m_pad;
@@ -1017,7 +992,6 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     c->num_read_other = num_other;
     c->algorithmic_bytes = 2 * num_read + m_active * (8 * (int64_t)k + 12);
 
-    init_process_knobs();
     // Host <-> device hand-off of the (tiny) parameter and result vectors goes through
     // pinned, device-mapped host memory that the kernels access directly: no copy
     // commands on the evaluation path.
@@ -1056,9 +1030,10 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     c->d_state = reinterpret_cast<unsigned int*>(hdev + p_state);
     c->h_result = reinterpret_cast<double*>(hbase + p_result);
     c->d_result = reinterpret_cast<double*>(hdev + p_result);
-    if (const char* ds = std::getenv("VB2_DEVICE_SIMPLEX")) c->device_simplex_enabled = std::atoi(ds) != 0;
-    if (const char* sw = std::getenv("VB2_SPIN_WAIT")) c->spin_wait = std::atoi(sw) != 0;
-    if (const char* rs = std::getenv("VB2_RESIDENT")) c->resident_enabled = std::atoi(rs) != 0;
+    c->device_simplex_enabled = tn.device_simplex != 0 && !(opt && (opt->flags & VB2_OPT_HOST_SEARCH));
+    c->spin_wait = tn.spin_wait != 0;
+    c->resident_enabled = tn.resident != 0 && !(opt && (opt->flags & VB2_OPT_LAUNCH_PER_STEP));
+    c->plain_launch = tn.coop == 0 || (opt && (opt->flags & VB2_OPT_PLAIN_LAUNCH)) || profiler_attached();
     c->dbg_timing = timing;
     // the upload has left the staging slab (which goes back to the cache now): wait for THIS
     // context's stream only -- other contexts' streams and the null stream are not touched
@@ -1124,7 +1099,7 @@ int Context::cohort_schedules(int bps, int block_waves, Schedule out[4], bool fu
     // micro-tiles a wave takes per item: two for <= 4 points (when paired), one for 8 points, four for one or two points.
     // Shapes with the same number share ONE schedule; !full: only the one- and two-point shapes (a search's steps but for
     // its first and its shrinks, which then take the in-kernel snake deal).
-    const int tpu[4] = {paired_mode() ? 2 : 1, 1, paired_mode() ? 4 : 1, paired_mode() ? 4 : 1};
+    const int tpu[4] = {2, 1, 4, 4};
     std::vector<char> blob;
     size_t where[4] = {0, 0, 0, 0};
     bool built[4] = {false, false, false, false};
@@ -1199,8 +1174,8 @@ bool Context::resident_begin()
         ResidentArgs ra;
         ra.h_cmd = d_cmd;
         ra.relay = d_relay;
-        ra.relay_reps = std::getenv("VB2_RELAY_REPS") ? std::max(1, std::min(kRelayReps, std::atoi(std::getenv("VB2_RELAY_REPS")))) : 8;
-        ra.own_rows = std::getenv("VB2_OWN_ROWS") ? std::atoi(std::getenv("VB2_OWN_ROWS")) : 1;
+        ra.relay_reps = 8;                                // (1 .. kRelayReps measured: 8 copies, 32 workgroups polling each)
+        ra.reserved1 = 0;
         ra.spec = d_relay + resident_words(num_pc);
         ra.h_out = d_out;
         ra.h_done = d_done;
@@ -1214,14 +1189,15 @@ bool Context::resident_begin()
         ra.state_off = 0;
         {
             const LaunchGeom gm = launch_geom(L, 1);
-            ra.sched_multi = get(paired_mode() ? 3 : 1, 1, gm.grid, gm.block_waves);
-            ra.sched_single = paired_mode() ? get(4, 1, gm.grid, gm.block_waves) : ra.sched_multi;
-            // the workgroups' own run lists in LDS for the whole search, if they fit (VB2_LDS_CACHE=0: the A/B knob)
-            static const bool lds_cache = !(std::getenv("VB2_LDS_CACHE") && std::atoi(std::getenv("VB2_LDS_CACHE")) == 0);
+            ra.sched_multi = get(3, 1, gm.grid, gm.block_waves);
+            ra.sched_single = get(4, 1, gm.grid, gm.block_waves);
+            // the workgroups' own run lists in LDS for the whole search, if they fit (Tunables::lds_cache 0: the A/B knob)
             ra.cache_tiles = (L.num_mt + gm.grid - 1) / gm.grid;
-            ra.cache_rows = lds_cache ? (int32_t)resident_cache_rows(h_mt_rows.data(), L.num_mt, gm.grid) : 0;
+            ra.cache_rows = tunables().lds_cache ? (int32_t)resident_cache_rows(h_mt_rows.data(), L.num_mt, gm.grid) : 0;
         }
-        ok = launch_llk_resident(L, &ra, d_partials, d_ticket, stream) == hipSuccess;
+        bool coop = !plain_launch;
+        ok = launch_llk_resident(L, &ra, d_partials, d_ticket, stream, &coop) == hipSuccess;
+        resident_cooperative = ok && coop;
         if (!ok) (void)hipGetLastError();
         resident_nmax = ok ? ra.state_nmax : 0;
     }
@@ -1261,8 +1237,27 @@ void Context::resident_end()
     g_resident_busy[device].store(0);
 }
 
+// The results of a step come back through mapped host memory as relaxed system-scope stores followed -- after the
+// storing lanes have their acknowledgements -- by the relaxed store of the sequence number the host spins on (round 4:
+// the release fences this replaced were half of an empty step's 20 us).  The memory model does not promise that the
+// acknowledged stores are visible to the HOST before the flag is, so the host does not rely on it: the
+// result words are set to NaN before every step, and a NaN found behind the flag is first taken for a store still on its
+// way (re-read for a few microseconds) and only then for the kernels' own "a workgroup never reported" marker.
+static bool settle_results(const double* out, int n)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        bool any_nan = false;
+        for (int b = 0; b < n; ++b) any_nan |= std::isnan(reinterpret_cast<const volatile double*>(out)[b]);
+        if (!any_nan) return true;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) return false;
+        __builtin_ia32_pause();
+    }
+}
+
 void Context::resident_submit(int n, const double* rows)
 {
+    for (int b = 0; b < n; ++b) h_out[b] = std::numeric_limits<double>::quiet_NaN();
     resident_post(h_cmd, resident_words(num_pc), ++done_seq_, n, 2 * num_pc + 1, rows);
     dbg_t_post = std::chrono::steady_clock::now();
     if (dbg_timing && dbg_have_prev)
@@ -1286,9 +1281,7 @@ bool Context::resident_collect(int n, double* out)
     // A NaN can only be the kernel's own "a workgroup never reported" marker (the partial-sum
     // hand-off gave up after a quarter of a second): part of the grid is not on the CUs.  Same treatment as no
     // answer at all.
-    if (seen)
-        for (int b = 0; b < n; ++b)
-            if (std::isnan(h_out[b])) seen = false;
+    if (seen && !settle_results(h_out, n)) seen = false;
     if (!seen) {
         // Give up on the mode: tell the kernel to leave (it may already have, on its idle
         // limit), wait for it, and let the caller redo the batch with plain launches.
@@ -1429,6 +1422,8 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
     }
     VB2_HIP(hipSetDevice(device));
     const int k = num_pc, stride = 2 * k + 1;
+    const double *const pc1_all = pc1, *const pc2_all = pc2, *const alpha_all = alpha;
+    double* const llk_all = llk_out;
     int served = 0;
     while (resident_active && served < num_point) {
         // the search kernel is already on the CUs: post <= 4 rows, spin on the sequence number
@@ -1467,6 +1462,7 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
         // survives that is the input's own (NaN parameters) and is passed on as the value it is.
         for (int attempt = 0; attempt < 2; ++attempt) {
             const unsigned long long seq = ++done_seq_;
+            for (int b = 0; b < n; ++b) h_out[b] = std::numeric_limits<double>::quiet_NaN();
             int rc = eval_device(n, d_points, d_out, stream, L.num_mt > 0 && spin_wait ? d_done : nullptr, seq,
                                  h_points, attempt == 0 ? 0 : 1);
             if (rc) return rc;
@@ -1481,12 +1477,22 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
                 }
             }
             if (!seen) VB2_HIP(hipStreamSynchronize(stream));
-            bool any_nan = false;
-            for (int b = 0; b < n; ++b) any_nan |= std::isnan(h_out[b]);
-            if (!any_nan) break;
+            if (settle_results(h_out, n)) break;
             if (attempt == 0) ++nan_retries;
         }
         std::memcpy(llk_out + done, h_out, sizeof(double) * n);
+    }
+    // NaN parameters: in the reference every marker's likelihood is then NaN, fails `markerLK > 0` (h:310) and is
+    // left out -- the sum over no markers, 0 (the kernels' clamps -- v_max / v_min quiet a NaN away -- would answer
+    // with the alpha-free part of the likelihood instead).  alpha enters every table entry, the PCs every allele
+    // frequency unless the frequencies are known.
+    for (int b = 0; b < num_point + served; ++b) {
+        const double* p1 = pc1_all + (size_t)b * k;
+        const double* p2 = pc2_all + (size_t)b * k;
+        bool bad = std::isnan(alpha_all[b]);
+        if (!L.known_af)
+            for (int j = 0; j < k; ++j) bad |= std::isnan(p1[j]) || std::isnan(p2[j]);
+        if (bad && L.num_mt > 0) llk_all[b] = 0.0;
     }
     return VB2_OK;
 }

@@ -150,8 +150,10 @@ public:
     unsigned long long* d_done = nullptr;
     unsigned long long done_seq_ = 0;
     bool spin_wait = true;
-    bool resident_enabled = true;            // VB2_RESIDENT=0 turns the mode off
+    bool resident_enabled = true;            // Tunables::resident / VB2_OPT_LAUNCH_PER_STEP turn the mode off
     bool resident_active = false;
+    bool plain_launch = false;               // the resident kernel goes up with a plain launch (profiler, VB2_OPT_PLAIN_LAUNCH)
+    bool resident_cooperative = false;       // ... and the one that is up went up cooperatively
     unsigned long long* h_cmd = nullptr;     // mailbox (mapped host memory) + device view
     unsigned long long* d_cmd = nullptr;
     unsigned long long* d_relay = nullptr;
@@ -160,7 +162,7 @@ public:
     double* h_result = nullptr;              // result block of an on-device Minimize() (mapped host memory)
     double* d_result = nullptr;
     int resident_nmax = 0;                   // largest simplex dimension the running resident kernel supports
-    bool device_simplex_enabled = true;      // VB2_DEVICE_SIMPLEX=0: the host optimiser drives every search
+    bool device_simplex_enabled = true;      // Tunables::device_simplex / VB2_OPT_HOST_SEARCH: the host optimiser drives every search
     unsigned long long resident_epoch_ = 0;
     int64_t device_minimizes = 0;            // Minimize() calls served on the device
     int64_t resident_evals = 0;              // batches served by the resident kernel

@@ -1,4 +1,5 @@
 // estimator.cpp -- see estimator.h.
+#include "tunables.h"
 #include "estimator.h"
 
 #include "context.h"
@@ -230,7 +231,7 @@ static bool run_minimizer(Estimator* e, AmoebaMinimizer& m, int dim,
     }
     m.func = &e->objective;
     m.speculate = e->speculate;
-    if (const char* sp = std::getenv("VB2_SPECULATE")) m.speculate = std::atoi(sp);     // A/B and test knob: 1, 2, 4
+    if (tunables().speculate > 0) m.speculate = tunables().speculate;     // A/B and test knob: 1, 2, 4
     m.Reset(dim);
     m.point = start;
     *ret = m.Minimize(e->epsilon);

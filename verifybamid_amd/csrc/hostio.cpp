@@ -1,4 +1,5 @@
 // hostio.cpp -- see hostio.h.
+#include "tunables.h"
 #include "hostio.h"
 
 #include <fcntl.h>
@@ -83,9 +84,9 @@ bool slurp(const std::string& path, std::string* all, size_t pad = 0)
 // (strtod is what libstdc++'s num_get ends in), and reports anything else as "not plain": the
 // caller then runs the original stringstream statements on that line, so odd input (short
 // lines, "1e", hex, overflow, locale digits, ...) keeps the iostream behaviour bit for bit.
-// VB2_SLOW_PARSE=1 (read per call): every line takes the stringstream statements -- the
+// Tunables::slow_parse = 1: every line takes the stringstream statements -- the
 // differential tests compare the two paths on deliberately odd files.
-inline bool slow_parse() { const char* e = std::getenv("VB2_SLOW_PARSE"); return e && e[0] == '1'; }
+inline bool slow_parse() { return tunables().slow_parse != 0; }
 
 struct WsTable {
     unsigned char ws[256];
@@ -518,8 +519,7 @@ bool parse_bases(const std::string& seq, const std::string& qual, std::string* p
 inline bool cpu_has_avx2()
 {
     static const bool hw = __builtin_cpu_supports("avx2");
-    const char* e = std::getenv("VB2_SCALAR_PARSE");           // (read per call: the differential tests switch it)
-    return hw && !(e && e[0] == '1');
+    return hw && tunables().scalar_parse == 0;                  // (the differential tests switch it)
 }
 
 __attribute__((target("avx2"))) inline unsigned nonkeep_mask32(__m256i x)

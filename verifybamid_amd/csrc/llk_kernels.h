@@ -24,7 +24,7 @@ constexpr int kMaxWideCodes = 65535 / kRowBytesWide - 1;   // run words hold 16-
 constexpr int kMaxRunCount = 31;           // the 16-bit prefix of a double holds integers up to 31 exactly
 // d_ticket of launch_llk_eval: kTicketWords zero-initialised unsigned ints -- [0, kTicketScratchWord) the arrival tickets of a
 // launch's passes (llk_eval_passes_kernel; a plain launch uses [0]), two words from kTicketScratchWord on a scratch flag
-constexpr int kTicketScratchWord = 8, kTicketSplitWord = 12, kTicketWords = 16;   // [12]: llk_eval_split_kernel's count of finished halves
+constexpr int kTicketScratchWord = 8, kTicketWords = 16;
 constexpr int kInlinePointDoubles = 96;    // parameter rows that travel as kernel arguments (768 B)
 
 // Everything the kernels read, in HBM.  "Sorted order" = active markers sorted by
@@ -57,13 +57,10 @@ struct DeviceLayout {
     int32_t num_pc;
     int32_t num_cu;               // compute units of the device
     int32_t dyn_limit;            // work items per wave up to which the waves of a workgroup pull items from an
-                                  // LDS queue (per-item result slots); above it the static snake deal.
-                                  // default 10 (the queue adapts to the waves' actual speeds: 76.5 us against
-                                  // 78.1 us for the host-built static schedule at 9 items per wave);
-                                  // VB2_DYN_TILES=n is the A/B knob, 0 = always static
+                                  // LDS queue (per-item result slots); above it the static deal.  Tunables::dyn_tiles
+                                  // (10: the queue adapts to the waves' actual speeds), 0 = always static
     int32_t stagger;              // the second half of a workgroup's waves starts its tiles this many x 64
-                                  // cycles late (VB2_STAGGER): de-phases the LDS-bound read loops and the
-                                  // VALU-bound epilogues of the waves that share a SIMD
+                                  // cycles late (Tunables::stagger)
     int32_t reserved0;
     unsigned long long* stamps;   // profiling aid: [grid][8] wall-clock stamps, or nullptr
     int64_t num_active;
@@ -84,7 +81,7 @@ struct Schedule {
 // Returns false (and leaves the vectors empty) when a workgroup has more than 65535 items.
 bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int tiles_per_unit, int ngrp,
                     std::vector<uint32_t>* off, std::vector<uint16_t>* item);
-// Supplies the schedule of a launch shape (mode = wave shape 1..4 of llk_kernels.hip).
+// Supplies the schedule of a launch shape (mode = wave shape 2..4 of llk_kernels.hip).
 struct ScheduleProvider {
     virtual Schedule get(int mode, int ngrp, int grid, int block_waves) = 0;
     virtual ~ScheduleProvider() {}
@@ -112,10 +109,6 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            unsigned long long* tag_counter, hipStream_t stream,
                            int reduce_override = 0,      // 1 ticket / 2 tagged for this call only
                            ScheduleProvider* sched = nullptr);
-void set_single_launch(bool on);
-void set_eval_split(int on);       // llk_eval_split_kernel (two workgroups per CU, half the point groups each) for calls of >= 2 point groups (default on)
-void set_eval_passes(bool on);     // llk_eval_passes_kernel for calls of more points than one launch's tables hold (default on)
-void set_reduce_mode(int mode);     // 0 auto, 1 arrival ticket, 2 tagged sets (VB2_REDUCE)
 
 // A cohort step's point counts and parameter rows as kernel arguments (count = doubles valid in v; 0 = the kernel reads
 // d_num_valid / d_points): rows of sample s at v[s * np * (2k+1) ..)
@@ -154,7 +147,7 @@ bool eval_takes_the_queue(const DeviceLayout& L, int nblk, int nwave, int ngrp);
 size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);   // groups of 4*btl points
 size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp, int exp_tab_doubles = 0 /* the 16-KiB table */);
 int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves);
-hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);   // VB2_SINGLE_LAUNCH=0 -> eval + finalize kernels
+hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 // codes / mt_rec -> codes16 / mt_rec16 on the device (rec16 already holds the tiles' {first row, rows};
 // rows16_total + kCodeSlackRows rows are written, the slack as padding words)
@@ -221,16 +214,15 @@ struct ResidentArgs {
     unsigned long long epoch;            // distinguishes this launch's hand-off tags from any earlier one's
     int32_t state_off;                   // doubles from the start of dynamic LDS to workgroup 0's search state
     int32_t state_nmax;                  // largest simplex dimension the state was sized for (0 = no MINIMIZE)
-    int32_t relay_reps;                  // copies of the relay word in use (1..kRelayReps; VB2_RELAY_REPS)
-    int32_t own_rows;                    // 1: workgroup 0 starts a short-way round from its own copy of the rows sets
-                                         // without waiting for its relay word (VB2_OWN_ROWS, A/B knob)
+    int32_t relay_reps;                  // copies of the relay word in use (1..kRelayReps)
+    int32_t reserved1;
     // LDS areas behind the search state (offsets in doubles from the start of dynamic LDS; filled in by
     // launch_llk_resident): workgroup 0's staging of the partial sums ([4][grid]; 0 = over the dead tables, round 3),
     // and the workgroup's own run lists (LCACHE, resident_kernel.inc: cache_start).
     int32_t sum_stage_off;
     int32_t cache_off;
     // in: what the run-list cache needs -- the most micro-tiles a workgroup owns (rounded up to even) and the most rows
-    // (placement pads and 4 slack rows included); 0 rows = no cache (VB2_LDS_CACHE=0, or the host saw it cannot fit)
+    // (placement pads and 4 slack rows included); 0 rows = no cache (Tunables::lds_cache 0, or the host saw it cannot fit)
     int32_t cache_tiles;
     int32_t cache_rows;
 };
@@ -271,14 +263,14 @@ inline __host__ __device__ int resident_relay_words(int num_pc) { return residen
 // Words of dynamic LDS the resident kernel needs beyond the evaluation body's (search state + command image +
 // every workgroup's staging of the round's rows).
 size_t resident_state_doubles(int nmax, int num_pc);
-bool paired_mode();
-void set_paired_mode(bool on);     // VB2_PAIRED=0: 4-point launches use MODE 1 instead of MODE 3
-void set_coop_launch(bool on);     // VB2_COOP=1: cooperative launch of the resident kernel
+// *cooperative: in: ask for hipLaunchCooperativeKernel (every workgroup guaranteed on the CUs together); out: whether
+// the kernel went up that way (a refused cooperative launch falls back to a plain one: the bounded waits on both sides
+// then turn a partly resident grid into a retry, not a hang)
 hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra, double* d_partials,
-                               unsigned int* d_ticket, hipStream_t stream);
-// A/B switch: lanes of one ds_read_b128 service group share a candidate slot (default) or plain
-void set_lane_mapping(bool hardware_groups);
-void set_geom_override(int btl, int max_waves, int blocks_per_cu);
+                               unsigned int* d_ticket, hipStream_t stream, bool* cooperative);
+// a profiler's tool library (rocprofv3: librocprofiler-sdk-tool) is loaded in this process: ROCm 7.2's crashes in its
+// exit handler after a cooperative launch, so the library launches plainly under it
+bool profiler_attached();
 
 }  // namespace vb2
 #endif

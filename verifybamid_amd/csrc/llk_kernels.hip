@@ -4,7 +4,7 @@
 // Work decomposition:
 //   * a wave = 16 markers x 4 candidate slots: lane (m, g) walks marker m's reads for the BTL
 //     candidate points of slot g (MODE 2: 8 points per group); 4-point launches use two
-//     16-marker micro-tiles x 2 slots x 2 points instead (MODE 3).  Markers are sorted by depth
+//     16-marker micro-tiles x 2 slots x 2 points instead (MODE 3), 1- and 2-point launches four (MODE 4, 5).  Markers are sorted by depth
 //     at context creation and grouped in 16-marker micro-tiles so all lanes of a wave run about
 //     the same number of steps;
 //   * a marker's reads are run-length coded over the (class x quality) dictionary: one 32-bit run
@@ -33,10 +33,15 @@
 #include "llk_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <link.h>
+
+#include "kernel_debug.h"
 #include "tile_sched.h"
+#include "tunables.h"
 
 #include <algorithm>
 #include <atomic>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -58,11 +63,6 @@ __device__ __forceinline__ void pair_of(int p, int& g1, int& g2)
 // this once (workgroup 0's four sums), a cross-lane LDS round trip per step before.
 __device__ __forceinline__ double wave_sum(double v)
 {
-#ifdef VB2_OLD_WAVE_SUM
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-#else
     {
         const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
         const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
@@ -90,7 +90,6 @@ __device__ __forceinline__ double wave_sum(double v)
     v += dpp(v, std::integral_constant<int, 0x4E>());                        // quad_perm [2,3,0,1]
     v += dpp(v, std::integral_constant<int, 0xB1>());                        // quad_perm [1,0,3,2]
     return v;
-#endif
 }
 
 // 2^(j/64), j = 0..63, correctly rounded (generated with 60-digit decimal arithmetic).
@@ -233,10 +232,24 @@ __device__ __forceinline__ double log_tab(double x, uint32_t ltab_addr /* LDS by
 {
     const double kLn2Hi = 0x1.62e42fefa3800p-1, kLn2Lo = 0x1.ef35793c76730p-45;
     constexpr double kP[5] = {VB2_LOG_POLY};
-    const uint32_t hi = (uint32_t)__double2hiint(x);
+    uint32_t hi = (uint32_t)__double2hiint(x);
+    // Outside the table's domain (one compare on the high word, a branch no wave of a search ever takes):
+    // zero -> -inf (the reference's log(0): entries whose probability is exactly 0); a positive subnormal (alpha below
+    // 2^-1022: a logit under -708) -> scaled into the normal range, 64 ln2 taken off again through k; NaN, a negative
+    // "probability" (alpha outside [0, 1]) -> NaN; +inf -> +inf: libm's answers, so that a NaN likelihood reaches the
+    // caller as NaN and not as a plausible number.
+    int kadj = 0;
+    bool special = false;
+    double special_value = 0.0;
+    if (__builtin_expect(hi - 0x00100000u >= 0x7FE00000u, 0)) {
+        if (x == 0.0) { special = true; special_value = -__builtin_huge_val(); }
+        else if (!(x > 0.0)) { special = true; special_value = __builtin_nan(""); }
+        else if (hi >= 0x7FF00000u) { special = true; special_value = x; }
+        else { x *= 0x1p64; kadj = 64; hi = (uint32_t)__double2hiint(x); }
+    }
     const uint32_t tmp = hi - 0x3FE5F000u;
     const uint32_t i = (tmp >> 13) & 127u;
-    const int k = (int)tmp >> 20;
+    const int k = ((int)tmp >> 20) - kadj;
     const double z = __hiloint2double((int)(hi - (tmp & 0xFFF00000u)), __double2loint(x));
     const vdouble2 t = *reinterpret_cast<lds_cdouble2*>(ltab_addr + i * 16u);
     const double r = fma(z, t.x, -1.0);
@@ -250,7 +263,7 @@ __device__ __forceinline__ double log_tab(double x, uint32_t ltab_addr /* LDS by
     const double p = fma(r2, q1, q0);
     const double rl = fma(kd, kLn2Lo, r);
     const double y = fma(r2, p, rl);
-    return x == 0.0 ? -__builtin_huge_val() : w + y;
+    return special ? special_value : w + y;
 }
 
 // A positive value as (mantissa in [0.5,1), binary exponent): products of likelihoods are
@@ -291,11 +304,7 @@ __device__ __forceinline__ double table_entry(double alpha, double perr_signed, 
     const double one_minus_alpha = 1.0 - alpha;
     const double val = (alpha * e1 + one_minus_alpha * e2) * p_err +
                        (alpha * n1 + one_minus_alpha * n2) * p_ok;
-#ifdef VB2_OLD_LOG        // (A/B: the fdlibm-style logarithm)
-    return log_nonneg(val);
-#else
     return log_tab(val, ltab_addr);
-#endif
 }
 
 __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
@@ -315,116 +324,61 @@ __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
 // slots for ds_read_b128 (bank = (addr/4) % 64).
 
 constexpr int kExpTabDoubles = 64 * 32;    // exp_nonpos's table in LDS (16 KiB)
-// The in-kernel profiling stamps (tools/stamps*.py) are compiled in only with -DVB2_WITH_STAMPS (csrc/Makefile builds
-// that variant as libvb2_stamps.so): the tests they leave behind in every kernel cost 0.6 % of a 48-point launch
-// and 4 % of a small sample's search.
-#ifdef VB2_WITH_STAMPS
-#define VB2_STAMPS_OF(L) ((L).stamps)
-#else
-#define VB2_STAMPS_OF(L) (static_cast<unsigned long long*>(nullptr))
-#endif
-constexpr int kPrefetch = 8;               // rows of run dwords in flight per lane
+constexpr int kPrefetch = 8;               // rows of run dwords in flight per lane: cohort steps (lists from HBM)
+constexpr int kPrefetchL2 = 2;             // ... a single sample's launches and search rounds (lists in L2 / LDS)
 
-// Lane -> (marker m in the micro-tile, candidate slot g).
-// HWMAP: the 16 lanes that ds_read_b128 services in one LDS pass (lanes {0-3,12-15,
-// 20-27}, {4-11,16-19,28-31} and the same +32; MI355X_MICROARCH.md, LDS) share one
-// candidate slot, so within a pass the addresses differ only by the code.
-template <bool HWMAP>
+// Lane -> (marker m in the micro-tile, candidate slot g): the 16 lanes that ds_read_b128 services in one LDS pass
+// (lanes {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32; MI355X_MICROARCH.md, LDS) share one candidate
+// slot, so within a pass the addresses differ only by the code.
 __device__ __forceinline__ void lane_map(int lane, int& m, int& g)
 {
-    if (HWMAP) {
-        const int q = (lane >> 2) & 7;                       // quad within the 32-lane half
-        const int nib = (0x76452310u >> (4 * q)) & 7;        // (rank<<1 | group) of quad q
-        g = (nib & 1) + 2 * (lane >> 5);
-        m = ((nib >> 1) << 2) + (lane & 3);
-    } else {
-        m = lane & 15;
-        g = lane >> 4;
-    }
+    const int q = (lane >> 2) & 7;                       // quad within the 32-lane half
+    const int nib = (0x76452310u >> (4 * q)) & 7;        // (rank<<1 | group) of quad q
+    g = (nib & 1) + 2 * (lane >> 5);
+    m = ((nib >> 1) << 2) + (lane & 3);
+}
+__device__ __forceinline__ int lane_of(int m, int g)
+{
+    const int idx = ((g & 1) << 2) + (m >> 2);           // group*4 + quad-rank
+    const int q = (0x74216530u >> (4 * idx)) & 7;
+    return ((g >> 1) << 5) + (q << 2) + (m & 3);
 }
 
-// The value of lane `partner` = the lane whose marker index differs in bit `off` (same slot).  Both lane maps keep the low
+// The value of lane `partner` = the lane whose marker index differs in bit `off` (same slot).  The lane map keeps the low
 // two marker bits in the low two lane bits, so the exchanges over off = 1 and 2 stay inside a quad: DPP quad permutes -- VALU
-// moves, no trip through the LDS crossbar (a ds_bpermute per dword and ~100 cycles before the dependent multiply); the
-// exchange over 4 crosses quads inside a 16-lane row (HW4 below), the one over 8 crosses rows and stays a ds_bpermute.
-// Measured (48-point launch, same box): every exchange a ds_bpermute (-DVB2_DPP_XCHG=0) 70.1 us; off = 1, 2 as quad permutes
-// (=1) 68.4 us; off = 4 as two masked row rotations too (=2, the default) 68.0 us; OptimizeLLK 6.41 -> 6.32 ms; cohort steps
-// unchanged (the static deal exchanges once per wave, not per item).  Multiplication commutes: the same bits.
-#ifndef VB2_DPP_XCHG
-#define VB2_DPP_XCHG 2
-#endif
-// HW4 (the hardware lane map, off = 4; -DVB2_DPP_XCHG=2): marker bit 2 selects between the quads {0,3}, {1,2} of a 16-lane
-// row (lane_of: ranks 0,1,2,3 of slot-parity 0 sit in quads 0,3,5,6, of parity 1 in 1,2,4,7), i.e. quad j <-> 3 - j with
-// the lane in the quad kept: a row rotation by 4 for the quads 0 and 2, by 12 for 1 and 3 (tools/ubench/dpp_map.hip:
-// row_ror:n gives lane i the value of lane i - n of its row) -- two DPP moves with bank masks.
-template <bool HW4 = false>
+// moves, no trip through the LDS crossbar (a ds_bpermute per dword and ~100 cycles before the dependent multiply).  Marker
+// bit 2 selects between the quads {0,3}, {1,2} of a 16-lane row (lane_of: ranks 0,1,2,3 of slot-parity 0 sit in quads
+// 0,3,5,6, of parity 1 in 1,2,4,7), i.e. quad j <-> 3 - j with the lane in the quad kept: a row rotation by 4 for the
+// quads 0 and 2, by 12 for 1 and 3 (tools/ubench/dpp_map.hip: row_ror:n gives lane i the value of lane i - n of its row)
+// -- two DPP moves with bank masks.  The exchange over 8 crosses rows and stays a ds_bpermute (as three VALU moves per dword
+// -- lane ^ 4, then v_permlane16_swap -- it was measured slower: HISTORY.md, round 4).  Multiplication commutes: the same bits
+// whatever the route.
 __device__ __forceinline__ int lane_xchg_i32(int x, int off, int partner)
 {
-    if (VB2_DPP_XCHG && off == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
-    if (VB2_DPP_XCHG && off == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-    if (VB2_DPP_XCHG >= 2 && HW4 && off == 4) {
+    if (off == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    if (off == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    if (off == 4) {
         const int a = __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0x5, false);       // row_ror:4  -> quads 0 and 2 of every row
         return __builtin_amdgcn_update_dpp(a, x, 0x12C, 0xf, 0xa, false);              // row_ror:12 -> quads 1 and 3
     }
-    // HW8 (-DVB2_DPP_XCHG=3; the hardware lane map, off = 8): marker bit 3 selects between the two 16-lane rows of a 32-lane half,
-    // quad position p of row 0 <-> position p ^ 1 of row 1 (ranks 0,1 sit in row 0, ranks 2,3 in row 1).  The exchange over
-    // 8 is the FIRST of the four and only the lanes of markers 0..7 -- row 0 -- are read afterwards (the product ends in
-    // marker 0's lane), so a one-way move is enough: lane ^ 4 by two masked row rotations, then gfx950's v_permlane16_swap
-    // brings row 1 down to row 0.  Three VALU moves per dword instead of a ds_bpermute.  Rows 1 and 3 hold no product after it.
-    // MEASURED AND DROPPED (bit-identical): 48-point launch 62.27 -> 62.62 us, OptimizeLLK 5.89 -> 6.06 ms -- eighteen VALU moves
-    // per item cost more than the six ds_bpermutes they replace; the default stays 2.
-    if (VB2_DPP_XCHG >= 3 && HW4 && off == 8) {
-        const int a = __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xa, false);       // row_ror:4  -> quads 1 and 3 <- lane - 4
-        const int y = __builtin_amdgcn_update_dpp(a, x, 0x12C, 0xf, 0x5, false);       // row_ror:12 -> quads 0 and 2 <- lane + 4
-        return (int)__builtin_amdgcn_permlane16_swap((unsigned)y, (unsigned)y, false, false)[1];
-    }
     return __shfl(x, partner, 64);
 }
-template <bool HW4 = false>
 __device__ __forceinline__ double lane_xchg_f64(double x, int off, int partner)
 {
-    if (VB2_DPP_XCHG && (off == 1 || off == 2 || (VB2_DPP_XCHG >= 2 && HW4 && off == 4) || (VB2_DPP_XCHG >= 3 && HW4 && off == 8)))
-        return __hiloint2double(lane_xchg_i32<HW4>(__double2hiint(x), off, partner), lane_xchg_i32<HW4>(__double2loint(x), off, partner));
+    if (off == 1 || off == 2 || off == 4)
+        return __hiloint2double(lane_xchg_i32(__double2hiint(x), off, partner), lane_xchg_i32(__double2loint(x), off, partner));
     return __shfl(x, partner, 64);
-}
-
-template <bool HWMAP>
-__device__ __forceinline__ int lane_of(int m, int g)
-{
-    if (HWMAP) {
-        const int idx = ((g & 1) << 2) + (m >> 2);           // group*4 + quad-rank
-        const int q = (0x74216530u >> (4 * idx)) & 7;
-        return ((g >> 1) << 5) + (q << 2) + (m & 3);
-    }
-    return (g << 4) + m;
 }
 
 // Occupancy target: one 1024-thread workgroup per CU (4 waves/SIMD, <=128 VGPRs).  Two
 // smaller workgroups per CU were measured slower: the per-alpha table is built once per
 // workgroup, and that redundant work is 9 % of a launch's transcendentals at one
 // workgroup per CU but 18 % at two.
-template <int MODE> struct Geom;
-#ifdef VB2_M1_W8     // (experiment: the one-point-per-lane shape held to 64 registers, two workgroups per CU)
-template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 8; };
-#else
-template <> struct Geom<1> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
-#endif
-#ifndef VB2_G2_WAVES      // (experiment: the 8-point shape in smaller workgroups at a smaller register budget, two per CU)
-#define VB2_G2_WAVES 16
-#define VB2_G2_WPS 4
-#endif
-#ifndef VB2_SPLIT_WAVES   // waves of a workgroup of llk_eval_split_kernel (two workgroups per CU)
-#define VB2_SPLIT_WAVES 8
-#endif
-template <> struct Geom<2> { static constexpr int kMaxWaves = VB2_G2_WAVES, kBlocksPerCU = 1, kWavesPerSimd = VB2_G2_WPS; };
-template <> struct Geom<3> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
-template <> struct Geom<4> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
-template <> struct Geom<5> { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
+template <int MODE> struct Geom { static constexpr int kMaxWaves = 16, kBlocksPerCU = 1, kWavesPerSimd = 4; };
 // points per group of a wave shape
 template <int MODE> struct ModeNp { static constexpr int value = MODE == 2 ? 8 : MODE == 4 ? 1 : MODE == 5 ? 2 : 4; };
 
 // MODE picks the wave shape.  BTL = candidate points per lane, SLOTS = candidate slots per wave:
-//   MODE 1: 16 markers x 4 slots x 1 point   (NP = 4 points per group; A/B alternative to 3)
 //   MODE 2: 16 markers x 4 slots x 2 points  (NP = 8)
 //   MODE 3: 2 x 16 markers x 2 slots x 2 points (NP = 4): the wave takes TWO micro-tiles, so a
 //           4-point launch (a Nelder-Mead iteration) amortises the per-run bookkeeping over two
@@ -470,21 +424,17 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // QUEUE: 1 = the launch is known (on the host, by eval_is_dynamic) to take its work items through the LDS queue, 0 = the
 // static deal, -1 = decided in the kernel.  The single-sample kernels are compiled for both: with the other way's code
 // gone a 48-point launch is 1.8 % shorter and a search round 5 % (fewer scalar registers spilled to vector lanes).
-// ONEGRP: the launch is known to carry ONE group of points (every shape but the 8-point one always does; cohort steps
-// and search rounds too): the group loops and the item -> (group, unit) division go at compile time.
-// KAF: 0 = the context is known to have no known-allele-frequency column (the usual case: AF from UD x PC): its tests go
-// at compile time (+1.2 % on the 48-point launch, the only shape compiled this way); -1 = decided in the kernel.
-// KSEL: --NumPC when it is 2 (the reference's default) or 4 (its usual setting), else 0 = read from the layout: the
-// guards and address multiples of the projection go at compile time (+1.4 % on the 48-point launch; that shape only).
+// KSEL: --NumPC when it is 2 (the reference's default) or 4 (its usual setting) AND the context has no known-allele-
+// frequency column (the usual case: AF from UD x PC), else 0 = both read from the layout: the guards and address
+// multiples of the projection and the known-AF tests go at compile time (+2.6 % on the 48-point launch).
 // LCACHE (the resident search kernel): this workgroup's run lists and tile records were copied to LDS when the kernel
 // started (a workgroup owns the same micro-tiles in every round), so a round's read loops begin without the two dependent
 // trips to L2 (tile record, then its first rows) and never wait for a row again.
-// SWP (VERDICT r3 #3a, the 8-point shape on the work queue only): a software-pipelined item loop -- the twelve exponentials
-// of item i's epilogue ride in the first twelve row steps of item i+1, one per step, so that a wave's LDS-bound read loop and
-// its VALU-bound epilogue overlap inside the wave itself; the finished sums and constants of item i stay in registers
-// meanwhile (3 waves per SIMD, <= 168 VGPRs: the kernel is launched with 12-wave workgroups).  See the item loop.
-template <int MODE, bool HWMAP, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1,
-          bool ONEGRP = (MODE >= 3), int KAF = -1, int KSEL = 0, bool LCACHE = false, bool SWP = false, int ESH = 8>
+// ESH: log2 of the byte stride between the entries of exp_nonpos's table (8: conflict-free; 6: the compact copy).
+// (Measured and dropped over the rounds, all bit-identical: a software-pipelined item loop, a run-ahead ring of table reads,
+// the next item drawn a whole item early, two half-sized workgroups per CU -- HISTORY.md.)
+template <int MODE, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1, int KSEL = 0,
+          bool LCACHE = false, int ESH = 8>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -496,7 +446,12 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
           Hook hook = Hook())
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int BTL = (MODE == 1 || MODE == 4) ? 1 : 2;
+    static_assert(MODE >= 2 && MODE <= 5, "wave shapes 2..5");
+    // the launch is known to carry ONE group of points (every shape but the 8-point one always does; cohort steps too):
+    // the group loops and the item -> (group, unit) division go at compile time
+    constexpr bool ONEGRP = MODE != 2 || STREAM;
+    constexpr int KAF = KSEL > 0 ? 0 : -1;      // 0: no known-AF column, known at compile time
+    constexpr int BTL = MODE == 4 ? 1 : 2;
     constexpr int TPW = MODE == 3 ? 2 : (MODE == 4 || MODE == 5) ? 4 : 1;   // micro-tiles per wave
     constexpr int SLOTS = 4 / TPW;                           // candidate slots per wave
     constexpr int NP = SLOTS * BTL;
@@ -534,15 +489,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it)
     int m, g4;
-    lane_map<HWMAP>(lane, m, g4);
+    lane_map(lane, m, g4);
     const int g = g4 & (SLOTS - 1);              // candidate slot
     const int half = TPW == 1 ? 0 : g4 / SLOTS;  // which of the item's TPW micro-tiles
     // profiling aid: 100 MHz wall-clock stamps per workgroup (stamps pointer null normally)
-    // (-DVB2_STAMP_ROUND=n: the per-workgroup stamps are those of round n of the resident kernel -- a search round that
-    // took the short way -- instead of the last evaluation's; the accumulated figures cover every round either way)
-#ifndef VB2_STAMP_ROUND
-#define VB2_STAMP_ROUND 0
-#endif
+    // (kernel_debug.h: VB2_STAMP_ROUND; the accumulated figures cover every round either way)
     const bool stamp_this = VB2_STAMP_ROUND == 0 || (unsigned)(tag & 0xffffffffull) == (unsigned)VB2_STAMP_ROUND;
 #ifdef VB2_ITEM_PROF
     unsigned long long* stamps = nullptr;                 // (the per-workgroup slots hold the item profile's sums in this build)
@@ -559,14 +510,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const int src = b < num_valid ? b : num_valid - 1;
         const int idx = src * stride + (e - b * stride);
         // resident mode: the rows were just written by another workgroup -> L1-bypassing loads
-#ifdef VB2_ABL_NOMAP
-        const double v = 0.01 * (double)(1 + idx % 7);
-#else
-        const double v = lds_rows ? lds_rows[idx]
+        const double v = (kAblate & kAblNoMap) ? 0.01 * (double)(1 + idx % 7)
+                         : lds_rows ? lds_rows[idx]
                          : ip_count > 0 ? ip_v[idx]
                          : coherent_points ? __hip_atomic_load(&points[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                            : points[idx];
-#endif
         pts[e] = v;
         const int c = e - b * stride;                       // 0..2k-1: a PC coordinate, 2k: alpha
         if (c < 2 * k) ptq[((b / BTL) * 2 * k + c) * BTL + (b % BTL)] = v;
@@ -606,11 +554,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // (a thread's entries for the different groups are independent: computed side by side so
     // that their long dependent logarithm chains overlap)
     const uint32_t ltab_addr = lds_byte_addr(ltab);
-#ifdef VB2_ABL_NOTABLE   // (ablation build)
-    for (int e = tid; e < 0; e += nthread) {
-#else
-    for (int e = tid; e < L.num_prim * 6 * NP; e += nthread) {
-#endif
+    for (int e = tid; e < ((kAblate & kAblNoTable) ? 0 : L.num_prim * 6 * NP); e += nthread) {
         const int pi = e / (6 * NP);
         const int bp = e - pi * (6 * NP);
         const int bb = bp / 6, p = bp - bb * 6;
@@ -656,11 +600,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     const size_t mp = L.m_pad;
     // work items: (tile, group), or (TPW consecutive owned tiles, group)
     const uint32_t nunit = (ntile_blk + TPW - 1) / TPW;
-#ifdef VB2_ABL_ITEMS     // (ablation build: no work items at all -- what is left is the launch's fixed cost)
-    const uint32_t nitem = 0u * nunit * (uint32_t)ngrp;
-#else
-    const uint32_t nitem = nunit * (uint32_t)ngrp;
-#endif
+    const uint32_t nitem = (kAblate & kAblNoItems) ? 0u : nunit * (uint32_t)ngrp;
     const float inv_nunit = 1.0f / (float)(nunit ? nunit : 1u);
     // Decided on ceil(tiles / workgroups), the same for every workgroup and exactly what
     // eval_shmem_np sized the result slots for (a workgroup with one tile fewer must not choose
@@ -684,17 +624,17 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     auto tile_product = [&](ScaledProd* p, bool cross) {  // over the 16 lanes sharing slot g (+ the item's other tiles)
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) {
-            const int partner = lane_of<HWMAP>(m ^ off, g4);
+            const int partner = lane_of(m ^ off, g4);
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
-                p[t].m *= lane_xchg_f64<HWMAP>(p[t].m, off, partner);    // 16 factors in [0.5,1): no underflow
-                p[t].e += lane_xchg_f64<HWMAP>(p[t].e, off, partner);
+                p[t].m *= lane_xchg_f64(p[t].m, off, partner);    // 16 factors in [0.5,1): no underflow
+                p[t].e += lane_xchg_f64(p[t].e, off, partner);
             }
         }
         if (!cross) return;
 #pragma unroll
         for (int off = SLOTS; off < 4; off <<= 1) {       // the item's other micro-tiles
-            const int partner = lane_of<HWMAP>(m, g4 ^ off);
+            const int partner = lane_of(m, g4 ^ off);
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
                 p[t].m *= __shfl(p[t].m, partner, 64);    // factors >= 2^-16 each: no underflow
@@ -749,43 +689,21 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #ifdef VB2_STAMP_CTRL     // (profiling build: workgroup 0's slot 3 = the control wave is back from its tile-phase work)
     if (stamps && hook_mine && lane == 0) stamps[3] = wall_clock64();
 #endif
-#ifndef VB2_PF_M2
-#define VB2_PF_M2 2
-#endif
-#ifndef VB2_PF_SEARCH
-#define VB2_PF_SEARCH 2
-#endif
     typedef __attribute__((address_space(3))) const vuint2 lds_cuint2v;
-    constexpr int kPf = STREAM ? kPrefetch : MODE == 2 ? VB2_PF_M2 : VB2_PF_SEARCH;
+    constexpr int kPf = STREAM ? kPrefetch : kPrefetchL2;
     vuint2 w[kPf];                                        // this lane's run words, kPf rows in flight
     // PIPE (a cohort step under the static deal: every sample's lists come from HBM, one item = ~8 KB per wave, and a
-    // wave of round 3 requested an item's bytes, waited ~2 us for ALL of them -- the compiler's vmcnt(0) at the head of
-    // the row loop --, computed for ~2 us and only then requested the next item's: half its time waiting, and four waves
-    // per SIMD do not cover that).  Now the next item's run words are requested BEFORE this item's epilogue and its tile
+    // wave that requests an item's bytes, waits ~2 us for ALL of them -- the compiler's vmcnt(0) at the head of the row
+    // loop --, computes for ~2 us and only then requests the next item's spends half its time waiting, and four waves
+    // per SIMD do not cover that).  So the next item's run words are requested BEFORE this item's epilogue and its tile
     // record an item earlier still; this item's per-marker constants are requested at its top and awaited at its epilogue;
     // the first kPf rows of an item are walked in straight-line code, where the compiler counts the loads in flight
     // instead of draining them.
-#ifndef VB2_PIPE
-#define VB2_PIPE 1
-#endif
     // (compiled for the static deal only -- QUEUE == 0 --: with the way of dealing decided at run time the carried
     // registers of the two ways meet in copies after every item, and a copy of a register that is being loaded drains the
-    // loads: the 4-point cohort step, whose kernel decides at run time, went 199 -> 228 us that way)
-    constexpr bool PIPES = VB2_PIPE && STREAM && ONEGRP && !LCACHE && QUEUE == 0;
-    // PIPEQ (round 4, second half; MEASURED AND DROPPED, compiled only with -DVB2_PIPEQ=1): the same for the 8-point shape on
-    // the work queue.  Ablation of the 48-point launch: 73.5 us; without the epilogue's arithmetic 55.5; without the table
-    // reads 42.3; with NEITHER 40.2 -- a launch's skeleton alone (a wave draws an item, loads its tile record, then its first
-    // rows, nine to ten times) takes more than half a launch.  So: a wave draws its NEXT item at the top of the current one,
-    // requests that item's record at once and its first rows when the current item's rows are walked, under the epilogue.
-    // Bit-identical, 69.5 -> 70.8 us per 48-point launch (8 / 16 / 32 points: 18.55 -> 18.77, 27.98 -> 28.97, 48.26 -> 49.65):
-    // with arithmetic in the loop the other three waves of the SIMD already cover those trips; the skeleton's 40 us is not
-    // additive.  (Round 3's version of this lost 4 %.)
-#ifndef VB2_PIPEQ
-#define VB2_PIPEQ 0
-#endif
-    constexpr bool PIPEQ = VB2_PIPEQ && MODE == 2 && QUEUE == 1 && !STREAM && !LCACHE && !SWP && !W16;
-    constexpr bool PIPE = PIPES || PIPEQ;
-    const bool pipe = PIPEQ || (PIPES && !dyn);
+    // loads: the 4-point cohort step, whose kernel decides at run time, went 199 -> 228 us that way.  The same for the
+    // 8-point shape on the work queue was measured and dropped twice: HISTORY.md.)
+    constexpr bool PIPE = STREAM && ONEGRP && !LCACHE && QUEUE == 0;
     // the item after position (s_pos, rnd) of this wave's static deal
     auto static_item = [&](uint32_t s_pos, uint32_t rnd) -> uint32_t {
         if (have_sched) return s_pos < s_end ? (uint32_t)sch.item[s_pos] : nitem;
@@ -796,16 +714,6 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const uint32_t it_ = TPW * idx_ + (uint32_t)half;
         have_ = idx_ < nitem && (TPW == 1 || it_ < ntile_blk);
         return have_ ? blk + it_ * nblk : blk;
-    };
-    // (several groups, one tile per item: the work queue's items) item -> this lane's micro-tile
-    auto tile_of_q = [&](uint32_t idx_, bool& have_) -> uint32_t {
-        uint32_t grp_ = ngrp == 1 ? 0u : (uint32_t)(((float)idx_ + 0.5f) * inv_nunit);
-        if (ngrp != 1) {
-            if (grp_ * nunit > idx_) --grp_;
-            else if ((grp_ + 1) * nunit <= idx_) ++grp_;
-        }
-        have_ = idx_ < nitem;
-        return have_ ? blk + (idx_ - grp_ * nunit) * nblk : blk;
     };
     auto draw_item = [&]() -> uint32_t {                             // the workgroup's next item, whichever wave asks first
         uint32_t nxt = 0;
@@ -821,10 +729,10 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     };
     // ---- one uint2 of run words (2 runs, or 4 of the 16-bit lists) into the accumulators ----
     auto walk_word = [&](const vuint2 w_cur, double* acc, const uint32_t my_tab, const uint32_t my_tab_w16) {
-#ifdef VB2_ABL_LOOP      // (ablation build: the run words are consumed, the table is not read)
-        acc[0] += __hiloint2double((int)((w_cur.x ^ w_cur.y) & 0x000f0000u) | 0x3ff00000, 0);
-        return;
-#endif
+        if constexpr ((kAblate & kAblNoReads) != 0) {        // (ablation build: the run words are consumed, the table is not read)
+            acc[0] += __hiloint2double((int)((w_cur.x ^ w_cur.y) & 0x000f0000u) | 0x3ff00000, 0);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < (W16 ? 4 : 2); ++j) {
             // one run: `n` reads of the same (class, quality) -> n * table row.  The run
@@ -832,9 +740,6 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             // double n} -- one add and one and, no multiply, no int -> double conversion.
             // W16 (cohort steps): {low byte: dictionary index, next byte: n} -- two field
             // extractions, a multiply-add and a conversion, for half the bytes from HBM
-            // (Requesting a run's table values one run ahead of their use -- a software pipeline
-            // across the per-row exit test -- was measured in round 3: 74 -> 96 us per 48-point
-            // launch; the second set of twelve doubles does not fit the 128-register budget.)
             double n;
             uint32_t row_addr;
             if constexpr (W16) {
@@ -866,18 +771,15 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     };
     // ---- per-marker epilogue: a marker's likelihood as (mantissa, exponent) per point, from its six sums per point ----
     auto marker_lk = [&](const bool live, const size_t pos, const double* acc, const double e0, const double e1, const double e2,
-                         const double* udr, const double mur, const uint32_t my_ptq, double* lk_m, int* lk_e,
-                         const bool exps_taken = false /* acc holds exp(sum) already (SWP) */) {
+                         const double* udr, const double mur, const uint32_t my_ptq, double* lk_m, int* lk_e) {
 #pragma unroll
         for (int t = 0; t < BTL; ++t) { lk_m[t] = 1.0; lk_e[t] = 0; }
-#ifdef VB2_ABL_EPI       // (ablation build: the sums and the constants are consumed, nothing is computed from them)
-        {
+        if constexpr ((kAblate & kAblNoEpi) != 0) {          // (ablation build: the sums and the constants are consumed, nothing is computed from them)
             double z = e0 + e1 + e2 + mur + udr[0] + udr[1] + udr[2] + udr[3];
             for (int i = 0; i < BTL * 6; ++i) z += acc[i];
             if (z == 12345.678) lk_m[0] = 0.75;
             return;
         }
-#endif
         if (live) {
             double af1[BTL], af2[BTL];
             if (known_af_p) {
@@ -923,9 +825,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 // of 27; the rounding differs from the reference's term-by-term sum at the 1e-16
                 // level, like the marker summation order does).  The three g1==g2 exponentials do
                 // not depend on (alpha, PC) and were taken at context creation.
-                const double x01 = exps_taken ? a[0] : exp_nonpos<ESH>(a[0], etab_lane), x02 = exps_taken ? a[1] : exp_nonpos<ESH>(a[1], etab_lane);
-                const double x10 = exps_taken ? a[2] : exp_nonpos<ESH>(a[2], etab_lane), x12 = exps_taken ? a[3] : exp_nonpos<ESH>(a[3], etab_lane);
-                const double x20 = exps_taken ? a[4] : exp_nonpos<ESH>(a[4], etab_lane), x21 = exps_taken ? a[5] : exp_nonpos<ESH>(a[5], etab_lane);
+                const double x01 = exp_nonpos<ESH>(a[0], etab_lane), x02 = exp_nonpos<ESH>(a[1], etab_lane);
+                const double x10 = exp_nonpos<ESH>(a[2], etab_lane), x12 = exp_nonpos<ESH>(a[3], etab_lane);
+                const double x20 = exp_nonpos<ESH>(a[4], etab_lane), x21 = exp_nonpos<ESH>(a[5], etab_lane);
                 const double s0 = fma(x02, gf2[2], fma(x01, gf2[1], e0 * gf2[0]));
                 const double s1 = fma(x12, gf2[2], fma(e1, gf2[1], x10 * gf2[0]));
                 const double s2 = fma(e2, gf2[2], fma(x21, gf2[1], x20 * gf2[0]));
@@ -967,142 +869,25 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     const uint32_t idx_first = hook_mine ? nitem
                                : have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem)
                                             : (uint32_t)(wave - (hook_blk ? 1 : 0));
-    if (pipe && idx_first < nitem) {
+    if (PIPE && idx_first < nitem) {
         bool h0;
-        const uint32_t mt0 = PIPEQ ? tile_of_q(idx_first, h0) : tile_of(idx_first, h0);
+        const uint32_t mt0 = tile_of(idx_first, h0);
         rec_nx = g_rec[mt0];
         cst_nx = other_const(mt0, h0);
         issue_rows(rec_nx, h0);
     }
-    if constexpr (SWP) {
-        static_assert(MODE == 2 && QUEUE == 1 && !STREAM && !LCACHE && !W16, "the software-pipelined loop: 8-point shape on the work queue");
-        // state of the previous item, its epilogue still to be finished
-        double pa[BTL * 6];                               // its six sums per point; exp()'d in place, one per row step
-        double pe0 = 0.0, pe1 = 0.0, pe2 = 0.0, pud[4] = {0.0, 0.0, 0.0, 0.0}, pmu = 0.0;
-        size_t ppos = 0;
-        uint32_t pptq = ptq_addr, pslot = 0;
-        bool pvalid = false, plive = false;
-#pragma unroll
-        for (int i = 0; i < BTL * 6; ++i) pa[i] = 0.0;
-        auto finish_prev = [&]() {                        // (every exponential taken) priors, 9-term sums, tile product, slot
-            double lk_m[BTL];
-            int lk_e[BTL];
-            marker_lk(plive, ppos, pa, pe0, pe1, pe2, pud, pmu, pptq, lk_m, lk_e, true);
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {
-                const int partner = lane_of<HWMAP>(m ^ off, g4);
-#pragma unroll
-                for (int t = 0; t < BTL; ++t) {
-                    lk_m[t] *= __shfl(lk_m[t], partner, 64);
-                    lk_e[t] += __shfl(lk_e[t], partner, 64);
-                }
-            }
-            if (m == 0 && pvalid) {
-#pragma unroll
-                for (int t = 0; t < BTL; ++t) {
-                    const size_t o = ((size_t)pslot * NP + g * BTL + t) * 2;
-                    tile_llk[o] = lk_m[t];
-                    tile_llk[o + 1] = (double)lk_e[t];
-                }
-            }
-        };
-        for (uint32_t idx = idx_first; idx < nitem;) {
-            uint32_t grp = ngrp == 1 ? 0u : (uint32_t)(((float)idx + 0.5f) * inv_nunit);
-            if (ngrp != 1) {
-                if (grp * nunit > idx) --grp;
-                else if ((grp + 1) * nunit <= idx) ++grp;
-            }
-            const uint32_t it = idx - grp * nunit;
-            const uint32_t mt = blk + it * nblk;
-            const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)row_bytes + (uint32_t)g * (6 * BTL * 8));
-            const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
-            const vuint2 rec = g_rec[mt];
-            const size_t pos = (size_t)mt * kMtMarkers + m;
-            const bool live = pos < (size_t)L.num_active;
-            const size_t posc = live ? pos : 0;
-            const double cst = g_ediag[posc];
-            const double e0 = g_ediag[mp + posc], e1 = g_ediag[2 * mp + posc], e2 = g_ediag[3 * mp + posc];
-            double udr[4], mur = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) udr[kk] = (!known_af_p && kk < k) ? g_ud[(size_t)kk * mp + posc] : 0.0;
-            if (!known_af_p) mur = g_mu[posc];
-            double acc[BTL * 6];
-#pragma unroll
-            for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
-            g_cuint2* cp = g_codes + (size_t)rec.x * kMtMarkers + m;
-            const int rows = (int)rec.y;
-#pragma unroll
-            for (int j = 0; j < kPf; ++j) w[j] = cp[(size_t)j * kMtMarkers];
-            // the first BTL * 6 row steps, straight-line: a row of this item's run words, then ONE exponential of the previous item
-            constexpr int kSteps = BTL * 6;
-            // (no branch per step: a step past the tile's last row walks a padding word -- the zero table row, count 0, an
-            // exact no-op -- so that the twelve steps are ONE basic block: with a branch per step every exponential sat in a
-            // block of its own behind the step's FMAs, a serial chain of 17 instructions, and the run-word ring was drained
-            // at every step by the copies the branches forced: 80 us per 48 points against 73 for the plain 12-wave geometry)
-            vuint2 padw;
-            padw.x = padw.y = (uint32_t)(L.num_code * row_bytes);
-#pragma unroll
-            for (int s_ = 0; s_ < kSteps; ++s_) {
-                {
-                    vuint2 w_cur = w[s_ % kPf];
-                    w[s_ % kPf] = cp[(size_t)(s_ + kPf) * kMtMarkers];
-                    if (s_ >= rows) w_cur = padw;
-                    walk_word(w_cur, acc, my_tab, 0u);
-                }
-                // (pinned here: left alone, the compiler sinks all twelve exponentials below the row steps, next to their uses
-                // in finish_prev -- i.e. rebuilds the un-pipelined loop)
-                pa[s_] = exp_nonpos<ESH>(pa[s_], etab_lane);
-                asm volatile("" : "+v"(pa[s_]));
-            }
-            for (int s0 = kSteps; s0 < rows; s0 += kPf) {         // (kSteps is a multiple of kPf: the ring's phase carries over)
-#pragma unroll
-                for (int u = 0; u < kPf; ++u) {
-                    if (s0 + u >= rows) break;
-                    const vuint2 w_cur = w[u];
-                    w[u] = cp[(size_t)(s0 + u + kPf) * kMtMarkers];
-                    walk_word(w_cur, acc, my_tab, 0u);
-                }
-            }
-            finish_prev();
-            // this item becomes the previous one
-#pragma unroll
-            for (int i = 0; i < BTL * 6; ++i) pa[i] = acc[i];
-            pe0 = e0; pe1 = e1; pe2 = e2; pmu = mur;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) pud[kk] = udr[kk];
-            ppos = pos; plive = live; pptq = my_ptq; pvalid = true;
-            pslot = grp * ntile_blk + it;
-            uint32_t nxt = 0;
-            if (lane == 0) nxt = atomicAdd(queue, 1u);
-            idx = __builtin_amdgcn_readfirstlane(nxt);
-        }
-        // the last item's epilogue, un-overlapped
-#pragma unroll
-        for (int i = 0; i < BTL * 6; ++i) pa[i] = exp_nonpos<ESH>(pa[i], etab_lane);
-        finish_prev();
-    } else {
 #ifdef VB2_ITEM_PROF     // (profiling build, with VB2_WITH_STAMPS: where a wave's time per work item goes -- tools/item_prof.py)
     unsigned long long ip_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define VB2_IP_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#define VB2_IP_USE(x) asm volatile("" :: "v"(x))
-#else
-#define VB2_IP_T(var)
-#define VB2_IP_USE(x)
 #endif
     for (uint32_t idx = idx_first; idx < nitem;) {
         VB2_IP_T(ip_t0);
         // grp = idx / nunit without the ~25-instruction integer division: float estimate (exact for
         // these magnitudes up to one) and a correction step
         uint32_t grp, unit;
-#ifndef VB2_TILE_MAJOR
-#define VB2_TILE_MAJOR 1
-#endif
-        if (VB2_TILE_MAJOR && MODE == 2 && QUEUE == 1 && !ONEGRP && !STREAM) {
+        if (MODE == 2 && QUEUE == 1 && !ONEGRP) {
             // The queue walks the tiles deepest first and every tile's point groups side by side: the waves that hold a tile's items at
             // the same time read the same run words and per-marker constants (one trip to L2 instead of up to six), and the order is
-            // still longest-first.  Group by group (-DVB2_TILE_MAJOR=0, rounds 1-3) every pass over a workgroup's 25 tiles came
-            // from L2 again.  The slots and their order do not change: the same bits.  48 points 63.34 -> 62.93 us, 32 points 44.67
-            // -> 44.19 us, 16 points 26.56 -> 26.31 us on the same box.
+            // still longest-first.  The slots and their order are those of a group-by-group walk: the same bits.
             unit = (uint32_t)(((float)idx + 0.5f) / (float)ngrp);
             if (unit * (uint32_t)ngrp > idx) --unit;
             else if ((unit + 1) * (uint32_t)ngrp <= idx) ++unit;
@@ -1130,7 +915,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // {first row, rows}; one scalar load when TPW == 1.  LCACHE: {LDS byte address of the tile's first row, rows}
         vuint2 rec;
         if constexpr (LCACHE) rec = *reinterpret_cast<lds_cuint2v*>(hook.cache_rec() + (have_tile ? it : 0u) * 8u);
-        else if (pipe) rec = rec_nx;
+        else if (PIPE) rec = rec_nx;
         else rec = g_rec[mt];
         VB2_IP_USE(rec.x);
         VB2_IP_T(ip_t1);
@@ -1140,21 +925,16 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         uint32_t mt_next = blk;
         vuint2 rec_n2;
         rec_n2.x = rec_n2.y = 0u;
-        if (pipe) {
-            if constexpr (PIPEQ) {
-                idx_next = draw_item();
-                mt_next = tile_of_q(idx_next, have_next);
-            } else {
-                idx_next = static_item(s_i + 1, round + 1);
-                mt_next = tile_of(idx_next, have_next);
-            }
+        if (PIPE) {
+            idx_next = static_item(s_i + 1, round + 1);
+            mt_next = tile_of(idx_next, have_next);
             rec_n2 = g_rec[mt_next];
         }
         // per-marker constants: issued now, consumed after the read loop
         const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
         const bool live = have_tile && pos < (size_t)L.num_active;
         const size_t posc = live ? pos : 0;
-        const double cst = pipe ? cst_nx : g_ediag[posc];
+        const double cst = PIPE ? cst_nx : g_ediag[posc];
         const double e0 = g_ediag[mp + posc], e1 = g_ediag[2 * mp + posc], e2 = g_ediag[3 * mp + posc];
 
         // (the panel row of the marker too: up to four UD columns and the mean)
@@ -1196,54 +976,10 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             if constexpr (LCACHE) return *reinterpret_cast<lds_cuint2v*>(crow + (uint32_t)j * (kMtMarkers * 8u));
             else return cp[(size_t)(STREAM ? (j < last_row ? j : last_row) : j) * kMtMarkers];
         };
-        if (!pipe) {
+        if (!PIPE) {
 #pragma unroll
             for (int j = 0; j < kPf; ++j) w[j] = load_row(j);
         }
-        // AHEAD (-DVB2_RUN_AHEAD=1, the 8-point shape on the 32-bit lists): a ring of kRing table reads in flight ACROSS runs and
-        // rows -- read q of a row is requested kRing reads before its two multiply-adds, also past the per-row exit test (a
-        // row that does not exist is read from whatever run word the ring holds there and never consumed) -- where the
-        // compiler's own schedule keeps 3-4 in flight and drains them at every row's end.  Same multiply-adds, same order.
-#ifndef VB2_RUN_AHEAD
-#define VB2_RUN_AHEAD 0
-#endif
-        constexpr bool AHEAD = VB2_RUN_AHEAD != 0 && MODE == 2 && !W16 && !LCACHE && !SWP && !PIPE;
-        constexpr int kRp = 3 * BTL, kRing = 8;              // 16-byte reads per run; reads in flight
-        static_assert(!AHEAD || (16 * 2 * kRp) % kRing == 0, "the ring's phase must carry over a block of rows");
-        vdouble2 ring[AHEAD ? kRing : 1];
-        auto tab_read = [&](const vuint2 w_, const int q) -> vdouble2 {        // read q (0 .. 2 kRp - 1) of a row's two runs
-            const uint32_t rw = q < kRp ? w_.x : w_.y;
-            return reinterpret_cast<lds_cdouble2*>(my_tab + (rw & 0xffffu))[q % kRp];
-        };
-        if constexpr (AHEAD) {
-            if (rows > 0) {
-#pragma unroll
-                for (int q = 0; q < kRing; ++q) ring[q] = tab_read(w[0], q);
-            }
-        }
-        // (kAheadRows rows of straight-line code: the ring lives in registers that change name from read to read, and a loop's
-        // back edge would pin them -- copies of registers that are being loaded, i.e. a drain of all reads per trip)
-        constexpr int kAheadRows = 16;
-        auto walk_ahead = [&](const int s0) {
-#pragma unroll
-            for (int u = 0; u < kAheadRows; ++u) {
-                if (s0 + u >= rows) break;
-                const vuint2 w_cur = w[u % kPf];
-                w[u % kPf] = load_row(s0 + u + kPf);
-                const vuint2 w_nxt = w[(u + 1) % kPf];                 // the next row's word
-                const double n0 = __hiloint2double((int)(w_cur.x & 0xffff0000u), 0);
-                const double n1 = __hiloint2double((int)(w_cur.y & 0xffff0000u), 0);
-#pragma unroll
-                for (int q = 0; q < 2 * kRp; ++q) {
-                    const int slot = (u * 2 * kRp + q) % kRing;
-                    const double n = q < kRp ? n0 : n1;
-                    const int i = q % kRp;
-                    acc[2 * i] = fma(n, ring[slot].x, acc[2 * i]);
-                    acc[2 * i + 1] = fma(n, ring[slot].y, acc[2 * i + 1]);
-                    ring[slot] = q + kRing < 2 * kRp ? tab_read(w_cur, q + kRing) : tab_read(w_nxt, q + kRing - 2 * kRp);
-                }
-            }
-        };
         auto walk_block = [&](const int s0, const bool refill) {     // rows s0 .. s0 + kPf - 1 of the tile
 #pragma unroll
             for (int u = 0; u < kPf; ++u) {
@@ -1256,22 +992,16 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         VB2_IP_USE(w[0].x);
         VB2_IP_T(ip_t2);
         if constexpr (PIPE) {
-            if (pipe) {
-                // the first kPf rows outside any loop (loads in flight are counted, not drained); an item with more
-                // rows -- wide quality alphabets -- refills the ring as before
-                const bool more = __any(rows > kPf);
-                walk_block(0, more);
-                if (more)
-                    for (int s0 = kPf; s0 < rows; s0 += kPf) walk_block(s0, true);
-                // this item's rows are walked: the next item's go out now, under the epilogue
-                issue_rows(rec_n2, have_next);
-                cst_nx = other_const(mt_next, have_next);
-                rec_nx = rec_n2;
-            } else {
-                for (int s0 = 0; s0 < rows; s0 += kPf) walk_block(s0, true);
-            }
-        } else if constexpr (AHEAD) {
-            for (int s0 = 0; s0 < rows; s0 += kAheadRows) walk_ahead(s0);
+            // the first kPf rows outside any loop (loads in flight are counted, not drained); an item with more
+            // rows -- wide quality alphabets -- refills the ring as before
+            const bool more = __any(rows > kPf);
+            walk_block(0, more);
+            if (more)
+                for (int s0 = kPf; s0 < rows; s0 += kPf) walk_block(s0, true);
+            // this item's rows are walked: the next item's go out now, under the epilogue
+            issue_rows(rec_n2, have_next);
+            cst_nx = other_const(mt_next, have_next);
+            rec_nx = rec_n2;
         } else {
             for (int s0 = 0; s0 < rows; s0 += kPf) walk_block(s0, true);
         }
@@ -1301,7 +1031,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             if (++nfactor == kLazyRenorm) renorm_wave();
             if (have_sched) {
                 ++s_i;
-                idx = pipe ? idx_next : (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem);
+                idx = PIPE ? idx_next : (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem);
                 continue;
             }
             // next round, direction reversed: the items are depth-sorted, and a plain deal would
@@ -1317,11 +1047,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // [0.5, 1): no underflow), exponents add as integers (three dwords per exchange, not four)
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) {
-            const int partner = lane_of<HWMAP>(m ^ off, g4);
+            const int partner = lane_of(m ^ off, g4);
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
-                lk_m[t] *= lane_xchg_f64<HWMAP>(lk_m[t], off, partner);
-                lk_e[t] += lane_xchg_i32<HWMAP>(lk_e[t], off, partner);
+                lk_m[t] *= lane_xchg_f64(lk_m[t], off, partner);
+                lk_e[t] += lane_xchg_i32(lk_e[t], off, partner);
             }
         }
         if (m == 0 && have_tile) {
@@ -1333,9 +1063,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             }
         }
         VB2_IP_T(ip_t6);
-        // next work item of this workgroup, whichever wave gets there first (PIPEQ: drawn at this item's top)
-        if constexpr (PIPEQ) idx = idx_next;
-        else idx = draw_item();
+        // next work item of this workgroup, whichever wave gets there first
+        idx = draw_item();
 #ifdef VB2_ITEM_PROF
         {
             const unsigned long long ip_t7 = __builtin_readcyclecounter();
@@ -1348,7 +1077,6 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     if (VB2_STAMPS_OF(L) && lane == 0 && dyn)
         for (int i = 0; i < 8; ++i) atomicAdd(&VB2_STAMPS_OF(L)[(size_t)blk * 8 + i], ip_sum[i]);
 #endif
-    }
     if (!dyn) {                                           // slots (wave, group): factor 1 if idle
         for (uint32_t grp = grp_wave; grp < (uint32_t)ngrp; ++grp) flush_wave(grp);
     }
@@ -1497,19 +1225,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const unsigned long long want = resident_mix(tag);
         const unsigned long long t_wait = wall_clock64();
         for (int b = tid; b < nb; b += nthread) {      // one thread per workgroup's set
-            // This workgroup's own sums are in its LDS (red[]) since the block reduction's closing barrier: its own set
-            // -- the one stored LAST, by definition, when this workgroup is the slowest, and a store needs a trip to
-            // memory before the poll's trip can find it (~2 us from the block reduction to "all sets in" even when
-            // every other set has been there for microseconds: round 4, 10 000-marker timeline) -- is not waited for.
-            // No branch: the thread polls like the others and overrides what it loaded.  MEASURED AND DROPPED (round 4, like
-            // round 3's branchy version): OptimizeLLK 6.41 -> 6.48 ms at C3, 6.30 -> 6.48 ms at 10 000 markers on the same
-            // box -- the set that arrives last is not this workgroup's own; compiled out unless -DVB2_OWN_SUMS=1.
-#ifndef VB2_OWN_SUMS
-#define VB2_OWN_SUMS 0
-#endif
-            // (only while red[] is not under the staging area: a forced tagged hand-off of many points stages over it)
-            const bool own = VB2_OWN_SUMS && b == (int)blk &&
-                             (hook.sum_stage() != nullptr || (size_t)NPT * (size_t)nb <= (size_t)(red - lds));
+            // (Not waiting for this workgroup's own set -- it is in its LDS already -- was measured twice and dropped: the set
+            // that arrives last is not this workgroup's own.  HISTORY.md, rounds 3 and 4.)
             for (unsigned it = 0;; ++it) {
                 // check word and the first words are requested together, NP + 1 loads in flight
                 unsigned long long x = __hip_atomic_load(&pw[(size_t)NPT * nb + b], __ATOMIC_RELAXED,
@@ -1522,12 +1239,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                                                  __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int u = 0; u < NP; ++u) {
-                        if (own) v[u] = (unsigned long long)__double_as_longlong(red[w0 + u]);
                         x ^= word_hash(v[u], (unsigned)(w0 + u));
                         stage[(size_t)(w0 + u) * nb + b] = __longlong_as_double((long long)v[u]);
                     }
                 }
-                if (x == want || own) break;
+                if (x == want) break;
                 // a quarter of a second (100 MHz ticks): a workgroup is missing -- part of the grid is not on the CUs
                 // (a shared GPU).  The caller sees NaN and redoes the step with the arrival-ticket hand-off, which
                 // waits for nobody.  (Round 2 waited two seconds: the hiccup of a co-residency failure is this wait.)
@@ -1563,11 +1279,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         if (stamps) stamps[6] = t6;
         if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[21 * 8 + 7] += t6 - VB2_STAMPS_OF(L)[7];
     }
-#ifdef VB2_ABL_NOSIGNAL  // (ablation build: no hand-off to the host)
-    if (false) {
-#else
-    if (done_flag) {
-#endif
+    if (done_flag && !(kAblate & kAblNoSignal)) {
         // host hand-off without a stream synchronisation: results (in mapped host memory)
         // first, then the sequence number the host is spinning on.  In a multi-sample launch
         // the sample that completes last (batch_done counter) is the one that signals.
@@ -1588,15 +1300,15 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     }
 }
 
-template <int MODE, bool HWMAP, int QUEUE, int KAF = -1, int KSEL = 0>
+template <int MODE, int QUEUE, int KSEL = 0>
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
                 int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
                 unsigned long long done_seq, int ngrp, unsigned long long tag, const Schedule sch)
 {
-    eval_body<MODE, HWMAP, false, NoHook, false, QUEUE, (MODE >= 3), KAF, KSEL>(L, ip.v, ip.count, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
-                           blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
+    eval_body<MODE, false, NoHook, false, QUEUE, KSEL>(L, ip.v, ip.count, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
+                                                       blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
 }
 
 // A call of more points than the LDS holds tables for -- wide quality alphabets: 118 codes x 8 points are 48.5 KB per point
@@ -1622,61 +1334,19 @@ llk_eval_passes_kernel(const DeviceLayout L, const double* __restrict__ points, 
         const int nv = left < points_per_pass ? left : points_per_pass;
         const bool last = left <= points_per_pass;
         if (pass > 0) __syncthreads();                      // the pass before is done with the workgroup's LDS
-        eval_body<2, true, false, NoHook, false, 1, false, (KSEL > 0 ? 0 : -1), KSEL, false, false, 6>(
+        eval_body<2, false, NoHook, false, 1, KSEL, false, 6>(
             L, nullptr, 0, points + (size_t)first * stride, nv, partials + (size_t)first * gridDim.x, llk_out + first,
             tickets + pass, (last || !done_flag) ? done_flag : scratch_flag, done_seq, blockIdx.x, gridDim.x, nullptr, 0u,
             (nv + 7) / 8, 0ull, Schedule{nullptr, nullptr});
     }
 }
 
-// A many-point call as TWO workgroups per CU (round 4, second session): workgroup (b, h) owns the micro-tiles of workgroup b
-// of the plain launch and the h-th half of the call's point groups -- so it builds only its own three tables (80 KB of LDS:
-// two such workgroups share a CU), has eight waves and a work queue, result slots, block reduction and arrival ticket of its
-// own.  The same tiles, the same slots, the same order of every product and sum as the plain launch: the same bits.  What
-// it buys: the phases in which a workgroup's waves mostly wait -- table build behind its barrier, the queue running dry,
-// block reduction, hand-off -- overlap with the other workgroup's tile work instead of leaving the CU idle.
-// blockIdx = h * (gridDim / 2) + b: both halves of b sit on the XCD b mod 8 (the same slice of the pileup in that L2), and
-// the dispatcher hands out every h = 0 workgroup before the first h = 1 one.
-template <int KSEL>
-__global__ void __launch_bounds__(VB2_SPLIT_WAVES * 64, 4)
-llk_eval_split_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid, int points_first_half,
-                      double* __restrict__ partials, double* __restrict__ llk_out, unsigned int* __restrict__ tickets,
-                      unsigned long long* __restrict__ done_flag, unsigned long long done_seq,
-                      unsigned int* __restrict__ halves_done)
-{
-    const uint32_t nblk = gridDim.x >> 1;
-    const uint32_t h = blockIdx.x >= nblk ? 1u : 0u;
-    const uint32_t blk = blockIdx.x - h * nblk;
-    const int stride = 2 * L.num_pc + 1;
-    const int first = h ? points_first_half : 0;
-    const int nv = h ? num_valid - points_first_half : points_first_half;       // (the host splits so that both are > 0)
-    eval_body<2, true, false, NoHook, false, 1, false, (KSEL > 0 ? 0 : -1), KSEL>(
-        L, nullptr, 0, points + (size_t)first * stride, nv, partials + (size_t)first * nblk, llk_out + first, tickets + h,
-        done_flag, done_seq, blk, nblk, halves_done, 2u, (nv + 7) / 8, 0ull, Schedule{nullptr, nullptr});
-}
-
-// The software-pipelined form of the 8-point shape (eval_body: SWP): 12-wave workgroups, 3 waves per SIMD.  MEASURED AND
-// DROPPED in round 4: 80.5-83.3 us per 48-point launch against 70.4 (16 waves) and 73.1 (12 waves, plain loop) on
-// the same box, every variant bit-identical.  Compiled only with -DVB2_WITH_SWP (then VB2_SWP=1 selects it).
-#ifdef VB2_WITH_SWP
-template <int KSEL>
-__global__ void __launch_bounds__(768, 3)
-llk_eval_swp_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
-                    int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
-                    unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
-                    unsigned long long done_seq, int ngrp, unsigned long long tag, const Schedule sch)
-{
-    eval_body<2, true, false, NoHook, false, 1, false, 0, KSEL, false, true>(L, ip.v, ip.count, points, num_valid, partials, llk_out, ticket,
-                                                                              done_flag, done_seq, blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
-}
-#endif
-
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
 // w / bps as that sample's workgroup w % bps.  Every sample has its own layout, parameter rows,
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
 // STATIC: every sample of the launch is known (on the host) to run the static deal: the item loop is compiled for it
 // alone, and pipelined across items (eval_body: PIPE).
-template <int MODE, bool HWMAP, bool W16, int KSEL = 0, int STATIC = 0>     // KSEL 2 / 4: every sample has that --NumPC and no known-AF column
+template <int MODE, bool W16, int KSEL = 0, int STATIC = 0>     // KSEL 2 / 4: every sample has that --NumPC and no known-AF column
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* __restrict__ scheds,
                       const double* __restrict__ points,
@@ -1691,15 +1361,11 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
     // (mi: the step's point counts and parameter rows as kernel arguments when they fit -- a step of 32 samples x 1 point
     // or 16 x 2 --: otherwise every workgroup reads them from mapped host memory, two dependent trips over PCIe, ~2.4 us
     // of the ~20 an empty step took in round 3)
-#ifdef VB2_ABL_NOMAP     // (ablation build: nothing is read from mapped host memory)
-    const int nv = NP;
-#else
-    const int nv = mi.count > 0 ? (int)mi.nv[s] : num_valid[s];
-#endif
+    const int nv = (kAblate & kAblNoMap) ? NP : mi.count > 0 ? (int)mi.nv[s] : num_valid[s];
     if (nv <= 0) return;                                   // uniform for the workgroup
     const DeviceLayout L = layouts[s];
     const int stride = 2 * L.num_pc + 1;
-    eval_body<MODE, HWMAP, W16, NoHook, true, (STATIC ? 0 : -1), true, (KSEL > 0 ? 0 : -1), KSEL>(L, mi.v + (size_t)s * NP * stride, mi.count, points + (size_t)s * NP * stride, nv,
+    eval_body<MODE, W16, NoHook, true, (STATIC ? 0 : -1), KSEL>(L, mi.v + (size_t)s * NP * stride, mi.count, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1, use_ticket ? 0ull : done_seq,
@@ -1753,22 +1419,11 @@ bool eval_takes_the_queue(const DeviceLayout& L, int nblk, int nwave, int ngrp)
     return eval_is_dynamic(L, (uint32_t)nblk, nwave, ngrp);
 }
 
-static int g_geom_override[2][2] = {{0, 0}, {0, 0}};
-void set_geom_override(int btl, int max_waves, int blocks_per_cu)
-{
-    g_geom_override[btl - 1][0] = max_waves;
-    g_geom_override[btl - 1][1] = blocks_per_cu;
-}
-
 LaunchGeom launch_geom(const DeviceLayout& L, int btl, int ngrp)
 {
-    int max_waves = btl == 1 ? Geom<1>::kMaxWaves : Geom<2>::kMaxWaves;
-    int per_cu = btl == 1 ? Geom<1>::kBlocksPerCU : Geom<2>::kBlocksPerCU;
-    if (g_geom_override[btl - 1][0] > 0) {          // experiment knob: VB2_GEOM1 / VB2_GEOM2
-        max_waves = g_geom_override[btl - 1][0] < max_waves ? g_geom_override[btl - 1][0] : max_waves;
-        per_cu = g_geom_override[btl - 1][1];
-    }
-    const int grid_target = per_cu * L.num_cu;
+    const int max_waves = Geom<2>::kMaxWaves;
+    const int grid_target = Geom<2>::kBlocksPerCU * L.num_cu;
+    (void)btl;
     int bw = (L.num_mt + grid_target - 1) / grid_target;
     bw = bw < 4 ? 4 : (bw > max_waves ? max_waves : bw);
     int grid = (L.num_mt + bw - 1) / bw;
@@ -1783,9 +1438,6 @@ LaunchGeom launch_geom(const DeviceLayout& L, int btl, int ngrp)
     }
     return LaunchGeom{grid, bw};
 }
-
-static bool g_hwmap = true;
-void set_lane_mapping(bool hw) { g_hwmap = hw; }
 
 // More than 64 KiB of dynamic LDS is an opt-in per kernel function AND per device (the function
 // object is per device in the runtime), so the flag is kept per (function slot, device).
@@ -1815,11 +1467,7 @@ static hipError_t raise_lds_limit(const void* fn)
     return hipSuccess;
 }
 
-static bool g_paired = true;          // 4-point launches: MODE 3 (two micro-tiles per wave) or MODE 1
-void set_paired_mode(bool on) { g_paired = on; }
-bool paired_mode() { return g_paired; }
-
-template <int MODE, bool HWMAP>
+template <int MODE>
 static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, const double* h_points,
                              int num_valid, int ngrp,
                              double* d_partials, double* d_out, unsigned int* d_ticket,
@@ -1828,60 +1476,22 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
 {
     constexpr int NP = ModeNp<MODE>::value;     // points per group
     const LaunchGeom gm = launch_geom(L, MODE == 2 ? 2 : 1, ngrp);
-    // VB2_SWP=1 (experiment, VERDICT r3 #3a): the 8-point shape with the software-pipelined item loop -- 12-wave workgroups,
-    // work queue (its limit raised to 16 items per wave for this launch)
-#ifdef VB2_WITH_SWP
-    if constexpr (MODE == 2 && HWMAP) {
-        static const bool swp_on = std::getenv("VB2_SWP") && std::atoi(std::getenv("VB2_SWP")) != 0;
-        if (swp_on && L.known_af == nullptr && (L.num_pc == 4 || L.num_pc == 2) && gm.block_waves >= 12) {
-            DeviceLayout Ls = L;
-            Ls.dyn_limit = 16;
-            const int bw = 12;
-            if (eval_is_dynamic(Ls, (uint32_t)gm.grid, bw, ngrp)) {
-                const size_t shm = eval_shmem_np(Ls, NP, gm.grid, bw, ngrp);
-                if (shm > (size_t)kLdsLimitBytes) return hipErrorInvalidConfiguration;
-                const void* fns = L.num_pc == 4 ? reinterpret_cast<const void*>(&llk_eval_swp_kernel<4>)
-                                                : reinterpret_cast<const void*>(&llk_eval_swp_kernel<2>);
-                hipError_t e = raise_lds_limit(fns);
-                if (e != hipSuccess) return e;
-                InlinePoints ip;
-                ip.count = 0;
-                const int ndbl = num_valid * (2 * L.num_pc + 1);
-                if (h_points && ndbl <= kInlinePointDoubles) {
-                    ip.count = ndbl;
-                    for (int i = 0; i < ndbl; ++i) ip.v[i] = h_points[i];
-                }
-                const double* a_points = d_points;
-                int a_nv = num_valid, a_ngrp = ngrp;
-                unsigned long long a_seq = done_seq, a_tag = tag;
-                Schedule a_sch{nullptr, nullptr};
-                void* args[] = {&Ls, &ip, &a_points, &a_nv, &d_partials, &d_out, &d_ticket, &done_flag, &a_seq, &a_ngrp, &a_tag, &a_sch};
-                return hipLaunchKernel(fns, dim3(gm.grid), dim3(bw * 64), args, shm, stream);
-            }
-        }
-    }
-#endif
     const Schedule sch = sp ? sp->get(MODE, ngrp, gm.grid, gm.block_waves) : Schedule{nullptr, nullptr};
     const size_t shmem = eval_shmem_np(L, NP, gm.grid, gm.block_waves, ngrp);
-    // (ADVICE r3: the group cap of launch_llk_eval is worked out on the geometry of a kMaxGroups launch; this launch's own
+    // (the group cap of launch_llk_eval is worked out on the geometry of a kMaxGroups launch; this launch's own
     // geometry -- fewer groups, maybe fewer waves -- needs no more LDS than that today, but nothing else says so)
     if (shmem > (size_t)kLdsLimitBytes) return hipErrorInvalidConfiguration;
-    // (the plain lane map is an A/B knob: one kernel that decides in the kernel; the hardware lane map: one per way)
+    // one kernel per way of dealing (queue / static); --NumPC 2 and 4 without a known-AF column have kernels of their own
+    // (the static deal of the search shapes only in the general form: a search takes the queue)
     const bool dyn = eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, ngrp);
-    const bool no_kaf = MODE == 2 && HWMAP && L.known_af == nullptr;      // (the 8-point shape: also compiled without that column)
-    constexpr bool kSpecK = MODE >= 2;                                       // (not the A/B shape 1)
-    constexpr int kKaf0 = MODE == 2 ? 0 : -1, kKafK = kSpecK ? 0 : -1, kK2 = kSpecK ? 2 : 0, kK4 = kSpecK ? 4 : 0;
-    const bool plain_ctx = HWMAP && L.known_af == nullptr;
-    const int ksel = plain_ctx && kSpecK && (MODE == 2 || dyn) ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
-    const void* fn = !HWMAP ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, -1>)
-                     : ksel == 4 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKafK, kK4>)
-                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, (MODE == 2 ? 0 : 1), kKafK, kK4>))
-                     : ksel == 2 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKafK, kK2>)
-                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, (MODE == 2 ? 0 : 1), kKafK, kK2>))
-                     : no_kaf ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1, kKaf0>)
-                                     : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0, kKaf0>))
-                     : dyn  ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 1>)
-                            : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, HWMAP, 0>);
+    const int ksel = (L.known_af == nullptr && (MODE == 2 || dyn)) ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
+    constexpr int kStaticQ = MODE == 2 ? 0 : 1;     // (never selected for MODE != 2: ksel is 0 there)
+    const void* fn = ksel == 4 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 1, 4>)
+                                      : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, kStaticQ, 4>))
+                     : ksel == 2 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 1, 2>)
+                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, kStaticQ, 2>))
+                     : dyn  ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 1>)
+                            : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 0>);
     {
         hipError_t e = raise_lds_limit(fn);
         if (e != hipSuccess) return e;
@@ -1947,43 +1557,6 @@ static hipError_t launch_passes(const DeviceLayout& L, const double* d_points, i
     return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
 }
 
-// see llk_eval_split_kernel.  Taken for a call of two or more point groups on a sample big enough for a full grid.
-static int g_split = 0;                // VB2_SPLIT=1 / vb2_debug_set_eval_split(1): taken; default: the plain launch (measured equal to slower: DESIGN 3.3e)
-void set_eval_split(int on) { g_split = on; }
-static hipError_t launch_split(const DeviceLayout& L, const double* d_points, int num_valid, int ngrp,
-                               double* d_partials, double* d_out, unsigned int* d_tickets,
-                               unsigned long long* done_flag, unsigned long long done_seq, hipStream_t stream, bool* taken)
-{
-    *taken = false;
-    if (L.known_af != nullptr || ngrp < 2) return hipSuccess;
-    const LaunchGeom gm = launch_geom(L, 2, ngrp);
-    if (gm.grid != Geom<2>::kBlocksPerCU * L.num_cu || gm.block_waves != Geom<2>::kMaxWaves) return hipSuccess;   // a full grid only
-    const int g0 = (ngrp + 1) / 2, bw = VB2_SPLIT_WAVES;
-    if (!eval_is_dynamic(L, (uint32_t)gm.grid, bw, g0)) return hipSuccess;
-    const size_t shmem = eval_shmem_np(L, 8, gm.grid, bw, g0);
-    if (2 * shmem > (size_t)kLdsLimitBytes) return hipSuccess;                    // two workgroups per CU
-    const void* fn = L.num_pc == 4 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<4>)
-                     : L.num_pc == 2 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<2>)
-                                     : reinterpret_cast<const void*>(&llk_eval_split_kernel<0>);
-    hipError_t e = raise_lds_limit(fn);
-    if (e != hipSuccess) return e;
-    DeviceLayout Lc = L;
-    const double* a_points = d_points;
-    int a_nv = num_valid, a_first = 8 * g0;
-    unsigned long long a_seq = done_seq;
-    unsigned int* a_halves = d_tickets + kTicketSplitWord;
-    void* args[] = {&Lc, &a_points, &a_nv, &a_first, &d_partials, &d_out, &d_tickets, &done_flag, &a_seq, &a_halves};
-    *taken = true;
-    return hipLaunchKernel(fn, dim3(2 * gm.grid), dim3(bw * 64), args, shmem, stream);
-}
-
-static bool g_eval_passes = true;      // VB2_PASSES=0 / vb2_debug_set_eval_passes(0): a launch per table-load of points
-void set_eval_passes(bool on) { g_eval_passes = on; }
-static int g_reduce_mode = 0;          // 0 auto, 1 ticket, 2 tagged
-void set_reduce_mode(int m) { g_reduce_mode = m; }
-static bool g_single_launch = true;
-void set_single_launch(bool on) { g_single_launch = on; }
-
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
                            const double* h_points, double* d_partials, double* d_out,
                            unsigned int* d_ticket,
@@ -1991,8 +1564,9 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
                            unsigned long long* tag_counter, hipStream_t stream, int reduce_override,
                            ScheduleProvider* sched)
 {
-    unsigned int* tk = g_single_launch ? d_ticket : nullptr;
-    const int reduce_mode = reduce_override ? reduce_override : g_reduce_mode;
+    const Tunables& tn = tunables();
+    unsigned int* tk = tn.single_launch ? d_ticket : nullptr;
+    const int reduce_mode = reduce_override ? reduce_override : tn.reduce;
     const int stride = 2 * L.num_pc + 1;
     int done = 0;
     while (done < num_point) {
@@ -2003,14 +1577,9 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         const LaunchGeom gm2 = launch_geom(L, 2, kMaxGroups);
         // (8-point groups need the wide table rows; a context whose dictionary is too big for
         // 16-bit offsets into wide rows has narrow ones and evaluates 4 points per launch)
-        // (VB2_ONE_POINT=n, an experiment knob for narrow-row contexts: n groups of FOUR points per launch in the
-        // one-point-per-lane shape)
-        static const int one_point = std::getenv("VB2_ONE_POINT") ? std::atoi(std::getenv("VB2_ONE_POINT")) : 0;
-        const bool m1 = one_point > 0 && L.row_bytes != kRowBytesWide;
-        const int cap = m1 ? 4 * std::min(one_point, max_groups(L, 1, gm2.grid, gm2.block_waves))
-                           : L.row_bytes == kRowBytesWide ? 8 * max_groups(L, 2, gm2.grid, gm2.block_waves) : 4;
-        // more points than one launch's tables hold: the passes of ONE launch (VB2_PASSES=0: a launch per `cap` points)
-        if (g_eval_passes && tk && g_hwmap && !m1 && reduce_mode != 2 && L.row_bytes == kRowBytesWide && cap >= 8 && left > cap) {
+        const int cap = L.row_bytes == kRowBytesWide ? 8 * max_groups(L, 2, gm2.grid, gm2.block_waves) : 4;
+        // more points than one launch's tables hold: the passes of ONE launch (Tunables::passes 0: a launch per `cap` points)
+        if (tn.passes && tk && reduce_mode != 2 && L.row_bytes == kRowBytesWide && cap >= 8 && left > cap) {
             const int take = left < kMaxPointsPerLaunch ? left : kMaxPointsPerLaunch;
             bool taken = false;
             unsigned long long* dfp = (done + take >= num_point) ? done_flag : nullptr;
@@ -2022,41 +1591,21 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
             }
         }
         const int step = left < cap ? left : cap;
-        const int ngrp = step > 4 ? (m1 ? (step + 3) / 4 : (step + 7) / 8) : 1;
+        const int ngrp = step > 4 ? (step + 7) / 8 : 1;
         unsigned long long* df = (done + step >= num_point) ? done_flag : nullptr;   // last launch signals
         unsigned long long* df_eval = tk ? df : nullptr;
         hipError_t e;
-        // hand-off protocol: tagged sets for <= 16 points (one fabric round trip less, latency
-        // matters), arrival ticket for bigger batches (cheaper per point); VB2_REDUCE overrides
-        // (round 4, second session: the tagged sets up to 16 points -- 8 points 18.6 -> 16.4 us, 16 points 27.7 -> 26.6 us on the
-        // same box; 32 points 45.5 -> 47.6 us, 48 points 64.3 -> 68.5 us: there workgroup 0's polling passes cost more than the
-        // ticket's third trip.  VB2_TAGGED_MAX=n moves the limit.)
-        static const int tagged_max = std::getenv("VB2_TAGGED_MAX") ? std::atoi(std::getenv("VB2_TAGGED_MAX")) : 16;
-        const bool tagged = reduce_mode == 2 || (reduce_mode == 0 && step <= tagged_max);
+        // hand-off protocol: tagged sets for <= 16 points (one fabric round trip less: latency matters -- 8 points 18.6 ->
+        // 16.4 us, 16 points 27.7 -> 26.6 us), arrival ticket for bigger batches (32 points 45.5 against 47.6 us, 48 points
+        // 64.3 against 68.5 us: there workgroup 0's polling passes cost more than the ticket's third trip)
+        const bool tagged = reduce_mode == 2 || (reduce_mode == 0 && step <= tn.tagged_max);
         const unsigned long long tag = tagged ? ++*tag_counter : 0ull;   // unique per launch on this buffer
-        if (g_split && step > 8 && !m1 && tk && g_hwmap && !tagged && L.row_bytes == kRowBytesWide) {
-            bool taken = false;
-            e = launch_split(L, p, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, stream, &taken);
-            if (e != hipSuccess) return e;
-            if (taken) {
-                done += step;
-                continue;
-            }
-        }
-        if (step > 4 && m1)
-            e = launch_btl<1, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
-        else if (step > 4)
-            e = g_hwmap ? launch_btl<2, true>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched)
-                        : launch_btl<2, false>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
-        else if (g_paired && step == 1)
-            e = g_hwmap ? launch_btl<4, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched)
-                        : launch_btl<4, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
-        else if (g_paired)
-            e = g_hwmap ? launch_btl<3, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched)
-                        : launch_btl<3, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
+        if (step > 4)
+            e = launch_btl<2>(L, p, hp, step, ngrp, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
+        else if (step == 1)
+            e = launch_btl<4>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
         else
-            e = g_hwmap ? launch_btl<1, true>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched)
-                        : launch_btl<1, false>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
+            e = launch_btl<3>(L, p, hp, step, 1, d_partials, d_out + done, tk, df_eval, done_seq, tag, stream, sched);
         if (e != hipSuccess) return e;
         if (!tk) {
             hipLaunchKernelGGL(llk_finalize_kernel, dim3(1), dim3(256), 0, stream, d_partials,
@@ -2096,19 +1645,17 @@ int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves)
     return g;
 }
 
-// The cohort kernels of one wave shape: [plain lane map, hardware lane map, hardware lane map + 16-bit run lists]
+// The cohort kernels of one wave shape
 template <int MODE>
-static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream, int slot_base)
+static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream)
 {
     const dim3 grid(ml.num_sample * ml.bps), block(ml.block_waves * 64);
     // The 16-bit run lists pay where a step is bound by the bytes it streams -- 1 and 2 points per sample
     // (32 C3 samples: 130.6 -> 117.5 us and 139.2 -> 127.9 us) -- and cost where it is VALU-bound: 4 points per
     // sample 230.8 -> 306.6 us with them (two more instructions per run).  So: MODE 4 and 5 only.
     constexpr bool kHas16 = MODE == 4 || MODE == 5;
-    const int variant = !g_hwmap ? 0 : (kHas16 && ml.w16) ? 2 : 1;
     const int use_ticket = ml.force_ticket ? 1 : 0;
-    auto go = [&](auto kernel, int kslot) -> hipError_t {
-        (void)kslot;
+    auto go = [&](auto kernel) -> hipError_t {
         hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kernel));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, grid, block, ml.shmem, stream, ml.d_layouts, ml.d_scheds, ml.d_points,
@@ -2116,41 +1663,32 @@ static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream, i
                            ml.d_batch_done, ml.batch_active, use_ticket, ml.inl);
         return hipGetLastError();
     };
-    if (variant == 0) return go(&llk_eval_multi_kernel<MODE, false, false>, 0);
-    // (the shapes a cohort search uses -- not the A/B shape 1 -- also compiled for --NumPC 2 / 4 without a known-AF
-    // column: one-point steps of 32 samples 99 -> 94 us)
-    constexpr bool kSpec = MODE >= 2;
+    // (every shape also compiled for --NumPC 2 / 4 without a known-AF column: one-point steps of 32 samples 99 -> 94 us)
     if constexpr (kHas16) {
-        if (variant == 2) {
+        if (ml.w16) {
             if (ml.all_static) {          // (the pipelined item loop: compiled for the static deal only)
-                if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, true, 4, 1>, 3);
-                if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, true, 2, 1>, 4);
-                return go(&llk_eval_multi_kernel<MODE, true, true, 0, 1>, 5);
+                if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, 4, 1>);
+                if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, 2, 1>);
+                return go(&llk_eval_multi_kernel<MODE, true, 0, 1>);
             }
-            if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, true, 4>, 1);
-            if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, true, 2>, 2);
-            return go(&llk_eval_multi_kernel<MODE, true, true>, 0);
+            if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, 4>);
+            if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, 2>);
+            return go(&llk_eval_multi_kernel<MODE, true>);
         }
     }
-    if constexpr (kSpec) {
-        if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, false, 4>, 1);
-        if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, false, 2>, 2);
-    }
-    return go(&llk_eval_multi_kernel<MODE, true, false>, 0);
+    if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, false, 4>);
+    if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, false, 2>);
+    return go(&llk_eval_multi_kernel<MODE, false>);
 }
 
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
 {
-    // wave shape by points per sample: 8 -> MODE 2, 4 -> 3, 2 -> 5, 1 -> 4 (MODE 1 for everything
-    // below 8 when the paired shapes are switched off: VB2_PAIRED=0)
-    const int mode = ml.np == 8 ? 2 : !g_paired ? 1 : ml.np == 1 ? 4 : ml.np == 2 ? 5 : 3;
-    const int slot_base = 10 + (mode - 1) * 3;
-    switch (mode) {
-    case 2: return launch_multi_mode<2>(ml, stream, slot_base);
-    case 3: return launch_multi_mode<3>(ml, stream, slot_base);
-    case 4: return launch_multi_mode<4>(ml, stream, slot_base);
-    case 5: return launch_multi_mode<5>(ml, stream, slot_base);
-    default: return launch_multi_mode<1>(ml, stream, slot_base);
+    // wave shape by points per sample: 8 -> MODE 2, 4 -> 3, 2 -> 5, 1 -> 4
+    switch (ml.np) {
+    case 8: return launch_multi_mode<2>(ml, stream);
+    case 1: return launch_multi_mode<4>(ml, stream);
+    case 2: return launch_multi_mode<5>(ml, stream);
+    default: return launch_multi_mode<3>(ml, stream);
     }
 }
 
@@ -2318,8 +1856,26 @@ bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int t
     return true;
 }
 
-static bool g_coop_launch = false;
-void set_coop_launch(bool on) { g_coop_launch = on; }
+// A profiler's tool library in the process (rocprofv3 preloads librocprofiler-sdk-tool.so; rocprof v1/v2 their own)?
+bool profiler_attached()
+{
+    static const bool attached = [] {
+        bool found = false;
+        dl_iterate_phdr(
+            [](struct dl_phdr_info* info, size_t, void* data) -> int {
+                const char* n = info->dlpi_name;
+                if (n && (std::strstr(n, "rocprofiler-sdk-tool") || std::strstr(n, "librocprofiler64") ||
+                          std::strstr(n, "libroctracer") || std::strstr(n, "rocprofv3"))) {
+                    *static_cast<bool*>(data) = true;
+                    return 1;
+                }
+                return 0;
+            },
+            &found);
+        return found;
+    }();
+    return attached;
+}
 
 size_t resident_state_doubles(int nmax, int num_pc)
 {
@@ -2339,11 +1895,11 @@ uint32_t resident_cache_rows(const uint32_t* rows, int num_mt, int nblk)
         }
         most = std::max(most, off);
     }
-    return most + 4;        // slack: the read loop requests up to VB2_PF_SEARCH rows past a tile's last
+    return most + 4;        // slack: the read loop requests up to kPrefetchL2 rows past a tile's last
 }
 
 hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, double* d_partials,
-                               unsigned int* d_ticket, hipStream_t stream)
+                               unsigned int* d_ticket, hipStream_t stream, bool* cooperative)
 {
     const LaunchGeom gm = launch_geom(L, 1);
     // dynamic LDS: the evaluation body's, then workgroup 0's search state (16-byte aligned)
@@ -2366,11 +1922,11 @@ hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, doubl
         }
     }
     const bool dyn = eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, 1);
-    const int ksel = (g_paired && g_hwmap && dyn && L.known_af == nullptr) ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
+    const int ksel = (dyn && L.known_af == nullptr) ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
     // the run-list cache: the paired shape on the work queue (what a search on one device runs), at most 8 tiles per wave
     bool lcache = false;
     ra.cache_off = 0;
-    if (ra.cache_rows > 0 && g_paired && g_hwmap && dyn && ra.cache_tiles <= 8 * gm.block_waves) {
+    if (ra.cache_rows > 0 && dyn && ra.cache_tiles <= 8 * gm.block_waves) {
         ra.cache_tiles = (ra.cache_tiles + 1) & ~1;
         const size_t at = (shmem + 15) / 16 * 16;
         const size_t need = (size_t)ra.cache_tiles * 8 + (size_t)ra.cache_rows * kMtMarkers * 8;
@@ -2381,36 +1937,32 @@ hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, doubl
         }
     }
     if (!lcache) ra.cache_rows = 0;
-    const void* fn = lcache ? (ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 4, true>)
-                               : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 2, true>)
-                                           : reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 0, true>))
-                     : ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 4>)
-                     : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1, 2>)
-                     : g_paired ? (!g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<3, false, -1>)
-                                 : dyn    ? reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 1>)
-                                          : reinterpret_cast<const void*>(&llk_resident_kernel<3, true, 0>))
-                              : (!g_hwmap ? reinterpret_cast<const void*>(&llk_resident_kernel<1, false, -1>)
-                                 : dyn    ? reinterpret_cast<const void*>(&llk_resident_kernel<1, true, 1>)
-                                          : reinterpret_cast<const void*>(&llk_resident_kernel<1, true, 0>));
+    const void* fn = lcache ? (ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 4, true>)
+                               : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 2, true>)
+                                           : reinterpret_cast<const void*>(&llk_resident_kernel<1, 0, true>))
+                     : ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 4>)
+                     : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 2>)
+                     : dyn       ? reinterpret_cast<const void*>(&llk_resident_kernel<1>)
+                                 : reinterpret_cast<const void*>(&llk_resident_kernel<0>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
-    // Every workgroup must be on a CU at the same time (they all wait for the host).  The grid
-    // is at most one 1024-thread workgroup per CU, so on a device that is not running other
-    // kernels a plain launch is resident as a whole; VB2_COOP=1 asks the runtime to guarantee
-    // it (hipLaunchCooperativeKernel).  Not the default: under rocprofv3 a process that made a
-    // cooperative launch crashes in the profiler's exit handler (ROCm 7.2), and the bounded
-    // waits on both sides already turn a partly resident grid into a fallback, not a hang.
+    // Every workgroup must be on a CU at the same time (they all wait for the control wave and for each other's sums).
+    // The grid is at most one 1024-thread workgroup per CU; a cooperative launch makes the runtime GUARANTEE that it is
+    // resident as a whole (hipLaunchCooperativeKernel), where a plain one merely finds it so on a device that runs
+    // nothing else.  Cooperative is the default.  Plain launches remain for: a process under a profiler (ROCm 7.2's
+    // rocprofv3 crashes in its exit handler after a cooperative launch: the caller checks profiler_attached()), a
+    // runtime that refuses the cooperative launch, and Tunables::coop = 0 -- the bounded waits on both sides then turn
+    // a partly resident grid into a retry with plain per-step launches, not a hang.
     DeviceLayout Lc = L;
     ResidentArgs rc = ra;
-    if (g_coop_launch) {
-        void* args[] = {&Lc, &rc, &d_partials, &d_ticket};
-        return hipLaunchCooperativeKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args,
-                                          (unsigned int)shmem, stream);
+    void* args[] = {&Lc, &rc, &d_partials, &d_ticket};
+    if (cooperative && *cooperative) {
+        e = hipLaunchCooperativeKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, (unsigned int)shmem, stream);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+        *cooperative = false;
     }
-    {   // the plain launch goes through the same entry point with explicit arguments
-        void* args[] = {&Lc, &rc, &d_partials, &d_ticket};
-        return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
-    }
+    return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
 }
 
 // After a collective on the same stream: the reduced values go to mapped host memory, then the sequence

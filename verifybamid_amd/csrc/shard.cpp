@@ -1,4 +1,5 @@
 // shard.cpp -- see shard.h.
+#include "tunables.h"
 #include "shard.h"
 
 #include <dlfcn.h>
@@ -177,8 +178,8 @@ int ShardGroup::create(const vb2_input* in, const int32_t* devices, int num_devi
     // a real all-reduce needs one rank per DEVICE; shards that share a device (tests on one GPU)
     // are summed on the host instead -- unless the test stand-in for librccl is bound (VB2_RCCL_LIB), whose
     // ranks may share a device: then the launch -> grouped all-reduce -> publish path runs with N > 1 there too
-    const bool host_forced = std::getenv("VB2_SHARD_REDUCE") && !std::strcmp(std::getenv("VB2_SHARD_REDUCE"), "host");
-    const bool shared_ok = (int)distinct.size() < num_device && std::getenv("VB2_RCCL_LIB") && rccl().ok && rccl().stub;
+    const bool host_forced = tunables().shard_reduce_host != 0;
+    const bool shared_ok = (int)distinct.size() < num_device && rccl().ok && rccl().stub;
     g->use_rccl = ((int)distinct.size() == num_device || shared_ok) && !host_forced;
     for (int d = 0; d < num_device; ++d) {
         int lo, hi;

@@ -4,7 +4,7 @@
 // next set starts only when those are over.  Here the device keeps `capacity` slots (two lanes taking turns, as in
 // Batch::optimize): a sample that has converged hands its slot to the next sample that is ready -- the idea of continuous
 // batching in an inference server -- so every step carries (nearly) a full load as long as samples keep coming, and nothing
-// waits for a group to fill.  Every slot has num_cu / lane workgroups of 16 waves whatever its neighbours are, so a
+// waits for a group to fill.  Every slot has the same number of 8-wave workgroups (cohort_waves(): 2 x num_cu / lane of them) whatever its neighbours are, so a
 // sample's estimate does not depend on which samples it met on the device, nor on when it arrived: a run is reproducible
 // bit for bit although its schedule is not.
 #ifndef VB2_STREAM_SEARCH_H_
