@@ -1789,8 +1789,9 @@ def _layout_digest(ctx):
 def test_data_arrays_on_the_device_are_the_host_flattens_bytes(tunable):
     """The device holds, byte for byte, what the host half of vb2_ctx_create produces without a device
     (vb2_debug_flatten_digest, whose thread-count independence the CPU suite checks): run words in [tile][row][marker]
-    order, tile records, sorted panel rows and diagonal terms, dictionary and primitive records -- whether the pack step
-    ran as pack_layout_kernel on the GPU (default) or on the host (tunable host_pack).  Shapes: the bench shape in small, a wide
+    order, tile records, sorted panel rows and diagonal terms, dictionary and primitive records -- whether the flatten ran
+    on the GPU (default: classify_kernel + pack_layout_kernel / pack_sched_kernel), half there (tunable host_flatten) or on
+    the host (tunable host_pack).  Shapes: the bench shape in small, a wide
     quality alphabet, missing markers with the depth filter, deep/ragged/empty markers with odd characters, a known-AF input,
     one marker, and a sample with no reads at all."""
     from test_abi_and_host import _flatten_digest
@@ -1808,16 +1809,32 @@ def test_data_arrays_on_the_device_are_the_host_flattens_bytes(tunable):
     kaf = np.clip(rng.uniform(0, 1, size=M), 0.01, 0.99)
     one = vb.synth.make_pileup(1, 30, 2, seed=3)
     none = vb.synth.make_pileup(40, 0.0, 2, seed=4)
+    # markers of a thousand reads and more: the alpha-free terms exp(c_other + D[g]) run through libm's subnormal and
+    # underflow cases (the device's libm_exp_any restates them); quality 0 ('!'): log c = -inf for the hom-ref pair
+    Md = 300
+    ddepth = rng.choice([1, 40, 700, 1000, 1500, 2500, 6000], size=Md)
+    doff = np.zeros(Md + 1, dtype=np.int64)
+    np.cumsum(ddepth, out=doff[1:])
+    Rd = int(doff[-1])
+    dbases = rng.choice(np.frombuffer(b".,.,.,.,ACGTacgtN", dtype=np.uint8), size=Rd)
+    dquals = (rng.choice([0, 1, 2, 3, 10, 20, 30, 40], size=Rd) + 33).astype(np.uint8)
+    dalt = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=Md)
+    deep = vb.PileupData(2, rng.normal(size=(Md, 2)), rng.uniform(0.1, 1.9, size=Md), doff, dbases, dquals, dalt, None,
+                         30.0, 0.0, True, {})
     cases = [vb.synth.make_pileup(3000, 30, 4, seed=5),
              vb.synth.make_pileup(3000, 30, 2, seed=6, q_lo=2, q_hi=93),
              vb.synth.with_sanity_stats(vb.synth.make_pileup(2000, 33, 3, seed=7, missing_frac=0.2)),
              ragged,
              vb.PileupData(2, ragged.ud, ragged.means, off, bases, quals, alt, kaf, 30.0, 0.0, True, {}),
-             one, none,
+             one, none, deep,
+             vb.synth.make_pileup(4000, 4, 2, seed=12, q_lo=2, q_hi=60),      # 118 codes over 2-4 steps: more than 16 per step
+             vb.synth.make_pileup(20000, 30, 4, seed=13, q_lo=2, q_hi=60),    # the wide alphabet of the bench, scheduled tiles
              vb.synth.make_pileup(20000, 30, 4, seed=11)]
     for d in cases:
         want = _flatten_digest(d)
-        for host in ("0", "1"):
-            tunable("host_pack", int(host))
+        # classify + pack on the device (default) | host classifies, device packs | everything on the host
+        for host_flatten, host_pack in ((0, 0), (1, 0), (1, 1)):
+            tunable("host_flatten", host_flatten)
+            tunable("host_pack", host_pack)
             with vb.LikelihoodContext(d, device=0) as ctx:
-                assert _layout_digest(ctx) == want, (d.num_marker, host)
+                assert _layout_digest(ctx) == want, (d.num_marker, host_flatten, host_pack)

@@ -377,7 +377,6 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     for (int idx = 0; idx < kMaxCode; ++idx)
         for (int g = 0; g < 3; ++g) lc3[(size_t)idx * 3 + g] = logc[((idx & 1) * kNumQual + qof[idx >> 1]) * 3 + g];
 
-    std::vector<int32_t> eff_all(M, -1);                       // -1: marker does not count
     // a marker's runs, in dictionary order, at the position of its reads (runs <= reads): low byte idx, high byte count
     // (scratch that a thread creating one context after the other keeps: fresh pages cost more
     // than the passes that fill them)
@@ -387,40 +386,80 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         size_t runs_cap = 0, cd_cap = 0;
     };
     static thread_local Scratch scratch;
-    // Pass B on the device (round 4; VB2_HOST_PACK=1: on the host, as before): the host uploads the INPUTS of
-    // pack_layout_kernel as it has them -- the run lists at their reads' positions, the per-marker constants and the panel
-    // rows in panel order, three words per sorted marker -- instead of the packed arrays; 2-3 ms of host CPU per C3 sample
-    // (scattered reads, 2 M table look-ups) become a ~30 us kernel.  The run lists and the constants are WRITTEN into the
-    // pinned slab the upload leaves from (no scratch arrays, no copy).
+    // The flatten runs on the device (flatten_kernels.hip).  What the pileup viewer holds -- bases, qualities, read offsets,
+    // alt alleles -- goes up as it is, with the byte tables and the panel rows in panel order: one copy into a pinned slab,
+    // one hipMemcpyAsync.  classify_kernel (pass A) leaves every marker's run list, constants and run count in device
+    // memory; the run counts and the code histogram come back (0.4 MB), the host sorts the markers by run count, cuts the
+    // tiles, builds the dictionary, and uploads three words per sorted marker; pack_layout_kernel (pass B) writes the
+    // kernel-order arrays.  Tunable host_flatten = 1: pass A on the host (below; the checker of the device's, and the only
+    // way for an input of 2^32 reads or more), its run lists and constants written straight into the pinned slab the
+    // upload leaves from; host_pack = 1: pass B on the host as well, one upload of the finished arrays.
     const bool host_pack_forced = tn.host_pack != 0;
     const bool device_pack_wanted = !dry && !host_pack_forced && M > 0 && total_reads > 0 && total_reads < ((int64_t)1 << 32);
+    const bool device_flatten = device_pack_wanted && tn.host_flatten == 0;
     size_t in_total = 0;
     auto icarve = [&](size_t bytes) {
         const size_t off = (in_total + 255) & ~(size_t)255;
         in_total = off + bytes;
         return off;
     };
-    const size_t i_runs = icarve((size_t)std::max<int64_t>(total_reads, 1) * sizeof(uint16_t));
-    const size_t i_src = icarve((size_t)M * sizeof(uint32_t));           // (sized for every marker: how many are active is not known yet)
-    const size_t i_eff = icarve((size_t)M * sizeof(uint32_t));
-    const size_t i_pidx = icarve((size_t)M * sizeof(int32_t));
-    const size_t i_cd = icarve((size_t)M * 4 * sizeof(double));
+    const size_t n_reads_al = (size_t)std::max<int64_t>(total_reads, 1);
+    // (a) uploaded before pass A (device flatten only)
+    const size_t i_bases = icarve(device_flatten ? n_reads_al : 0);
+    const size_t i_quals = icarve(device_flatten ? n_reads_al : 0);
+    const size_t i_off = icarve(device_flatten ? ((size_t)M + 1) * sizeof(uint32_t) : 0);
+    const size_t i_alt = icarve(device_flatten ? (size_t)M : 0);
+    const size_t i_qidx = icarve(device_flatten ? 256 : 0);
+    const size_t i_olc = icarve(device_flatten ? 256 * sizeof(double) : 0);
+    const size_t i_lc3 = icarve(device_flatten ? (size_t)kMaxCode * 3 * sizeof(double) : 0);
     const size_t i_ud = icarve(in->known_af ? 0 : (size_t)M * k * sizeof(double));
     const size_t i_mu = icarve(in->known_af ? 0 : (size_t)M * sizeof(double));
     const size_t i_kaf = icarve(in->known_af ? (size_t)M * sizeof(double) : 0);
+    const size_t up1_end = in_total;
+    // (b) uploaded before pass B: three words per sorted marker (sized for every marker: how many are active is not known yet)
+    const size_t i_src = icarve((size_t)M * sizeof(uint32_t));
+    const size_t i_eff = icarve((size_t)M * sizeof(uint32_t));
+    const size_t i_pidx = icarve((size_t)M * sizeof(int32_t));
+    const size_t up2_end = in_total;
+    // (c) pass A's results: written by the host flatten (and uploaded), or by classify_kernel (eff_all and hist come back)
+    const size_t i_effall = icarve(device_flatten ? (size_t)M * sizeof(int32_t) : 0);
+    const size_t i_hist = icarve(device_flatten ? (size_t)(kMaxCode + 2) * sizeof(unsigned long long) : 0);
+    const size_t down_end = in_total;
+    const size_t i_runs = icarve(n_reads_al * sizeof(uint16_t));
+    const size_t i_cd = icarve((size_t)M * 4 * sizeof(double));
     in_total = (in_total + 255) & ~(size_t)255;
+    const size_t pinned_need = device_flatten ? ((down_end + 255) & ~(size_t)255) : in_total;   // (the device keeps runs and cd to itself)
     struct InGuard {                          // the pinned slab of the pack kernel's inputs: back to the cache on every way out
         char* p = nullptr; size_t bytes = 0; int dev = 0;
         ~InGuard() { if (p && !slab_cache().give(slab_cache().stage, p, bytes, dev)) (void)hipHostFree(p); }
     } in_stage;
     in_stage.dev = dev;
     if (device_pack_wanted) {
-        in_stage.p = static_cast<char*>(slab_cache().take(slab_cache().stage, in_total, dev, &in_stage.bytes));
+        in_stage.p = static_cast<char*>(slab_cache().take(slab_cache().stage, pinned_need, dev, &in_stage.bytes));
         if (!in_stage.p) {
-            VB2_HIP(hipHostMalloc((void**)&in_stage.p, in_total, hipHostMallocDefault));
-            in_stage.bytes = in_total;
+            VB2_HIP(hipHostMalloc((void**)&in_stage.p, pinned_need, hipHostMallocDefault));
+            in_stage.bytes = pinned_need;
         }
     }
+    struct DevGuard {                          // the flatten's arrays on the device: back to the cache after the create's sync
+        void* p = nullptr; size_t bytes = 0; int dev = 0; hipStream_t st = nullptr;
+        ~DevGuard() {
+            if (!p) return;
+            (void)hipStreamSynchronize(st);    // (an early error return: a kernel may still be reading)
+            if (!slab_cache().give(slab_cache().dev, p, bytes, dev)) (void)hipFree(p);
+        }
+    } d_in;
+    d_in.dev = dev;
+    d_in.st = c->stream;
+    if (device_pack_wanted) {
+        d_in.p = slab_cache().take(slab_cache().dev, in_total, dev, &d_in.bytes);
+        if (!d_in.p) {
+            VB2_HIP(hipMalloc(&d_in.p, in_total));
+            d_in.bytes = in_total;
+        }
+    }
+    std::vector<int32_t> eff_host(device_flatten ? 0 : M, -1);   // -1: marker does not count
+    int32_t* const eff_all = device_flatten ? reinterpret_cast<int32_t*>(in_stage.p + i_effall) : eff_host.data();
     const size_t runs_need = (size_t)std::max<int64_t>(total_reads, 1), cd_need = (size_t)std::max(M, 1) * 4;
     if (!device_pack_wanted) {
         if (scratch.runs_cap < runs_need || scratch.runs_cap > 4 * runs_need + (1u << 20)) {
@@ -432,11 +471,53 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             scratch.cd_cap = cd_need;
         }
     }
-    uint16_t* const runs = device_pack_wanted ? reinterpret_cast<uint16_t*>(in_stage.p + i_runs) : scratch.runs.get();
+    uint16_t* const runs = device_flatten ? nullptr : device_pack_wanted ? reinterpret_cast<uint16_t*>(in_stage.p + i_runs) : scratch.runs.get();
     // c_other, exp(c_other + D[g]) in panel order
-    double* const cd_tmp = device_pack_wanted ? reinterpret_cast<double*>(in_stage.p + i_cd) : scratch.cd.get();
+    double* const cd_tmp = device_flatten ? nullptr : device_pack_wanted ? reinterpret_cast<double*>(in_stage.p + i_cd) : scratch.cd.get();
     std::vector<int64_t> code_hist(kMaxCode, 0);
-    {
+    if (device_flatten) {
+        char* const inp = in_stage.p;
+        char* const din = static_cast<char*>(d_in.p);
+        std::memcpy(inp + i_bases, in->bases + read_base, (size_t)total_reads);
+        std::memcpy(inp + i_quals, in->quals + read_base, (size_t)total_reads);
+        uint32_t* const off32 = reinterpret_cast<uint32_t*>(inp + i_off);
+        for (int i = 0; i <= M; ++i) off32[i] = (uint32_t)(in->read_off[i] - read_base);
+        std::memcpy(inp + i_alt, in->alt_base, (size_t)M);
+        std::memcpy(inp + i_qidx, lut->qidx, 256);
+        std::memcpy(inp + i_olc, lut->other_lc, 256 * sizeof(double));
+        std::memcpy(inp + i_lc3, lc3.data(), (size_t)kMaxCode * 3 * sizeof(double));
+        if (in->known_af) std::memcpy(inp + i_kaf, in->known_af, (size_t)M * sizeof(double));
+        else {
+            std::memcpy(inp + i_ud, in->ud, (size_t)M * k * sizeof(double));
+            std::memcpy(inp + i_mu, in->means, (size_t)M * sizeof(double));
+        }
+        VB2_HIP(hipMemcpyAsync(din, inp, up1_end, hipMemcpyHostToDevice, c->stream));
+        VB2_HIP(hipMemsetAsync(din + i_hist, 0, (size_t)(kMaxCode + 2) * sizeof(unsigned long long), c->stream));
+        ClassifyArgs ca;
+        std::memset(&ca, 0, sizeof(ca));
+        ca.bases = reinterpret_cast<const unsigned char*>(din + i_bases);
+        ca.quals = reinterpret_cast<const unsigned char*>(din + i_quals);
+        ca.off = reinterpret_cast<const uint32_t*>(din + i_off);
+        ca.alt = reinterpret_cast<const unsigned char*>(din + i_alt);
+        ca.qidx = reinterpret_cast<const unsigned char*>(din + i_qidx);
+        ca.other_lc = reinterpret_cast<const double*>(din + i_olc);
+        ca.lc3 = reinterpret_cast<const double*>(din + i_lc3);
+        ca.runs = reinterpret_cast<uint16_t*>(din + i_runs);
+        ca.eff = reinterpret_cast<int32_t*>(din + i_effall);
+        ca.cd = reinterpret_cast<double*>(din + i_cd);
+        ca.hist = reinterpret_cast<unsigned long long*>(din + i_hist);
+        ca.M = M;
+        ca.sanity = in->sanity_disabled ? 0 : 1;
+        ca.lo = lo;
+        ca.hi = hi;
+        VB2_HIP(launch_classify(ca, c->stream));
+        VB2_HIP(hipMemcpyAsync(inp + i_effall, din + i_effall, down_end - i_effall, hipMemcpyDeviceToHost, c->stream));
+        VB2_HIP(hipStreamSynchronize(c->stream));
+        const unsigned long long* hist = reinterpret_cast<const unsigned long long*>(inp + i_hist);
+        for (int c2 = 0; c2 < kMaxCode; ++c2) code_hist[c2] = (int64_t)hist[c2];
+        num_read = (int64_t)hist[kMaxCode];
+        num_other = (int64_t)hist[kMaxCode + 1];
+    } else {
         std::vector<std::vector<int64_t>> hist_t(nthr, std::vector<int64_t>(kMaxCode, 0));
         std::vector<int64_t> reads_t(nthr, 0), other_t(nthr, 0);
         // class of a base given the marker's alt allele, one table row per (upper-cased) alt: 0 ref
@@ -740,8 +821,9 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // ---- pass B (kernel order: markers sorted by run count, i.e. scattered reads of the panel
     // order arrays -- prefetched): run words, panel rows, diagonal terms into the staging slab ----
     if (device_pack) {
-        char* const inp = in_stage.p;            // (run lists and constants are there already)
-        if (in->known_af) std::memcpy(inp + i_kaf, in->known_af, (size_t)M * sizeof(double));
+        char* const inp = in_stage.p;            // (run lists and constants are there already, or on the device)
+        if (device_flatten) {
+        } else if (in->known_af) std::memcpy(inp + i_kaf, in->known_af, (size_t)M * sizeof(double));
         else {
             std::memcpy(inp + i_ud, in->ud, (size_t)M * k * sizeof(double));
             std::memcpy(inp + i_mu, in->means, (size_t)M * sizeof(double));
@@ -873,24 +955,12 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     }
     char* const dbase = static_cast<char*>(c->d_slab);
     // the data arrays in ONE asynchronous copy; partial sums, ticket, relay, stamps and schedule space start as zeros
-    struct DevGuard {                          // the pack kernel's inputs on the device: back to the cache after the create's sync
-        void* p = nullptr; size_t bytes = 0; int dev = 0; hipStream_t st = nullptr;
-        ~DevGuard() {
-            if (!p) return;
-            (void)hipStreamSynchronize(st);    // (an early error return: the kernel may still be reading)
-            if (!slab_cache().give(slab_cache().dev, p, bytes, dev)) (void)hipFree(p);
-        }
-    } d_in;
-    d_in.dev = dev;
-    d_in.st = c->stream;
     if (device_pack) {
-        d_in.p = slab_cache().take(slab_cache().dev, in_total, dev, &d_in.bytes);
-        if (!d_in.p) {
-            VB2_HIP(hipMalloc(&d_in.p, in_total));
-            d_in.bytes = in_total;
-        }
         char* const din = static_cast<char*>(d_in.p);
-        VB2_HIP(hipMemcpyAsync(din, in_stage.p, in_total, hipMemcpyHostToDevice, c->stream));
+        if (device_flatten)     // (the reads, the panel rows and pass A's results are there: the three words per sorted marker follow)
+            VB2_HIP(hipMemcpyAsync(din + up1_end, in_stage.p + up1_end, up2_end - up1_end, hipMemcpyHostToDevice, c->stream));
+        else
+            VB2_HIP(hipMemcpyAsync(din, in_stage.p, in_total, hipMemcpyHostToDevice, c->stream));
         // the small tables of the data block, each to its place
         VB2_HIP(hipMemcpyAsync(dbase + o_rec, stage + o_rec, (size_t)num_mt * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
         if (!dict_perr.empty())

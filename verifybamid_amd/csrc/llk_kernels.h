@@ -153,9 +153,30 @@ hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 // rows16_total + kCodeSlackRows rows are written, the slack as padding words)
 hipError_t launch_pack_codes16(const DeviceLayout& L, uint2* codes16, const uint2* mt_rec16, uint32_t rows16_total,
                                hipStream_t stream);
-// Pass B of the flatten on the device (round 4): the host classifies, run-length codes and sorts; this kernel writes the
-// kernel-order arrays -- run words [tile][row][marker], panel rows, per-marker constants -- from the panel-order inputs the
-// host uploaded as they were.  Pure data movement: the same bytes as the host's pass B (tested).
+// The flatten on the device (flatten_kernels.hip).  Pass A, classify_kernel: what the pileup viewer holds goes up as it is --
+// bases, qualities, read offsets, alt alleles -- and one thread per marker classifies, counts, run-length codes and sums
+// the alpha-free terms; the host keeps the dictionary order (known from a sample of the qualities before any read is
+// walked), the sort of the markers by run count and the tile records.
+struct ClassifyArgs {
+    const unsigned char* bases;    // [reads]
+    const unsigned char* quals;    // [reads]
+    const uint32_t* off;           // [M + 1] read offsets, relative to the first read
+    const unsigned char* alt;      // [M] alt allele
+    const unsigned char* qidx;     // [256] quality character -> 2 * rank of its (clamped) quality in the dictionary order
+    const double* other_lc;        // [256] quality character -> log c of class "other"
+    const double* lc3;             // [kMaxCode][3] code index -> log c[g], g = 0, 1, 2
+    uint16_t* runs;                // out [reads]: a marker's runs (code index | count << 8) at its reads' position
+    int32_t* eff;                  // out [M]: runs of the marker, -1 = the marker does not count (h:239-249)
+    double* cd;                    // out [M][4]: c_other, exp(c_other + D[g])
+    unsigned long long* hist;      // out [kMaxCode + 2], zero on entry: reads per code index, reads of counted markers, reads of class "other"
+    int32_t M;
+    int32_t sanity;                // 1: the +-3 sd depth filter is on
+    double lo, hi;                 // its bounds
+};
+hipError_t launch_classify(const ClassifyArgs& a, hipStream_t stream);
+// Pass B, pack_layout_kernel (+ pack_sched_kernel for wide alphabets): the kernel-order arrays -- run words
+// [tile][row][marker], panel rows, per-marker constants -- from the panel-order arrays above.  Pure data movement: the same
+// bytes as the host's pass B (tested).
 struct PackArgs {
     const uint16_t* runs;          // a marker's runs (dictionary index | count << 8), at src_off[m]
     const uint32_t* src_off;       // [m_active] sorted marker m -> offset of its runs

@@ -1692,123 +1692,8 @@ hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
     }
 }
 
-// One thread per (micro-tile, row of four runs, marker): the 32-bit run words of `codes` re-coded as
-// dictionary index | count code << 8 (count code: llk_kernels.h, codes16).  Rows past a tile's own (and the slack rows at the end) hold padding
-// words: the zero table row with count 0.
-__global__ void __launch_bounds__(256)
-pack_codes16_kernel(const DeviceLayout L, uint2* __restrict__ codes16, const uint2* __restrict__ mt_rec16,
-                    uint32_t rows16_total)
-{
-    const uint32_t pad = (uint32_t)L.num_code;                       // count 0
-    const uint32_t pad2 = pad | (pad << 16);
-    const int mt = blockIdx.x;
-    if (mt >= L.num_mt) {                                            // the last block writes the slack rows
-        for (uint32_t e = threadIdx.x; e < (uint32_t)kCodeSlackRows * kMtMarkers; e += blockDim.x)
-            codes16[(size_t)rows16_total * kMtMarkers + e] = make_uint2(pad2, pad2);
-        return;
-    }
-    const uint2 r32 = L.mt_rec[mt], r16 = mt_rec16[mt];
-    for (uint32_t e = threadIdx.x; e < r16.y * kMtMarkers; e += blockDim.x) {
-        const uint32_t row = e / kMtMarkers, m = e % kMtMarkers;
-        uint32_t w[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t row32 = 2 * row + h;
-            uint2 v = make_uint2(0u, 0u);
-            const bool have = row32 < r32.y;
-            if (have) v = L.codes[((size_t)r32.x + row32) * kMtMarkers + m];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t rw = j ? v.y : v.x;
-                const uint32_t idx = (rw & 0xffffu) / (uint32_t)L.row_bytes;
-                // count code: the run word's top half IS the top half of double(n); relative to that of 1.0 it fits a byte
-                // (n <= 31 -> <= 0x4f); a padding run (count 0, the zero table row) gets code 0
-                const uint32_t top = rw >> 16;
-                const uint32_t code = top >= 0x3ff0u ? (top - 0x3ff0u) & 0xffu : 0u;
-                w[2 * h + j] = have ? (idx | (code << 8)) : pad;
-            }
-        }
-        codes16[((size_t)r16.x + row) * kMtMarkers + m] = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
-    }
-}
-
-hipError_t launch_pack_codes16(const DeviceLayout& L, uint2* codes16, const uint2* mt_rec16, uint32_t rows16_total,
-                               hipStream_t stream)
-{
-    hipLaunchKernelGGL(pack_codes16_kernel, dim3(L.num_mt + 1), dim3(256), 0, stream, L, codes16, mt_rec16, rows16_total);
-    return hipGetLastError();
-}
-
-// One thread per position of the padded, sorted marker list (see PackArgs): 16 consecutive threads = one micro-tile, so a
-// row of run words leaves as one 128-byte store per tile.
-__global__ void __launch_bounds__(256)
-pack_layout_kernel(const PackArgs a)
-{
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < a.m_pad) {
-        const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
-        const uint2 rec = a.mt_rec[t];
-        const bool have = m < a.m_active;
-        const uint32_t eff = have ? a.eff[m] : 0u;
-        const uint16_t* src = a.runs + (have ? a.src_off[m] : 0u);
-        uint2* out = a.codes + (size_t)rec.x * kMtMarkers + lane;
-        for (uint32_t r = 0; r < (a.sched ? 0u : rec.y); ++r) {         // (sched: pack_sched_kernel writes the run words)
-            uint32_t w0 = a.pad4, w1 = a.pad4;
-            if (2 * r < eff) { const uint32_t rw = src[2 * r]; w0 = a.row_of_idx[rw & 0xffu] | a.hi_of_count[rw >> 8]; }
-            if (2 * r + 1 < eff) { const uint32_t rw = src[2 * r + 1]; w1 = a.row_of_idx[rw & 0xffu] | a.hi_of_count[rw >> 8]; }
-            out[(size_t)r * kMtMarkers] = make_uint2(w0, w1);
-        }
-        const int64_t i = have ? (int64_t)a.pidx[m] : 0;
-        if (a.kaf_s) a.kaf_s[m] = have ? a.kaf[i] : 0.0;
-        else {
-            for (int kk = 0; kk < a.k; ++kk) a.ud_s[(size_t)kk * a.m_pad + m] = have ? a.ud[(size_t)i * a.k + kk] : 0.0;
-            a.mu_s[m] = have ? a.mu[i] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a.cdiag[(size_t)q * a.m_pad + m] = have ? a.cd[(size_t)i * 4 + q] : 0.0;
-    }
-    // the slack rows behind the last tile (the read loops request past a tile's rows): padding words
-    const int64_t nslack = (int64_t)a.slack_rows * kMtMarkers;
-    for (int64_t e = m; e < nslack; e += (int64_t)gridDim.x * blockDim.x)
-        a.codes[(size_t)a.total_rows * kMtMarkers + e] = make_uint2(a.pad4, a.pad4);
-}
-
-// Wide quality alphabets: one THREAD per micro-tile places the tile's run words (schedule_tile, tile_sched.h -- the very
-// function the host pack calls, so the two write the same bytes); ~1 KB of scratch per thread, a few thousand integer
-// operations per tile.
-__global__ void __launch_bounds__(64)
-pack_sched_kernel(const PackArgs a)
-{
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= a.num_mt) return;
-    const uint2 rec = a.mt_rec[t];
-    uint32_t eff[kMtMarkers];
-    const uint16_t* src[kMtMarkers];
-    for (int l = 0; l < kMtMarkers; ++l) {
-        const int64_t m = (int64_t)t * kMtMarkers + l;
-        const bool have = m < a.m_active;
-        eff[l] = have ? a.eff[m] : 0u;
-        src[l] = a.runs + (have ? a.src_off[m] : 0u);
-    }
-    uint32_t* const out = reinterpret_cast<uint32_t*>(a.codes + (size_t)rec.x * kMtMarkers);
-    TileSched S;
-    schedule_tile(S, eff, (int)(2u * rec.y), a.num_code, a.dict_of,
-                  [&](int l, int j) -> uint32_t { return src[l][j]; },
-                  [&](int l, int c, uint32_t rw) {
-                      out[((size_t)(c >> 1) * kMtMarkers + l) * 2 + (c & 1)] = a.row_of_idx[rw & 0xffu] | a.hi_of_count[rw >> 8];
-                  },
-                  [&](int l, int c) { out[((size_t)(c >> 1) * kMtMarkers + l) * 2 + (c & 1)] = a.pad4; });
-}
-
-hipError_t launch_pack_layout(const PackArgs& a, hipStream_t stream)
-{
-    const int64_t n = std::max<int64_t>(a.m_pad, (int64_t)a.slack_rows * kMtMarkers);
-    hipLaunchKernelGGL(pack_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || !a.sched || a.num_mt <= 0) return e;
-    hipLaunchKernelGGL(pack_sched_kernel, dim3((unsigned)((a.num_mt + 63) / 64)), dim3(64), 0, stream, a);
-    return hipGetLastError();
-}
+// (the kernels of the flatten -- classify_kernel, pack_layout_kernel, pack_sched_kernel, pack_codes16_kernel -- are in
+// flatten_kernels.hip)
 
 bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int tpu, int ngrp,
                     std::vector<uint32_t>* off, std::vector<uint16_t>* item)

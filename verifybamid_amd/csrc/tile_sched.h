@@ -15,8 +15,19 @@
 //     than 16 of them, so they never collide, and markers that share a code read it in the same step (a broadcast);
 //   * a marker's second run of a step (and repeats of a code: runs hold at most 31 reads) moves to the nearest step where
 //     the marker is idle and the run's bank group is free -- or already holds the same code; else to the nearest idle step.
-// Expected passes per step on the synthetic wide alphabet: 1.85 -> 1.24 (72 codes: 1.38 -> 1.15; 42 codes would go 1.00 ->
-// 1.10, so contexts of at most kSchedMinCodes codes keep the plain order).
+// Expected passes per step on the synthetic wide alphabet: 1.88 -> 1.29 (72 codes: 1.37 -> 1.19; 42 codes would go 1.00 ->
+// 1.12, so contexts of at most kSchedMinCodes codes keep the plain order) -- tools/ubench/sched_sim.cpp.
+//
+// The state is kept as bit sets over the steps -- per code the steps where it holds its bank group, per bank group the
+// steps where the group is free, per lane the steps taken -- so that "the nearest step where ..." is a handful of bit
+// operations instead of a walk, and the work comes in three phases per lane (sched_home, sched_rest, sched_pad) that the
+// device runs with one 16-lane row per tile and the state in LDS (flatten_kernels.hip: pack_sched_kernel; its first
+// version ran the whole tile in one thread over byte arrays in private scratch: 8.5 ms per context):
+//   * sched_home of different lanes commute whenever a step's home codes fall into distinct bank groups (sched_home_commutes:
+//     at most 16 codes per step) -- the only shared words are then set to the same values by whoever comes first -- so the
+//     16 lanes run it side by side; otherwise, and always for sched_rest, lane after lane in index order;
+//   * sched_pad touches nothing shared.
+// schedule_tile below is the serial composition the host uses; both write the same bytes (tested through the digests).
 #pragma once
 #include <cstdint>
 
@@ -24,22 +35,115 @@ namespace vb2 {
 
 constexpr int kSchedMaxSteps = 64;     // steps (= 2 x rows) and runs per marker the scheduler handles; beyond: plain order
 constexpr int kSchedMinCodes = 48;     // dictionaries up to this size keep the plain order
+constexpr int kSchedMaxPos = 192;      // dictionary positions (<= kMaxCode = 188)
 
-struct TileSched {                     // scratch of one tile (~1.2 KB)
-    uint8_t occ[kSchedMaxSteps][16];   // step -> bank group -> dictionary position + 1 of the code read there (0: free)
+struct TileSched {                     // scratch of one tile (1.8 KB)
+    uint64_t holds[kSchedMaxPos];      // dictionary position -> steps where that code holds its bank group
+    uint64_t open[16];                 // bank group -> steps where the group is still free
     uint64_t used[16];                 // lane -> steps taken
-    uint64_t placed[16];               // lane -> runs placed
+    uint64_t placed[16];               // lane -> runs placed by sched_home
 };
+
+struct SchedSerialOps {                // how a shared word changes: plainly on the host, with LDS atomics on the device
+    static __host__ __device__ inline void set(uint64_t& w, uint64_t bits) { w |= bits; }
+    static __host__ __device__ inline void clear(uint64_t& w, uint64_t bits) { w &= ~bits; }
+};
+
+// the set bit of x nearest to position h (x != 0); of two equally near the lower one
+__host__ __device__ inline int sched_nearest(uint64_t x, int h)
+{
+    const uint64_t below = x & ((2ull << h) - 1ull);          // positions <= h (h = 63: 2 << 63 wraps to 0, minus 1 = all)
+    const uint64_t above = h >= 63 ? 0ull : x >> (h + 1);     // positions > h, shifted down
+    const int lo = below ? 63 - __builtin_clzll(below) : -1;
+    const int hi = above ? h + 1 + __builtin_ctzll(above) : -1;
+    if (lo < 0) return hi;
+    if (hi < 0) return lo;
+    return (h - lo) <= (hi - h) ? lo : hi;
+}
+
+__host__ __device__ inline uint64_t sched_all_steps(int steps) { return steps >= 64 ? ~0ull : (1ull << steps) - 1ull; }
+__host__ __device__ inline int sched_home_step(int d, int steps, int num_code)
+{
+    const int h = d * steps / num_code;
+    return h < steps ? h : steps - 1;
+}
+// plain dictionary order (no scheduling) for tiles the bit sets cannot describe
+template <class Eff>
+__host__ __device__ inline bool sched_is_plain(const Eff& eff, int steps, int num_code)
+{
+    bool plain = steps > kSchedMaxSteps || num_code <= 0 || num_code > kSchedMaxPos;
+    for (int l = 0; l < 16; ++l) plain = plain || eff[l] > (uint32_t)kSchedMaxSteps || eff[l] > (uint32_t)steps;
+    return plain;
+}
+// a step's home codes are consecutive dictionary positions: at most 16 of them = distinct bank groups
+__host__ __device__ inline bool sched_home_commutes(int steps, int num_code) { return (num_code + steps - 1) / steps <= 16; }
+
+// lane l's runs that find their home step free.  home(d) = sched_home_step(d, steps, num_code), possibly from a table
+template <class Ops, class State, class Dict, class Home, class GetRun, class Put>
+__host__ __device__ inline void sched_home(State& S, int l, uint32_t eff_l, const Dict& dict_of, Home home, GetRun get, Put put)
+{
+    uint64_t used = 0, placed = 0;
+    for (uint32_t j = 0; j < eff_l; ++j) {
+        const uint32_t rw = get(l, (int)j);
+        const int d = dict_of[rw & 0xffu];
+        const int h = home(d);
+        const uint64_t bit = 1ull << h;
+        const int r = d & 15;
+        if (!(used & bit) && ((S.open[r] | S.holds[d]) & bit)) {
+            used |= bit;
+            Ops::set(S.holds[d], bit);                  // (in this order: another lane with the same code never sees neither)
+            Ops::clear(S.open[r], bit);
+            placed |= 1ull << j;
+            put(l, h, rw);
+        }
+    }
+    S.used[l] = used;
+    S.placed[l] = placed;
+}
+
+// lane l's other runs: the nearest idle step where the code already holds its bank group, else the nearest idle step where
+// the group is free, else the nearest idle step.  Lane after lane (lane 0 holds the most runs, i.e. the fewest idle steps).
+template <class State, class Dict, class Home, class GetRun, class Put>
+__host__ __device__ inline void sched_rest(State& S, int l, uint32_t eff_l, uint64_t all, const Dict& dict_of, Home home,
+                                           GetRun get, Put put)
+{
+    uint64_t used = S.used[l];
+    const uint64_t placed = S.placed[l];
+    for (uint32_t j = 0; j < eff_l; ++j) {
+        if ((placed >> j) & 1ull) continue;
+        const uint32_t rw = get(l, (int)j);
+        const int d = dict_of[rw & 0xffu];
+        const int h = home(d);
+        const int r = d & 15;
+        const uint64_t idle = all & ~used;
+        const uint64_t same = idle & S.holds[d], open = idle & S.open[r];
+        const int c = sched_nearest(same ? same : open ? open : idle, h);
+        const uint64_t bit = 1ull << c;
+        if (S.open[r] & bit) {
+            S.open[r] &= ~bit;
+            S.holds[d] |= bit;
+        }
+        used |= bit;
+        put(l, c, rw);
+    }
+    S.used[l] = used;
+}
+
+template <class State, class Pad>
+__host__ __device__ inline void sched_pad(State& S, int l, int steps, Pad pad)
+{
+    const uint64_t used = S.used[l];
+    for (int c = 0; c < steps; ++c)
+        if (!((used >> c) & 1ull)) pad(l, c);
+}
 
 // eff[l]: runs of lane l (0 for a lane without a marker); get(l, j) -> run word (dictionary index | count << 8);
 // dict_of[index] -> dictionary position; put(l, step, run word) for every run, pad(l, step) for every step left over.
-template <class GetRun, class Put, class Pad>
-__host__ __device__ inline void schedule_tile(TileSched& S, const uint32_t* eff, const int steps, const int num_code,
-                                              const uint8_t* dict_of, GetRun get, Put put, Pad pad)
+template <class State, class Eff, class Dict, class GetRun, class Put, class Pad>
+inline void schedule_tile(State& S, const Eff& eff, const int steps, const int num_code, const Dict& dict_of, GetRun get,
+                          Put put, Pad pad)
 {
-    bool plain = steps > kSchedMaxSteps || num_code <= 0;
-    for (int l = 0; l < 16; ++l) plain = plain || eff[l] > (uint32_t)kSchedMaxSteps || eff[l] > (uint32_t)steps;
-    if (plain) {
+    if (sched_is_plain(eff, steps, num_code)) {
         for (int l = 0; l < 16; ++l) {
             for (int j = 0; j < steps; ++j) {
                 if ((uint32_t)j < eff[l]) put(l, j, get(l, j));
@@ -48,51 +152,13 @@ __host__ __device__ inline void schedule_tile(TileSched& S, const uint32_t* eff,
         }
         return;
     }
-    for (int c = 0; c < steps; ++c)
-        for (int r = 0; r < 16; ++r) S.occ[c][r] = 0;
-    for (int l = 0; l < 16; ++l) S.used[l] = S.placed[l] = 0;
-    // the runs that find their home step free
-    for (int l = 0; l < 16; ++l)
-        for (uint32_t j = 0; j < eff[l]; ++j) {
-            const uint32_t rw = get(l, (int)j);
-            const int d = dict_of[rw & 0xffu];
-            int h = d * steps / num_code;
-            h = h < steps ? h : steps - 1;
-            const int r = d & 15;
-            if (!((S.used[l] >> h) & 1ull) && (S.occ[h][r] == 0 || S.occ[h][r] == (uint8_t)(d + 1))) {
-                S.used[l] |= 1ull << h;
-                S.occ[h][r] = (uint8_t)(d + 1);
-                S.placed[l] |= 1ull << j;
-                put(l, h, rw);
-            }
-        }
-    // the others, lane by lane (lane 0 holds the most runs, i.e. the fewest idle steps)
-    for (int l = 0; l < 16; ++l)
-        for (uint32_t j = 0; j < eff[l]; ++j) {
-            if ((S.placed[l] >> j) & 1ull) continue;
-            const uint32_t rw = get(l, (int)j);
-            const int d = dict_of[rw & 0xffu];
-            int h = d * steps / num_code;
-            h = h < steps ? h : steps - 1;
-            const int r = d & 15;
-            int best_same = -1, best_free = -1, best_any = -1;
-            for (int k = 0; k < steps && best_same < 0; ++k)
-                for (int s = 0; s < (k ? 2 : 1); ++s) {
-                    const int c = s ? h + k : h - k;
-                    if (c < 0 || c >= steps || ((S.used[l] >> c) & 1ull)) continue;
-                    const uint8_t o = S.occ[c][r];
-                    if (o == (uint8_t)(d + 1)) { best_same = c; break; }
-                    if (best_free < 0 && o == 0) best_free = c;
-                    if (best_any < 0) best_any = c;
-                }
-            const int c = best_same >= 0 ? best_same : best_free >= 0 ? best_free : best_any;
-            if (S.occ[c][r] == 0) S.occ[c][r] = (uint8_t)(d + 1);
-            S.used[l] |= 1ull << c;
-            put(l, c, rw);
-        }
-    for (int l = 0; l < 16; ++l)
-        for (int c = 0; c < steps; ++c)
-            if (!((S.used[l] >> c) & 1ull)) pad(l, c);
+    const uint64_t all = sched_all_steps(steps);
+    for (int d = 0; d < num_code; ++d) S.holds[d] = 0;
+    for (int r = 0; r < 16; ++r) S.open[r] = all;
+    auto home = [&](int d) { return sched_home_step(d, steps, num_code); };
+    for (int l = 0; l < 16; ++l) sched_home<SchedSerialOps>(S, l, eff[l], dict_of, home, get, put);
+    for (int l = 0; l < 16; ++l) sched_rest(S, l, eff[l], all, dict_of, home, get, put);
+    for (int l = 0; l < 16; ++l) sched_pad(S, l, steps, pad);
 }
 
 }  // namespace vb2
