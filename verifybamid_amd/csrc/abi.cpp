@@ -187,6 +187,16 @@ int vb2_debug_flatten_digest(const vb2_input* in, unsigned long long* digest)
 }
 
 // (test hook, not in vb2_abi.h) the same digest over the data arrays as they are on the device
+// What the device sustains with the evaluation kernels' instruction mix (calib_kernels.hip): out[0] FP64 FMA
+// lane-instructions / s, arithmetic alone; out[1] with the table reads feeding it; out[2] the latter counting every VALU
+// instruction of the loop.  bench.py's roofline quotes the kernels against these instead of a nominal clock.
+int vb2_debug_issue_ceiling(int device, double* out)
+{
+    if (!out) return VB2_ERR_INVALID;
+    if (vb2::usable_device_count() < 1) return VB2_ERR_NO_DEVICE;
+    return vb2::measure_issue_ceiling(device, out) == hipSuccess ? VB2_OK : VB2_ERR_HIP;
+}
+
 int vb2_debug_layout_digest(vb2_ctx* ctx, unsigned long long* digest)
 {
     if (int rc = guard_ctx(ctx)) return rc;

@@ -475,6 +475,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // c_other, exp(c_other + D[g]) in panel order
     double* const cd_tmp = device_flatten ? nullptr : device_pack_wanted ? reinterpret_cast<double*>(in_stage.p + i_cd) : scratch.cd.get();
     std::vector<int64_t> code_hist(kMaxCode, 0);
+    auto t_staged = t_start;
     if (device_flatten) {
         char* const inp = in_stage.p;
         char* const din = static_cast<char*>(d_in.p);
@@ -491,6 +492,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             std::memcpy(inp + i_ud, in->ud, (size_t)M * k * sizeof(double));
             std::memcpy(inp + i_mu, in->means, (size_t)M * sizeof(double));
         }
+        t_staged = tnow();
         VB2_HIP(hipMemcpyAsync(din, inp, up1_end, hipMemcpyHostToDevice, c->stream));
         VB2_HIP(hipMemsetAsync(din + i_hist, 0, (size_t)(kMaxCode + 2) * sizeof(unsigned long long), c->stream));
         ClassifyArgs ca;
@@ -1108,11 +1110,14 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // the upload has left the staging slab (which goes back to the cache now): wait for THIS
     // context's stream only -- other contexts' streams and the null stream are not touched
     VB2_HIP(hipStreamSynchronize(c->stream));
-    if (timing)
-        std::fprintf(stderr, "vb2_ctx_create: flatten %.1f ms (classify %.1f, dictionary+sort %.1f, pack %.1f; "
-                     "%d threads), device alloc+upload %.1f ms\n",
-                     tms(t_start, t_flat), tms(t_start, t_pass1), tms(t_pass1, t_sort), tms(t_sort, t_flat), nthr,
-                     tms(t_flat, tnow()));
+    if (timing) {
+        std::fprintf(stderr, "vb2_ctx_create: flatten %.2f ms (%s %.2f, dictionary+sort %.2f, pack %.2f; "
+                     "%d threads), device alloc+upload%s %.2f ms\n",
+                     tms(t_start, t_flat), device_flatten ? "stage" : "classify",
+                     device_flatten ? tms(t_start, t_staged) : tms(t_start, t_pass1), tms(t_pass1, t_sort), tms(t_sort, t_flat), nthr,
+                     device_pack ? "+pack kernels" : "", tms(t_flat, tnow()));
+        if (device_flatten) std::fprintf(stderr, "  upload + classify_kernel + read-back: %.2f ms\n", tms(t_staged, t_pass1));
+    }
     *out = c.release();
     return VB2_OK;
 }

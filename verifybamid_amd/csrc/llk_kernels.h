@@ -292,6 +292,8 @@ hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra, double* 
 // a profiler's tool library (rocprofv3: librocprofiler-sdk-tool) is loaded in this process: ROCm 7.2's crashes in its
 // exit handler after a cooperative launch, so the library launches plainly under it
 bool profiler_attached();
+// calib_kernels.hip: FP64 issue rates of this device with the read loop's instruction mix (lane-instructions per second)
+hipError_t measure_issue_ceiling(int device, double out[3]);
 
 }  // namespace vb2
 #endif

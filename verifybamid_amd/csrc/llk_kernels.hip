@@ -866,9 +866,15 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const size_t pos_ = (size_t)mt_ * kMtMarkers + m;
         return g_ediag[(have_ && pos_ < (size_t)L.num_active) ? pos_ : 0];
     };
+    // The workgroup of the resident kernel's control wave (wave 0, busy with the simplex during the tile phase): the waves w, w + 4,
+    // w + 8, ... of a workgroup run on one SIMD (tools/ubench/wave_simd.hip), so the waves 4, 8, 12 share the control wave's.
+    // They come LAST in the order in which the waves take their first items: a search round has fewer items than waves (13 for
+    // 15 at C3), and the idle waves are then the control wave's neighbours instead of the last two.  Same items, same slots: the
+    // same bits.  OptimizeLLK 6.09 -> 6.04 ms on the same box.
+    const int spare_rank = (wave & 3) ? (wave >> 2) * 3 + (wave & 3) - 1 : (nwave - (nwave >> 2)) + (wave >> 2) - 1;
     const uint32_t idx_first = hook_mine ? nitem
                                : have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem)
-                                            : (uint32_t)(wave - (hook_blk ? 1 : 0));
+                                            : (uint32_t)(hook_blk ? spare_rank : wave);
     if (PIPE && idx_first < nitem) {
         bool h0;
         const uint32_t mt0 = tile_of(idx_first, h0);
@@ -959,7 +965,16 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // are spread over both phases at any time: waves in the read loop get issue priority, so that
         // their ds_reads go out as soon as they can and the LDS pipe stays busy, while the epilogue
         // waves fill the VALU slots in between (-0.8 % per launch measured; the other way round: +0.8 %)
-        __builtin_amdgcn_s_setprio(1);
+        // A search round (the four-point shape on the work queue) has at most one item per wave, and the round ends with the
+        // wave that holds the deepest tiles (17 rows at C3 against a median of 9: the first items of the low-numbered
+        // workgroups): the deeper a wave's item -- the lower its index -- the higher its priority on its SIMD (the four
+        // deepest items of a workgroup are on four different SIMDs).  OptimizeLLK 5.98 -> 5.90 ms on the same box.
+        if (MODE == 3 && ONEGRP && dyn) {
+            if (idx < 4u) __builtin_amdgcn_s_setprio(3);
+            else if (idx < 8u) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(1);
+        } else
+            __builtin_amdgcn_s_setprio(1);
         g_cuint2* cp = g_codes + (LCACHE ? (size_t)0 : (size_t)rec.x * kMtMarkers + m);
         const uint32_t crow = rec.x + (uint32_t)m * 8u;      // (LCACHE: this lane's word of the tile's first row, LDS)
         const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
