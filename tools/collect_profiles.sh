@@ -4,7 +4,7 @@
 #   WRITE_SIZE, SQ counters, GRBM_GUI_ACTIVE; each in its own run, with --kernel-trace only),
 #   kernel stats of the other wave shapes (4-point / 1-point launches, cohort steps) and of a search.
 # Usage: bash tools/collect_profiles.sh r02
-R=${1:-r04}
+R=${1:-r05}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
@@ -36,6 +36,13 @@ W="$B --q-lo 2 --q-hi 60"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_wide -o w -- $W > $O/trace_wide.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_wide_sq1 -o w -- $W $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_wide_grbm -o w -- $W $P > /dev/null 2>&1
+# vb2_ctx_create (the flatten on the device: classify_kernel, pack_layout_kernel, pack_sched_kernel): host times and kernel stats
+cd /tmp
+python $GRAFT_REPO_ROOT/tools/create_time.py > $O/create_time.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_create -o cr -- python $GRAFT_REPO_ROOT/tools/create_time.py > /dev/null 2>&1
+# the issue ceilings bench.py quotes the kernels against, stand-alone: FP64 FMA alone / LDS reads alone / both, by waves per CU
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off $GRAFT_REPO_ROOT/tools/ubench/lds_fma_mix.hip -o /tmp/lds_fma_mix 2>/dev/null && /tmp/lds_fma_mix > $O/ubench_lds_fma_mix.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off $GRAFT_REPO_ROOT/tools/ubench/valu_rates.hip -o /tmp/valu_rates 2>/dev/null && /tmp/valu_rates > $O/ubench_valu_rates.txt 2>&1
 # a search round's timeline (in-kernel stamps; the build with the stamps frozen at round 200 if it was made: make stamps_round)
 cd $GRAFT_REPO_ROOT
 python tools/stamps_resident.py > $O/search_round_stamps.txt 2>&1

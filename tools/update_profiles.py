@@ -5,7 +5,7 @@ search), PMC summary, batch sweep, and the two derived files bench.py reads back
 instructions per marker x point).
 Usage: python tools/update_profiles.py r02"""
 import csv, json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles", R)
 os.makedirs(dst, exist_ok=True)
@@ -170,16 +170,30 @@ if ws:
               "lds_bank_conflict_frac": round(avg_of(sq1, sub, "SQ_LDS_BANK_CONFLICT") / max(1.0, avg_of(sq1, sub, "SQ_LDS_IDX_ACTIVE")), 4)}
         json.dump(wv, open(os.path.join(dst, "valu_b%d_wide.json" % B), "w"), indent=1)
         print("wide alphabet:", wv["points_per_launch"], wv["lane_instr_per_marker_point"], wv["valu_busy_frac"], wv["lds_busy_frac"])
+cs = first_csv("trace_create", "kernel_stats.csv")
+if cs:
+    shutil.copy(cs, os.path.join(dst, "create_kernel_stats.csv"))
+    cj = {"_what": "device time of vb2_ctx_create's kernels on a C3 sample (100 000 markers x depth 30), average per call in us: "
+                   "rocprofv3 --kernel-trace --stats over tools/create_time.py (contexts of both alphabets -- 42 and 118 codes -- "
+                   "in the three flatten modes; pack_sched_kernel runs for the 118-code contexts only)"}
+    for r in csv.DictReader(open(cs)):
+        nm = r["Name"].split("(")[0].replace("vb2::", "")
+        if nm in ("classify_kernel", "pack_layout_kernel", "pack_sched_kernel", "pack_codes16_kernel"):
+            cj[nm + "_us"] = round(float(r["AverageNs"]) / 1e3, 1)
+    json.dump(cj, open(os.path.join(dst, "create_kernel_stats.json"), "w"), indent=1)
+for f in ("create_time.txt", "ubench_lds_fma_mix.txt", "ubench_valu_rates.txt"):
+    if os.path.exists(os.path.join(src, f)):
+        open(os.path.join(dst, f), "w").write("".join(l for l in open(os.path.join(src, f)) if "amdgpu.ids" not in l))
 for f in ("search_round_stamps.txt", "search_round200_stamps.txt"):
     if os.path.exists(os.path.join(src, f)):
         open(os.path.join(dst, f), "w").write("".join(l for l in open(os.path.join(src, f)) if "amdgpu.ids" not in l))
 
 print("value %.0f evals/s, %.2f us/launch, frac %.3f, optimize %.2f ms, traffic %d B/launch, %s lane instr per marker x point, "
-      "VALU busy %s, LDS busy %s" % (bench["value"], bench["roofline"]["device_us_per_launch"], bench["roofline"]["frac"],
+      "VALU busy %s, LDS busy %s" % (bench["value"], bench["roofline"]["device_us_per_launch"], bench["roofline"]["frac"] or 0.0,
                                      bench["optimize"]["wall_ms_to_converged_alpha"], t["traffic_bytes_per_launch"],
                                      v["lane_instr_per_marker_point"], v["valu_busy_frac"], v["lds_busy_frac"]))
 print(open(os.path.join(dst, "bench_b%d_kernel_stats.csv" % B)).read().splitlines()[1][:200])
 for l in open(os.path.join(dst, "bench_batch_sweep.jsonl")):
     r = json.loads(l)
     print(r["config"]["batch_points_per_step"], round(r["roofline"]["device_us_per_launch"], 2), round(r["value"]),
-          round(r["roofline"]["frac"], 3))
+          round(r["roofline"]["frac"] or 0.0, 3))

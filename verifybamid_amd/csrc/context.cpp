@@ -397,6 +397,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     const bool host_pack_forced = tn.host_pack != 0;
     const bool device_pack_wanted = !dry && !host_pack_forced && M > 0 && total_reads > 0 && total_reads < ((int64_t)1 << 32);
     const bool device_flatten = device_pack_wanted && tn.host_flatten == 0;
+    if (device_flatten) nthr = 1;     // (what is left for the host -- three words per sorted marker -- is not worth a thread's start)
     size_t in_total = 0;
     auto icarve = [&](size_t bytes) {
         const size_t off = (in_total + 255) & ~(size_t)255;
