@@ -326,9 +326,9 @@ pack_sched_kernel(const PackArgs a)
         TileSched& S = s_state[row];
         for (uint32_t j = 0; j < eff; ++j) s_runs[row][lane][j] = src[j];
         const uint64_t all = sched_all_steps(steps);
-        for (int d = lane; d < a.num_code; d += kMtMarkers) {
+        for (int d = lane; d <= a.num_code; d += kMtMarkers) {        // (num_code: the padding row's position)
             S.holds[d] = 0;
-            s_home[row][d] = (uint8_t)sched_home_step(d, steps, a.num_code);
+            s_home[row][d] = (uint8_t)sched_home_step(d < a.num_code ? d : a.num_code - 1, steps, a.num_code);
         }
         S.open[lane] = all;
     }
@@ -346,7 +346,7 @@ pack_sched_kernel(const PackArgs a)
         __syncthreads();
     }
     for (int l = 0; l < kMtMarkers; ++l) {
-        if (!plain && lane == l) sched_rest(s_state[row], lane, eff, sched_all_steps(steps), s_dict, home, get, put);
+        if (!plain && lane == l) sched_rest(s_state[row], lane, eff, steps, a.num_code, sched_all_steps(steps), s_dict, home, get, put);
         __syncthreads();
     }
     if (!plain) sched_pad(s_state[row], lane, steps, pad);

@@ -1,5 +1,5 @@
-// Order of a micro-tile's runs for wide quality alphabets (round 4).  Shared by the host pack (context.cpp: VB2_HOST_PACK=1
-// and the dry flatten of the CPU tests) and the device pack (llk_kernels.hip: pack_sched_kernel): integer work only, so the
+// Order of a micro-tile's runs for wide quality alphabets.  Shared by the host pack (context.cpp: tunable host_pack
+// and the dry flatten of the CPU tests) and the device pack (flatten_kernels.hip: pack_sched_kernel): integer work only, so the
 // two write the same bytes.
 //
 // At step p of a tile's read loop the 16 markers that one ds_read_b128 pass serves read the table rows of their p-th runs.
@@ -13,10 +13,17 @@
 // free:
 //   * every code d has a HOME step h(d) = d * steps / codes -- a step's home codes are consecutive dictionary positions, fewer
 //     than 16 of them, so they never collide, and markers that share a code read it in the same step (a broadcast);
+//   * the steps a marker will idle in (it has fewer runs than the tile has steps) read the padding row, which has a bank group
+//     like any code: they are chosen next, where another marker already idles or the padding row's group is free;
 //   * a marker's second run of a step (and repeats of a code: runs hold at most 31 reads) moves to the nearest step where
-//     the marker is idle and the run's bank group is free -- or already holds the same code; else to the nearest idle step.
-// Expected passes per step on the synthetic wide alphabet: 1.88 -> 1.29 (72 codes: 1.37 -> 1.19; 42 codes would go 1.00 ->
-// 1.12, so contexts of at most kSchedMinCodes codes keep the plain order) -- tools/ubench/sched_sim.cpp.
+//     the marker is idle and the run's bank group is free -- or already holds the same code;
+//   * if no idle step qualifies, ONE exchange is tried: a run of the marker that sits where this code fits moves to an idle step
+//     where ITS code fits, and this run takes its place; only if that fails too does the run go to the nearest idle step and
+//     cost a pass.
+// Expected passes per step on the synthetic wide alphabet (tools/ubench/sched_sim.cpp): plain order 1.88, scheduled 1.004
+// (72 codes: 1.37 -> 1.001; 188 codes at depth 60: 1.97 -> 1.004; without the exchange and with the padding row left to
+// chance it was 1.29 / 1.19 / 1.15).  42 codes: 1.004 either way, so contexts of at most kSchedMinCodes codes keep the plain
+// order.  Tiles of two to four steps cannot be helped (118 codes over 4 steps: 2.3 -> 1.9).
 //
 // The state is kept as bit sets over the steps -- per code the steps where it holds its bank group, per bank group the
 // steps where the group is free, per lane the steps taken -- so that "the nearest step where ..." is a handful of bit
@@ -37,11 +44,12 @@ constexpr int kSchedMaxSteps = 64;     // steps (= 2 x rows) and runs per marker
 constexpr int kSchedMinCodes = 48;     // dictionaries up to this size keep the plain order
 constexpr int kSchedMaxPos = 192;      // dictionary positions (<= kMaxCode = 188)
 
-struct TileSched {                     // scratch of one tile (1.8 KB)
+struct TileSched {                     // scratch of one tile (2.9 KB)
     uint64_t holds[kSchedMaxPos];      // dictionary position -> steps where that code holds its bank group
     uint64_t open[16];                 // bank group -> steps where the group is still free
     uint64_t used[16];                 // lane -> steps taken
     uint64_t placed[16];               // lane -> runs placed by sched_home
+    uint8_t run_at[16][kSchedMaxSteps]; // lane, step -> the lane's run there (valid where `used` says so)
 };
 
 struct SchedSerialOps {                // how a shared word changes: plainly on the host, with LDS atomics on the device
@@ -71,7 +79,7 @@ __host__ __device__ inline int sched_home_step(int d, int steps, int num_code)
 template <class Eff>
 __host__ __device__ inline bool sched_is_plain(const Eff& eff, int steps, int num_code)
 {
-    bool plain = steps > kSchedMaxSteps || num_code <= 0 || num_code > kSchedMaxPos;
+    bool plain = steps > kSchedMaxSteps || num_code <= 0 || num_code >= kSchedMaxPos;
     for (int l = 0; l < 16; ++l) plain = plain || eff[l] > (uint32_t)kSchedMaxSteps || eff[l] > (uint32_t)steps;
     return plain;
 }
@@ -94,6 +102,7 @@ __host__ __device__ inline void sched_home(State& S, int l, uint32_t eff_l, cons
             Ops::set(S.holds[d], bit);                  // (in this order: another lane with the same code never sees neither)
             Ops::clear(S.open[r], bit);
             placed |= 1ull << j;
+            S.run_at[l][h] = (uint8_t)j;
             put(l, h, rw);
         }
     }
@@ -104,26 +113,72 @@ __host__ __device__ inline void sched_home(State& S, int l, uint32_t eff_l, cons
 // lane l's other runs: the nearest idle step where the code already holds its bank group, else the nearest idle step where
 // the group is free, else the nearest idle step.  Lane after lane (lane 0 holds the most runs, i.e. the fewest idle steps).
 template <class State, class Dict, class Home, class GetRun, class Put>
-__host__ __device__ inline void sched_rest(State& S, int l, uint32_t eff_l, uint64_t all, const Dict& dict_of, Home home,
-                                           GetRun get, Put put)
+__host__ __device__ inline void sched_rest(State& S, int l, uint32_t eff_l, int steps, int num_code, uint64_t all,
+                                           const Dict& dict_of, Home home, GetRun get, Put put)
 {
     uint64_t used = S.used[l];
     const uint64_t placed = S.placed[l];
+    // The steps the lane will idle in read the padding row -- dictionary position num_code, a bank group like any other.  They are
+    // chosen first, as runs of that "code" (towards the end of the tile, where the other lanes' idle steps are): a step where
+    // another lane already idles, else one where the padding row's group is free.
+    uint64_t padded = 0;
+    {
+        const int rp = num_code & 15;
+        for (int p = (int)eff_l; p < steps; ++p) {
+            const uint64_t idle = all & ~used & ~padded;
+            const uint64_t same = idle & S.holds[num_code], open = idle & S.open[rp];
+            const int c = sched_nearest(same ? same : open ? open : idle, steps - 1);
+            const uint64_t bit = 1ull << c;
+            if (S.open[rp] & bit) {
+                S.open[rp] &= ~bit;
+                S.holds[num_code] |= bit;
+            }
+            padded |= bit;
+        }
+    }
     for (uint32_t j = 0; j < eff_l; ++j) {
         if ((placed >> j) & 1ull) continue;
         const uint32_t rw = get(l, (int)j);
         const int d = dict_of[rw & 0xffu];
         const int h = home(d);
         const int r = d & 15;
-        const uint64_t idle = all & ~used;
+        const uint64_t idle = all & ~used & ~padded;
         const uint64_t same = idle & S.holds[d], open = idle & S.open[r];
-        const int c = sched_nearest(same ? same : open ? open : idle, h);
+        int c = -1;
+        if (!same && !open) {
+            // Every idle step of the lane has this bank group taken by another code.  One exchange: a run of this lane that
+            // sits at a step s2 where THIS code fits (it holds its group there, or the group is free) moves to an idle
+            // step s where ITS code fits; this run takes s2.  The first such pair in step order.
+            const uint64_t fits_here = used & (S.holds[d] | S.open[r]);
+            for (uint64_t cand = fits_here; cand && c < 0; cand &= cand - 1) {
+                const int s2 = __builtin_ctzll(cand);
+                const int j2 = S.run_at[l][s2];
+                const uint32_t rw2 = get(l, j2);
+                const int d2 = dict_of[rw2 & 0xffu], r2 = d2 & 15;
+                // (the other run gives up its claim only if no other lane shares the cell: it keeps the claim -- the cell
+                // stays marked -- so nothing that was conflict-free becomes a conflict)
+                const uint64_t to = idle & (S.holds[d2] | S.open[r2]);
+                if (!to) continue;
+                const int s = sched_nearest(to, home(d2));
+                const uint64_t sbit = 1ull << s;
+                if (S.open[r2] & sbit) {
+                    S.open[r2] &= ~sbit;
+                    S.holds[d2] |= sbit;
+                }
+                S.run_at[l][s] = (uint8_t)j2;
+                put(l, s, rw2);
+                used |= sbit;
+                c = s2;                     // (already in `used`)
+            }
+        }
+        if (c < 0) c = sched_nearest(same ? same : open ? open : idle, h);
         const uint64_t bit = 1ull << c;
         if (S.open[r] & bit) {
             S.open[r] &= ~bit;
             S.holds[d] |= bit;
         }
         used |= bit;
+        S.run_at[l][c] = (uint8_t)j;
         put(l, c, rw);
     }
     S.used[l] = used;
@@ -153,11 +208,11 @@ inline void schedule_tile(State& S, const Eff& eff, const int steps, const int n
         return;
     }
     const uint64_t all = sched_all_steps(steps);
-    for (int d = 0; d < num_code; ++d) S.holds[d] = 0;
+    for (int d = 0; d <= num_code; ++d) S.holds[d] = 0;
     for (int r = 0; r < 16; ++r) S.open[r] = all;
     auto home = [&](int d) { return sched_home_step(d, steps, num_code); };
     for (int l = 0; l < 16; ++l) sched_home<SchedSerialOps>(S, l, eff[l], dict_of, home, get, put);
-    for (int l = 0; l < 16; ++l) sched_rest(S, l, eff[l], all, dict_of, home, get, put);
+    for (int l = 0; l < 16; ++l) sched_rest(S, l, eff[l], steps, num_code, all, dict_of, home, get, put);
     for (int l = 0; l < 16; ++l) sched_pad(S, l, steps, pad);
 }
 
