@@ -1838,3 +1838,20 @@ def test_data_arrays_on_the_device_are_the_host_flattens_bytes(tunable):
             tunable("host_pack", host_pack)
             with vb.LikelihoodContext(d, device=0) as ctx:
                 assert _layout_digest(ctx) == want, (d.num_marker, host_flatten, host_pack)
+
+
+@pytest.mark.gpu
+def test_issue_ceiling_is_measured_and_plausible():
+    """vb2_debug_issue_ceiling (calib_kernels.hip): what bench.py quotes the kernels against.  FP64 FMA issue of a gfx950 with
+    256 CUs is 39.3 T lane-instructions/s at the nominal 2.4 GHz; under sustained FP64 load the clock settles lower.  The read
+    loop's mix (6 ds_read_b128 per 12 FMAs) is bound by the LDS pipe well below that."""
+    import ctypes
+    L = _abi.lib()
+    L.vb2_debug_issue_ceiling.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    L.vb2_debug_issue_ceiling.restype = ctypes.c_int
+    out = (ctypes.c_double * 3)()
+    _abi.check(L.vb2_debug_issue_ceiling(0, out), "vb2_debug_issue_ceiling")
+    fma, fed, valu = out[0], out[1], out[2]
+    assert 15e12 < fma <= 1.02 * 1024 * 16 * 2.4e9, fma
+    assert 0.2 * fma < fed < 0.8 * fma, (fma, fed)
+    assert abs(valu - fed * 14.0 / 12.0) < 1e-3 * valu

@@ -130,22 +130,36 @@ classify_kernel(const ClassifyArgs a)
             unsigned long long bm0 = 0, bm1 = 0, bm2 = 0;
             double c_other = 0.0;
             unsigned n_other = 0;
-            for (uint32_t j = 0; j < depth; ++j) {
-                const unsigned b = bs[j], qv = qs[j];
-                unsigned up = b;
-                if (up >= 'a' && up <= 'z') up -= 32;
-                const unsigned cls = (b == '.' || b == ',') ? 0u : (up == alt_up ? 1u : 2u);
-                if (cls == 2u) {
-                    c_other += s_other[qv];
-                    ++n_other;
-                    continue;
+            // (eight reads' bytes are requested before the first of them is looked at: one trip to memory per eight reads, not
+            // per read; the reads are still taken in order -- c_other's sum is the host's)
+            constexpr uint32_t kAhead = 8;
+            for (uint32_t j0 = 0; j0 < depth; j0 += kAhead) {
+                unsigned bb[kAhead], qq[kAhead];
+#pragma unroll
+                for (uint32_t u = 0; u < kAhead; ++u) {
+                    const uint32_t j = j0 + u < depth ? j0 + u : depth - 1;
+                    bb[u] = bs[j];
+                    qq[u] = qs[j];
                 }
-                const unsigned idx = (unsigned)s_qidx[qv] + cls;
-                atomicAdd(&cnt[idx][tid], 1u);                      // (the thread's own column: ds_add_u32, nothing to wait for)
-                const unsigned long long bit = 1ull << (idx & 63u);
-                if (idx < 64u) bm0 |= bit;
-                else if (idx < 128u) bm1 |= bit;
-                else bm2 |= bit;
+#pragma unroll
+                for (uint32_t u = 0; u < kAhead; ++u) {
+                    if (j0 + u >= depth) break;
+                    const unsigned b = bb[u], qv = qq[u];
+                    unsigned up = b;
+                    if (up >= 'a' && up <= 'z') up -= 32;
+                    const unsigned cls = (b == '.' || b == ',') ? 0u : (up == alt_up ? 1u : 2u);
+                    if (cls == 2u) {
+                        c_other += s_other[qv];
+                        ++n_other;
+                        continue;
+                    }
+                    const unsigned idx = (unsigned)s_qidx[qv] + cls;
+                    atomicAdd(&cnt[idx][tid], 1u);                  // (the thread's own column: ds_add_u32, nothing to wait for)
+                    const unsigned long long bit = 1ull << (idx & 63u);
+                    if (idx < 64u) bm0 |= bit;
+                    else if (idx < 128u) bm1 |= bit;
+                    else bm2 |= bit;
+                }
             }
             uint16_t* out = a.runs + beg;
             eff = 0;
