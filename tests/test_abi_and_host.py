@@ -764,3 +764,21 @@ def test_run_scheduling_leaves_almost_no_bank_conflicts(tmp_path):
         assert m, out
         plain, sched, nopad = (float(x) for x in m.groups())
         assert plain > plain_min and sched < 1.02 and nopad <= sched, out
+
+
+def test_reads_without_their_arrays_are_an_argument_error_before_any_device_work():
+    """vb2_ctx_create with read offsets that announce reads but no bases / quals / alt_base arrays: VB2_ERR_INVALID from the
+    argument check (the device flatten uploads those arrays as they are; a NULL must not reach a memcpy)."""
+    import ctypes
+    lib = _abi.lib()
+    d = vb.synth.make_pileup(64, 10, 2, seed=3)
+    inp = d.as_input()
+    for field in ("bases", "quals", "alt_base"):
+        saved = getattr(inp, field)
+        setattr(inp, field, None)
+        h = ctypes.c_void_p()
+        lib.vb2_ctx_create.restype = ctypes.c_int
+        rc = lib.vb2_ctx_create(ctypes.byref(inp), None, ctypes.byref(h))
+        assert rc == _abi.VB2_ERR_INVALID and not h.value, (field, rc)
+        assert b"bases / quals / alt_base" in lib.vb2_last_error()
+        setattr(inp, field, saved)

@@ -243,6 +243,10 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         set_error("vb2_ctx_create: invalid input");
         return VB2_ERR_INVALID;
     }
+    if (in->num_marker > 0 && in->read_off[in->num_marker] > in->read_off[0] && (!in->bases || !in->quals || !in->alt_base)) {
+        set_error("vb2_ctx_create: reads without bases / quals / alt_base arrays");
+        return VB2_ERR_INVALID;
+    }
     int ndev = 0, dev = 0;
     hipDeviceProp_t prop;
     std::memset(&prop, 0, sizeof(prop));
