@@ -890,7 +890,7 @@ int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource
     bool ended = false;
     const bool dbg = tunables().debug_lockstep != 0;
     long dbg_steps = 0, dbg_active = 0, dbg_points = 0, dbg_samples = 0;
-    double dbg_blocked = 0, dbg_refill = 0;
+    double dbg_blocked = 0, dbg_refill = 0, dbg_wait = 0, dbg_resume = 0, dbg_launch = 0, dbg_retire = 0;
     const double dbg_t0 = wall_s();
     auto fail = [&](int rc) {
         if (!error) error = rc;
@@ -956,25 +956,33 @@ int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource
             ++dbg_steps;
             for (int i = 0; i < L.count; ++i) { dbg_active += L.npts[i] > 0; dbg_points += std::max(0, L.npts[i]); }
         }
+        const double tl = dbg ? wall_s() : 0.0;
         if (const int rc = L.batch->eval_begin(L.npts.data(), L.pc1.data(), L.pc2.data(), L.alpha.data(), L.llk.data())) {
             fail(rc);
             return;
         }
+        if (dbg) dbg_launch += wall_s() - tl;
         L.flying = true;
     };
     auto land = [&](StreamLane& L) {
         if (L.flying) {
             L.flying = false;
-            if (const int rc = L.batch->eval_end()) fail(rc);
+            const double tw = dbg ? wall_s() : 0.0;
+            const int rc_end = L.batch->eval_end();
+            if (dbg) dbg_wait += wall_s() - tw;
+            if (const int rc = rc_end) fail(rc);
             if (!error) {
                 std::vector<FiberGang::Request>& req = L.gang->requests();
                 for (int i = 0; i < L.count; ++i)
                     if (L.npts[i] > 0) std::memcpy(req[i].out, &L.llk[(size_t)i * kSlot], sizeof(double) * L.npts[i]);
             }
         }
+        const double tr = dbg ? wall_s() : 0.0;
         if (L.gang->pending()) L.gang->resume_parked();       // (after an error: the fibers unwind)
+        const double tr2 = dbg ? wall_s() : 0.0;
         for (int i = 0; i < L.count; ++i)
             if (L.id[i] >= 0 && L.gang->idle(i)) retire(L, i);
+        if (dbg) { dbg_resume += tr2 - tr; dbg_retire += wall_s() - tr2; }
     };
     for (;;) {
         bool busy = false;
@@ -998,9 +1006,12 @@ int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource
     }
     if (dbg)
         std::fprintf(stderr, "stream search: %ld samples through %d slots in %.1f ms: %ld steps, %.1f active samples and %.1f points "
-                             "per step (a lane holds %d); waited %.1f ms with nothing to do, %.1f ms taking samples in\n",
+                             "per step (a lane holds %d); waited %.1f ms with nothing to do, %.1f ms taking samples in; the pipeline thread per step: "
+                             "%.1f us waiting for a step to land, %.1f us in the samples' optimisers, %.1f us retiring, %.1f us launching\n",
                      dbg_samples, capacity, 1e3 * (wall_s() - dbg_t0), dbg_steps, (double)dbg_active / std::max(1L, dbg_steps),
-                     (double)dbg_points / std::max(1L, dbg_steps), lanes[0].count, 1e3 * dbg_blocked, 1e3 * dbg_refill);
+                     (double)dbg_points / std::max(1L, dbg_steps), lanes[0].count, 1e3 * dbg_blocked, 1e3 * dbg_refill,
+                     1e6 * dbg_wait / std::max(1L, dbg_steps), 1e6 * dbg_resume / std::max(1L, dbg_steps),
+                     1e6 * dbg_retire / std::max(1L, dbg_steps), 1e6 * dbg_launch / std::max(1L, dbg_steps));
     return error;
 }
 
