@@ -112,8 +112,12 @@ typedef struct vb2_info {
 
 /* Builds the device-resident SoA form of the input (classification, quality
  * clamping, marker filtering and the alpha-independent partial sums happen
- * here, once).  Replaces BuildResolvedMarkers + the per-call prologue of
- * ComputeMixLLKs (ContaminationEstimator.cpp:67-86; h:236-249, 285-299). */
+ * here, once -- on the device: the arrays of `in` go up as they are, through
+ * one pinned staging copy and hipMemcpyAsync on the context's stream, and
+ * kernels classify, run-length code and pack them; the host keeps the
+ * dictionary and the sort of the markers).  Replaces BuildResolvedMarkers + the
+ * per-call prologue of ComputeMixLLKs (ContaminationEstimator.cpp:67-86;
+ * h:236-249, 285-299).  `in` is not referenced after the call returns. */
 int vb2_ctx_create(const vb2_input *in, const vb2_options *opt, vb2_ctx **out);
 void vb2_ctx_destroy(vb2_ctx *ctx);
 int vb2_ctx_info(const vb2_ctx *ctx, vb2_info *info);
@@ -363,7 +367,7 @@ int vb2_run(const vb2_run_args *args, vb2_run_result *out);
 
 /* Cohort form of vb2_run (BASELINE configs[4]: many samples against one panel).  The reference
  * runs one process per sample; here the panel (.UD/.mu/.bed, optional AF file) is read once, the
- * pileups are read and flattened by host threads while the device searches the previous group of
+ * pileups are read by host threads (and flattened on the device) while the device searches the previous group of
  * samples in lock-step (one kernel launch per search step for the whole group, vb2_batch_*), and
  * every sample gets the outputs vb2_run would write (<prefix>.Ancestry, <prefix>.selfSM, optional
  * <prefix>.Pileup).  args->pileup_path / output_prefix of `base` are ignored.
