@@ -1821,7 +1821,17 @@ def test_data_arrays_on_the_device_are_the_host_flattens_bytes(tunable):
     dalt = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=Md)
     deep = vb.PileupData(2, rng.normal(size=(Md, 2)), rng.uniform(0.1, 1.9, size=Md), doff, dbases, dquals, dalt, None,
                          30.0, 0.0, True, {})
-    cases = [vb.synth.make_pileup(3000, 30, 4, seed=5),
+    # one marker of 70 000 reads: classify_kernel's 32-bit counters (below 65 536 reads per marker they are 16-bit halves)
+    Mh = 40
+    hdepth = np.full(Mh, 25); hdepth[7] = 70000
+    hoff = np.zeros(Mh + 1, dtype=np.int64)
+    np.cumsum(hdepth, out=hoff[1:])
+    Rh = int(hoff[-1])
+    huge = vb.PileupData(2, rng.normal(size=(Mh, 2)), rng.uniform(0.1, 1.9, size=Mh), hoff,
+                         rng.choice(np.frombuffer(b".,.,.,ACGTacgt", dtype=np.uint8), size=Rh),
+                         (rng.choice([20, 30, 40], size=Rh) + 33).astype(np.uint8),
+                         rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=Mh), None, 30.0, 0.0, True, {})
+    cases = [vb.synth.make_pileup(3000, 30, 4, seed=5), huge,
              vb.synth.make_pileup(3000, 30, 2, seed=6, q_lo=2, q_hi=93),
              vb.synth.with_sanity_stats(vb.synth.make_pileup(2000, 33, 3, seed=7, missing_frac=0.2)),
              ragged,

@@ -487,7 +487,11 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         std::memcpy(inp + i_bases, in->bases + read_base, (size_t)total_reads);
         std::memcpy(inp + i_quals, in->quals + read_base, (size_t)total_reads);
         uint32_t* const off32 = reinterpret_cast<uint32_t*>(inp + i_off);
-        for (int i = 0; i <= M; ++i) off32[i] = (uint32_t)(in->read_off[i] - read_base);
+        uint32_t max_depth = 0;
+        for (int i = 0; i <= M; ++i) {
+            off32[i] = (uint32_t)(in->read_off[i] - read_base);
+            if (i > 0) max_depth = std::max(max_depth, off32[i] - off32[i - 1]);
+        }
         std::memcpy(inp + i_alt, in->alt_base, (size_t)M);
         std::memcpy(inp + i_qidx, lut->qidx, 256);
         std::memcpy(inp + i_olc, lut->other_lc, 256 * sizeof(double));
@@ -514,6 +518,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         ca.cd = reinterpret_cast<double*>(din + i_cd);
         ca.hist = reinterpret_cast<unsigned long long*>(din + i_hist);
         ca.M = M;
+        ca.max_depth = max_depth;
         ca.sanity = in->sanity_disabled ? 0 : 1;
         ca.lo = lo;
         ca.hi = hi;

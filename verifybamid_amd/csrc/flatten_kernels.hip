@@ -91,13 +91,16 @@ constexpr int kCodeSlots = 192;            // >= kMaxCode, three 64-bit sets
 
 }  // namespace
 
-// One thread per marker, one wave per workgroup.  LDS: a column of kCodeSlots 32-bit counters per thread ([code][thread]: the 64
+// One thread per marker, one wave per workgroup.  LDS: a column of kCodeSlots counters per thread ([code][thread]: the 64
 // threads of a wave hit 64 different banks whatever their codes), the byte tables, the logarithm rows, the exp table, the
-// workgroup's histogram.
+// workgroup's histogram.  PACKED (no marker of 65 536 reads or more: the host knows from the offsets): two 16-bit counters
+// per word -- 24 KB of counters instead of 48, four workgroups per CU instead of two.
+template <bool PACKED>
 __global__ void __launch_bounds__(kClassifyThreads)
 classify_kernel(const ClassifyArgs a)
 {
-    __shared__ unsigned cnt[kCodeSlots][kClassifyThreads];
+    constexpr int kRows = PACKED ? kCodeSlots / 2 : kCodeSlots;
+    __shared__ unsigned cnt[kRows][kClassifyThreads];
     __shared__ unsigned long long s_exp[256];
     __shared__ double s_other[256];
     __shared__ double s_lc3[kMaxCode * 3];
@@ -105,7 +108,7 @@ classify_kernel(const ClassifyArgs a)
     __shared__ unsigned long long s_reads, s_others;
     __shared__ unsigned char s_qidx[256];
     const int tid = threadIdx.x;
-    for (int e = tid; e < kCodeSlots * kClassifyThreads; e += kClassifyThreads) (&cnt[0][0])[e] = 0u;
+    for (int e = tid; e < kRows * kClassifyThreads; e += kClassifyThreads) (&cnt[0][0])[e] = 0u;
     for (int e = tid; e < 256; e += kClassifyThreads) {
         s_exp[e] = kFlattenExpTab[e];
         s_other[e] = a.other_lc[e];
@@ -154,7 +157,9 @@ classify_kernel(const ClassifyArgs a)
                         continue;
                     }
                     const unsigned idx = (unsigned)s_qidx[qv] + cls;
-                    atomicAdd(&cnt[idx][tid], 1u);                  // (the thread's own column: ds_add_u32, nothing to wait for)
+                    // (the thread's own column: ds_add_u32, nothing to wait for)
+                    if (PACKED) atomicAdd(&cnt[idx >> 1][tid], 1u << ((idx & 1u) * 16u));
+                    else atomicAdd(&cnt[idx][tid], 1u);
                     const unsigned long long bit = 1ull << (idx & 63u);
                     if (idx < 64u) bm0 |= bit;
                     else if (idx < 128u) bm1 |= bit;
@@ -170,7 +175,7 @@ classify_kernel(const ClassifyArgs a)
                 while (bits) {
                     const unsigned idx = (unsigned)w * 64u + (unsigned)__builtin_ctzll(bits);
                     bits &= bits - 1ull;
-                    unsigned left = cnt[idx][tid];
+                    unsigned left = PACKED ? (cnt[idx >> 1][tid] >> ((idx & 1u) * 16u)) & 0xffffu : cnt[idx][tid];
                     atomicAdd(&s_hist[idx], left);
                     const double n = (double)left;
                     const double* lc = &s_lc3[idx * 3u];
@@ -204,8 +209,9 @@ classify_kernel(const ClassifyArgs a)
 hipError_t launch_classify(const ClassifyArgs& a, hipStream_t stream)
 {
     if (a.M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((a.M + kClassifyThreads - 1) / kClassifyThreads)), dim3(kClassifyThreads), 0,
-                       stream, a);
+    const dim3 grid((unsigned)((a.M + kClassifyThreads - 1) / kClassifyThreads)), block(kClassifyThreads);
+    if (a.max_depth < 65536u) hipLaunchKernelGGL(classify_kernel<true>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(classify_kernel<false>, grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

@@ -170,6 +170,7 @@ struct ClassifyArgs {
     double* cd;                    // out [M][4]: c_other, exp(c_other + D[g])
     unsigned long long* hist;      // out [kMaxCode + 2], zero on entry: reads per code index, reads of counted markers, reads of class "other"
     int32_t M;
+    uint32_t max_depth;            // reads of the deepest marker (below 65 536: 16-bit counters)
     int32_t sanity;                // 1: the +-3 sd depth filter is on
     double lo, hi;                 // its bounds
 };
