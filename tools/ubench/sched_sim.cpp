@@ -1,5 +1,5 @@
 // sched_sim.cpp -- LDS passes per read-loop step of a micro-tile's run order (host only, no GPU).
-//   g++ -O2 -std=c++17 -I../../verifybamid_amd/csrc -o /tmp/sched_sim sched_sim.cpp && /tmp/sched_sim [q_lo q_hi [markers [depth]]]
+//   g++ -O2 -std=c++17 -I../../verifybamid_amd/csrc -o /tmp/sched_sim sched_sim.cpp && /tmp/sched_sim [q_lo q_hi [markers [depth [skew]]]]
 // Synthetic sample like verifybamid_amd/synth.py (qualities uniform in q_lo..q_hi, depth Poisson), flattened the way
 // context.cpp does (codes ordered by quality frequency, ref/alt adjacent; markers sorted by run count; 16-marker tiles),
 // then every tile's runs placed by (a) plain dictionary order, (b) schedule_tile (tile_sched.h).  For each step the 16
@@ -20,6 +20,7 @@ int main(int argc, char** argv)
     const int q_lo = argc > 1 ? atoi(argv[1]) : 2, q_hi = argc > 2 ? atoi(argv[2]) : 60;
     const int M = argc > 3 ? atoi(argv[3]) : 100000;
     const double depth = argc > 4 ? atof(argv[4]) : 30.0;
+    const int skew = argc > 5 ? atoi(argv[5]) : 0;      // 1: qualities peaked near q_hi with a long tail down to q_lo (sequencer-like)
     std::mt19937_64 rng(7);
     std::poisson_distribution<int> pois(depth);
     std::uniform_int_distribution<int> uq(q_lo, q_hi);
@@ -34,7 +35,11 @@ int main(int argc, char** argv)
         const double af = std::min(0.99995, std::max(0.00005, u01(rng)));
         const int g = (u01(rng) < af) + (u01(rng) < af);
         for (int j = 0; j < d; ++j) {
-            const int q = uq(rng);
+            int q = uq(rng);
+            if (skew) {                                  // 70 % within a few units of the top, the rest spread over the range
+                std::exponential_distribution<double> ex(0.35);
+                if (u01(rng) < 0.7) q = std::max(q_lo, q_hi - (int)ex(rng));
+            }
             const bool alt = u01(rng) < g / 2.0;
             const bool err = u01(rng) < std::pow(10.0, -q / 10.0);
             int cls = alt ? 1 : 0;
