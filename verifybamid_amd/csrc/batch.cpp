@@ -858,7 +858,11 @@ int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource
         Batch* b = nullptr;
         if (const int rc = Batch::create_slots(L.count, device, k, num_cu, &b)) return rc;
         L.batch.reset(b);
-        L.gang.reset(new FiberGang(L.count, kSlot));
+        // A streamed sample starts whenever a slot falls free, alone.  The ten vertices of its fresh simplex as ONE request would be
+        // a class of their own in that step (strict shapes: eval_begin evaluates the minority classes synchronously first): an
+        // eight-point launch on that sample's sixteenth of the device, ~120 us during which the pipeline thread serves neither
+        // lane.  In pieces of two they ride along with the other slots' steps.
+        L.gang.reset(new FiberGang(L.count, std::max(1, std::min(kSlot, tunables().cohort_stream_points))));
         const size_t n = (size_t)L.count;
         L.id.assign(n, -1);
         L.rc.assign(n, 0);
