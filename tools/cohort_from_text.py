@@ -26,13 +26,14 @@ try:
     devnull = open(os.devnull, "w")
     saved = os.dup(2)
     group = int(os.environ.get("VB2_GROUP", "0"))
+    readers = int(os.environ.get("VB2_READERS", "0"))
     for mode in os.environ.get("VB2_MODES", "device,host,device,host").split(","):
         _abi.set_tunable("host_flatten", 0 if mode == "device" else 1)
         rates = []
         for _ in range(rep):
             if os.environ.get('VB2_DEBUG_LOCKSTEP', '') != '1': os.dup2(devnull.fileno(), 2)
             t1 = time.perf_counter(); p1 = time.process_time()
-            res = vb.run_cohort_files(pre, paths, outs, num_pc=k, group_size=group)
+            res = vb.run_cohort_files(pre, paths, outs, num_pc=k, group_size=group, num_host_thread=readers)
             dt = time.perf_counter() - t1; cpu = time.process_time() - p1
             os.dup2(saved, 2)
             assert all(r["status"] == 0 for r in res)

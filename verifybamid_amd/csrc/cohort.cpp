@@ -60,12 +60,13 @@ public:
         // 256 files 479 -> 546 samples/s)
         G_ = std::max(1, std::min(a->group_size != 0 ? std::abs(a->group_size) : 32, 64));
         const int hw = vb2::usable_cpu_count();
-        // readers: reading + flattening is ~15 ms of one CPU per C3-sized sample (round 4), the device needs ~1.6 ms per
-        // sample -> a device keeps ~10 readers busy (16 CPUs: 10 to 16 readers all give 550-590 samples/s).  The default is
-        // the process's allowance (cgroup quota / affinity, not the host's core count) less one: the thread of the lock-step
-        // search spins on the device's flag between steps, and when it has to queue for a CPU the device idles (one run in
-        // four at 16 readers on 16 CPUs: 330 samples/s instead of 480)
-        const int dflt = std::max(2, std::min(hw - 1, 64 * ndev_));
+        // readers: reading + resolving + creating the context is ~7 ms of one CPU per C3-sized sample (the flatten runs on the
+        // device), the device needs ~1.65 ms per sample -> a device keeps 4-5 readers busy.  The default is SIX per device,
+        // within the process's allowance (cgroup quota / affinity, not the host's core count) less one CPU per pipeline
+        // thread and one for the rest: the thread of a lock-step search spins on its device's flag between steps, and when it
+        // has to queue for a CPU -- or the whole cgroup is throttled because fifteen readers woke up at once -- the device
+        // idles (16 CPUs, 256 files: 15 readers 562-587 samples/s with runs at 390; 5 to 10 readers 600-633)
+        const int dflt = std::max(2, std::min(hw - 1 - ndev_, 6 * ndev_));
         T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, std::max(hw, 1) * 4, S_}));
         slots_.resize(S_);
         cnt_.assign(ndev_, 0);
