@@ -37,7 +37,7 @@ Batch::~Batch()
     if (stream_) (void)hipStreamSynchronize(stream_);          // nothing of this batch is in flight any more
     if (d_slab_ && !recycle_device_slab(d_slab_, d_slab_bytes_, device)) (void)hipFree(d_slab_);
     if (h_slab_ && !recycle_pinned_slab(h_slab_, h_slab_bytes_, device)) (void)hipHostFree(h_slab_);
-    if (stream_ && !recycle_stream(stream_, device)) (void)hipStreamDestroy(stream_);
+    if (stream_ && own_stream_ && !recycle_stream(stream_, device)) (void)hipStreamDestroy(stream_);
 }
 
 int Batch::create(vb2_ctx* const* ctxs, int num_sample, Batch** out)
@@ -841,7 +841,7 @@ int prepare_for_stream(Context* c, int capacity)
     return VB2_OK;
 }
 
-int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource& src)
+int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource& src, const hipStream_t* lane_streams)
 {
     capacity = std::max(1, std::min(capacity, 128));
     const int k = num_pc;
@@ -858,6 +858,7 @@ int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource
         Batch* b = nullptr;
         if (const int rc = Batch::create_slots(L.count, device, k, num_cu, &b)) return rc;
         L.batch.reset(b);
+        if (lane_streams && lane_streams[l]) b->borrow_stream(lane_streams[l]);
         // A streamed sample starts whenever a slot falls free, alone.  The ten vertices of its fresh simplex as ONE request would be
         // a class of their own in that step (strict shapes: eval_begin evaluates the minority classes synchronously first): an
         // eight-point launch on that sample's sixteenth of the device, ~120 us during which the pipeline thread serves neither

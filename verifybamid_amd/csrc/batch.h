@@ -26,6 +26,8 @@ public:
     // neighbours, nor on when it arrived.
     static int create_slots(int capacity, int device, int num_pc, int num_cu, Batch** out);
     int set_slot(int i, Context* c);
+    // the batch's launches go onto a stream it does not own (set before its first step)
+    void borrow_stream(hipStream_t s) { stream_ = s; own_stream_ = false; }
     Context* slot(int i) const { return ctx_[i]; }
     // launch geometry of a batch of num_sample samples whose biggest has max_mt micro-tiles: workgroups per sample and waves
     // per workgroup (what create() uses -- and what a reader thread prepares a sample's schedules for: prepare_for_cohort)
@@ -54,6 +56,7 @@ public:
 private:
     std::vector<Context*> ctx_;
     hipStream_t stream_ = nullptr;
+    bool own_stream_ = true;
     // device side: ONE slab (layouts, schedules, partial sums, tickets, step counter), pinned side:
     // ONE device-mapped slab (parameter rows, results, point counts, sequence word); both and the
     // stream come from / go back to the process-wide caches (context.h), and none of it exists

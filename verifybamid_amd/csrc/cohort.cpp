@@ -129,6 +129,27 @@ public:
         if (panel_->isAFknown) model_.is_af_known = 1;
         vb2::g_flatten_thread_cap.store(std::max(1, 16 / T_));
 
+        // HIP maps a process's streams onto FOUR hardware queues per device, each in order.  A context's creation (uploads, the
+        // flatten's kernels, and a barrier that waits for the 10-MB upload) on a stream that shares its hardware queue with a lane
+        // of the search holds that lane's next step back for as long -- a few hundred microseconds, for half of the samples when
+        // every context and every lane takes whatever stream the cache has (kernel trace of tools/cohort_from_text.py: steps
+        // on two queues, the flatten's kernels on all four).  So: per device four streams made back to back, after the idle cached
+        // ones are gone (the runtime gives a new stream the least used queue: four queues), two for the lanes and two that every
+        // context of this run is created on.
+        if (stream_ && vb2::tunables().cohort_own_queues) {
+            own_streams_.assign((size_t)ndev_ * 4, nullptr);
+            for (int d = 0; d < ndev_; ++d) {
+                int dev = devices_[d];
+                if (dev < 0) (void)hipGetDevice(&dev);
+                if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); continue; }
+                vb2::drop_cached_streams(dev);
+                for (int q = 0; q < 4; ++q)
+                    if (hipStreamCreateWithFlags(&own_streams_[(size_t)d * 4 + q], hipStreamNonBlocking) != hipSuccess) {
+                        (void)hipGetLastError();
+                        own_streams_[(size_t)d * 4 + q] = nullptr;
+                    }
+            }
+        }
         releaser_ = std::thread([this] { release_loop(); });
         for (int t = 0; t < T_; ++t) pool_.emplace_back([this] { reader_loop(); });
         for (int d = 0; d < ndev_; ++d) dev_threads_.emplace_back([this, d] { if (stream_) stream_loop(d); else device_loop(d); });
@@ -165,6 +186,7 @@ private:
     bool stop_ = false;
     int rc_all_ = VB2_OK;
     std::string err_all_;
+    std::vector<hipStream_t> own_streams_;      // [device][4]: two lanes' streams, two creation streams (or empty)
     std::vector<std::thread> pool_, dev_threads_;
     std::thread releaser_;
     std::mutex rel_mu_;
@@ -214,6 +236,12 @@ private:
                 sl.ctx = nullptr;
             }
         vb2::g_flatten_thread_cap.store(0);
+        for (hipStream_t& st : own_streams_)             // (every context and batch that used them is gone)
+            if (st) {
+                (void)hipStreamSynchronize(st);
+                (void)hipStreamDestroy(st);
+                st = nullptr;
+            }
     }
 
     void prepare(int s)
@@ -240,6 +268,8 @@ private:
         vb2_options opt{};
         opt.device = devices_[device_of_sample(s)];
         opt.flags = VB2_OPT_COHORT_LAYOUT;       // the lock-step search streams the 16-bit run lists
+        if (!own_streams_.empty())               // (one of the device's two creation streams: see run())
+            opt.stream = own_streams_[(size_t)device_of_sample(s) * 4 + 2 + (size_t)(s / ndev_) % 2];
         sl.rc = vb2_ctx_create(&f.input, &opt, &sl.ctx);
         if (sl.rc == VB2_OK && sl.ctx && sl.ctx->impl) {
             // the static schedules of the sample's group (and of the batches its lane is regrouped into): here, on one of many
@@ -380,7 +410,7 @@ private:
         try {
             int dev = devices_[d];
             if (dev < 0) (void)hipGetDevice(&dev);
-            rc = vb2::stream_search(dev, a_->base.num_pc, num_cu, G_, src);
+            rc = vb2::stream_search(dev, a_->base.num_pc, num_cu, G_, src, own_streams_.empty() ? nullptr : &own_streams_[(size_t)d * 4]);
         } catch (const std::exception& e) {
             set_error(e.what());
             rc = VB2_ERR_INVALID;

@@ -207,6 +207,10 @@ void* cached_pinned_slab(size_t bytes, int device, size_t* got) { return slab_ca
 bool recycle_pinned_slab(void* p, size_t bytes, int device) { return slab_cache().give(slab_cache().pin, p, bytes, device); }
 hipStream_t cached_stream(int device) { return slab_cache().take_stream(device); }
 bool recycle_stream(hipStream_t stream, int device) { return slab_cache().give_stream(stream, device); }
+void drop_cached_streams(int device)
+{
+    while (hipStream_t st = slab_cache().take_stream(device)) (void)hipStreamDestroy(st);
+}
 
 static thread_local unsigned long long* t_digest_out = nullptr;
 

@@ -39,6 +39,8 @@ void* cached_pinned_slab(size_t bytes, int device, size_t* got);
 bool recycle_pinned_slab(void* p, size_t bytes, int device);
 hipStream_t cached_stream(int device);
 bool recycle_stream(hipStream_t stream, int device);
+// destroys the idle streams the cache holds for `device` (the cohort runner, before it makes its own: see cohort.cpp)
+void drop_cached_streams(int device);
 extern std::atomic<int> g_flatten_thread_cap;   // 0 = no cap on the flatten threads of vb2_ctx_create
 
 constexpr int kStagePoints = 256;   // points per host<->device staging round

@@ -10,6 +10,8 @@
 #ifndef VB2_STREAM_SEARCH_H_
 #define VB2_STREAM_SEARCH_H_
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../include/vb2_abi.h"
 
 namespace vb2 {
@@ -29,7 +31,9 @@ struct StreamSource {
 
 // Runs until the source ends and every sample it delivered is done.  Non-zero: a device-level failure (every sample still
 // in a slot has been reported done with that code).
-int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource& src);
+// lane_streams: nullptr, or the two streams the lanes launch on (the caller's, outliving the call: cohort.cpp makes them
+// apart from the streams its contexts are created on)
+int stream_search(int device, int num_pc, int num_cu, int capacity, StreamSource& src, const hipStream_t* lane_streams = nullptr);
 // what a reader thread prepares for a sample that will be searched by stream_search(capacity): its schedules
 int prepare_for_stream(Context* c, int capacity);
 

@@ -51,6 +51,7 @@ namespace vb2 {
     X(cohort_lanes, 2)     /* lanes taking turns */                                                                      \
     X(cohort_regroup, 1)   /* 0: the fixed batch to the end */                                                           \
     X(cohort_stream, 1)    /* 0: groups searched one after the other instead of slots that change hands */              \
+    X(cohort_own_queues, 1) /* 0: the streamed search's lanes and the readers' contexts take whatever streams the cache has */ \
     X(cohort_stream_points, 2) /* points per request of a streamed sample (a simplex's first vertices leave in pieces) */   \
     X(cohort_dup_devices, 0) /* 1: vb2_cohort_run accepts a device listed twice (one-GPU test of several pipelines) */   \
     X(cohort_fail_sample, -1) /* test hook: the streamed search refuses this sample at its slot (error path) */         \
