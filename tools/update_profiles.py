@@ -177,7 +177,7 @@ if cs:
                    "rocprofv3 --kernel-trace --stats over tools/create_time.py (contexts of both alphabets -- 42 and 118 codes -- "
                    "in the three flatten modes; pack_sched_kernel runs for the 118-code contexts only)"}
     for r in csv.DictReader(open(cs)):
-        nm = r["Name"].split("(")[0].replace("vb2::", "")
+        nm = r["Name"].split("(")[0].replace("void ", "").replace("vb2::", "").split("<")[0]
         if nm in ("classify_kernel", "pack_layout_kernel", "pack_sched_kernel", "pack_codes16_kernel"):
             cj[nm + "_us"] = round(float(r["AverageNs"]) / 1e3, 1)
     json.dump(cj, open(os.path.join(dst, "create_kernel_stats.json"), "w"), indent=1)
