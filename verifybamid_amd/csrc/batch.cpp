@@ -34,6 +34,13 @@ constexpr int kSlot = 8;                     // point slots per sample and step 
 Batch::~Batch()
 {
     if (device >= 0) (void)hipSetDevice(device);
+    for (auto& h : half_) h.reset();                            // (they launch on lane_streams_)
+    for (hipStream_t& st : lane_streams_)
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+            st = nullptr;
+        }
     if (stream_) (void)hipStreamSynchronize(stream_);          // nothing of this batch is in flight any more
     if (d_slab_ && !recycle_device_slab(d_slab_, d_slab_bytes_, device)) (void)hipFree(d_slab_);
     if (h_slab_ && !recycle_pinned_slab(h_slab_, h_slab_bytes_, device)) (void)hipHostFree(h_slab_);
@@ -611,12 +618,21 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
     int nlane = 1;
     if (split) {
         nlane = std::max(2, std::min(std::min(kMaxLanes, tn.cohort_lanes), S));
+        if (tn.cohort_own_queues && !lane_streams_[0]) {
+            VB2_HIP(hipSetDevice(device));
+            for (int h = 0; h < nlane; ++h)
+                if (hipStreamCreateWithFlags(&lane_streams_[h], hipStreamNonBlocking) != hipSuccess) {
+                    (void)hipGetLastError();
+                    lane_streams_[h] = nullptr;
+                }
+        }
         for (int h = 0; h < nlane; ++h) {
             const int lo = (int)((long)S * h / nlane), hi = (int)((long)S * (h + 1) / nlane);
             if (!half_[h] || half_[h]->num_sample != hi - lo) {
                 std::vector<Context*> part(ctx_.begin() + lo, ctx_.begin() + hi);
                 Batch* hb = nullptr;
                 if (const int rc = Batch::create(part, &hb)) return rc;
+                if (lane_streams_[h]) hb->borrow_stream(lane_streams_[h]);
                 half_[h].reset(hb);
             }
             lanes[h].batch = half_[h].get(); lanes[h].base = lo; lanes[h].count = hi - lo;
@@ -691,6 +707,7 @@ int Batch::optimize(const vb2_model* models, int num_model, vb2_estimate* out)
                 Batch* nb = nullptr;
                 const auto tr0 = std::chrono::steady_clock::now();
                 int rc = Batch::create(part, &nb, regroup_bps(ctx_[0]->L.num_cu, (int)part.size()));
+                if (!rc && nlane > 1 && lane_streams_[&L - lanes]) nb->borrow_stream(lane_streams_[&L - lanes]);
                 if (!rc) rc = nb->ensure_resources();
                 if (rc) {
                     delete nb;

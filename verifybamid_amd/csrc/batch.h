@@ -97,6 +97,9 @@ private:
     // optimize() of a big cohort: two half-cohorts taking turns on the device (see batch.cpp)
     static constexpr int kMaxLanes = 4;
     std::unique_ptr<Batch> half_[kMaxLanes];
+    // the lanes' streams of optimize(): made back to back (different hardware queues: see cohort.cpp), lent to the lanes'
+    // batches and to the batches their unfinished samples are regrouped into; they outlive half_
+    hipStream_t lane_streams_[kMaxLanes] = {};
     int optimize_range(const vb2_model* models, int num_model, vb2_estimate* out);
 };
 
