@@ -1259,7 +1259,7 @@ def test_lockstep_search_regroups_the_unfinished_samples(S, tunable):
 
 
 def test_cohort_steps_on_16bit_run_lists_are_bit_identical():
-    """The 1- and 2-point steps of a cohort stream a 16-bit copy of every sample's run lists
+    """The steps of a cohort (every wave shape: 1, 2, 4 and 8 points per sample) stream a 16-bit copy of every sample's run lists
     (DeviceLayout::codes16: dictionary index | count << 8, re-coded on the device from the 32-bit run words;
     half the HBM bytes per step).  Same runs, same order, same FMAs: a batch on the 16-bit lists returns,
     BIT FOR BIT, what the same batch returns on the 32-bit lists -- for ragged depths (runs split at 31
@@ -1283,7 +1283,7 @@ def test_cohort_steps_on_16bit_run_lists_are_bit_identical():
         pc1 = rng.normal(0, 0.03, size=(S, 8, k))
         pc2 = rng.normal(0, 0.03, size=(S, 8, k))
         al = rng.uniform(0, 0.5, size=(S, 8))
-        shapes = ([1] * S, [2] * S, [4] * S, [1, 4, 0, 2, 3], [2, 1, 1, 0, 2])
+        shapes = ([1] * S, [2] * S, [4] * S, [8] * S, [1, 4, 0, 2, 3], [2, 1, 1, 0, 2], [5, 8, 0, 7, 6])
         results = {}
         before = [c.info()["cohort_step_bytes"] for c in ctxs]
         for w16 in (0, 1):

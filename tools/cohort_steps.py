@@ -29,7 +29,7 @@ with vb.CohortBatch(ctxs) as batch:
                 step()
             best = min(best, (time.perf_counter() - t0) / reps)
         return 1e6 * best
-    for n in (1, 2, 4):
+    for n in (1, 2, 4, 8):
         out["step_us_%d" % n] = round(time_steps(n), 2)
     if os.environ.get("VB2_STEPS_ONLY"):
         print(json.dumps(out), flush=True)

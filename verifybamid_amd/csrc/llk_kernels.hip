@@ -1665,10 +1665,12 @@ template <int MODE>
 static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream)
 {
     const dim3 grid(ml.num_sample * ml.bps), block(ml.block_waves * 64);
-    // The 16-bit run lists pay where a step is bound by the bytes it streams -- 1 and 2 points per sample
-    // (32 C3 samples: 130.6 -> 117.5 us and 139.2 -> 127.9 us) -- and cost where it is VALU-bound: 4 points per
-    // sample 230.8 -> 306.6 us with them (two more instructions per run).  So: MODE 4 and 5 only.
-    constexpr bool kHas16 = MODE == 4 || MODE == 5;
+    // The 16-bit run lists (half the bytes of the run words from HBM) in every wave shape.  With round 4's decode -- one
+    // byte permute + one 24-bit multiply per run, as many instructions as the 32-bit word's and + add -- and the item
+    // loop compiled for the static deal alone (PIPE), they also pay where a step is VALU-bound: 32 C3 samples x 4 points
+    // 202 -> 189 us, x 8 points 365 -> 346 us on one box (round 3, with a five-instruction decode and the deal decided
+    // in the kernel: 231 -> 307 us, hence "1 and 2 points only" until round 5); 1 point 130.6 -> 117.5, 2 points 139.2 ->
+    // 127.9 us when they came in.
     const int use_ticket = ml.force_ticket ? 1 : 0;
     auto go = [&](auto kernel) -> hipError_t {
         hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kernel));
@@ -1679,17 +1681,15 @@ static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream)
         return hipGetLastError();
     };
     // (every shape also compiled for --NumPC 2 / 4 without a known-AF column: one-point steps of 32 samples 99 -> 94 us)
-    if constexpr (kHas16) {
-        if (ml.w16) {
-            if (ml.all_static) {          // (the pipelined item loop: compiled for the static deal only)
-                if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, 4, 1>);
-                if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, 2, 1>);
-                return go(&llk_eval_multi_kernel<MODE, true, 0, 1>);
-            }
-            if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, 4>);
-            if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, 2>);
-            return go(&llk_eval_multi_kernel<MODE, true>);
+    if (ml.w16) {
+        if (ml.all_static) {          // (the pipelined item loop: compiled for the static deal only)
+            if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, 4, 1>);
+            if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, 2, 1>);
+            return go(&llk_eval_multi_kernel<MODE, true, 0, 1>);
         }
+        if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, 4>);
+        if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, 2>);
+        return go(&llk_eval_multi_kernel<MODE, true>);
     }
     if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, false, 4>);
     if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, false, 2>);
