@@ -247,6 +247,10 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         set_error("vb2_ctx_create: invalid input");
         return VB2_ERR_INVALID;
     }
+    if (in->num_marker > (1 << 29) - 1024) {      // (the kernels address a marker's constants with 32-bit byte offsets: 8 x position)
+        set_error("vb2_ctx_create: more than 2^29 - 1024 markers");
+        return VB2_ERR_INVALID;
+    }
     if (in->num_marker > 0 && in->read_off[in->num_marker] > in->read_off[0] && (!in->bases || !in->quals || !in->alt_base)) {
         set_error("vb2_ctx_create: reads without bases / quals / alt_base arrays");
         return VB2_ERR_INVALID;

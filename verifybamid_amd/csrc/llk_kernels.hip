@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t lds_byte_addr(const void* p)      // generic
 // above (16 KiB); 6: eight copies (4 KiB; lookups of different entries in one column collide) for the one kernel that needs
 // the 12 KiB for a third point group's table (llk_eval_passes_kernel).
 template <int ESH = 8>
-__device__ __forceinline__ double exp_nonpos(double x, uint32_t etab_lane)
+__device__ __forceinline__ double exp_nonpos(double x, uint32_t& etab_lane)
 {
     const double kInvStep = 0x1.71547652b82fep+6;        // 64/ln2
     const double kStepHi = 0x1.62e42fee00000p-7;         // ln2/64, 32 significant bits: k*hi is exact
@@ -166,7 +166,20 @@ __device__ __forceinline__ double exp_nonpos(double x, uint32_t etab_lane)
     r = fma(-kd, kStepLo, r);
     // (the table sits at LDS address 0 and etab_lane < 256, so the index bits are OR-ed in:
     // one v_lshlrev + one v_and_or)
-    const double t = *reinterpret_cast<lds_cdouble*>((((uint32_t)k << ESH) & (63u << ESH)) | etab_lane);
+    double t;
+    if constexpr (ESH == 8) {
+        // The conflict-free table: entry j of this lane's column sits at LDS address j << 8 | etab_lane, etab_lane < 256 -- the
+        // index IS byte 1 of the address.  One SDWA instruction masks k to six bits and drops them into byte 1 of the
+        // register that holds etab_lane, the other bytes kept (a shift and an and-or before: one of the seventeen
+        // instructions of an exponential, of which a marker x point takes six).  The register is the lane's for the whole
+        // kernel: byte 1 is rewritten by every call, byte 0 never.
+        asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+            : "+v"(etab_lane)
+            : "v"(k), "s"(63));
+        t = *reinterpret_cast<lds_cdouble*>(etab_lane);
+    } else {
+        t = *reinterpret_cast<lds_cdouble*>((((uint32_t)k << ESH) & (63u << ESH)) | etab_lane);
+    }
     // exp(r) - 1 = r + r^2 q(r), q of degree 3 through the Chebyshev nodes of |r| <= ln2/128 (60-digit arithmetic; relative error
     // of exp 4.4e-18): one multiply-add less than the degree-6 Taylor form of rounds 1-3, worst error against expl over
     // [-700, 0] 1.02 ulp (Taylor: 1.00) -- six of a marker x point's ~370 instructions
@@ -602,6 +615,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     const uint32_t nunit = (ntile_blk + TPW - 1) / TPW;
     const uint32_t nitem = (kAblate & kAblNoItems) ? 0u : nunit * (uint32_t)ngrp;
     const float inv_nunit = 1.0f / (float)(nunit ? nunit : 1u);
+    const uint32_t ngrp_magic = ngrp > 1 ? 0xFFFFFFFFu / (uint32_t)ngrp + 1u : 0u;      // ceil(2^32 / ngrp) for ngrp >= 2
     // Decided on ceil(tiles / workgroups), the same for every workgroup and exactly what
     // eval_shmem_np sized the result slots for (a workgroup with one tile fewer must not choose
     // differently: the queue needs a slot per item, the static deal only one per wave).
@@ -672,7 +686,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
         for (int t = 0; t < BTL; ++t) wave_prod[t] = LaneProd{1.0, 0};
     };
-    const uint32_t etab_lane = (uint32_t)(lane & (kEtabCopies - 1)) * 8u;     // etab is at LDS address 0 (no static LDS in this file)
+    uint32_t etab_lane = (uint32_t)(lane & (kEtabCopies - 1)) * 8u;     // etab is at LDS address 0 (no static LDS in this file)
     const uint32_t tab_addr = lds_byte_addr(tab);
     const uint32_t ptq_addr = lds_byte_addr(ptq);
     if (L.stagger > 0 && wave >= (nwave >> 1))
@@ -728,7 +742,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         for (int j = 0; j < kPf; ++j) w[j] = cp_[(size_t)(j < last_ ? j : last_) * kMtMarkers];
     };
     // ---- one uint2 of run words (2 runs, or 4 of the 16-bit lists) into the accumulators ----
-    auto walk_word = [&](const vuint2 w_cur, double* acc, const uint32_t my_tab, const uint32_t my_tab_w16) {
+    // (first_tag: the tile's first row under PEEL -- its first run starts the sums from `init`, the marker's "other base"
+    // constant, instead of adding to accumulators that were set to it: the same FMAs, twelve register moves fewer per item)
+    auto walk_word = [&](const vuint2 w_cur, double* acc, const uint32_t my_tab, const uint32_t my_tab_w16, auto first_tag,
+                         const double init) {
+        constexpr bool kFirst = decltype(first_tag)::value;
         if constexpr ((kAblate & kAblNoReads) != 0) {        // (ablation build: the run words are consumed, the table is not read)
             acc[0] += __hiloint2double((int)((w_cur.x ^ w_cur.y) & 0x000f0000u) | 0x3ff00000, 0);
             return;
@@ -764,13 +782,13 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
             for (int i = 0; i < 3 * BTL; ++i) {
                 const vdouble2 t = row[i];
-                acc[2 * i] = fma(n, t.x, acc[2 * i]);
-                acc[2 * i + 1] = fma(n, t.y, acc[2 * i + 1]);
+                acc[2 * i] = fma(n, t.x, (kFirst && j == 0) ? init : acc[2 * i]);
+                acc[2 * i + 1] = fma(n, t.y, (kFirst && j == 0) ? init : acc[2 * i + 1]);
             }
         }
     };
     // ---- per-marker epilogue: a marker's likelihood as (mantissa, exponent) per point, from its six sums per point ----
-    auto marker_lk = [&](const bool live, const size_t pos, const double* acc, const double e0, const double e1, const double e2,
+    auto marker_lk = [&](const bool live, const uint32_t pos, const double* acc, const double e0, const double e1, const double e2,
                          const double* udr, const double mur, const uint32_t my_ptq, double* lk_m, int* lk_e) {
 #pragma unroll
         for (int t = 0; t < BTL; ++t) { lk_m[t] = 1.0; lk_e[t] = 0; }
@@ -863,8 +881,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     rec_nx.x = rec_nx.y = 0u;
     double cst_nx = 0.0;                                  // ... and its markers' "other base" constants (the accumulators start from them)
     auto other_const = [&](uint32_t mt_, bool have_) -> double {
-        const size_t pos_ = (size_t)mt_ * kMtMarkers + m;
-        return g_ediag[(have_ && pos_ < (size_t)L.num_active) ? pos_ : 0];
+        const uint32_t pos_ = mt_ * (uint32_t)kMtMarkers + (uint32_t)m;
+        const uint32_t boff_ = ((have_ && pos_ < (uint32_t)L.num_active) ? pos_ : 0u) * 8u;
+        return *reinterpret_cast<g_cdouble*>(reinterpret_cast<__attribute__((address_space(1))) const char*>(g_ediag) + boff_);
     };
     // The workgroup of the resident kernel's control wave (wave 0, busy with the simplex during the tile phase): the waves w, w + 4,
     // w + 8, ... of a workgroup run on one SIMD (tools/ubench/wave_simd.hip), so the waves 4, 8, 12 share the control wave's.
@@ -894,9 +913,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             // The queue walks the tiles deepest first and every tile's point groups side by side: the waves that hold a tile's items at
             // the same time read the same run words and per-marker constants (one trip to L2 instead of up to six), and the order is
             // still longest-first.  The slots and their order are those of a group-by-group walk: the same bits.
-            unit = (uint32_t)(((float)idx + 0.5f) / (float)ngrp);
-            if (unit * (uint32_t)ngrp > idx) --unit;
-            else if ((unit + 1) * (uint32_t)ngrp <= idx) ++unit;
+            // (idx is uniform and so is the reciprocal: a scalar multiply-high -- exact for idx < 2^32 / ngrp -- where the float
+            // division of the uniform pair cost fifteen vector instructions per item)
+            unit = ngrp > 1 ? __umulhi(idx, ngrp_magic) : idx;
             grp = idx - unit * (uint32_t)ngrp;
         } else {
             grp = ngrp == 1 ? 0u : (uint32_t)(((float)idx + 0.5f) * inv_nunit);
@@ -937,23 +956,37 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             rec_n2 = g_rec[mt_next];
         }
         // per-marker constants: issued now, consumed after the read loop
-        const size_t pos = (size_t)mt * kMtMarkers + m;      // position in sorted order
-        const bool live = have_tile && pos < (size_t)L.num_active;
-        const size_t posc = live ? pos : 0;
-        const double cst = PIPE ? cst_nx : g_ediag[posc];
-        const double e0 = g_ediag[mp + posc], e1 = g_ediag[2 * mp + posc], e2 = g_ediag[3 * mp + posc];
+        const uint32_t pos = mt * (uint32_t)kMtMarkers + (uint32_t)m;      // position in sorted order
+        const bool live = have_tile && pos < (uint32_t)L.num_active;
+        // One 32-bit byte offset for all of a marker's constants, each array's base a scalar: the loads take the
+        // base-plus-offset form and cost no 64-bit vector address arithmetic (nine add pairs per item before).
+        const uint32_t boff = (live ? pos : 0u) * 8u;        // (m_pad < 2^29: vb2_ctx_create refuses more markers)
+        auto at = [&](g_cdouble* base_) -> double {
+            // (the base through an opaque scalar register: else the compiler re-associates base + offset + column stride
+            // and adds the uniform stride in 64-bit vector arithmetic)
+            unsigned long long b_ = (unsigned long long)base_;
+            asm volatile("" : "+s"(b_));
+            return *reinterpret_cast<g_cdouble*>(reinterpret_cast<__attribute__((address_space(1))) const char*>(b_) + boff);
+        };
+        const double cst = PIPE ? cst_nx : at(g_ediag);
+        const double e0 = at(g_ediag + mp), e1 = at(g_ediag + 2 * mp), e2 = at(g_ediag + 3 * mp);
 
         // (the panel row of the marker too: up to four UD columns and the mean)
         double udr[4], mur = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) udr[kk] = (!known_af_p && kk < k) ? g_ud[(size_t)kk * mp + posc] : 0.0;
-        if (!known_af_p) mur = g_mu[posc];
+        for (int kk = 0; kk < 4; ++kk) udr[kk] = (!known_af_p && kk < k) ? at(g_ud + (size_t)kk * mp) : 0.0;
+        if (!known_af_p) mur = at(g_mu);
 
         // the six off-diagonal sums start from the marker's "other base" constant (it is part of
         // every genotype pair's sum, h:299-303), so the epilogue needs no separate addition
+        // PEEL (one tile per wave, lists from L2: the launches of many points): a tile's row count is uniform, and its
+        // first row is walked outside the row loop
+        constexpr bool PEEL = TPW == 1 && !W16 && !PIPE && !LCACHE && QUEUE == 1 && (kAblate & kAblNoReads) == 0;
         double acc[BTL * 6];
+        if constexpr (!PEEL) {
 #pragma unroll
-        for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
+            for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
+        }
 
         // ---- per-read accumulate (h:288-303), one step per run ----
         // Rows are prefetched kPrefetch deep: with one sample its pileup sits in L2, but a cohort
@@ -995,13 +1028,15 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
             for (int j = 0; j < kPf; ++j) w[j] = load_row(j);
         }
-        auto walk_block = [&](const int s0, const bool refill) {     // rows s0 .. s0 + kPf - 1 of the tile
+        auto walk_block = [&](const int s0, const bool refill, auto first_tag) {     // rows s0 .. s0 + kPf - 1 of the tile
+            constexpr bool kFirstBlock = decltype(first_tag)::value;
 #pragma unroll
             for (int u = 0; u < kPf; ++u) {
                 if (s0 + u >= rows) break;
                 const vuint2 w_cur = w[u];
                 if (refill) w[u] = load_row(s0 + u + kPf);
-                walk_word(w_cur, acc, my_tab, my_tab_w16);
+                if (kFirstBlock && u == 0) walk_word(w_cur, acc, my_tab, my_tab_w16, std::true_type(), cst);
+                else walk_word(w_cur, acc, my_tab, my_tab_w16, std::false_type(), cst);
             }
         };
         VB2_IP_USE(w[0].x);
@@ -1010,15 +1045,23 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             // the first kPf rows outside any loop (loads in flight are counted, not drained); an item with more
             // rows -- wide quality alphabets -- refills the ring as before
             const bool more = __any(rows > kPf);
-            walk_block(0, more);
+            walk_block(0, more, std::false_type());
             if (more)
-                for (int s0 = kPf; s0 < rows; s0 += kPf) walk_block(s0, true);
+                for (int s0 = kPf; s0 < rows; s0 += kPf) walk_block(s0, true, std::false_type());
             // this item's rows are walked: the next item's go out now, under the epilogue
             issue_rows(rec_n2, have_next);
             cst_nx = other_const(mt_next, have_next);
             rec_nx = rec_n2;
+        } else if constexpr (PEEL) {
+            if (rows > 0) {
+                walk_block(0, true, std::true_type());
+                for (int s0 = kPf; s0 < rows; s0 += kPf) walk_block(s0, true, std::false_type());
+            } else {
+#pragma unroll
+                for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
+            }
         } else {
-            for (int s0 = 0; s0 < rows; s0 += kPf) walk_block(s0, true);
+            for (int s0 = 0; s0 < rows; s0 += kPf) walk_block(s0, true, std::false_type());
         }
 
         __builtin_amdgcn_s_setprio(0);
