@@ -708,7 +708,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         mt_rows[t] = (uint32_t)((dmax + 1) / 2);             // two runs per dword
         total_rows += mt_rows[t];
     }
-    if (total_rows >= (1ull << 32)) {
+    if (total_rows + kCodeSlackRows >= (1ull << 25)) {       // (rows of 128 bytes, addressed by 32-bit byte offsets in the kernels)
         set_error("vb2_ctx_create: input too large for 32-bit row offsets");
         return VB2_ERR_INVALID;
     }

@@ -241,25 +241,11 @@ __device__ __forceinline__ double log_nonneg(double x)
 #include "log_table.inc"
 constexpr int kLogTabDoubles = 256;
 __device__ const double2 kLogTabRows[128] = {VB2_LOG_TAB_ROWS};
-__device__ __forceinline__ double log_tab(double x, uint32_t ltab_addr /* LDS byte address of the table's copy */)
+// (the routine proper: x normal and positive, hi its high word, kadj what the caller scaled x by)
+__device__ __forceinline__ double log_tab_core(double x, uint32_t hi, int kadj, uint32_t ltab_addr)
 {
     const double kLn2Hi = 0x1.62e42fefa3800p-1, kLn2Lo = 0x1.ef35793c76730p-45;
     constexpr double kP[5] = {VB2_LOG_POLY};
-    uint32_t hi = (uint32_t)__double2hiint(x);
-    // Outside the table's domain (one compare on the high word, a branch no wave of a search ever takes):
-    // zero -> -inf (the reference's log(0): entries whose probability is exactly 0); a positive subnormal (alpha below
-    // 2^-1022: a logit under -708) -> scaled into the normal range, 64 ln2 taken off again through k; NaN, a negative
-    // "probability" (alpha outside [0, 1]) -> NaN; +inf -> +inf: libm's answers, so that a NaN likelihood reaches the
-    // caller as NaN and not as a plausible number.
-    int kadj = 0;
-    bool special = false;
-    double special_value = 0.0;
-    if (__builtin_expect(hi - 0x00100000u >= 0x7FE00000u, 0)) {
-        if (x == 0.0) { special = true; special_value = -__builtin_huge_val(); }
-        else if (!(x > 0.0)) { special = true; special_value = __builtin_nan(""); }
-        else if (hi >= 0x7FF00000u) { special = true; special_value = x; }
-        else { x *= 0x1p64; kadj = 64; hi = (uint32_t)__double2hiint(x); }
-    }
     const uint32_t tmp = hi - 0x3FE5F000u;
     const uint32_t i = (tmp >> 13) & 127u;
     const int k = ((int)tmp >> 20) - kadj;
@@ -276,7 +262,28 @@ __device__ __forceinline__ double log_tab(double x, uint32_t ltab_addr /* LDS by
     const double p = fma(r2, q1, q0);
     const double rl = fma(kd, kLn2Lo, r);
     const double y = fma(r2, p, rl);
-    return special ? special_value : w + y;
+    return w + y;
+}
+__device__ __forceinline__ double log_tab(double x, uint32_t ltab_addr /* LDS byte address of the table's copy */)
+{
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    double res = log_tab_core(x, hi, 0, ltab_addr);
+    // Outside the table's domain (one compare on the high word, and a branch no wave of a search ever takes --
+    // a real branch: as selects folded into the routine the four cases cost every entry a dozen instructions):
+    // zero -> -inf (the reference's log(0): entries whose probability is exactly 0); a positive subnormal (alpha below
+    // 2^-1022: a logit under -708) -> scaled into the normal range, 64 ln2 taken off again through k; NaN, a negative
+    // "probability" (alpha outside [0, 1]) -> NaN; +inf -> +inf: libm's answers, so that a NaN likelihood reaches the
+    // caller as NaN and not as a plausible number.
+    if (__builtin_expect(hi - 0x00100000u >= 0x7FE00000u, 0)) {
+        if (x == 0.0) res = -__builtin_huge_val();
+        else if (!(x > 0.0)) res = __builtin_nan("");
+        else if (hi >= 0x7FF00000u) res = x;
+        else {
+            const double xs = x * 0x1p64;
+            res = log_tab_core(xs, (uint32_t)__double2hiint(xs), 64, ltab_addr);
+        }
+    }
+    return res;
 }
 
 // A positive value as (mantissa in [0.5,1), binary exponent): products of likelihoods are
@@ -576,23 +583,21 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const int dc = (int)(pr & 0xffffu), twin = (int)(pr >> 16);
         int g1, g2;
         pair_of(p, g1, g2);
-        double v[kMaxGroups];
-#pragma unroll
-        for (int grp_e = 0; grp_e < kMaxGroups; ++grp_e)
-            if (grp_e < ngrp)
-                v[grp_e] = table_entry(early_table ? lds_rows[(bb < num_valid ? bb : num_valid - 1) * stride + 2 * k]
-                                                   : pts[(grp_e * NP + bb) * stride + 2 * k], rec.x, g1, g2, ltab_addr);
         // W16 (cohort steps on the 16-bit run lists): the run word's count field decodes to the double 2 * n with ONE
         // byte permute (see the read loop), so the table holds T / 2 -- both scalings are exact (powers of two), and
         // fma(2n, T/2, acc) rounds the same real number as fma(n, T, acc): bit-identical to the 32-bit lists.
-#pragma unroll
-        for (int grp_e = 0; grp_e < kMaxGroups; ++grp_e)
-            if (grp_e < ngrp) {
-                double* gtab = tab + (size_t)grp_e * nrow * RS;
-                const double tv = W16 ? 0.5 * v[grp_e] : v[grp_e];
-                gtab[dc * RS + bp] = tv;
-                if (twin != 0xffff) gtab[twin * RS + bb * 6 + (5 - p)] = tv;
-            }
+        // (the groups one after the other in a rolled loop: side by side -- six logarithms' chains interleaved -- the
+        // unrolled body held every group's temporaries and constants at once and spilled scalar registers to vector lanes;
+        // it cost 430 vector instructions per thread of a 48-point launch where this costs 285: headline +0.8 %, 118 codes +2.2 %)
+#pragma clang loop unroll(disable)
+        for (int grp_e = 0; grp_e < ngrp; ++grp_e) {
+            const double v = table_entry(early_table ? lds_rows[(bb < num_valid ? bb : num_valid - 1) * stride + 2 * k]
+                                                     : pts[(grp_e * NP + bb) * stride + 2 * k], rec.x, g1, g2, ltab_addr);
+            double* gtab = tab + (size_t)grp_e * nrow * RS;
+            const double tv = W16 ? 0.5 * v : v;
+            gtab[dc * RS + bp] = tv;
+            if (twin != 0xffff) gtab[twin * RS + bb * 6 + (5 - p)] = tv;
+        }
     }
     for (int e = tid; e < ngrp * RS; e += nthread) {                  // padding code: zero rows
         const int grp_e = e / RS;
@@ -627,6 +632,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     typedef unsigned int __attribute__((ext_vector_type(2))) vuint2;          // (a plain vector: loadable through address_space(1))
     typedef __attribute__((address_space(1))) const vuint2 g_cuint2;
     typedef __attribute__((address_space(1))) const double g_cdouble;
+    typedef __attribute__((address_space(1))) const char g_cchar;
     g_cuint2* const g_rec = (g_cuint2*)(W16 ? L.mt_rec16 : L.mt_rec);
     g_cuint2* const g_codes = (g_cuint2*)(W16 ? L.codes16 : L.codes);
     g_cdouble* const g_ediag = (g_cdouble*)L.ediag;
@@ -735,11 +741,12 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         return (uint32_t)__builtin_amdgcn_readfirstlane(nxt);
     };
     auto issue_rows = [&](const vuint2 rec_, bool have_) {           // the first kPf rows of a tile (clamped to its own)
-        g_cuint2* cp_ = g_codes + (size_t)rec_.x * kMtMarkers + m;
+        const uint32_t cb_ = rec_.x * (uint32_t)(kMtMarkers * 8) + (uint32_t)m * 8u;       // (32-bit byte offsets: see load_row)
         const int rows_ = have_ ? (int)rec_.y : 0;
         const int last_ = rows_ > 0 ? rows_ - 1 : 0;
 #pragma unroll
-        for (int j = 0; j < kPf; ++j) w[j] = cp_[(size_t)(j < last_ ? j : last_) * kMtMarkers];
+        for (int j = 0; j < kPf; ++j)
+            w[j] = *reinterpret_cast<g_cuint2*>(reinterpret_cast<g_cchar*>(g_codes) + (cb_ + (uint32_t)(j < last_ ? j : last_) * (uint32_t)(kMtMarkers * 8)));
     };
     // ---- one uint2 of run words (2 runs, or 4 of the 16-bit lists) into the accumulators ----
     // (first_tag: the tile's first row under PEEL -- its first run starts the sums from `init`, the marker's "other base"
@@ -1008,7 +1015,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             else __builtin_amdgcn_s_setprio(1);
         } else
             __builtin_amdgcn_s_setprio(1);
-        g_cuint2* cp = g_codes + (LCACHE ? (size_t)0 : (size_t)rec.x * kMtMarkers + m);
+        // the run words by 32-bit byte offsets from the array's (scalar) base: the list of one sample stays below 4 GiB
+        // (Context::create refuses more rows), and a row's address costs no 64-bit vector arithmetic
+        const uint32_t cbase = LCACHE ? 0u : rec.x * (uint32_t)(kMtMarkers * 8) + (uint32_t)m * 8u;
         const uint32_t crow = rec.x + (uint32_t)m * 8u;      // (LCACHE: this lane's word of the tile's first row, LDS)
         const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
         // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
@@ -1022,7 +1031,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const int last_row = rows > 0 ? rows - 1 : 0;
         auto load_row = [&](int j) -> vuint2 {               // row j of this lane's run words
             if constexpr (LCACHE) return *reinterpret_cast<lds_cuint2v*>(crow + (uint32_t)j * (kMtMarkers * 8u));
-            else return cp[(size_t)(STREAM ? (j < last_row ? j : last_row) : j) * kMtMarkers];
+            else return *reinterpret_cast<g_cuint2*>(reinterpret_cast<g_cchar*>(g_codes) +
+                                                      (cbase + (uint32_t)(STREAM ? (j < last_row ? j : last_row) : j) * (uint32_t)(kMtMarkers * 8)));
         };
         if (!PIPE) {
 #pragma unroll
