@@ -112,17 +112,24 @@ __device__ const double kExp2Tab[64] = {
     0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
 
 // exp(x) for x <= 0 (arguments here are sums of log-probabilities), FP64, <= 1.1 ulp:
-// x = k*ln2/64 + r, |r| <= ln2/128; exp(x) = 2^(k>>6) * 2^((k&63)/64) * (1 + p(r)), p = the degree-6
-// Taylor polynomial of exp(r)-1 (truncation 2e-19), the 2^(j/64) factor from an LDS table.
-// 17 VALU instructions + one ds_read_b64, against 23 for the table-free form (degree 13).
+// x = k*ln2/64 + r, |r| <= ln2/128; exp(x) = 2^(k>>6) * 2^((k&63)/64) * (1 + p(r)), p = r + r^2 q(r), q of degree 3, the
+// 2^(j/64) factor from an LDS table.
 // `etab_lane` = LDS byte address of this lane's column of the bank-replicated table: entry j sits
 // 256*j bytes further, i.e. in LDS banks 2*(lane%32), 2*(lane%32)+1 whatever j is, so the
 // 64 lanes' lookups of a wave never conflict (a 512-byte table would: random j's collide).
-// 2^k applied with ldexp so results degrade gracefully into subnormals and reach 0
-// exactly where the reference's exp() underflows (the `markerLK > 0` test, h:310).
 // v_max_f64 / v_min_f64 as single instructions: the compiler's fmax/fmin lowering first
 // canonicalises an operand it cannot prove free of signalling NaNs (one more v_max_f64 x, x);
 // the hardware instruction quiets them by itself.
+//
+// Two forms.  The one every marker x point takes six times applies 2^(k>>6) to the TABLE ENTRY before the last
+// multiply-add, by ONE integer add on the entry's high word: the table holds the entries with j << 14 taken off their high
+// words (exp_tab_entry), so that adding k << 14 = (k>>6) << 20 + j << 14 leaves exactly (k>>6) in the exponent field -- the
+// scaling is exact and the result the same bits as scaling afterwards; the shift and the v_ldexp_f64 of the other form (an
+// FP64-rate instruction: 2.8x an integer one, tools/ubench/valu_rates.hip) are gone, and so is the clamp.  It holds as long
+// as the scaled entry is a normal number, i.e. for x >= -708 (2^-1022 <= e^-708.39): the caller (marker_lk) takes the
+// minimum of a marker's six arguments -- five v_min_f64, integer-rate -- and sends markers with an argument below that
+// (deep pileups; -inf: a table entry that is log 0) through the EXACT form: clamp at -800, v_ldexp_f64, gradual underflow,
+// 0 exactly where the reference's exp() reaches it (the `markerLK > 0` test, h:310).  Either way the same bits as before.
 __device__ __forceinline__ double vmax_f64(double x, double c)
 {
     double r;
@@ -135,6 +142,12 @@ __device__ __forceinline__ double vmin_f64(double x, double c)
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(c));
     return r;
 }
+__device__ __forceinline__ double vmin2_f64(double x, double y)      // (both operands in vector registers)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 typedef double __attribute__((ext_vector_type(2))) vdouble2;      // (a plain vector: loadable through address_space(3))
@@ -144,19 +157,26 @@ __device__ __forceinline__ uint32_t lds_byte_addr(const void* p)      // generic
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
+// what the LDS copy of the table holds for 2^(j/64): the double with j << 14 taken off its high word
+__device__ __forceinline__ double exp_tab_entry(double t, int j)
+{
+    return __hiloint2double(__double2hiint(t) - (j << 14), __double2loint(t));
+}
+
 // ESH: log2 of the byte stride between two entries of the table -- 8: 32 copies of every entry, the conflict-free layout
 // above (16 KiB); 6: eight copies (4 KiB; lookups of different entries in one column collide) for the one kernel that needs
 // the 12 KiB for a third point group's table (llk_eval_passes_kernel).
-template <int ESH = 8>
+// EXACT: see above.
+template <int ESH = 8, bool EXACT = false>
 __device__ __forceinline__ double exp_nonpos(double x, uint32_t& etab_lane)
 {
     const double kInvStep = 0x1.71547652b82fep+6;        // 64/ln2
     const double kStepHi = 0x1.62e42fee00000p-7;         // ln2/64, 32 significant bits: k*hi is exact
     const double kStepLo = 0x1.a39ef35793c76p-39;
     const double kMagic = 0x1.8p52;                      // 2^52 + 2^51: x + kMagic rounds x to an integer
-    // below -800 the result is 0 anyway (2^-1154); the clamp also maps -inf to a finite
-    // argument, so no special case is needed after the ldexp
-    x = vmax_f64(x, -800.0);
+    // EXACT: below -800 the result is 0 anyway (2^-1154); the clamp also maps -inf to a finite
+    // argument, so no special case is needed after the ldexp.  (The other form is only called with x >= -708.)
+    if constexpr (EXACT) x = vmax_f64(x, -800.0);
     // k = rint(x * 64/ln2) by the magic-number addition: the low mantissa word of the sum IS the
     // integer (two's complement), so no v_rndne / v_cvt_i32 pair
     const double tk = fma(x, kInvStep, kMagic);
@@ -164,15 +184,12 @@ __device__ __forceinline__ double exp_nonpos(double x, uint32_t& etab_lane)
     const double kd = tk - kMagic;
     double r = fma(-kd, kStepHi, x);
     r = fma(-kd, kStepLo, r);
-    // (the table sits at LDS address 0 and etab_lane < 256, so the index bits are OR-ed in:
-    // one v_lshlrev + one v_and_or)
     double t;
     if constexpr (ESH == 8) {
         // The conflict-free table: entry j of this lane's column sits at LDS address j << 8 | etab_lane, etab_lane < 256 -- the
         // index IS byte 1 of the address.  One SDWA instruction masks k to six bits and drops them into byte 1 of the
-        // register that holds etab_lane, the other bytes kept (a shift and an and-or before: one of the seventeen
-        // instructions of an exponential, of which a marker x point takes six).  The register is the lane's for the whole
-        // kernel: byte 1 is rewritten by every call, byte 0 never.
+        // register that holds etab_lane, the other bytes kept (a shift and an and-or before).  The register is the lane's
+        // for the whole kernel: byte 1 is rewritten by every call, byte 0 never.
         asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
             : "+v"(etab_lane)
             : "v"(k), "s"(63));
@@ -181,13 +198,18 @@ __device__ __forceinline__ double exp_nonpos(double x, uint32_t& etab_lane)
         t = *reinterpret_cast<lds_cdouble*>((((uint32_t)k << ESH) & (63u << ESH)) | etab_lane);
     }
     // exp(r) - 1 = r + r^2 q(r), q of degree 3 through the Chebyshev nodes of |r| <= ln2/128 (60-digit arithmetic; relative error
-    // of exp 4.4e-18): one multiply-add less than the degree-6 Taylor form of rounds 1-3, worst error against expl over
-    // [-700, 0] 1.02 ulp (Taylor: 1.00) -- six of a marker x point's ~370 instructions
+    // of exp 4.4e-18): worst error against expl over [-700, 0] 1.02 ulp
     double p = fma(r, 0x1.11111d8fbe766p-7, 0x1.55556b3304ec0p-5);
     p = fma(p, r, 0x1.5555555555255p-3);
     p = fma(p, r, 0x1.ffffffffff57fp-2);
     p = fma(p, r * r, r);
-    return ldexp(fma(t, p, t), k >> 6);
+    if constexpr (EXACT) {
+        t = __hiloint2double(__double2hiint(t) + ((k & 63) << 14), __double2loint(t));     // the entry itself again
+        return ldexp(fma(t, p, t), k >> 6);
+    } else {
+        t = __hiloint2double(__double2hiint(t) + (int)((uint32_t)k << 14), __double2loint(t));   // 2^(k>>6) 2^(j/64), exactly
+        return fma(t, p, t);
+    }
 }
 
 // log(x) for x >= 0, FP64 (fdlibm's e_log algorithm with explicit FMAs, ~1 ulp):
@@ -547,8 +569,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     if (!hook.keep_etab())
         for (int jb = 2 * wave; jb < 64; jb += 2 * nwave) {
             const double t0 = kExp2Tab[jb], t1 = kExp2Tab[jb + 1];
-            if constexpr (ESH == 8) etab[jb * 32 + lane] = lane < 32 ? t0 : t1;
-            else if ((lane & 31) < kEtabCopies) etab[(jb + (lane >> 5)) * kEtabCopies + (lane & 31)] = lane < 32 ? t0 : t1;
+            const double tv = lane < 32 ? exp_tab_entry(t0, jb) : exp_tab_entry(t1, jb + 1);
+            if constexpr (ESH == 8) etab[jb * 32 + lane] = tv;
+            else if ((lane & 31) < kEtabCopies) etab[(jb + (lane >> 5)) * kEtabCopies + (lane & 31)] = tv;
         }
     // With several groups a thread builds several table entries: the primary-code records (a
     // few dozen) go to LDS first so that the loop below does not wait on a global load per
@@ -850,9 +873,17 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 // of 27; the rounding differs from the reference's term-by-term sum at the 1e-16
                 // level, like the marker summation order does).  The three g1==g2 exponentials do
                 // not depend on (alpha, PC) and were taken at context creation.
-                const double x01 = exp_nonpos<ESH>(a[0], etab_lane), x02 = exp_nonpos<ESH>(a[1], etab_lane);
-                const double x10 = exp_nonpos<ESH>(a[2], etab_lane), x12 = exp_nonpos<ESH>(a[3], etab_lane);
-                const double x20 = exp_nonpos<ESH>(a[4], etab_lane), x21 = exp_nonpos<ESH>(a[5], etab_lane);
+                double x01, x02, x10, x12, x20, x21;
+                const double a_min = vmin2_f64(vmin2_f64(vmin2_f64(a[0], a[1]), vmin2_f64(a[2], a[3])), vmin2_f64(a[4], a[5]));
+                if (__builtin_expect(a_min < -708.0, 0)) {      // (wave-divergent, and never taken on whole-genome depths: exp_nonpos)
+                    x01 = exp_nonpos<ESH, true>(a[0], etab_lane); x02 = exp_nonpos<ESH, true>(a[1], etab_lane);
+                    x10 = exp_nonpos<ESH, true>(a[2], etab_lane); x12 = exp_nonpos<ESH, true>(a[3], etab_lane);
+                    x20 = exp_nonpos<ESH, true>(a[4], etab_lane); x21 = exp_nonpos<ESH, true>(a[5], etab_lane);
+                } else {
+                    x01 = exp_nonpos<ESH>(a[0], etab_lane); x02 = exp_nonpos<ESH>(a[1], etab_lane);
+                    x10 = exp_nonpos<ESH>(a[2], etab_lane); x12 = exp_nonpos<ESH>(a[3], etab_lane);
+                    x20 = exp_nonpos<ESH>(a[4], etab_lane); x21 = exp_nonpos<ESH>(a[5], etab_lane);
+                }
                 const double s0 = fma(x02, gf2[2], fma(x01, gf2[1], e0 * gf2[0]));
                 const double s1 = fma(x12, gf2[2], fma(e1, gf2[1], x10 * gf2[0]));
                 const double s2 = fma(e2, gf2[2], fma(x21, gf2[1], x20 * gf2[0]));
