@@ -124,8 +124,8 @@ __device__ const double kExp2Tab[64] = {
 // Two forms.  The one every marker x point takes six times applies 2^(k>>6) to the TABLE ENTRY before the last
 // multiply-add, by ONE integer add on the entry's high word: the table holds the entries with j << 14 taken off their high
 // words (exp_tab_entry), so that adding k << 14 = (k>>6) << 20 + j << 14 leaves exactly (k>>6) in the exponent field -- the
-// scaling is exact and the result the same bits as scaling afterwards; the shift and the v_ldexp_f64 of the other form (an
-// FP64-rate instruction: 2.8x an integer one, tools/ubench/valu_rates.hip) are gone, and so is the clamp.  It holds as long
+// scaling is exact and the result the same bits as scaling afterwards; the shift and the v_ldexp_f64 of the other form
+// are gone, and so is the clamp (three of an exponential's sixteen instructions for one).  It holds as long
 // as the scaled entry is a normal number, i.e. for x >= -708 (2^-1022 <= e^-708.39): the caller (marker_lk) takes the
 // minimum of a marker's six arguments -- five v_min_f64, integer-rate -- and sends markers with an argument below that
 // (deep pileups; -inf: a table entry that is log 0) through the EXACT form: clamp at -800, v_ldexp_f64, gradual underflow,
