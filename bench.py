@@ -332,6 +332,20 @@ def main():
             valu["frac_of_nominal_2.4GHz_issue"] = issue_us / step_us
             if ceiling:
                 valu_frac = valu_achieved / ceiling["fp64_fma_alone"]
+        # the classical flop roofline next to it: FP64 vector flops of the launch (instruction classes counted by the committed
+        # PMC pass of this command: adds + multiplies + 2 x FMAs, x 64 lanes) / time against the FP64 vector peak,
+        # 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz = 78.6 TFLOP/s.  Unlike lane-instructions/s it does not move when
+        # integer or move instructions leave the kernel.
+        fj, fsrc = latest_profile("flops_b%d.json" % B)
+        fp64 = None
+        if fj and fj.get("markers") == args.markers and fj.get("num_pc") == k:
+            fl_ = float(fj["fp64_flops_per_launch"])
+            fp64 = {"achieved": fl_ / (step_us * 1e-6) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                    "frac": fl_ / (step_us * 1e-6) / 1e12 / 78.6,
+                    "fp64_flops_per_marker_point": fj["fp64_flops_per_marker_point"],
+                    "fp64_instr_per_marker_point": fj["fp64_instr_per_marker_point"], "source": fsrc,
+                    "note": "FP64 vector peak at the nominal 2.4 GHz; under FP64 load the clock settles near 1.9-2.0 GHz "
+                            "(roofline.ceiling): against the flops the device sustains at that clock the fraction is frac x 2.4 / clock"}
         ROOFLINE["valu_frac_headline"] = valu_frac
         ROOFLINE["us_per_point_headline"] = step_us / B
         result["roofline"] = {
@@ -348,7 +362,7 @@ def main():
                                 "side moves `traffic` bytes per launch (`hbm_actual_GBps`)"},
             "traffic": traffic, "traffic_source": traffic_src,
             "hbm_actual_GBps": (traffic / (step_us * 1e-6) / 1e9) if traffic else None,
-            "valu": valu, "mfma_util": 0.0,
+            "valu": valu, "fp64": fp64, "mfma_util": 0.0,
             "mfma_note": "no MFMA instruction on the path: FP64 MFMA and FP64 VALU share the unit on gfx950 "
                          "(profiles/r01/ubench_mfma_overlap.txt), and the UD x PC projection is 2k FMAs per marker",
             "kernel": "llk_eval_kernel<%d,true>" % (2 if B > 4 else 3),

@@ -20,6 +20,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq1 -o b -- $B $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_sq2 -o b -- $B $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm -o b -- $B $P > /dev/null 2>&1
+# FP64 vector instructions by class (the flop roofline of bench.py: roofline.fp64): adds, multiplies, FMAs, transcendentals
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d $O/pmc_f64 -o b -- $B $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_modes -o m -- python $GRAFT_REPO_ROOT/tools/prof_modes.py > $O/trace_modes.log 2>&1
 # HBM-side bytes of the cohort steps (32 samples; 1, 2, 4 and 8 points per sample): FETCH_SIZE of llk_eval_multi_kernel<*>
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_modes_fetch -o m -- python $GRAFT_REPO_ROOT/tools/prof_modes.py > /dev/null 2>&1

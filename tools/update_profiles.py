@@ -73,6 +73,26 @@ v = {"_what": "VALU / LDS pipe occupancy of llk_eval_kernel<2,true> per launch o
      "lds_busy_frac": round(lds_active / (256 * cycles), 3) if cycles else None}
 json.dump(v, open(os.path.join(dst, "valu_b%d.json" % B), "w"), indent=1)
 
+# FP64 vector instructions of the launch by class (wave-instructions; x 64 lanes; an FMA = 2 flops)
+if os.path.isdir(os.path.join(src, "pmc_f64")):
+    try:
+        fa, fm = avg("pmc_f64", "SQ_INSTS_VALU_ADD_F64"), avg("pmc_f64", "SQ_INSTS_VALU_MUL_F64")
+        ff, ft = avg("pmc_f64", "SQ_INSTS_VALU_FMA_F64"), avg("pmc_f64", "SQ_INSTS_VALU_TRANS_F64")
+        fl = {"_what": "FP64 vector instructions of llk_eval_kernel<2,true> per launch of %d points by class: rocprofv3 --pmc "
+                       "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 (wave-instructions; "
+                       "flops = (add + mul + trans + 2 x fma) x 64 lanes) -- the numerator of bench.py's roofline.fp64" % B,
+              "markers": markers, "batch": B, "num_pc": k,
+              "SQ_INSTS_VALU_ADD_F64": fa, "SQ_INSTS_VALU_MUL_F64": fm, "SQ_INSTS_VALU_FMA_F64": ff, "SQ_INSTS_VALU_TRANS_F64": ft,
+              "fp64_instr_per_marker_point": round((fa + fm + ff + ft) * 64 / (markers * B), 1),
+              "fp64_flops_per_launch": (fa + fm + ft + 2 * ff) * 64,
+              "fp64_flops_per_marker_point": round((fa + fm + ft + 2 * ff) * 64 / (markers * B), 1)}
+        json.dump(fl, open(os.path.join(dst, "flops_b%d.json" % B), "w"), indent=1)
+        print("FP64 instructions per marker x point: %.1f (add %.1f mul %.1f fma %.1f trans %.1f), %.1f flops" % (
+            fl["fp64_instr_per_marker_point"], fa * 64 / (markers * B), fm * 64 / (markers * B), ff * 64 / (markers * B),
+            ft * 64 / (markers * B), fl["fp64_flops_per_marker_point"]))
+    except Exception as exc:      # noqa: BLE001 -- a counter the box does not have: the other summaries still go out
+        print("pmc_f64: %s" % exc)
+
 # cohort steps: FETCH_SIZE per launch of llk_eval_multi_kernel<MODE, ...> (MODE 4: 1 point per sample, 5: 2, 3: 4, 2: 8)
 cm = os.path.join(src, "pmc_modes_fetch")
 if os.path.isdir(cm):
