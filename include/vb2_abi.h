@@ -117,7 +117,10 @@ typedef struct vb2_info {
  * kernels classify, run-length code and pack them; the host keeps the
  * dictionary and the sort of the markers).  Replaces BuildResolvedMarkers + the
  * per-call prologue of ComputeMixLLKs (ContaminationEstimator.cpp:67-86;
- * h:236-249, 285-299).  `in` is not referenced after the call returns. */
+ * h:236-249, 285-299).  `in` is not referenced after the call returns.
+ * Limits (VB2_ERR_INVALID beyond them; the reference has none short of memory): 2^29 - 1024 markers and 2^25 rows of
+ * run words -- a row is the k-th and (k+1)-th distinct (class, quality) pairs of 16 depth-sorted markers, so the second
+ * is about a billion reads of one sample: the kernels address both by 32-bit byte offsets. */
 int vb2_ctx_create(const vb2_input *in, const vb2_options *opt, vb2_ctx **out);
 void vb2_ctx_destroy(vb2_ctx *ctx);
 int vb2_ctx_info(const vb2_ctx *ctx, vb2_info *info);
