@@ -7,6 +7,6 @@ name=$1; shift
 out=../../build_variants/$name
 mkdir -p $out
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -mllvm -amdgpu-sched-strategy=iterative-ilp "$@" -c llk_kernels.hip -o $out/llk_kernels.o
-objs=$(ls *.o | grep -v llk_kernels)
+objs=$(ls *.o | grep -v 'llk_kernels\|llk_passes')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libvb2.so $out/llk_kernels.o $objs -lpthread -lz -ldl
 echo built $out/libvb2.so

@@ -1440,6 +1440,25 @@ llk_eval_passes_kernel(const DeviceLayout L, const double* __restrict__ points, 
     }
 }
 
+// Two translation units from this file (csrc/Makefile, CMakeLists.txt): the kernels of this file are compiled under LLVM's
+// iterative-ILP scheduler (+1.1 % on the 48-point launch, -1.2 % on OptimizeLLK), which costs llk_eval_passes_kernel 7 %
+// (118 codes: 566 -> 525 k evals/s) -- so that one kernel is instantiated in llk_passes.hip's unit (VB2_TU_PASSES: this
+// file up to here, under the default scheduler) and only declared in the main one (VB2_TU_MAIN).  Neither macro: everything
+// in one unit (the profiling builds, tools/build_variant.sh).
+#define VB2_PASSES_KERNEL_ARGS                                                                                           \
+    const DeviceLayout, const double*, int, int, double*, double*, unsigned int*, unsigned long long*, unsigned long long, \
+        unsigned long long*
+#if defined(VB2_TU_MAIN)
+extern template __global__ void llk_eval_passes_kernel<4>(VB2_PASSES_KERNEL_ARGS);
+extern template __global__ void llk_eval_passes_kernel<2>(VB2_PASSES_KERNEL_ARGS);
+extern template __global__ void llk_eval_passes_kernel<0>(VB2_PASSES_KERNEL_ARGS);
+#elif defined(VB2_TU_PASSES)
+template __global__ void llk_eval_passes_kernel<4>(VB2_PASSES_KERNEL_ARGS);
+template __global__ void llk_eval_passes_kernel<2>(VB2_PASSES_KERNEL_ARGS);
+template __global__ void llk_eval_passes_kernel<0>(VB2_PASSES_KERNEL_ARGS);
+#endif
+
+#ifndef VB2_TU_PASSES
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
 // w / bps as that sample's workgroup w % bps.  Every sample has its own layout, parameter rows,
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
@@ -1986,5 +2005,6 @@ hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream)
     hipLaunchKernelGGL(fill_zero_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_out, n);
     return hipGetLastError();
 }
+#endif  // !VB2_TU_PASSES
 
 }  // namespace vb2
