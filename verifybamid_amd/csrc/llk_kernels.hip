@@ -1440,11 +1440,13 @@ llk_eval_passes_kernel(const DeviceLayout L, const double* __restrict__ points, 
     }
 }
 
-// Two translation units from this file (csrc/Makefile, CMakeLists.txt): the kernels of this file are compiled under LLVM's
-// iterative-ILP scheduler (+1.1 % on the 48-point launch, -1.2 % on OptimizeLLK), which costs llk_eval_passes_kernel 7 %
-// (118 codes: 566 -> 525 k evals/s) -- so that one kernel is instantiated in llk_passes.hip's unit (VB2_TU_PASSES: this
-// file up to here, under the default scheduler) and only declared in the main one (VB2_TU_MAIN).  Neither macro: everything
-// in one unit (the profiling builds, tools/build_variant.sh).
+// Two translation units from this file (csrc/Makefile, CMakeLists.txt): the single-sample kernels and the resident search
+// kernel are compiled under LLVM's iterative-ILP scheduler (+1.1 % on the 48-point launch, -1.2 % on OptimizeLLK), which
+// costs llk_eval_passes_kernel 7 % (118 codes: 566 -> 525 k evals/s) and the cohort steps of two and more points 1 % (a
+// cohort search 3 %: 700 -> 678 samples/s) -- so those are instantiated in llk_passes.hip's unit (VB2_TU_PASSES: the
+// device code, llk_eval_passes_kernel's instantiations, llk_eval_multi_kernel with its launcher; default scheduler) and
+// the main unit (VB2_TU_MAIN) only declares them.  Neither macro: everything in one unit (the profiling builds,
+// tools/build_variant.sh).
 #define VB2_PASSES_KERNEL_ARGS                                                                                           \
     const DeviceLayout, const double*, int, int, double*, double*, unsigned int*, unsigned long long*, unsigned long long, \
         unsigned long long*
@@ -1458,7 +1460,6 @@ template __global__ void llk_eval_passes_kernel<2>(VB2_PASSES_KERNEL_ARGS);
 template __global__ void llk_eval_passes_kernel<0>(VB2_PASSES_KERNEL_ARGS);
 #endif
 
-#ifndef VB2_TU_PASSES
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
 // w / bps as that sample's workgroup w % bps.  Every sample has its own layout, parameter rows,
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
@@ -1490,7 +1491,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
                           scheds ? scheds[s] : Schedule{nullptr, nullptr});
 }
 
-
+#ifndef VB2_TU_PASSES      // ---- main unit only, down to raise_lds_limit ----
 
 #include "resident_kernel.inc"
 
@@ -1557,6 +1558,8 @@ LaunchGeom launch_geom(const DeviceLayout& L, int btl, int ngrp)
     return LaunchGeom{grid, bw};
 }
 
+#endif  // !VB2_TU_PASSES
+
 // More than 64 KiB of dynamic LDS is an opt-in per kernel function AND per device (the function
 // object is per device in the runtime), so the flag is kept per (function slot, device).
 // (keyed by the function's address and the device -- ADVICE r3: the hand-numbered slots of round 3 were one
@@ -1585,6 +1588,7 @@ static hipError_t raise_lds_limit(const void* fn)
     return hipSuccess;
 }
 
+#ifndef VB2_TU_PASSES      // ---- main unit only, down to the cohort kernels' launcher ----
 template <int MODE>
 static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, const double* h_points,
                              int num_valid, int ngrp,
@@ -1763,6 +1767,9 @@ int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves)
     return g;
 }
 
+#endif  // !VB2_TU_PASSES
+
+#ifndef VB2_TU_MAIN         // ---- the cohort kernels are instantiated (here, by their launcher) in the second unit ----
 // The cohort kernels of one wave shape
 template <int MODE>
 static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream)
@@ -1809,7 +1816,9 @@ hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
     default: return launch_multi_mode<3>(ml, stream);
     }
 }
+#endif  // !VB2_TU_MAIN
 
+#ifndef VB2_TU_PASSES      // ---- main unit only, to the end ----
 // (the kernels of the flatten -- classify_kernel, pack_layout_kernel, pack_sched_kernel, pack_codes16_kernel -- are in
 // flatten_kernels.hip)
 
