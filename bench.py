@@ -527,7 +527,7 @@ def main():
                 }
                 return obj, wide, w_llk
             result["roofline_wide_alphabet"], wide, wide_llk = alphabet_leg(2, 60, "valu_b%d_wide.json" % B)
-            result["roofline_mid_alphabet"], _, _ = alphabet_leg(10, 45, None)
+            result["roofline_mid_alphabet"], _, _ = alphabet_leg(10, 45, "valu_b%d_mid.json" % B)
         if world == 1 and not args.no_optimize:
             # second half of the metric: wall-clock of OptimizeLLK (Initialize + Homo + Heter +
             # LLK0), best of 3; measured before the CPU leg so no OpenMP threads are around

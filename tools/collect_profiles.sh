@@ -33,11 +33,15 @@ VB2_STEPS=40 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCL
 VB2_STEPS=40 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_cohort_sq2 -o c -- $C > /dev/null 2>&1
 VB2_STEPS=40 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_cohort_fetch -o c -- $C > /dev/null 2>&1
 VB2_STEPS=40 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_cohort_grbm -o c -- $C > /dev/null 2>&1
-# the headline launch on the BAQ-like quality alphabet (2..60: bench.py -> roofline_wide_alphabet): kernel stats + the SQ / GRBM passes
-W="$B --q-lo 2 --q-hi 60"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_wide -o w -- $W > $O/trace_wide.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_wide_sq1 -o w -- $W $P > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_wide_grbm -o w -- $W $P > /dev/null 2>&1
+# the headline launch on wider quality alphabets (2..60 = BAQ-like, 118 codes: bench.py -> roofline_wide_alphabet; 10..45, 72 codes:
+# roofline_mid_alphabet): kernel stats + the SQ / GRBM passes of each
+for A in "wide 2 60" "mid 10 45"; do
+  set -- $A
+  W="$B --q-lo $2 --q-hi $3"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$1 -o w -- $W > $O/trace_$1.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_$1_sq1 -o w -- $W $P > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_$1_grbm -o w -- $W $P > /dev/null 2>&1
+done
 # vb2_ctx_create (the flatten on the device: classify_kernel, pack_layout_kernel, pack_sched_kernel): host times and kernel stats
 cd /tmp
 python $GRAFT_REPO_ROOT/tools/create_time.py > $O/create_time.txt 2>&1

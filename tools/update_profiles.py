@@ -165,31 +165,32 @@ if ks:
     json.dump(ct2, open(ctp, "w"), indent=1)
     print("cohort steps:", {n: (kk["valu_busy_frac"], kk["lds_busy_frac"], kk["parked_frac"], kk["traffic_bytes_per_step"]) for n, kk in cp["kernels"].items()})
 
-ws = first_csv("trace_wide", "kernel_stats.csv")
-if ws:
-    shutil.copy(ws, os.path.join(dst, "bench_b%d_wide_kernel_stats.csv" % B))
-    sq1, gr = first_csv("pmc_wide_sq1", "counter_collection.csv"), first_csv("pmc_wide_grbm", "counter_collection.csv")
-    if sq1 and gr:
-        sub = "llk_eval_passes_kernel"          # (one launch of two passes of 24 points since round 4; VB2_PASSES=0: llk_eval_kernel x 3)
-        if avg_of(gr, sub, "GRBM_GUI_ACTIVE") is None:
-            sub = "llk_eval_kernel"
-        cyc = avg_of(gr, sub, "GRBM_GUI_ACTIVE") / 8.0
-        iv = avg_of(sq1, sub, "SQ_INSTS_VALU")
-        # (a %d-point call on this alphabet is several launches: per-launch counters, points per launch from the instruction count's
-        # ratio is not needed -- lane instructions are per marker x point of the launch's own points)
-        launches = len([1 for r in csv.DictReader(open(sq1)) if sub in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU"])
-        calls = 50 + 20
-        ppl = B / max(1.0, round(launches / float(calls)))
-        wv = {"_what": "the headline call on base qualities 2..60 (118 dictionary codes: three point groups' tables fit the LDS "
-                       "beside a compact exp table, a 48-point call is ONE launch of two passes -- llk_eval_passes_kernel): SQ / "
-                       "GRBM passes of `bench.py --q-lo 2 --q-hi 60 --no-extras`, per LAUNCH", "kernel": sub,
-              "markers": markers, "batch": B, "num_pc": k, "points_per_launch": ppl,
-              "lane_instr_per_marker_point": round(iv * 64 / (markers * ppl), 1),
-              "valu_busy_frac": round(avg_of(sq1, sub, "SQ_ACTIVE_INST_VALU") * 4 / (1024 * cyc), 3),
-              "lds_busy_frac": round(avg_of(sq1, sub, "SQ_LDS_IDX_ACTIVE") / (256 * cyc), 3),
-              "lds_bank_conflict_frac": round(avg_of(sq1, sub, "SQ_LDS_BANK_CONFLICT") / max(1.0, avg_of(sq1, sub, "SQ_LDS_IDX_ACTIVE")), 4)}
-        json.dump(wv, open(os.path.join(dst, "valu_b%d_wide.json" % B), "w"), indent=1)
-        print("wide alphabet:", wv["points_per_launch"], wv["lane_instr_per_marker_point"], wv["valu_busy_frac"], wv["lds_busy_frac"])
+for aname, qlo, qhi in (("wide", 2, 60), ("mid", 10, 45)):
+    ws = first_csv("trace_%s" % aname, "kernel_stats.csv")
+    if ws:
+        shutil.copy(ws, os.path.join(dst, "bench_b%d_%s_kernel_stats.csv" % (B, aname)))
+        sq1, gr = first_csv("pmc_%s_sq1" % aname, "counter_collection.csv"), first_csv("pmc_%s_grbm" % aname, "counter_collection.csv")
+        if sq1 and gr:
+            sub = "llk_eval_passes_kernel"          # (one launch of two passes of 24 points since round 4; VB2_PASSES=0: llk_eval_kernel x 3)
+            if avg_of(gr, sub, "GRBM_GUI_ACTIVE") is None:
+                sub = "llk_eval_kernel"
+            cyc = avg_of(gr, sub, "GRBM_GUI_ACTIVE") / 8.0
+            iv = avg_of(sq1, sub, "SQ_INSTS_VALU")
+            # (a %d-point call on this alphabet is several launches: per-launch counters, points per launch from the instruction count's
+            # ratio is not needed -- lane instructions are per marker x point of the launch's own points)
+            launches = len([1 for r in csv.DictReader(open(sq1)) if sub in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU"])
+            calls = 50 + 20
+            ppl = B / max(1.0, round(launches / float(calls)))
+            wv = {"_what": "the headline call on base qualities %d..%d (a dictionary this wide: three point groups' tables fit the LDS "
+                           "beside a compact exp table, a 48-point call is ONE launch of two passes -- llk_eval_passes_kernel): SQ / "
+                           "GRBM passes of `bench.py --q-lo %d --q-hi %d --no-extras`, per LAUNCH" % (qlo, qhi, qlo, qhi), "kernel": sub,
+                  "markers": markers, "batch": B, "num_pc": k, "points_per_launch": ppl,
+                  "lane_instr_per_marker_point": round(iv * 64 / (markers * ppl), 1),
+                  "valu_busy_frac": round(avg_of(sq1, sub, "SQ_ACTIVE_INST_VALU") * 4 / (1024 * cyc), 3),
+                  "lds_busy_frac": round(avg_of(sq1, sub, "SQ_LDS_IDX_ACTIVE") / (256 * cyc), 3),
+                  "lds_bank_conflict_frac": round(avg_of(sq1, sub, "SQ_LDS_BANK_CONFLICT") / max(1.0, avg_of(sq1, sub, "SQ_LDS_IDX_ACTIVE")), 4)}
+            json.dump(wv, open(os.path.join(dst, "valu_b%d_%s.json" % (B, aname)), "w"), indent=1)
+            print(aname, "alphabet:", wv["points_per_launch"], wv["lane_instr_per_marker_point"], wv["valu_busy_frac"], wv["lds_busy_frac"])
 cs = first_csv("trace_create", "kernel_stats.csv")
 if cs:
     shutil.copy(cs, os.path.join(dst, "create_kernel_stats.csv"))
