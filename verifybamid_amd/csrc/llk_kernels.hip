@@ -38,6 +38,9 @@
 #include "kernel_debug.h"
 #include "tile_sched.h"
 #include "tunables.h"
+#ifndef VB2_SIMD_DEAL
+#define VB2_SIMD_DEAL 1     // (0: wave w takes item w -- the A/B of the SIMD-balanced first deal, see eval_body)
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -929,9 +932,34 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // 15 at C3), and the idle waves are then the control wave's neighbours instead of the last two.  Same items, same slots: the
     // same bits.  OptimizeLLK 6.09 -> 6.04 ms on the same box.
     const int spare_rank = (wave & 3) ? (wave >> 2) * 3 + (wave & 3) - 1 : (nwave - (nwave >> 2)) + (wave >> 2) - 1;
+    // FEWER ITEMS THAN WAVES (a search round, the launches of one to four points): which wave takes which item decides how
+    // the rows are spread over the CU's four SIMDs (waves w, w + 4, w + 8, w + 12 share one).  The items are depth-sorted, so
+    // "wave w takes item w" gives SIMD 0 the deepest item of every four -- and a fourth item when there are thirteen -- and the
+    // round ends with that SIMD's last wave.  Instead: one SIMD takes the ceil(n / 4) SHALLOWEST items (in the control wave's
+    // workgroup: its SIMD, and one item fewer), the others share the rest in snake order; up to eight items: a snake over all
+    // four.  On the queue a tile's product has its own slot whichever wave computes it: the same bits.  OptimizeLLK at C3
+    // 5.86 -> 5.60 ms on one box (three alternating rounds; either workgroup kind alone: no gain -- the round ends with the
+    // other kind), the control wave's SIMD with ONE item as before: no gain; tables for 13 items built by hand: the same 5.59-5.61.
+    int deal_rank = hook_blk ? spare_rank : wave;
+    if (VB2_SIMD_DEAL && dyn && nwave == 16 && ONEGRP && nitem <= (uint32_t)(hook_blk ? 15 : 16)) {
+        const int n = (int)nitem, sd = wave & 3, sj = wave >> 2;
+        int r;
+        if (!hook_blk && n <= 8) r = sj == 0 ? sd : sj == 1 ? 7 - sd : n;
+        else {
+            const int c0 = ((n + 3) >> 2) - (hook_blk ? 1 : 0), nrest = n - c0;
+            if (sd == 0) {
+                const int j0 = sj - (hook_blk ? 1 : 0);
+                r = (j0 >= 0 && j0 < c0) ? nrest + j0 : n;
+            } else {
+                r = 3 * sj + ((sj & 1) ? 3 - sd : sd - 1);
+                if (r >= nrest) r = n;
+            }
+        }
+        deal_rank = r < n ? r : n;
+    }
     const uint32_t idx_first = hook_mine ? nitem
                                : have_sched ? (s_i < s_end ? (uint32_t)sch.item[s_i] : nitem)
-                                            : (uint32_t)(hook_blk ? spare_rank : wave);
+                                            : (uint32_t)deal_rank;
     if (PIPE && idx_first < nitem) {
         bool h0;
         const uint32_t mt0 = tile_of(idx_first, h0);
@@ -1038,8 +1066,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // waves fill the VALU slots in between (-0.8 % per launch measured; the other way round: +0.8 %)
         // A search round (the four-point shape on the work queue) has at most one item per wave, and the round ends with the
         // wave that holds the deepest tiles (17 rows at C3 against a median of 9: the first items of the low-numbered
-        // workgroups): the deeper a wave's item -- the lower its index -- the higher its priority on its SIMD (the four
-        // deepest items of a workgroup are on four different SIMDs).  OptimizeLLK 5.98 -> 5.90 ms on the same box.
+        // workgroups): the deeper a wave's item -- the lower its index -- the higher its priority on its SIMD (the three
+        // deepest items of a workgroup are on three different SIMDs: the first deal above).  OptimizeLLK 5.98 -> 5.90 ms on the same box.
         if (MODE == 3 && ONEGRP && dyn) {
             if (idx < 4u) __builtin_amdgcn_s_setprio(3);
             else if (idx < 8u) __builtin_amdgcn_s_setprio(2);
