@@ -522,8 +522,11 @@ def main():
                     "lds_busy_frac": wj.get("lds_busy_frac") if wj else None,
                     "lds_bank_conflict_frac": wj.get("lds_bank_conflict_frac") if wj else None, "pmc_source": wsrc,
                     "optimize": wopt, "create_ms": create_times(wide),
-                    "launch": "one launch of two passes of 24 points (llk_eval_passes_kernel: three point groups' tables fit in "
-                              "LDS beside a compact exp table) when the dictionary is this wide; VB2_PASSES=0: three launches of 16",
+                    "launch": ("one launch of two passes of 24 points (llk_eval_passes_kernel: three point groups' tables fit in "
+                               "LDS beside a compact exp table) when the dictionary is this wide; VB2_PASSES=0: three launches of 16"
+                               if winfo["num_code"] > 80 else
+                               "two launches of llk_eval_kernel<2,true>, 32 + 16 points (four point groups' tables fit in LDS); "
+                               "device_us_per_launch is the 48-point CALL, lane_instr_per_marker_point per launch's own points"),
                 }
                 return obj, wide, w_llk
             result["roofline_wide_alphabet"], wide, wide_llk = alphabet_leg(2, 60, "valu_b%d_wide.json" % B)
