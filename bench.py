@@ -132,10 +132,28 @@ def timed_launches(ctx, pts, out, B, stream, steps, torch):
     return 1e3 * e0.elapsed_time(e1) / steps          # us per launch
 
 
+_REAL_STDOUT = None
+
+
+def emit(result):
+    """The JSON line, on the process's real stdout (see main)."""
+    data = (json.dumps(result) + "\n").encode()
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args.gpus)
+
+    # stdout carries ONE line, the JSON: whatever native libraries print there on the way (librccl's version banner at
+    # communicator creation, ...) goes to stderr -- file descriptor 1 points at stderr until emit() writes the line
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -383,7 +401,7 @@ def main():
             if rank == 0:
                 import ctypes
                 ctypes.CDLL(None).fflush(None)
-                print(json.dumps(result), flush=True)
+                emit(result)
             os._exit(0)
         watchdog = threading.Timer(240.0, bail)
         watchdog.daemon = True
@@ -766,7 +784,7 @@ def main():
     import ctypes
     ctypes.CDLL(None).fflush(None)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     sys.stdout.flush()
     if not args.soft_exit:
         os._exit(0)
