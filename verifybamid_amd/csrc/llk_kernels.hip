@@ -38,6 +38,12 @@
 #include "kernel_debug.h"
 #include "tile_sched.h"
 #include "tunables.h"
+#ifndef VB2_PD_EMU
+#define VB2_PD_EMU 0        // (timing experiment, round 6: the instruction mix of a probability-domain body -- garbage results)
+#endif
+#ifndef VB2_PD_EXTRA
+#define VB2_PD_EXTRA 0
+#endif
 #ifndef VB2_SIMD_DEAL
 #define VB2_SIMD_DEAL 1     // (0: wave w takes item w -- the A/B of the SIMD-balanced first deal, see eval_body)
 #endif
@@ -349,6 +355,7 @@ __device__ __forceinline__ double table_entry(double alpha, double perr_signed, 
     const double one_minus_alpha = 1.0 - alpha;
     const double val = (alpha * e1 + one_minus_alpha * e2) * p_err +
                        (alpha * n1 + one_minus_alpha * n2) * p_ok;
+    if (VB2_PD_EMU) return val;
     return log_tab(val, ltab_addr);
 }
 
@@ -815,6 +822,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
             for (int i = 0; i < 3 * BTL; ++i) {
                 const vdouble2 t = row[i];
+                if (VB2_PD_EMU) {
+                    acc[2 * i] = t.x * ((kFirst && j == 0) ? init : acc[2 * i]);
+                    acc[2 * i + 1] = t.y * ((kFirst && j == 0) ? init : acc[2 * i + 1]);
+                    continue;
+                }
                 acc[2 * i] = fma(n, t.x, (kFirst && j == 0) ? init : acc[2 * i]);
                 acc[2 * i + 1] = fma(n, t.y, (kFirst && j == 0) ? init : acc[2 * i + 1]);
             }
@@ -878,6 +890,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 // not depend on (alpha, PC) and were taken at context creation.
                 double x01, x02, x10, x12, x20, x21;
                 const double a_min = vmin2_f64(vmin2_f64(vmin2_f64(a[0], a[1]), vmin2_f64(a[2], a[3])), vmin2_f64(a[4], a[5]));
+                if (VB2_PD_EMU) {
+                    x01 = a[0]; x02 = a[1]; x10 = a[2]; x12 = a[3]; x20 = a[4]; x21 = a[5];
+                } else
                 if (__builtin_expect(a_min < -708.0, 0)) {      // (wave-divergent, and never taken on whole-genome depths: exp_nonpos)
                     x01 = exp_nonpos<ESH, true>(a[0], etab_lane); x02 = exp_nonpos<ESH, true>(a[1], etab_lane);
                     x10 = exp_nonpos<ESH, true>(a[2], etab_lane); x12 = exp_nonpos<ESH, true>(a[3], etab_lane);
@@ -897,7 +912,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 // of LLK apart (markers with ~1000 reads).  There the sum is redone term by term in the
                 // reference's own order (g1 outer, g2 inner, h:307-309), as round 1 did everywhere;
                 // wave-divergent, and never taken on whole-genome depths.
-                if (__builtin_expect(lk < 0x1p-960, 0)) {
+                if (!VB2_PD_EMU && __builtin_expect(lk < 0x1p-960, 0)) {
                     double r = 0;
                     r += e0 * gf[0] * gf2[0];
                     r += x01 * gf[0] * gf2[1];
@@ -1078,7 +1093,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // (Context::create refuses more rows), and a row's address costs no 64-bit vector arithmetic
         const uint32_t cbase = LCACHE ? 0u : rec.x * (uint32_t)(kMtMarkers * 8) + (uint32_t)m * 8u;
         const uint32_t crow = rec.x + (uint32_t)m * 8u;      // (LCACHE: this lane's word of the tile's first row, LDS)
-        const int rows = have_tile ? (int)rec.y : 0;         // a scalar when TPW == 1
+        const int rows = have_tile ? (VB2_PD_EXTRA ? (int)(rec.y + (rec.y + 3u) / 7u) : (int)rec.y) : 0;         // a scalar when TPW == 1
         // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
         // tile's last row -- up to kPf useless row loads per item of 6..16 rows -- and every block of kPf rows begins
         // by waiting for all of them.  Measured on one box, depth 8 / 4 / 2: 48-point launch 74.9 / 74.4 / 76.6 us;
