@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VB2_ABI_VERSION 6
+#define VB2_ABI_VERSION 7
 
 typedef enum vb2_status {
     VB2_OK = 0,
@@ -108,6 +108,13 @@ typedef struct vb2_info {
     /* (ABI 4) HBM bytes ONE lock-step cohort step (vb2_batch_*) reads of this sample: run lists (16-bit
      * once built, see VB2_OPT_COHORT_LAYOUT) + tile records + panel rows + per-marker constants */
     int64_t cohort_step_bytes;
+    /* (ABI 7) how the sample is laid out in HBM: 1 = probability domain -- the per-alpha table holds the powers P^n of
+     * P(read | genotype pair, alpha) per quality and a marker's likelihoods are PRODUCTS of table rows, one step per row: no
+     * exp() per genotype pair (ContaminationEstimator.h:288-311 sums logarithms and exponentiates) -- taken when no marker's
+     * products can leave the normal double range; 0 = run words and sums of logarithms (any depth, quality 0).  The
+     * values agree to rounding either way.  num_table_row: rows of the per-alpha table. */
+    int32_t layout;
+    int32_t num_table_row;
 } vb2_info;
 
 /* Builds the device-resident SoA form of the input (classification, quality

@@ -34,7 +34,7 @@ def test_header_symbols_exported():
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vb2_abi_version() == 6
+    assert lib.vb2_abi_version() == 7
 
 
 def test_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
@@ -608,7 +608,8 @@ def test_run_scheduling_only_reorders_the_runs_of_a_marker():
     """Wide quality alphabets: a tile's runs are placed by schedule_tile (tile_sched.h) instead of in dictionary order.  The
     flatten's digest with the run words taken as a per-marker multiset (tunable digest_multiset) is the same with the
     scheduling on and off -- every run of every marker is still there, once, next to the same padding -- while the plain digest
-    differs (the order did change); a narrow alphabet is left alone either way."""
+    differs (the order did change); a narrow alphabet is left alone either way.  (Run-word layout only: VB2_PD=0 keeps the
+    samples out of the probability-domain layout, which has one step order.)"""
     import json
     import subprocess
     import sys
@@ -627,7 +628,7 @@ print(json.dumps([_flatten_digest(vb.synth.make_pileup(3000, 30, 2, seed=6, q_lo
     res = {}
     for sched in ("0", "1"):
         for mode in ("bytes", "multiset"):
-            env = dict(os.environ, VB2_RUN_SCHED=sched, VB2_DIGEST_MULTISET="1" if mode == "multiset" else "0")
+            env = dict(os.environ, VB2_RUN_SCHED=sched, VB2_DIGEST_MULTISET="1" if mode == "multiset" else "0", VB2_PD="0")
             if sched == "1":
                 del env["VB2_RUN_SCHED"]                   # (the default: scheduled above 48 codes)
             p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)

@@ -40,6 +40,7 @@ class Info(C.Structure):
         ("num_read_other", C.c_int64), ("num_code", C.c_int32), ("num_tile", C.c_int32),
         ("device_bytes", C.c_int64), ("algorithmic_bytes_per_eval", C.c_int64),
         ("device_name", C.c_char * 64), ("arch", C.c_char * 32), ("cohort_step_bytes", C.c_int64),
+        ("layout", C.c_int32), ("num_table_row", C.c_int32),
     ]
 
 

@@ -388,6 +388,24 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     }
     if (max_n == 0) return VB2_OK;
     if (const int rc = ensure_resources()) return rc;
+    {
+        // Samples of both layouts in one step (a probability-domain context next to one that could not take that layout: deep
+        // markers, quality 0): a launch runs ONE kind of kernel, so the probability-domain samples are evaluated first, on their
+        // own, and the others go on as this step.  A sample's values do not depend on which launch carries it.
+        bool any_pd = false, any_log = false;
+        for (int s = 0; s < num_sample; ++s)
+            if (num_point[s] > 0 && ctx_[s] && ctx_[s]->L.num_mt > 0) (ctx_[s]->L.pd ? any_pd : any_log) = true;
+        if (any_pd && any_log) {
+            std::vector<int32_t> np((size_t)num_sample);
+            const bool was_split = in_split_;
+            for (int s = 0; s < num_sample; ++s) np[s] = (ctx_[s] && ctx_[s]->L.pd) ? num_point[s] : 0;
+            if (const int rc = eval(np.data(), pc1, pc2, alpha, llk_out)) return rc;
+            for (int s = 0; s < num_sample; ++s) np[s] = (ctx_[s] && ctx_[s]->L.pd) ? 0 : num_point[s];
+            const int rc = eval_begin(np.data(), pc1, pc2, alpha, llk_out);
+            in_split_ = was_split;
+            return rc;
+        }
+    }
     if (strict_shapes && !in_split_) {
         // A step's wave shape follows from the LARGEST request in it, and under the static deal the shape decides which tiles a
         // wave multiplies together -- so a sample's sums would move in their last bits with what its neighbours happen to ask
@@ -493,6 +511,9 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     ml.shmem = shmem_[shape];
     ml.force_ticket = false;
     ml.w16 = w16_;
+    for (int s2 = 0; s2 < num_sample; ++s2)
+        if (h_nv_[s2] > 0 && ctx_[s2] && ctx_[s2]->L.pd) ml.pd = true;      // (the step's samples are of one layout: see the top)
+    if (ml.pd) ml.w16 = false;
     {   // (the pipelined item loop is compiled for the static deal: every sample of the cohort must run it)
         bool st = true;
         for (int s2 = 0; s2 < num_sample && st; ++s2)

@@ -389,6 +389,67 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     for (int idx = 0; idx < kMaxCode; ++idx)
         for (int g = 0; g < 3; ++g) lc3[(size_t)idx * 3 + g] = logc[((idx & 1) * kNumQual + qof[idx >> 1]) * 3 + g];
 
+    // ---- probability-domain layout (round 6; llk_kernels.h: kMaxPow): which powers P^n of a quality's table row exist ----
+    // A step multiplies a marker's six products by ONE table row, so a run of count c costs ceil(c / K) steps, K = the
+    // highest power its quality has a row for.  The K's must be known before the reads are walked (pass A counts steps),
+    // so they come from the run counts of a strided sample of markers: every quality starts at K = 1, and the rows the
+    // LDS has room for beyond that (pd_row_budget: the tables of a 48-point launch) go, one at a time, to the quality
+    // whose next power saves the most steps.  Any K's are correct; these are the cheapest.
+    const bool pd_wanted = tn.pd != 0 && M > 0 && in->bases && in->quals;
+    unsigned char kpow[kNumQual];
+    double lmin[kNumQual];
+    std::fill(kpow, kpow + kNumQual, (unsigned char)1);
+    for (int r = 0; r < kNumQual; ++r) {
+        const double pe = phred[qof[r]];
+        const double least = std::min(pe / 3.0, 1.0 - pe);            // the least P(read | genotype) of the quality, either class
+        lmin[r] = least > 0.0 ? -std::log2(least) : std::numeric_limits<double>::infinity();
+    }
+    if (pd_wanted) {
+        std::vector<int64_t> H((size_t)kNumQual * 64, 0);             // [rank][count, 63 = more] runs in the sample
+        uint32_t cnt2[2 * kNumQual];
+        std::fill(cnt2, cnt2 + 2 * kNumQual, 0u);
+        const int stride_m = std::max(1, M / kPdSampleMarkers);
+        bool seen[kNumQual];
+        std::fill(seen, seen + kNumQual, false);
+        for (int i = 0; i < M; i += stride_m) {
+            const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
+            if (depth <= 0 || depth > 4096) continue;                  // (deep markers: the context will not take this layout anyway)
+            const uint8_t alt_up = lut->up[(unsigned char)in->alt_base[i]];
+            for (int64_t j = 0; j < depth; ++j) {
+                const unsigned char b = (unsigned char)in->bases[beg + j];
+                const unsigned cls = lut->dot[b] ? 0u : (lut->up[b] == alt_up ? 1u : 2u);
+                if (cls == 2u) continue;
+                ++cnt2[lut->qidx[(unsigned char)in->quals[beg + j]] + cls];
+            }
+            for (int idx = 0; idx < 2 * kNumQual; ++idx)
+                if (cnt2[idx]) {
+                    ++H[(size_t)(idx >> 1) * 64 + std::min<uint32_t>(cnt2[idx], 63u)];
+                    seen[idx >> 1] = true;
+                    cnt2[idx] = 0;
+                }
+        }
+        int rows = 2;                                                   // (room for qualities the sample did not meet)
+        for (int r = 0; r < kNumQual; ++r) rows += seen[r] ? 1 : 0;
+        const int budget = tn.pd_rows > 0 ? tn.pd_rows : pd_row_budget(M, k, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+        auto steps_at = [&](int r, int kq) {
+            int64_t st = 0;
+            for (int c = 1; c < 64; ++c) st += H[(size_t)r * 64 + c] * ((c + kq - 1) / kq);
+            return st;
+        };
+        while (rows < budget) {
+            int best = -1;
+            int64_t best_gain = 0;
+            for (int r = 0; r < kNumQual; ++r) {
+                if (!seen[r] || kpow[r] >= kMaxPow) continue;
+                const int64_t gain = steps_at(r, kpow[r]) - steps_at(r, kpow[r] + 1);
+                if (gain > best_gain) { best_gain = gain; best = r; }
+            }
+            if (best < 0) break;
+            ++kpow[best];
+            ++rows;
+        }
+    }
+
     // a marker's runs, in dictionary order, at the position of its reads (runs <= reads): low byte idx, high byte count
     // (scratch that a thread creating one context after the other keeps: fresh pages cost more
     // than the passes that fill them)
@@ -425,6 +486,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     const size_t i_qidx = icarve(device_flatten ? 256 : 0);
     const size_t i_olc = icarve(device_flatten ? 256 * sizeof(double) : 0);
     const size_t i_lc3 = icarve(device_flatten ? (size_t)kMaxCode * 3 * sizeof(double) : 0);
+    const size_t i_kpow = icarve(device_flatten && pd_wanted ? (size_t)kNumQual : 0);
+    const size_t i_lmin = icarve(device_flatten && pd_wanted ? (size_t)kNumQual * sizeof(double) : 0);
     const size_t i_ud = icarve(in->known_af ? 0 : (size_t)M * k * sizeof(double));
     const size_t i_mu = icarve(in->known_af ? 0 : (size_t)M * sizeof(double));
     const size_t i_kaf = icarve(in->known_af ? (size_t)M * sizeof(double) : 0);
@@ -436,10 +499,12 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     const size_t up2_end = in_total;
     // (c) pass A's results: written by the host flatten (and uploaded), or by classify_kernel (eff_all and hist come back)
     const size_t i_effall = icarve(device_flatten ? (size_t)M * sizeof(int32_t) : 0);
-    const size_t i_hist = icarve(device_flatten ? (size_t)(kMaxCode + 2) * sizeof(unsigned long long) : 0);
+    const size_t i_effpd = icarve(device_flatten && pd_wanted ? (size_t)M * sizeof(uint32_t) : 0);
+    const size_t i_hist = icarve(device_flatten ? (size_t)kHistWords * sizeof(unsigned long long) : 0);
     const size_t down_end = in_total;
     const size_t i_runs = icarve(n_reads_al * sizeof(uint16_t));
     const size_t i_cd = icarve((size_t)M * 4 * sizeof(double));
+    const size_t i_pother = icarve(pd_wanted ? (size_t)M * sizeof(double) : 0);
     in_total = (in_total + 255) & ~(size_t)255;
     const size_t pinned_need = device_flatten ? ((down_end + 255) & ~(size_t)255) : in_total;   // (the device keeps runs and cd to itself)
     struct InGuard {                          // the pinned slab of the pack kernel's inputs: back to the cache on every way out
@@ -473,6 +538,13 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     }
     std::vector<int32_t> eff_host(device_flatten ? 0 : M, -1);   // -1: marker does not count
     int32_t* const eff_all = device_flatten ? reinterpret_cast<int32_t*>(in_stage.p + i_effall) : eff_host.data();
+    // probability-domain bookkeeping of pass A: a marker's steps (ref | alt << 16) and exp(c_other)
+    std::vector<uint32_t> effpd_host(device_flatten || !pd_wanted ? 0 : M, 0u);
+    uint32_t* const eff_pd = !pd_wanted ? nullptr : device_flatten ? reinterpret_cast<uint32_t*>(in_stage.p + i_effpd) : effpd_host.data();
+    std::vector<double> pother_host((device_flatten || device_pack_wanted || !pd_wanted) ? 0 : M, 0.0);
+    double* const pother = !pd_wanted || device_flatten ? nullptr
+                           : device_pack_wanted ? reinterpret_cast<double*>(in_stage.p + i_pother) : pother_host.data();
+    double max_bound = 0.0;
     const size_t runs_need = (size_t)std::max<int64_t>(total_reads, 1), cd_need = (size_t)std::max(M, 1) * 4;
     if (!device_pack_wanted) {
         if (scratch.runs_cap < runs_need || scratch.runs_cap > 4 * runs_need + (1u << 20)) {
@@ -504,6 +576,10 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         std::memcpy(inp + i_qidx, lut->qidx, 256);
         std::memcpy(inp + i_olc, lut->other_lc, 256 * sizeof(double));
         std::memcpy(inp + i_lc3, lc3.data(), (size_t)kMaxCode * 3 * sizeof(double));
+        if (pd_wanted) {
+            std::memcpy(inp + i_kpow, kpow, kNumQual);
+            std::memcpy(inp + i_lmin, lmin, kNumQual * sizeof(double));
+        }
         if (in->known_af) std::memcpy(inp + i_kaf, in->known_af, (size_t)M * sizeof(double));
         else {
             std::memcpy(inp + i_ud, in->ud, (size_t)M * k * sizeof(double));
@@ -511,7 +587,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         }
         t_staged = tnow();
         VB2_HIP(hipMemcpyAsync(din, inp, up1_end, hipMemcpyHostToDevice, c->stream));
-        VB2_HIP(hipMemsetAsync(din + i_hist, 0, (size_t)(kMaxCode + 2) * sizeof(unsigned long long), c->stream));
+        VB2_HIP(hipMemsetAsync(din + i_hist, 0, (size_t)kHistWords * sizeof(unsigned long long), c->stream));
         ClassifyArgs ca;
         std::memset(&ca, 0, sizeof(ca));
         ca.bases = reinterpret_cast<const unsigned char*>(din + i_bases);
@@ -530,6 +606,12 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         ca.sanity = in->sanity_disabled ? 0 : 1;
         ca.lo = lo;
         ca.hi = hi;
+        if (pd_wanted) {
+            ca.kpow = reinterpret_cast<const unsigned char*>(din + i_kpow);
+            ca.lmin = reinterpret_cast<const double*>(din + i_lmin);
+            ca.eff_pd = reinterpret_cast<uint32_t*>(din + i_effpd);
+            ca.pother = reinterpret_cast<double*>(din + i_pother);
+        }
         VB2_HIP(launch_classify(ca, c->stream));
         VB2_HIP(hipMemcpyAsync(inp + i_effall, din + i_effall, down_end - i_effall, hipMemcpyDeviceToHost, c->stream));
         VB2_HIP(hipStreamSynchronize(c->stream));
@@ -537,9 +619,11 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         for (int c2 = 0; c2 < kMaxCode; ++c2) code_hist[c2] = (int64_t)hist[c2];
         num_read = (int64_t)hist[kMaxCode];
         num_other = (int64_t)hist[kMaxCode + 1];
+        std::memcpy(&max_bound, &hist[kMaxCode + 2], sizeof(double));
     } else {
         std::vector<std::vector<int64_t>> hist_t(nthr, std::vector<int64_t>(kMaxCode, 0));
         std::vector<int64_t> reads_t(nthr, 0), other_t(nthr, 0);
+        std::vector<double> bound_t(nthr, 0.0);
         // class of a base given the marker's alt allele, one table row per (upper-cased) alt: 0 ref
         // ('.' ','), 1 alt, 2 other
         static const struct ClassTable {
@@ -560,6 +644,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             std::fill(&cnt[0][0], &cnt[0][0] + 4 * 3 * 64, 0u);
             std::vector<int64_t>& hist = hist_t[t];
             int64_t n_read = 0, n_other = 0;          // thread-local: no shared cache lines in the loop
+            double bound_max = 0.0;
             const Luts& T = *lut;
             for (int64_t i = i0; i < i1; ++i) {
                 const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
@@ -601,6 +686,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 uint16_t* out = runs + (beg - read_base);
                 int32_t eff = 0;
                 double dg[3] = {0.0, 0.0, 0.0};
+                uint32_t steps_ref = 0, steps_alt = 0;
+                double bound = 0.0;
                 for (int w = 0; w < 3; ++w)
                     for (uint64_t bits = bm[w]; bits; bits &= bits - 1) {
                         const unsigned idx = (unsigned)w * 64u + (unsigned)__builtin_ctzll(bits);
@@ -610,10 +697,14 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                         const double n = (double)left;
                         const double* lc = &lc3[(size_t)idx * 3];
                         dg[0] += n * lc[0]; dg[1] += n * lc[1]; dg[2] += n * lc[2];
+                        const uint32_t kq = kpow[idx >> 1];
+                        if (pd_wanted) bound += n * lmin[idx >> 1];
                         while (left > 0) {
                             const uint32_t c1 = left > (uint32_t)kMaxRunCount ? (uint32_t)kMaxRunCount : left;
                             out[eff++] = (uint16_t)(idx | (c1 << 8));
                             left -= c1;
+                            const uint32_t st = (c1 + kq - 1u) / kq;
+                            if (idx & 1u) steps_alt += st; else steps_ref += st;
                         }
                     }
                 // the g1 == g2 terms of h:307-311 are constants of the marker
@@ -622,13 +713,23 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 cd[1] = std::exp(dg[0] + c_other);
                 cd[2] = std::exp(dg[1] + c_other);
                 cd[3] = std::exp(dg[2] + c_other);
+                if (pd_wanted) {
+                    pother[i] = std::exp(c_other);
+                    bound += c_other * -0x1.71547652b82fep+0;
+                    if (steps_ref > 0xffffu || steps_alt > 0xffffu) bound = 1e300;
+                    if (!(bound >= 0.0)) bound = 1e300;
+                    bound_max = std::max(bound_max, bound);
+                    eff_pd[i] = (steps_ref & 0xffffu) | (steps_alt << 16);
+                }
                 n_read += depth;
                 eff_all[i] = eff;
             }
             reads_t[t] = n_read;
             other_t[t] = n_other;
+            bound_t[t] = bound_max;
         });
         for (int t = 0; t < nthr; ++t) {
+            max_bound = std::max(max_bound, bound_t[t]);
             num_read += reads_t[t];
             num_other += other_t[t];
             for (int c2 = 0; c2 < kMaxCode; ++c2) code_hist[c2] += hist_t[t][c2];
@@ -650,64 +751,152 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             dict_of[idx] = (uint8_t)order.size();
             order.push_back((idx & 1) * kNumQual + qof[idx >> 1]);
         }
-    const int num_code = (int)order.size();
-    std::vector<double> dict_perr(num_code);
-    for (int d = 0; d < num_code; ++d) {
-        const double pe = phred[order[d] % kNumQual];
-        dict_perr[d] = (order[d] / kNumQual) ? -pe : pe;      // sign carries the class
-    }
-
-    // ---- primary codes of the per-alpha table: all ref codes (with the alt code of the same
-    // quality as twin, if that occurs) and the alt codes without a ref partner ----
+    const int num_code_seen = (int)order.size();              // distinct (class, quality) codes of the data
+    // The probability-domain layout is taken when no counted marker can underflow in it (max_bound: every read at its least
+    // likely genotype pair, times the "other" reads' constant, stays a normal double) -- which also rules out quality 0,
+    // whose entries can be exactly 0 or arbitrarily small (bound = inf) -- and the table's rows fit 16-bit offsets.
+    int pd_rows = 0;
+    for (int r = 0; r < kNumQual; ++r)
+        if (code_hist[2 * r] + code_hist[2 * r + 1] > 0) pd_rows += kpow[r];
+    const bool pd = pd_wanted && m_active > 0 && max_bound <= kPdMaxBound && pd_rows <= kMaxWideCodes && tn.force_narrow == 0;
+    int num_code = num_code_seen;                             // rows of the per-alpha table (the padding row not counted)
+    std::vector<double> dict_perr;
     std::vector<double2> prim;
-    auto prim_rec = [&](int d, uint32_t twin) {
-        const unsigned long long bits = (unsigned long long)((uint32_t)d | (twin << 16));
-        double y;
-        std::memcpy(&y, &bits, sizeof(y));
-        prim.push_back(make_double2(dict_perr[d], y));
-    };
-    for (int idx = 0; idx < kMaxCode; ++idx) {
-        const int d = dict_of[idx];
-        if (d == kPadCode) continue;
-        if ((idx & 1) == 0) {
-            const int t = dict_of[idx | 1];
-            prim_rec(d, t == kPadCode ? 0xffffu : (uint32_t)t);
-        } else if (dict_of[idx & ~1] == kPadCode) {
-            prim_rec(d, 0xffffu);
+    uint16_t row_off_pd[kNumQual][kMaxPow + 1];
+    std::memset(row_off_pd, 0, sizeof(row_off_pd));
+    if (!pd) {
+        dict_perr.resize(num_code);
+        for (int d = 0; d < num_code; ++d) {
+            const double pe = phred[order[d] % kNumQual];
+            dict_perr[d] = (order[d] / kNumQual) ? -pe : pe;      // sign carries the class
+        }
+        // ---- primary codes of the per-alpha table: all ref codes (with the alt code of the same
+        // quality as twin, if that occurs) and the alt codes without a ref partner ----
+        auto prim_rec = [&](int d, uint32_t twin) {
+            const unsigned long long bits = (unsigned long long)((uint32_t)d | (twin << 16));
+            double y;
+            std::memcpy(&y, &bits, sizeof(y));
+            prim.push_back(make_double2(dict_perr[d], y));
+        };
+        for (int idx = 0; idx < kMaxCode; ++idx) {
+            const int d = dict_of[idx];
+            if (d == kPadCode) continue;
+            if ((idx & 1) == 0) {
+                const int t = dict_of[idx | 1];
+                prim_rec(d, t == kPadCode ? 0xffffu : (uint32_t)t);
+            } else if (dict_of[idx & ~1] == kPadCode) {
+                prim_rec(d, 0xffffu);
+            }
+        }
+    } else {
+        // rows: quality after quality in rank order, P^1 .. P^K of each -- a marker's steps walk the table upwards
+        num_code = pd_rows;
+        for (int r = 0; r < kNumQual; ++r) {
+            if (code_hist[2 * r] + code_hist[2 * r + 1] == 0) continue;
+            for (int n = 1; n <= kpow[r]; ++n) {
+                row_off_pd[r][n] = (uint16_t)(prim.size() * kRowBytesWide);
+                prim.push_back(make_double2(phred[qof[r]], (double)n));
+                dict_perr.push_back(phred[qof[r]]);
+            }
         }
     }
 
     // ---- sort markers by effective depth (descending, stable); 16-marker micro-tiles ----
     // counting sort = the stable descending sort by run count (ties keep panel order)
     std::vector<int64_t> perm(m_active);
-    {
+    int num_mt = (int)((m_active + kMtMarkers - 1) / kMtMarkers);
+    std::vector<uint32_t> mt_row_off, mt_rows, mt_rec_y;
+    uint64_t total_rows = 0;
+    if (!pd) {
         int32_t dmax = 0;
         for (int64_t a = 0; a < m_active; ++a) dmax = std::max(dmax, eff_depth[a]);
         std::vector<int64_t> start((size_t)dmax + 2, 0);
         for (int64_t a = 0; a < m_active; ++a) ++start[(size_t)(dmax - eff_depth[a]) + 1];
         for (size_t d = 1; d < start.size(); ++d) start[d] += start[d - 1];
         for (int64_t a = 0; a < m_active; ++a) perm[start[(size_t)(dmax - eff_depth[a])]++] = a;
+        // (Measured and dropped, round 4.  Workgroup b owns the micro-tiles b, b + grid, ...: in this plainly descending list it gets
+        // the deepest tile of every stripe of `grid` tiles and the last workgroup the shallowest, ~4 % more rows at C3.  (a) Every
+        // other stripe of num_cu tiles in ASCENDING order, a snake that evens the workgroups out: 48-point launch 65.17 / 65.47 us
+        // plain, 65.30 / 65.27 us snaked on the same box, OptimizeLLK 6.12 / 6.10 ms either way -- the 61-67 us over which the
+        // workgroups of a launch finish their tiles follow the CUs (two or three XCDs of a box run slower), not the tile list.
+        // (b) The snake plus position 0 of every stripe = the stripe's SHALLOWEST tile, so that workgroup 0 -- it hosts the wave
+        // that runs the simplex and is the last to have its block sums in a search round, 9.6 us against a median of 8.3 -- has
+        // the least tile work: its block sums were as late as before (its lateness is not tile work) and OptimizeLLK went
+        // 6.12 -> 6.22-6.28 ms.)
+        mt_row_off.resize(num_mt);
+        mt_rows.resize(num_mt);
+        for (int t = 0; t < num_mt; ++t) {
+            const int32_t dm = eff_depth[perm[(int64_t)t * kMtMarkers]];   // first lane is deepest
+            mt_row_off[t] = (uint32_t)total_rows;
+            mt_rows[t] = (uint32_t)((dm + 1) / 2);             // two runs per dword
+            total_rows += mt_rows[t];
+        }
+        mt_rec_y = mt_rows;
+    } else {
+        // Two phases per tile: its markers' ref steps, then their alt steps (class alt reads the table rows mirrored: the
+        // second loop of the kernels names the accumulators the other way round).  A tile's phases are as long as its
+        // longest marker's, so the markers are sorted by (alt rows, ref steps) -- descending, stable -- and cut into tiles of
+        // 16 neighbours; the FULL tiles are then put in descending order of their rows (ties: more alt rows first), so that
+        // workgroups and waves take them longest first and the two tiles a paired wave shape walks side by side have the
+        // same phases; the last, partial tile stays last (positions past the last marker are at the end of every array).
+        std::vector<uint32_t> sref(m_active), salt(m_active);
+        uint32_t ra_max = 0, sr_max = 0;
+        for (int64_t a = 0; a < m_active; ++a) {
+            const uint32_t e = eff_pd[active[a]];
+            sref[a] = e & 0xffffu;
+            salt[a] = e >> 16;
+            ra_max = std::max(ra_max, (salt[a] + 1) / 2);
+            sr_max = std::max(sr_max, sref[a]);
+        }
+        std::vector<int64_t> p1(m_active);
+        {
+            const uint64_t width = (uint64_t)sr_max + 1, nkey = ((uint64_t)ra_max + 1) * width;
+            auto key = [&](int64_t a) { return (uint64_t)((salt[a] + 1) / 2) * width + sref[a]; };
+            if (nkey <= (1u << 22)) {
+                std::vector<int64_t> start((size_t)nkey + 1, 0);
+                for (int64_t a = 0; a < m_active; ++a) ++start[(size_t)(nkey - 1 - key(a)) + 1];
+                for (size_t d = 1; d < start.size(); ++d) start[d] += start[d - 1];
+                for (int64_t a = 0; a < m_active; ++a) p1[start[(size_t)(nkey - 1 - key(a))]++] = a;
+            } else {
+                std::iota(p1.begin(), p1.end(), (int64_t)0);
+                std::stable_sort(p1.begin(), p1.end(), [&](int64_t x, int64_t y) { return key(x) > key(y); });
+            }
+        }
+        const int full = (int)(m_active / kMtMarkers), tiles = num_mt;
+        std::vector<uint32_t> rr(tiles, 0), ra(tiles, 0);
+        for (int t = 0; t < tiles; ++t)
+            for (int64_t m = (int64_t)t * kMtMarkers; m < std::min<int64_t>(m_active, (int64_t)(t + 1) * kMtMarkers); ++m) {
+                rr[t] = std::max(rr[t], (sref[p1[m]] + 1) / 2);
+                ra[t] = std::max(ra[t], (salt[p1[m]] + 1) / 2);
+            }
+        std::vector<int> torder(tiles);
+        std::iota(torder.begin(), torder.end(), 0);
+        std::stable_sort(torder.begin(), torder.begin() + full, [&](int x, int y) {
+            const uint32_t rx = rr[x] + ra[x], ry = rr[y] + ra[y];
+            return rx != ry ? rx > ry : ra[x] > ra[y];
+        });
+        if (num_mt & 1) ++num_mt;                               // (a workgroup owns PAIRS of tiles: llk_kernels.h, owned_tile)
+        mt_row_off.resize(num_mt);
+        mt_rows.assign(num_mt, 0u);
+        mt_rec_y.assign(num_mt, 0u);
+        for (int t = 0; t < num_mt; ++t) {
+            mt_row_off[t] = (uint32_t)total_rows;
+            if (t >= tiles) continue;
+            const int src_t = torder[t];
+            if (rr[src_t] > 0xffffu || ra[src_t] > 0xffffu) {     // (ruled out by pass A's bound: steps beyond 16 bits)
+                set_error("vb2_ctx_create: a marker needs more than 131070 steps");
+                return VB2_ERR_INVALID;
+            }
+            mt_rows[t] = rr[src_t] + ra[src_t];
+            mt_rec_y[t] = rr[src_t] | (ra[src_t] << 16);
+            total_rows += mt_rows[t];
+            for (int64_t l = 0; l < kMtMarkers; ++l) {
+                const int64_t from = (int64_t)src_t * kMtMarkers + l;
+                if (from < m_active) perm[(int64_t)t * kMtMarkers + l] = p1[from];
+            }
+        }
     }
-    const int num_mt = (int)((m_active + kMtMarkers - 1) / kMtMarkers);
     const int64_t m_pad = (int64_t)num_mt * kMtMarkers;
-    // (Measured and dropped, round 4.  Workgroup b owns the micro-tiles b, b + grid, ...: in this plainly descending list it gets
-    // the deepest tile of every stripe of `grid` tiles and the last workgroup the shallowest, ~4 % more rows at C3.  (a) Every
-    // other stripe of num_cu tiles in ASCENDING order, a snake that evens the workgroups out: 48-point launch 65.17 / 65.47 us
-    // plain, 65.30 / 65.27 us snaked on the same box, OptimizeLLK 6.12 / 6.10 ms either way -- the 61-67 us over which the
-    // workgroups of a launch finish their tiles follow the CUs (two or three XCDs of a box run slower), not the tile list.
-    // (b) The snake plus position 0 of every stripe = the stripe's SHALLOWEST tile, so that workgroup 0 -- it hosts the wave
-    // that runs the simplex and is the last to have its block sums in a search round, 9.6 us against a median of 8.3 -- has
-    // the least tile work: its block sums were as late as before (its lateness is not tile work) and OptimizeLLK went
-    // 6.12 -> 6.22-6.28 ms.)
-
-    std::vector<uint32_t> mt_row_off(num_mt), mt_rows(num_mt);
-    uint64_t total_rows = 0;
-    for (int t = 0; t < num_mt; ++t) {
-        const int32_t dmax = eff_depth[perm[(int64_t)t * kMtMarkers]];   // first lane is deepest
-        mt_row_off[t] = (uint32_t)total_rows;
-        mt_rows[t] = (uint32_t)((dmax + 1) / 2);             // two runs per dword
-        total_rows += mt_rows[t];
-    }
     if (total_rows + kCodeSlackRows >= (1ull << 25)) {       // (rows of 128 bytes, addressed by 32-bit byte offsets in the kernels)
         set_error("vb2_ctx_create: input too large for 32-bit row offsets");
         return VB2_ERR_INVALID;
@@ -723,7 +912,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // Two runs per (row, marker) entry.  16-bit offsets reach 163 wide rows; a bigger dictionary
     // gets the narrow rows (and 4-point launches only).
     const bool force_narrow = tn.force_narrow != 0;
-    const int row_bytes = (num_code <= kMaxWideCodes && !force_narrow) ? kRowBytesWide : kRowBytesNarrow;
+    const int row_bytes = (pd || (num_code <= kMaxWideCodes && !force_narrow)) ? kRowBytesWide : kRowBytesNarrow;
     auto run_word = [&](int d, uint32_t n) {
         const double nd = (double)n;
         unsigned long long bits;
@@ -731,12 +920,14 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         return (uint32_t)(d * row_bytes) | ((uint32_t)(bits >> 48) << 16);
     };
     const uint32_t pad4 = run_word(num_code, 0);
+    const uint32_t pad_off = (uint32_t)(num_code * row_bytes);        // probability domain: the row of ones
     uint32_t row_of_idx[kMaxCode], hi_of_count[kMaxRunCount + 1];     // the two halves of a run word, by table
     for (int idx = 0; idx < kMaxCode; ++idx) row_of_idx[idx] = dict_of[idx] == kPadCode ? 0u : (uint32_t)(dict_of[idx] * row_bytes);
     for (int n = 0; n <= kMaxRunCount; ++n) hi_of_count[n] = run_word(0, (uint32_t)n);
     // wide quality alphabets: a tile's runs are placed by schedule_tile (tile_sched.h) instead of in plain dictionary order
     // (Tunables::run_sched 0: plain order always; 1: scheduled whatever the dictionary's size)
-    const bool run_sched = tn.run_sched < 0 ? num_code > kSchedMinCodes : tn.run_sched != 0;
+    const bool run_sched = pd ? false : tn.run_sched < 0 ? num_code > kSchedMinCodes : tn.run_sched != 0;
+    const bool pd_sched = pd && tn.run_sched != 0;            // (probability domain: a phase's steps are always placed; 0: plain order)
 
     // ---- device memory: ONE allocation per context, carved into 256-byte aligned pieces.
     // (A cohort creates contexts from many host threads; allocation calls go through driver
@@ -756,7 +947,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         dev_total = off + bytes;
         return off;
     };
-    const size_t n_codes = (size_t)(total_rows + kCodeSlackRows) * kMtMarkers * 2;   // + prefetch slack
+    const size_t n_codes = (size_t)(total_rows + kCodeSlackRows) * kMtMarkers * (pd ? 1 : 2);   // + prefetch slack (pd: two 16-bit steps per word)
     const size_t o_codes = carve(n_codes * sizeof(uint32_t));
     const size_t o_rec = carve((size_t)num_mt * sizeof(uint2));
     const size_t o_ud = carve(in->known_af ? 0 : (size_t)k * m_pad * sizeof(double));
@@ -767,7 +958,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     const size_t o_prim = carve(prim.size() * sizeof(double2));
     // cohort-step run lists (VB2_OPT_COHORT_LAYOUT): the tile records travel with the data block, the
     // 16-bit words themselves are made on the device from `codes` (pack_codes16_kernel)
-    const bool want16 = opt && (opt->flags & VB2_OPT_COHORT_LAYOUT) && num_mt > 0;
+    const bool want16 = !pd && opt && (opt->flags & VB2_OPT_COHORT_LAYOUT) && num_mt > 0;
     std::vector<uint2> rec16;
     uint64_t total_rows16 = 0;
     if (want16) {
@@ -821,12 +1012,15 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     double* const mu_s = reinterpret_cast<double*>(stage + o_mu);
     double* const kaf_s = reinterpret_cast<double*>(stage + o_kaf);
     double* const cdiag = reinterpret_cast<double*>(stage + o_cd);
-    for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rows[t]);
+    for (int t = 0; t < num_mt; ++t) mt_rec[t] = make_uint2(mt_row_off[t], mt_rec_y[t]);
     if (!dict_perr.empty()) std::memcpy(stage + o_dpe, dict_perr.data(), dict_perr.size() * sizeof(double));
     if (!prim.empty()) std::memcpy(stage + o_prim, prim.data(), prim.size() * sizeof(double2));
     if (want16) std::memcpy(stage + o_rec16, rec16.data(), rec16.size() * sizeof(uint2));
     // padding: the slack rows behind the last tile, and the (< 16) marker positions past the last active one
-    if (!device_pack) std::fill(codes + (size_t)total_rows * kMtMarkers * 2, codes + n_codes, pad4);
+    if (!device_pack) {
+        if (pd) std::fill(codes + (size_t)total_rows * kMtMarkers, codes + n_codes, pad_off | (pad_off << 16));
+        else std::fill(codes + (size_t)total_rows * kMtMarkers * 2, codes + n_codes, pad4);
+    }
     for (int64_t m = device_pack ? m_pad : m_active; m < m_pad; ++m) {
         if (in->known_af) kaf_s[m] = 0.0;
         else {
@@ -835,6 +1029,11 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         }
         for (int q = 0; q < 4; ++q) cdiag[(size_t)q * m_pad + m] = 0.0;
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
+        if (pd) {
+            uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers;
+            for (size_t r = 0; r < (size_t)mt_rows[t]; ++r) row0[r * kMtMarkers + lane] = pad_off | (pad_off << 16);
+            continue;
+        }
         uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
         for (size_t j = 0; j < (size_t)mt_rows[t] * 2; ++j) row0[((j >> 1) * kMtMarkers + lane) * 2 + (j & 1)] = pad4;
     }
@@ -883,6 +1082,35 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         // runs in dictionary order: lanes of a wave then tend to hit the same or
         // neighbouring LDS table rows at the same step (bank-friendly)
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
+        if (pd && pd_sched) {
+            // (the tiles' steps are written below, placed by schedule_tile)
+        } else if (pd) {
+            // the marker's steps (pack_pd_kernel, statement for statement): ref runs, then alt runs, a run of count c as
+            // ceil(c / K) row offsets; either phase padded to the tile's rows with the row of ones
+            uint32_t* out = codes + (size_t)mt_row_off[t] * kMtMarkers + lane;
+            const uint32_t rows_ref = mt_rec_y[t] & 0xffffu, rows_alt = mt_rec_y[t] >> 16;
+            uint32_t step = 0, cur = 0;
+            auto put = [&](uint32_t off) {
+                if (step & 1u) out[(size_t)(step >> 1) * kMtMarkers] = cur | (off << 16);
+                else cur = off;
+                ++step;
+            };
+            for (uint32_t cls = 0; cls < 2; ++cls) {
+                for (size_t j = 0; j < eff; ++j) {
+                    const uint32_t rw = src[j], idx = rw & 0xffu;
+                    if ((idx & 1u) != cls) continue;
+                    const uint32_t rank = idx >> 1, kq = kpow[rank];
+                    uint32_t left = rw >> 8;
+                    while (left > 0u) {
+                        const uint32_t c1 = left > kq ? kq : left;
+                        put(row_off_pd[rank][c1]);
+                        left -= c1;
+                    }
+                }
+                const uint32_t end = 2u * (cls == 0 ? rows_ref : rows_ref + rows_alt);
+                while (step < end) put(pad_off);
+            }
+        } else {
         uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
         const size_t slots = (size_t)mt_rows[t] * 2;
         size_t j = run_sched ? slots : 0;                  // (scheduled: the tiles' run words are written below)
@@ -891,6 +1119,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             row0[((j >> 1) * kMtMarkers + lane) * 2 + (j & 1)] = row_of_idx[rw & 0xffu] | hi_of_count[rw >> 8];
         }
         for (; j < slots; ++j) row0[((j >> 1) * kMtMarkers + lane) * 2 + (j & 1)] = pad4;
+        }
         if (in->known_af) {
             kaf_s[m] = in->known_af[i];
         } else {
@@ -898,13 +1127,57 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             mu_s[m] = in->means[i];
         }
         const double* cd = cd_tmp + (size_t)i * 4;
-        cdiag[m] = cd[0];
+        cdiag[m] = pd ? pother[i] : cd[0];
         cdiag[m_pad + m] = cd[1];
         cdiag[2 * m_pad + m] = cd[2];
         cdiag[3 * m_pad + m] = cd[3];
     }
     });
 
+    if (!device_pack && pd && pd_sched)
+        parallel_for(num_mt, [&](int, int64_t t0, int64_t t1) {
+            // pack_pd_sched_kernel's work, tile after tile: a phase's steps as row indices, placed by schedule_tile
+            TileSched S;
+            struct Ident { int operator[](uint32_t i) const { return (int)i; } } ident;
+            std::vector<uint16_t> lst[kMtMarkers];
+            for (int64_t t = t0; t < t1; ++t) {
+                uint32_t first_step = 0;
+                for (uint32_t cls = 0; cls < 2; ++cls) {
+                    const int steps = (int)(2u * (cls == 0 ? (mt_rec_y[t] & 0xffffu) : (mt_rec_y[t] >> 16)));
+                    uint32_t* out = codes + ((size_t)mt_row_off[t] + (first_step >> 1)) * kMtMarkers;
+                    uint32_t eff16[kMtMarkers];
+                    for (int l = 0; l < kMtMarkers; ++l) {
+                        lst[l].clear();
+                        const int64_t m = t * kMtMarkers + l;
+                        if (m < m_active) {
+                            const int i = active[perm[m]];
+                            const uint16_t* src = runs + (in->read_off[i] - read_base);
+                            for (int32_t j = 0; j < eff_all[i]; ++j) {
+                                const uint32_t rw = src[j], idx = rw & 0xffu;
+                                if ((idx & 1u) != cls) continue;
+                                const uint32_t rank = idx >> 1, kq = kpow[rank];
+                                uint32_t left = rw >> 8;
+                                while (left > 0u) {
+                                    const uint32_t c1 = left > kq ? kq : left;
+                                    lst[l].push_back((uint16_t)(row_off_pd[rank][c1] / (uint32_t)row_bytes));
+                                    left -= c1;
+                                }
+                            }
+                        }
+                        eff16[l] = (uint32_t)lst[l].size();
+                    }
+                    auto half = [&](int l, int c, uint32_t off) {
+                        uint32_t& w = out[(size_t)(c >> 1) * kMtMarkers + l];
+                        w = (c & 1) ? ((w & 0xffffu) | (off << 16)) : ((w & 0xffff0000u) | off);
+                    };
+                    schedule_tile(S, eff16, steps, num_code, ident,
+                                  [&](int l, int j) -> uint32_t { return lst[l][j]; },
+                                  [&](int l, int c, uint32_t rw) { half(l, c, rw * (uint32_t)row_bytes); },
+                                  [&](int l, int c) { half(l, c, pad_off); });
+                    first_step += (uint32_t)steps;
+                }
+            }
+        });
     if (!device_pack && run_sched)
         parallel_for(num_mt, [&](int, int64_t t0, int64_t t1) {
             TileSched S;
@@ -938,7 +1211,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         };
         // (Tunables::digest_multiset, a test aid: the run words enter as a SUM of word hashes per micro-tile -- the same for
         // any order of a tile's words: what schedule_tile may change and nothing else)
-        if (tn.digest_multiset) {
+        if (tn.digest_multiset && !pd) {
             for (int t = 0; t < num_mt; ++t) {
                 uint64_t sum = 0;
                 const uint32_t* w = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
@@ -989,6 +1262,38 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             VB2_HIP(hipMemcpyAsync(dbase + o_prim, stage + o_prim, prim.size() * sizeof(double2), hipMemcpyHostToDevice, c->stream));
         if (want16)
             VB2_HIP(hipMemcpyAsync(dbase + o_rec16, stage + o_rec16, rec16.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+        if (pd) {
+            PackPdArgs pp;
+            std::memset(&pp, 0, sizeof(pp));
+            pp.runs = reinterpret_cast<const uint16_t*>(din + i_runs);
+            pp.src_off = reinterpret_cast<const uint32_t*>(din + i_src);
+            pp.nrun = reinterpret_cast<const uint32_t*>(din + i_eff);
+            pp.pidx = reinterpret_cast<const int32_t*>(din + i_pidx);
+            pp.cd = reinterpret_cast<const double*>(din + i_cd);
+            pp.pother = reinterpret_cast<const double*>(din + i_pother);
+            pp.ud = in->known_af ? nullptr : reinterpret_cast<const double*>(din + i_ud);
+            pp.mu = in->known_af ? nullptr : reinterpret_cast<const double*>(din + i_mu);
+            pp.kaf = in->known_af ? reinterpret_cast<const double*>(din + i_kaf) : nullptr;
+            pp.mt_rec = reinterpret_cast<const uint2*>(dbase + o_rec);
+            pp.codes = reinterpret_cast<uint32_t*>(dbase + o_codes);
+            pp.ud_s = reinterpret_cast<double*>(dbase + o_ud);
+            pp.mu_s = reinterpret_cast<double*>(dbase + o_mu);
+            pp.kaf_s = in->known_af ? reinterpret_cast<double*>(dbase + o_kaf) : nullptr;
+            pp.cdiag = reinterpret_cast<double*>(dbase + o_cd);
+            pp.m_active = m_active;
+            pp.m_pad = m_pad;
+            pp.k = k;
+            pp.num_mt = num_mt;
+            pp.total_rows = (uint32_t)total_rows;
+            pp.slack_rows = (uint32_t)kCodeSlackRows;
+            pp.pad_off = pad_off;
+            std::memcpy(pp.row_off, row_off_pd, sizeof(pp.row_off));
+            std::memcpy(pp.kpow, kpow, sizeof(pp.kpow));
+            pp.sched = pd_sched ? 1 : 0;
+            pp.num_code = num_code;
+            pp.row_bytes = row_bytes;
+            VB2_HIP(launch_pack_pd(pp, c->stream));
+        } else {
         PackArgs pa;
         std::memset(&pa, 0, sizeof(pa));
         pa.runs = reinterpret_cast<const uint16_t*>(din + i_runs);
@@ -1018,6 +1323,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         pa.num_code = num_code;
         for (int idx = 0; idx < kMaxCode; ++idx) pa.dict_of[idx] = dict_of[idx];
         VB2_HIP(launch_pack_layout(pa, c->stream));
+        }
     } else {
         VB2_HIP(hipMemcpyAsync(dbase, stage, data_bytes, hipMemcpyHostToDevice, c->stream));
     }
@@ -1058,6 +1364,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     c->sched_enabled = tn.sched != 0;
     c->device_bytes = (int64_t)dev_total;
     L.num_prim = (int32_t)prim.size();
+    L.pd = pd ? 1 : 0;
+    c->num_code_seen = num_code_seen;
     L.num_code = num_code;
     L.row_bytes = row_bytes;
     L.num_mt = num_mt;
@@ -1069,7 +1377,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     L.m_pad = m_pad;
     // bytes one cohort step reads of this sample: run lists + tile records + panel rows + diagonal terms
     const int64_t panel_bytes = (int64_t)(in->known_af ? 1 : k + 1) * m_pad * 8 + 4 * m_pad * 8 + (int64_t)num_mt * 8;
-    c->cohort_bytes = (int64_t)total_rows * kMtMarkers * 8 + panel_bytes;
+    c->cohort_bytes = (int64_t)total_rows * kMtMarkers * (pd ? 4 : 8) + panel_bytes;
     if (want16) {
         L.mt_rec16 = reinterpret_cast<const uint2*>(dbase + o_rec16);
         uint2* d16 = reinterpret_cast<uint2*>(dbase + o_codes16);
@@ -1164,7 +1472,7 @@ Schedule Context::get(int mode, int ngrp, int grid, int block_waves)
     std::vector<uint32_t> off;
     std::vector<uint16_t> item;
     const int tpu = mode == 3 ? 2 : mode == 4 ? 4 : 1;
-    if (!build_schedule(h_mt_rows.data(), L.num_mt, grid, block_waves, tpu, ngrp, &off, &item)) return sl.s;
+    if (!build_schedule(h_mt_rows.data(), L.num_mt, grid, block_waves, tpu, ngrp, &off, &item, L.pd ? 1 : 0)) return sl.s;
     const size_t off_bytes = (off.size() * sizeof(uint32_t) + 15) / 16 * 16;
     if (off_bytes + item.size() * sizeof(uint16_t) > sl.bytes) return sl.s;
     if (hipMemcpyAsync(sl.d_base, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream) != hipSuccess ||
@@ -1213,7 +1521,7 @@ int Context::cohort_schedules(int bps, int block_waves, Schedule out[4], bool fu
         }
         std::vector<uint32_t> off;
         std::vector<uint16_t> item;
-        if (!build_schedule(h_mt_rows.data(), L.num_mt, bps, block_waves, tpu[sh], 1, &off, &item)) {
+        if (!build_schedule(h_mt_rows.data(), L.num_mt, bps, block_waves, tpu[sh], 1, &off, &item, L.pd ? 1 : 0)) {
             e.full = true;                                  // (nothing more to be had for this geometry)
             cohort_sched_.push_back(e);                     // (every shape: the snake deal)
             return VB2_OK;
@@ -1285,8 +1593,8 @@ bool Context::resident_begin()
             ra.sched_multi = get(3, 1, gm.grid, gm.block_waves);
             ra.sched_single = get(4, 1, gm.grid, gm.block_waves);
             // the workgroups' own run lists in LDS for the whole search, if they fit (Tunables::lds_cache 0: the A/B knob)
-            ra.cache_tiles = (L.num_mt + gm.grid - 1) / gm.grid;
-            ra.cache_rows = tunables().lds_cache ? (int32_t)resident_cache_rows(h_mt_rows.data(), L.num_mt, gm.grid) : 0;
+            ra.cache_tiles = (int32_t)owned_most(L.pd ? 1 : 0, (uint32_t)L.num_mt, (uint32_t)gm.grid);
+            ra.cache_rows = tunables().lds_cache ? (int32_t)resident_cache_rows(h_mt_rows.data(), L.num_mt, gm.grid, L.pd ? 1 : 0) : 0;
         }
         bool coop = !plain_launch;
         ok = launch_llk_resident(L, &ra, d_partials, d_ticket, stream, &coop) == hipSuccess;
@@ -1595,7 +1903,7 @@ int Context::ensure_codes16()
     //  two threads may build batches over one context: one of them makes the copy, the other waits
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    if (L.codes16 || L.num_mt == 0) return VB2_OK;
+    if (L.codes16 || L.num_mt == 0 || L.pd) return VB2_OK;      // (a probability-domain context has one list format)
     // the pack kernel goes on this context's stream: behind a resident search kernel it would only start when that
     // kernel gives up after its idle second (and end the session without a word) -- end the session first
     if (resident_active) resident_end();
@@ -1672,11 +1980,13 @@ void Context::fill_info(vb2_info* info) const
     info->num_active_marker = L.num_active;
     info->num_read = num_read;
     info->num_read_other = num_read_other;
-    info->num_code = L.num_code;
+    info->num_code = num_code_seen;
     info->num_tile = L.num_mt;
     info->device_bytes = device_bytes;
     info->algorithmic_bytes_per_eval = algorithmic_bytes;
     info->cohort_step_bytes = cohort_bytes;
+    info->layout = L.pd;
+    info->num_table_row = L.num_code;
     std::snprintf(info->device_name, sizeof(info->device_name), "%s", device_name);
     std::snprintf(info->arch, sizeof(info->arch), "%s", arch);
 }

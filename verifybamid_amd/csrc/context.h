@@ -131,6 +131,7 @@ public:
     int ensure_codes16();
     void* d_codes16_own = nullptr;
     int64_t cohort_bytes = 0;                 // device bytes one cohort step streams for this sample
+    int num_code_seen = 0;                    // distinct (class, quality) codes of the data (vb2_info::num_code)
 
     int device = -1;
     int num_marker = 0;

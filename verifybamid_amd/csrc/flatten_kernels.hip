@@ -86,6 +86,11 @@ __device__ __forceinline__ double libm_exp_any(double x, const unsigned long lon
     return 0x1p-1022 * y;
 }
 
+constexpr int kSchedTilesPerBlock = 4;
+struct SchedLdsOps {
+    static __device__ __forceinline__ void set(uint64_t& w, uint64_t bits) { atomicOr(reinterpret_cast<unsigned long long*>(&w), (unsigned long long)bits); }
+    static __device__ __forceinline__ void clear(uint64_t& w, uint64_t bits) { atomicAnd(reinterpret_cast<unsigned long long*>(&w), ~(unsigned long long)bits); }
+};
 constexpr int kClassifyThreads = 64;
 constexpr int kCodeSlots = 192;            // >= kMaxCode, three 64-bit sets
 
@@ -104,7 +109,10 @@ classify_kernel(const ClassifyArgs a)
     __shared__ unsigned long long s_exp[256];
     __shared__ double s_other[256];
     __shared__ double s_lc3[kMaxCode * 3];
-    __shared__ unsigned s_hist[kCodeSlots + 2];          // + reads counted (two halves would overflow: kept as 64-bit below)
+    __shared__ unsigned s_hist[kCodeSlots + 2];
+    __shared__ unsigned char s_kpow[kNumQual];
+    __shared__ double s_lmin[kNumQual];
+    __shared__ unsigned long long s_bound;          // + reads counted (two halves would overflow: kept as 64-bit below)
     __shared__ unsigned long long s_reads, s_others;
     __shared__ unsigned char s_qidx[256];
     const int tid = threadIdx.x;
@@ -116,7 +124,10 @@ classify_kernel(const ClassifyArgs a)
     }
     for (int e = tid; e < kMaxCode * 3; e += kClassifyThreads) s_lc3[e] = a.lc3[e];
     for (int e = tid; e < kCodeSlots + 2; e += kClassifyThreads) s_hist[e] = 0u;
-    if (tid == 0) { s_reads = 0ull; s_others = 0ull; }
+    if (tid == 0) { s_reads = 0ull; s_others = 0ull; s_bound = 0ull; }
+    const bool pd = a.kpow != nullptr;
+    if (pd)
+        for (int e = tid; e < kNumQual; e += kClassifyThreads) { s_kpow[e] = a.kpow[e]; s_lmin[e] = a.lmin[e]; }
     __syncthreads();
 
     const int i = blockIdx.x * kClassifyThreads + tid;
@@ -125,6 +136,8 @@ classify_kernel(const ClassifyArgs a)
         bool counts = depth != 0;
         if (counts && a.sanity && ((double)depth < a.lo || (double)depth > a.hi)) counts = false;
         int32_t eff = -1;
+        uint32_t steps_ref = 0, steps_alt = 0;
+        double p_other = 0.0;
         if (counts) {
             unsigned alt_up = a.alt[i];
             if (alt_up >= 'a' && alt_up <= 'z') alt_up -= 32;
@@ -168,7 +181,7 @@ classify_kernel(const ClassifyArgs a)
             }
             uint16_t* out = a.runs + beg;
             eff = 0;
-            double dg0 = 0.0, dg1 = 0.0, dg2 = 0.0;
+            double dg0 = 0.0, dg1 = 0.0, dg2 = 0.0, bound = 0.0;
 #pragma unroll 1
             for (int w = 0; w < 3; ++w) {
                 unsigned long long bits = w == 0 ? bm0 : w == 1 ? bm1 : bm2;
@@ -180,10 +193,16 @@ classify_kernel(const ClassifyArgs a)
                     const double n = (double)left;
                     const double* lc = &s_lc3[idx * 3u];
                     dg0 += n * lc[0]; dg1 += n * lc[1]; dg2 += n * lc[2];
+                    const unsigned kq = pd ? (unsigned)s_kpow[idx >> 1] : 1u;
+                    if (pd) bound += n * s_lmin[idx >> 1];
                     while (left > 0u) {
                         const unsigned c1 = left > (unsigned)kMaxRunCount ? (unsigned)kMaxRunCount : left;
                         out[eff++] = (uint16_t)(idx | (c1 << 8));
                         left -= c1;
+                        if (pd) {
+                            const unsigned st = (c1 + kq - 1u) / kq;
+                            if (idx & 1u) steps_alt += st; else steps_ref += st;
+                        }
                     }
                 }
             }
@@ -192,10 +211,22 @@ classify_kernel(const ClassifyArgs a)
             cd[1] = libm_exp_any(dg0 + c_other, s_exp);
             cd[2] = libm_exp_any(dg1 + c_other, s_exp);
             cd[3] = libm_exp_any(dg2 + c_other, s_exp);
+            if (pd) {
+                p_other = libm_exp_any(c_other, s_exp);
+                bound += c_other * -0x1.71547652b82fep+0;             // (c_other <= 0: binary orders of magnitude it takes)
+                // (steps beyond 16 bits: the marker cannot be laid out -- an impossible bound keeps the context out of the layout)
+                if (steps_ref > 0xffffu || steps_alt > 0xffffu) bound = 1e300;
+                if (!(bound >= 0.0)) bound = 1e300;                    // (NaN / -inf: quality 0)
+                atomicMax(&s_bound, (unsigned long long)__double_as_longlong(bound));
+            }
             atomicAdd(&s_reads, (unsigned long long)depth);
             atomicAdd(&s_others, (unsigned long long)n_other);
         }
         a.eff[i] = eff;
+        if (pd) {
+            a.eff_pd[i] = (steps_ref & 0xffffu) | (steps_alt << 16);
+            a.pother[i] = p_other;
+        }
     }
     __syncthreads();
     for (int e = tid; e < kMaxCode; e += kClassifyThreads)
@@ -203,6 +234,7 @@ classify_kernel(const ClassifyArgs a)
     if (tid == 0) {
         if (s_reads) atomicAdd(&a.hist[kMaxCode], s_reads);
         if (s_others) atomicAdd(&a.hist[kMaxCode + 1], s_others);
+        if (pd && s_bound) atomicMax(&a.hist[kMaxCode + 2], s_bound);
     }
 }
 
@@ -296,16 +328,184 @@ pack_layout_kernel(const PackArgs a)
         a.codes[(size_t)a.total_rows * kMtMarkers + e] = make_uint2(a.pad4, a.pad4);
 }
 
+// Pass B of a probability-domain context (PackPdArgs): one thread per position of the sorted, padded marker list.
+__global__ void __launch_bounds__(256)
+pack_pd_kernel(const PackPdArgs a)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < a.m_pad) {
+        const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
+        const uint2 rec = a.mt_rec[t];
+        const uint32_t rows_ref = rec.y & 0xffffu, rows_alt = rec.y >> 16;
+        const bool have = m < a.m_active;
+        const uint32_t nrun = have ? a.nrun[m] : 0u;
+        const uint16_t* src = a.runs + (have ? a.src_off[m] : 0u);
+        uint32_t* out = a.codes + (size_t)rec.x * kMtMarkers + lane;
+        uint32_t step = 0, cur = 0;
+        auto put = [&](uint32_t off) {
+            if (step & 1u) out[(size_t)(step >> 1) * kMtMarkers] = cur | (off << 16);
+            else cur = off;
+            ++step;
+        };
+#pragma unroll 1
+        for (uint32_t cls = 0; cls < (a.sched ? 0u : 2u); ++cls) {      // (sched: pack_pd_sched_kernel writes the steps)
+            for (uint32_t j = 0; j < nrun; ++j) {
+                const uint32_t rw = src[j], idx = rw & 0xffu;
+                if ((idx & 1u) != cls) continue;
+                const uint32_t rank = idx >> 1, kq = a.kpow[rank];
+                uint32_t left = rw >> 8;
+                while (left > 0u) {
+                    const uint32_t c1 = left > kq ? kq : left;
+                    put(a.row_off[rank][c1]);
+                    left -= c1;
+                }
+            }
+            const uint32_t end = 2u * (cls == 0 ? rows_ref : rows_ref + rows_alt);
+            while (step < end) put(a.pad_off);
+        }
+        const int64_t i = have ? (int64_t)a.pidx[m] : 0;
+        if (a.kaf_s) a.kaf_s[m] = have ? a.kaf[i] : 0.0;
+        else {
+            for (int kk = 0; kk < a.k; ++kk) a.ud_s[(size_t)kk * a.m_pad + m] = have ? a.ud[(size_t)i * a.k + kk] : 0.0;
+            a.mu_s[m] = have ? a.mu[i] : 0.0;
+        }
+        a.cdiag[m] = have ? a.pother[i] : 0.0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) a.cdiag[(size_t)q * a.m_pad + m] = have ? a.cd[(size_t)i * 4 + q] : 0.0;
+    }
+    const uint32_t pad2 = a.pad_off | (a.pad_off << 16);
+    const int64_t nslack = (int64_t)a.slack_rows * kMtMarkers;
+    for (int64_t e = m; e < nslack; e += (int64_t)gridDim.x * blockDim.x)
+        a.codes[(size_t)a.total_rows * kMtMarkers + e] = pad2;
+}
+
+// The steps of a probability-domain tile, placed (PackPdArgs::sched; tile_sched.h): one 16-lane row per micro-tile, four tiles
+// per workgroup, phase after phase -- the tile's ref steps into its ref rows, then its alt steps into its alt rows.  A lane's
+// steps of the phase (its runs of that class, a run of count c as ceil(c / K) table rows) are staged in LDS as row indices;
+// the three passes of the scheduler are those of pack_sched_kernel; the host pack composes them serially: the same bytes.
+namespace {
+struct SchedIdentity {
+    __host__ __device__ int operator[](uint32_t i) const { return (int)i; }
+};
+}  // namespace
+
+__global__ void __launch_bounds__(4 * kMtMarkers)
+pack_pd_sched_kernel(const PackPdArgs a)
+{
+    constexpr int kTiles = 4;
+    __shared__ TileSched s_state[kTiles];
+    __shared__ uint16_t s_runs[kTiles][kMtMarkers][kSchedMaxSteps];
+    __shared__ uint16_t s_at[kTiles][kSchedMaxSteps][kMtMarkers];
+    __shared__ uint32_t s_eff[kTiles][kMtMarkers];
+    __shared__ uint8_t s_home[kTiles][kSchedMaxPos];
+    const int row = threadIdx.x / kMtMarkers, lane = threadIdx.x % kMtMarkers;
+    const int t = (int)blockIdx.x * kTiles + row;
+    const bool live = t < a.num_mt;
+    uint2 rec = make_uint2(0u, 0u);
+    uint32_t nrun = 0;
+    const uint16_t* src = a.runs;
+    if (live) {
+        rec = a.mt_rec[t];
+        const int64_t m = (int64_t)t * kMtMarkers + lane;
+        if (m < a.m_active) {
+            nrun = a.nrun[m];
+            src = a.runs + a.src_off[m];
+        }
+    }
+    const SchedIdentity ident;
+    uint32_t first_step = 0;
+#pragma unroll 1
+    for (uint32_t cls = 0; cls < 2; ++cls) {
+        const int steps = (int)(2u * (cls == 0 ? (rec.y & 0xffffu) : (rec.y >> 16)));
+        uint32_t* const out = a.codes + ((size_t)rec.x + (first_step >> 1)) * kMtMarkers + lane;
+        // the lane's steps of this phase, as row indices
+        uint32_t n = 0;
+        for (uint32_t j = 0; j < nrun; ++j) {
+            const uint32_t rw = src[j], idx = rw & 0xffu;
+            if ((idx & 1u) != cls) continue;
+            const uint32_t rank = idx >> 1, kq = a.kpow[rank];
+            uint32_t left = rw >> 8;
+            while (left > 0u) {
+                const uint32_t c1 = left > kq ? kq : left;
+                if (n < (uint32_t)kSchedMaxSteps) s_runs[row][lane][n] = (uint16_t)(a.row_off[rank][c1] / (uint32_t)a.row_bytes);
+                ++n;
+                left -= c1;
+            }
+        }
+        s_eff[row][lane] = n;
+        __syncthreads();
+        const bool plain = sched_is_plain(s_eff[row], steps, a.num_code);      // (the same for the 16 lanes of a row)
+        if (plain) {
+            if (live) {              // the steps in plain order (pack_pd_kernel's loop)
+                uint32_t step = 0, cur = 0;
+                auto put_plain = [&](uint32_t off) {
+                    if (step & 1u) out[(size_t)(step >> 1) * kMtMarkers] = cur | (off << 16);
+                    else cur = off;
+                    ++step;
+                };
+                for (uint32_t j = 0; j < nrun; ++j) {
+                    const uint32_t rw = src[j], idx = rw & 0xffu;
+                    if ((idx & 1u) != cls) continue;
+                    const uint32_t rank = idx >> 1, kq = a.kpow[rank];
+                    uint32_t left = rw >> 8;
+                    while (left > 0u) {
+                        const uint32_t c1 = left > kq ? kq : left;
+                        put_plain(a.row_off[rank][c1]);
+                        left -= c1;
+                    }
+                }
+                while (step < (uint32_t)steps) put_plain(a.pad_off);
+            }
+        } else {
+            TileSched& S = s_state[row];
+            const uint64_t all = sched_all_steps(steps);
+            for (int d = lane; d <= a.num_code; d += kMtMarkers) {        // (num_code: the padding row's position)
+                S.holds[d] = 0;
+                s_home[row][d] = (uint8_t)sched_home_step(d < a.num_code ? d : a.num_code - 1, steps, a.num_code);
+            }
+            S.open[lane] = all;
+        }
+        __syncthreads();
+        auto get = [&](int l, int j) -> uint32_t { return s_runs[row][l][j]; };
+        auto put = [&](int l, int c, uint32_t rw) { s_at[row][c][l] = (uint16_t)(rw + 1u); };
+        auto pad = [&](int l, int c) { s_at[row][c][l] = 0; };
+        auto home = [&](int d) -> int { return s_home[row][d]; };
+        const bool side_by_side = sched_home_commutes(steps > 0 ? steps : 1, a.num_code > 0 ? a.num_code : 1);
+        if (!plain && side_by_side) sched_home<SchedLdsOps>(s_state[row], lane, n, ident, home, get, put);
+        __syncthreads();
+        for (int l = 0; l < kMtMarkers; ++l) {
+            if (!plain && !side_by_side && lane == l) sched_home<SchedSerialOps>(s_state[row], lane, n, ident, home, get, put);
+            __syncthreads();
+        }
+        for (int l = 0; l < kMtMarkers; ++l) {
+            if (!plain && lane == l) sched_rest(s_state[row], lane, n, steps, a.num_code, sched_all_steps(steps), ident, home, get, put);
+            __syncthreads();
+        }
+        if (!plain) sched_pad(s_state[row], lane, steps, pad);
+        __syncthreads();
+        if (!plain && live) {
+            auto off_of = [&](uint32_t v) { return v ? (v - 1u) * (uint32_t)a.row_bytes : a.pad_off; };
+            for (int c = 0; c < steps; c += 2)
+                out[(size_t)(c >> 1) * kMtMarkers] = off_of(s_at[row][c][lane]) | (off_of(s_at[row][c + 1][lane]) << 16);
+        }
+        __syncthreads();
+        first_step += (uint32_t)steps;
+    }
+}
+
+hipError_t launch_pack_pd(const PackPdArgs& a, hipStream_t stream)
+{
+    const int64_t n = std::max<int64_t>(a.m_pad, (int64_t)a.slack_rows * kMtMarkers);
+    hipLaunchKernelGGL(pack_pd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !a.sched || a.num_mt <= 0) return e;
+    hipLaunchKernelGGL(pack_pd_sched_kernel, dim3((unsigned)((a.num_mt + 3) / 4)), dim3(4 * kMtMarkers), 0, stream, a);
+    return hipGetLastError();
+}
+
 // Wide quality alphabets: one 16-lane row per micro-tile (a wave = four tiles) places the tile's run words -- the phases of
 // tile_sched.h, which the host pack composes serially: the same bytes.  The tile's runs are staged in LDS, the schedule
 // is built there as 16-bit run words [step][lane] (0 = padding), and leaves as 128-byte rows.
-namespace {
-constexpr int kSchedTilesPerBlock = 4;
-struct SchedLdsOps {
-    static __device__ __forceinline__ void set(uint64_t& w, uint64_t bits) { atomicOr(reinterpret_cast<unsigned long long*>(&w), (unsigned long long)bits); }
-    static __device__ __forceinline__ void clear(uint64_t& w, uint64_t bits) { atomicAnd(reinterpret_cast<unsigned long long*>(&w), ~(unsigned long long)bits); }
-};
-}  // namespace
 
 __global__ void __launch_bounds__(kSchedTilesPerBlock * kMtMarkers)
 pack_sched_kernel(const PackArgs a)

@@ -22,6 +22,13 @@ constexpr int kRowBytesWide = 400;         // 8 points x 6 doubles + 2 doubles o
 constexpr int kRowBytesNarrow = 208;       // 4 points x 6 doubles + 2 (13 slots)
 constexpr int kMaxWideCodes = 65535 / kRowBytesWide - 1;   // run words hold 16-bit byte offsets (pad row included)
 constexpr int kMaxRunCount = 31;           // the 16-bit prefix of a double holds integers up to 31 exactly
+// Probability-domain contexts (DeviceLayout::pd, round 6): a table row is P^n of one quality, class ref (class alt reads it
+// mirrored), n = 1 .. its quality's K <= kMaxPow; a marker's list is one 16-bit row offset per STEP (a run of count c takes
+// ceil(c / K) steps), ref steps first, then alt steps
+constexpr int kMaxPow = 8;
+constexpr int kPdSampleMarkers = 2048;     // markers whose run counts choose the K's (before the reads are walked)
+constexpr double kPdMaxBound = 1000.0;     // a marker may lose this many binary orders of magnitude at most (all reads at their
+                                           // least likely genotype pair) for its products to stay normal numbers
 // d_ticket of launch_llk_eval: kTicketWords zero-initialised unsigned ints -- [0, kTicketScratchWord) the arrival tickets of a
 // launch's passes (llk_eval_passes_kernel; a plain launch uses [0]), two words from kTicketScratchWord on a scratch flag
 constexpr int kTicketScratchWord = 8, kTicketWords = 16;
@@ -61,7 +68,9 @@ struct DeviceLayout {
                                   // (10: the queue adapts to the waves' actual speeds), 0 = always static
     int32_t stagger;              // the second half of a workgroup's waves starts its tiles this many x 64
                                   // cycles late (Tunables::stagger)
-    int32_t reserved0;
+    int32_t pd;                   // 1: probability-domain layout (see kMaxPow): codes = [rows][16] x uint32 {step, step} of 16-bit
+                                  // row offsets, mt_rec = {first row, ref rows | alt rows << 16}, prim = [num_code] {pErr, n},
+                                  // ediag[0] = exp(c_other); a workgroup owns PAIRS of neighbouring micro-tiles (owned_tile)
     unsigned long long* stamps;   // profiling aid: [grid][8] wall-clock stamps, or nullptr
     int64_t num_active;
     int64_t m_pad;                // num_mt * 16
@@ -80,12 +89,28 @@ struct Schedule {
 // takes per item (1, 2 or 4), ngrp = point groups of the launch.  rows[t] = rows of micro-tile t.
 // Returns false (and leaves the vectors empty) when a workgroup has more than 65535 items.
 bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int tiles_per_unit, int ngrp,
-                    std::vector<uint32_t>* off, std::vector<uint16_t>* item);
+                    std::vector<uint32_t>* off, std::vector<uint16_t>* item, int own_shift = 0 /* DeviceLayout::pd: owned_tile */);
 // Supplies the schedule of a launch shape (mode = wave shape 2..4 of llk_kernels.hip).
 struct ScheduleProvider {
     virtual Schedule get(int mode, int ngrp, int grid, int block_waves) = 0;
     virtual ~ScheduleProvider() {}
 };
+
+// Which micro-tiles a workgroup owns: blk, blk + nblk, ... -- or, probability-domain contexts, the PAIRS blk, blk + nblk, ... of
+// neighbouring tiles (num_mt is even there): the two tiles a wave of the paired shapes walks side by side are then neighbours
+// in the sorted order, with the same number of ref and alt rows, so that both halves of the wave are in the same phase.
+__host__ __device__ inline uint32_t owned_tile(int sh, uint32_t blk, uint32_t nblk, uint32_t it)
+{
+    return (((it >> sh) * nblk + blk) << sh) | (it & ((1u << sh) - 1u));
+}
+__host__ __device__ inline uint32_t owned_count(int sh, uint32_t num_mt, uint32_t blk, uint32_t nblk)
+{
+    return (((num_mt >> sh) + nblk - 1u - blk) / nblk) << sh;
+}
+__host__ __device__ inline uint32_t owned_most(int sh, uint32_t num_mt, uint32_t nblk)     // (workgroup 0's count)
+{
+    return (((num_mt >> sh) + nblk - 1u) / nblk) << sh;
+}
 
 struct LaunchGeom { int grid, block_waves; };
 // Workgroups / waves per workgroup used for a launch of 4*btl points.
@@ -135,6 +160,7 @@ struct MultiLaunch {
     int np;                          // points per sample of this step: 1, 2, 4 or 8 (picks the wave shape)
     bool force_ticket;               // arrival-ticket hand-off instead of tagged sets (the retry after a NaN)
     bool w16;                        // every sample has codes16: stream the 16-bit run lists
+    bool pd;                         // every sample is a probability-domain context (DeviceLayout::pd)
     bool all_static;                 // every sample runs the static deal (eval_takes_the_queue is false for all): the
                                      // 16-bit one- and two-point steps then take the kernels with the pipelined item loop
     int ksel;                        // 2 or 4: every sample has --NumPC of that and no known-AF column (the kernels compiled
@@ -147,6 +173,8 @@ bool eval_takes_the_queue(const DeviceLayout& L, int nblk, int nwave, int ngrp);
 size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp = 1);   // groups of 4*btl points
 size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, int ngrp, int exp_tab_doubles = 0 /* the 16-KiB table */);
 int max_groups(const DeviceLayout& L, int btl, int nblk, int block_waves);
+// table rows of a probability-domain context of ~M markers that leave a 48-point launch (six point groups) its LDS
+int pd_row_budget(int num_marker, int num_pc, int num_cu);
 hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream);
 hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 // codes / mt_rec -> codes16 / mt_rec16 on the device (rec16 already holds the tiles' {first row, rows};
@@ -173,7 +201,15 @@ struct ClassifyArgs {
     uint32_t max_depth;            // reads of the deepest marker (below 65 536: 16-bit counters)
     int32_t sanity;                // 1: the +-3 sd depth filter is on
     double lo, hi;                 // its bounds
+    // probability-domain bookkeeping (kpow == nullptr: none): per marker its steps, ref | alt << 16, under the K's chosen
+    // from the sample; exp(c_other); and, in hist[kMaxCode + 2], the largest kPdMaxBound-style bound of a counted marker
+    // (bits of a non-negative double)
+    const unsigned char* kpow;     // [kNumQual] quality rank -> K
+    const double* lmin;            // [kNumQual] quality rank -> -log2 of the least entry a read of it can meet (inf: none)
+    uint32_t* eff_pd;              // out [M]
+    double* pother;                // out [M]
 };
+constexpr int kHistWords = kMaxCode + 3;
 hipError_t launch_classify(const ClassifyArgs& a, hipStream_t stream);
 // Pass B, pack_layout_kernel (+ pack_sched_kernel for wide alphabets): the kernel-order arrays -- run words
 // [tile][row][marker], panel rows, per-marker constants -- from the panel-order arrays above.  Pure data movement: the same
@@ -203,6 +239,37 @@ struct PackArgs {
     uint8_t dict_of[kMaxCode];     // dictionary index -> dictionary position (the scheduler's bank groups)
 };
 hipError_t launch_pack_layout(const PackArgs& a, hipStream_t stream);
+// Pass B of a probability-domain context: a marker's runs (dictionary index | count << 8, classes interleaved) become its
+// steps -- ref runs first, then alt runs, a run of count c split into ceil(c / K) steps of its quality's rows -- as 16-bit row
+// offsets, two per word, [tile][row][marker]; the tile's ref phase padded to rows_ref rows, its alt phase to rows_alt
+// (padding = the row of ones).  Panel rows and constants as in pack_layout_kernel, ediag[0] = exp(c_other).
+struct PackPdArgs {
+    const uint16_t* runs;
+    const uint32_t* src_off;       // [m_active]
+    const uint32_t* nrun;          // [m_active] runs of the marker
+    const int32_t* pidx;           // [m_active]
+    const double* cd;              // [M][4]
+    const double* pother;          // [M]
+    const double* ud;
+    const double* mu;
+    const double* kaf;
+    const uint2* mt_rec;           // [num_mt] {first row, rows_ref | rows_alt << 16}
+    uint32_t* codes;               // out: [rows + slack][16]
+    double* ud_s;
+    double* mu_s;
+    double* kaf_s;
+    double* cdiag;
+    int64_t m_active, m_pad;
+    int32_t k, num_mt;
+    uint32_t total_rows, slack_rows, pad_off;
+    uint16_t row_off[kNumQual][kMaxPow + 1];     // [rank][n] byte offset of the row P^n (n = 1 .. K)
+    uint8_t kpow[kNumQual];
+    int32_t sched;                 // 1: the steps of a tile's phase are placed by schedule_tile (tile_sched.h), as the runs of a
+                                   // wide alphabet's tile are: the rows the 16 markers read in a step then start in 16 different
+                                   // bank groups (plain order: 1.25 LDS passes per step at 42 codes; placed: 1.01)
+    int32_t num_code, row_bytes;
+};
+hipError_t launch_pack_pd(const PackPdArgs& a, hipStream_t stream);
 // n doubles from device memory to mapped host memory, then done_seq to the mapped flag (stream-ordered
 // hand-off to a spinning host: see publish_kernel)
 hipError_t launch_publish(const double* d_src, double* d_dst_mapped, int n, unsigned long long* done_flag,
@@ -250,7 +317,7 @@ struct ResidentArgs {
 };
 // Rows of LDS a workgroup's run-list cache takes (the placement rule of resident_kernel.inc on the host):
 // rows[] = rows per micro-tile, workgroup b of nblk owns tiles b, b + nblk, ...
-uint32_t resident_cache_rows(const uint32_t* rows, int num_mt, int nblk);
+uint32_t resident_cache_rows(const uint32_t* rows, int num_mt, int nblk, int own_shift = 0);
 constexpr unsigned long long kHandoffGiveUpTicks = 25000000ull;   // 0.25 s of the 100 MHz wall clock (tagged hand-off)
 constexpr unsigned long long kResidentMinimize = 0xffffffffull;   // mailbox word [1]: a Minimize() request
 constexpr int kDeviceSimplexMaxDim = 63;                           // one lane per coordinate, one per vertex (n + 1 <= 64)

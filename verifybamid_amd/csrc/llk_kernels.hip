@@ -38,12 +38,6 @@
 #include "kernel_debug.h"
 #include "tile_sched.h"
 #include "tunables.h"
-#ifndef VB2_PD_EMU
-#define VB2_PD_EMU 0        // (timing experiment, round 6: the instruction mix of a probability-domain body -- garbage results)
-#endif
-#ifndef VB2_PD_EXTRA
-#define VB2_PD_EXTRA 0
-#endif
 #ifndef VB2_SIMD_DEAL
 #define VB2_SIMD_DEAL 1     // (0: wave w takes item w -- the A/B of the SIMD-balanced first deal, see eval_body)
 #endif
@@ -355,8 +349,25 @@ __device__ __forceinline__ double table_entry(double alpha, double perr_signed, 
     const double one_minus_alpha = 1.0 - alpha;
     const double val = (alpha * e1 + one_minus_alpha * e2) * p_err +
                        (alpha * n1 + one_minus_alpha * n2) * p_ok;
-    if (VB2_PD_EMU) return val;
     return log_tab(val, ltab_addr);
+}
+
+// The same entry BEFORE its logarithm, class ref, to the power n (probability-domain contexts: llk_kernels.h, kMaxPow):
+// the value the reference takes the logarithm of (h:223-225, the same expression order), multiplied up n - 1 times.  A
+// negative "probability" (alpha outside [0, 1]) or a NaN becomes NaN, like the reference's log() of it: the marker's
+// likelihood is then NaN, fails `markerLK > 0` and the marker is left out.
+__device__ __forceinline__ double prob_entry(double alpha, double p_err, int n, int g1, int g2)
+{
+    const double p_ok = 1.0 - p_err;
+    const double e1 = (double)g1 * (1.0 / 6.0), e2 = (double)g2 * (1.0 / 6.0);
+    const double n1 = 1.0 - 0.5 * (double)g1, n2 = 1.0 - 0.5 * (double)g2;
+    const double one_minus_alpha = 1.0 - alpha;
+    double val = (alpha * e1 + one_minus_alpha * e2) * p_err +
+                 (alpha * n1 + one_minus_alpha * n2) * p_ok;
+    val = val >= 0.0 ? val : __builtin_nan("");
+    double r = val;
+    for (int i = 1; i < n; ++i) r *= val;
+    return r;
 }
 
 __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
@@ -378,6 +389,7 @@ __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
 constexpr int kExpTabDoubles = 64 * 32;    // exp_nonpos's table in LDS (16 KiB)
 constexpr int kPrefetch = 8;               // rows of run dwords in flight per lane: cohort steps (lists from HBM)
 constexpr int kPrefetchL2 = 2;             // ... a single sample's launches and search rounds (lists in L2 / LDS)
+constexpr int kPrefetchPd = 4;             // ... cohort steps of probability-domain samples (a window that moves up a row at a time)
 
 // Lane -> (marker m in the micro-tile, candidate slot g): the 16 lanes that ds_read_b128 services in one LDS pass
 // (lanes {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32; MI355X_MICROARCH.md, LDS) share one candidate
@@ -467,7 +479,7 @@ struct NoHook {
 // are at most dyn_limit of them per wave; else the static deal (cohort launches).
 __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, uint32_t nblk, int nwave, int ngrp)
 {
-    const uint32_t max_tiles_blk = ((uint32_t)L.num_mt + nblk - 1) / nblk;
+    const uint32_t max_tiles_blk = owned_most(L.pd ? 1 : 0, (uint32_t)L.num_mt, nblk);
     return max_tiles_blk * (uint32_t)ngrp <= (uint32_t)(L.dyn_limit * nwave);
 }
 
@@ -485,8 +497,12 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // ESH: log2 of the byte stride between the entries of exp_nonpos's table (8: conflict-free; 6: the compact copy).
 // (Measured and dropped over the rounds, all bit-identical: a software-pipelined item loop, a run-ahead ring of table reads,
 // the next item drawn a whole item early, two half-sized workgroups per CU -- HISTORY.md.)
+// PD: a probability-domain context (DeviceLayout::pd; llk_kernels.h, kMaxPow): the table holds P^n rows of class ref only,
+// a marker's list is one 16-bit row offset per step, ref steps first and alt steps behind them; the six sums are PRODUCTS,
+// class alt multiplies them with the row read the other way round (g -> 2 - g, h:164-177: T[alt][q][g1][g2] is T[ref][q][2-g1][2-g2]),
+// and the epilogue needs no exponential.  Only for contexts whose markers cannot underflow that way (Context::create).
 template <int MODE, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1, int KSEL = 0,
-          bool LCACHE = false, int ESH = 8>
+          bool LCACHE = false, int ESH = 8, bool PD = false>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -499,6 +515,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     static_assert(MODE >= 2 && MODE <= 5, "wave shapes 2..5");
+    static_assert(!PD || (!W16 && ESH == 8), "probability-domain contexts have one list format and no exp table");
+    constexpr int OSH = PD ? 1 : 0;             // a workgroup owns pairs of neighbouring micro-tiles (owned_tile)
     // the launch is known to carry ONE group of points (every shape but the 8-point one always does; cohort steps too):
     // the group loops and the item -> (group, unit) division go at compile time
     constexpr bool ONEGRP = MODE != 2 || STREAM;
@@ -520,10 +538,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     const int ngrp = ONEGRP ? 1 : ngrp_in;
     const double* const known_af_p = KAF == 0 ? nullptr : L.known_af;
     const int NPT = NP * ngrp;                  // points of this launch
-    constexpr int kEtabCopies = (1 << ESH) / 8, kEtabDoubles = 64 * kEtabCopies;
+    constexpr int kEtabCopies = (1 << ESH) / 8, kEtabDoubles = PD ? 0 : 64 * kEtabCopies;
+    constexpr int kLtabDoubles = PD ? 0 : kLogTabDoubles;
     double* etab = lds;                         // [64][32] exp_nonpos's 2^(j/64), bank-replicated; at LDS address 0
     double* ltab = lds + kEtabDoubles;          // [128] {1 / c, log c} of log_tab
-    double* tab = ltab + kLogTabDoubles;        // [ngrp][nrow][RS]
+    double* tab = ltab + kLtabDoubles;          // [ngrp][nrow][RS]  (PD: neither table above: this one is at address 0)
     double* red = tab + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
     unsigned int* queue = reinterpret_cast<unsigned int*>(red + NPT);
     double* pts = red + NPT + 2;                // [NPT][2k+1] this launch's parameter rows
@@ -574,9 +593,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // 2^(j/64) table of exp_nonpos, one copy per pair of LDS banks (see there)
     // (entry j = e / 32 is the same for a half-wave: two SCALAR loads per step, no vector-memory
     // round trip before the first barrier)
-    if (!hook.keep_etab() && tid < kLogTabDoubles / 2)
+    if (!PD && !hook.keep_etab() && tid < kLogTabDoubles / 2)
         reinterpret_cast<double2*>(ltab)[tid] = kLogTabRows[tid];
-    if (!hook.keep_etab())
+    if (!PD && !hook.keep_etab())
         for (int jb = 2 * wave; jb < 64; jb += 2 * nwave) {
             const double t0 = kExp2Tab[jb], t1 = kExp2Tab[jb + 1];
             const double tv = lane < 32 ? exp_tab_entry(t0, jb) : exp_tab_entry(t1, jb + 1);
@@ -624,17 +643,23 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // it cost 430 vector instructions per thread of a 48-point launch where this costs 285: headline +0.8 %, 118 codes +2.2 %)
 #pragma clang loop unroll(disable)
         for (int grp_e = 0; grp_e < ngrp; ++grp_e) {
-            const double v = table_entry(early_table ? lds_rows[(bb < num_valid ? bb : num_valid - 1) * stride + 2 * k]
-                                                     : pts[(grp_e * NP + bb) * stride + 2 * k], rec.x, g1, g2, ltab_addr);
+            const double alpha_e = early_table ? lds_rows[(bb < num_valid ? bb : num_valid - 1) * stride + 2 * k]
+                                               : pts[(grp_e * NP + bb) * stride + 2 * k];
             double* gtab = tab + (size_t)grp_e * nrow * RS;
-            const double tv = W16 ? 0.5 * v : v;
-            gtab[dc * RS + bp] = tv;
-            if (twin != 0xffff) gtab[twin * RS + bb * 6 + (5 - p)] = tv;
+            if constexpr (PD) {
+                // record pi IS row pi: {pErr of its quality, the power n}; class alt reads the same row mirrored
+                gtab[pi * RS + bp] = prob_entry(alpha_e, rec.x, (int)rec.y, g1, g2);
+            } else {
+                const double v = table_entry(alpha_e, rec.x, g1, g2, ltab_addr);
+                const double tv = W16 ? 0.5 * v : v;
+                gtab[dc * RS + bp] = tv;
+                if (twin != 0xffff) gtab[twin * RS + bb * 6 + (5 - p)] = tv;
+            }
         }
     }
-    for (int e = tid; e < ngrp * RS; e += nthread) {                  // padding code: zero rows
+    for (int e = tid; e < ngrp * RS; e += nthread) {                  // padding code: zero rows (PD: ones)
         const int grp_e = e / RS;
-        tab[((size_t)grp_e * nrow + L.num_code) * RS + (e - grp_e * RS)] = 0.0;
+        tab[((size_t)grp_e * nrow + L.num_code) * RS + (e - grp_e * RS)] = PD ? 1.0 : 0.0;
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[2] = wall_clock64();
@@ -647,7 +672,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // an A/B knob -- pulled longest-first through an LDS counter, each item's product going to its
     // own LDS slot.  Either way the multiplication order is fixed, so the schedule does not
     // change a single bit of the result.
-    const uint32_t ntile_blk = ((uint32_t)L.num_mt + nblk - 1 - blk) / nblk;
+    const uint32_t ntile_blk = owned_count(OSH, (uint32_t)L.num_mt, blk, nblk);
     const size_t mp = L.m_pad;
     // work items: (tile, group), or (TPW consecutive owned tiles, group)
     const uint32_t nunit = (ntile_blk + TPW - 1) / TPW;
@@ -668,6 +693,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     typedef __attribute__((address_space(1))) const char g_cchar;
     g_cuint2* const g_rec = (g_cuint2*)(W16 ? L.mt_rec16 : L.mt_rec);
     g_cuint2* const g_codes = (g_cuint2*)(W16 ? L.codes16 : L.codes);
+    // (PD: a row of the list is 16 x 4 bytes -- two 16-bit steps per marker -- where the run words' rows are 16 x 8)
+    typedef __attribute__((address_space(1))) const uint32_t g_cuint;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cuint;
+    typedef typename std::conditional<PD, uint32_t, vuint2>::type RowWord;
+    constexpr uint32_t kRowBytes = PD ? kMtMarkers * 4u : kMtMarkers * 8u, kLaneBytes = PD ? 4u : 8u;
     g_cdouble* const g_ediag = (g_cdouble*)L.ediag;
     g_cdouble* const g_ud = (g_cdouble*)L.ud;
     g_cdouble* const g_mu = (g_cdouble*)L.mu;
@@ -743,8 +773,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     if (stamps && hook_mine && lane == 0) stamps[3] = wall_clock64();
 #endif
     typedef __attribute__((address_space(3))) const vuint2 lds_cuint2v;
-    constexpr int kPf = STREAM ? kPrefetch : kPrefetchL2;
-    vuint2 w[kPf];                                        // this lane's run words, kPf rows in flight
+    constexpr int kPf = STREAM ? (PD ? kPrefetchPd : kPrefetch) : kPrefetchL2;
+    RowWord w[kPf];                                       // this lane's run words, kPf rows in flight
     // PIPE (a cohort step under the static deal: every sample's lists come from HBM, one item = ~8 KB per wave, and a
     // wave that requests an item's bytes, waits ~2 us for ALL of them -- the compiler's vmcnt(0) at the head of the row
     // loop --, computes for ~2 us and only then requests the next item's spends half its time waiting, and four waves
@@ -766,7 +796,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     auto tile_of = [&](uint32_t idx_, bool& have_) -> uint32_t {
         const uint32_t it_ = TPW * idx_ + (uint32_t)half;
         have_ = idx_ < nitem && (TPW == 1 || it_ < ntile_blk);
-        return have_ ? blk + it_ * nblk : blk;
+        return have_ ? owned_tile(OSH, blk, nblk, it_) : owned_tile(OSH, blk, nblk, 0u);
     };
     auto draw_item = [&]() -> uint32_t {                             // the workgroup's next item, whichever wave asks first
         uint32_t nxt = 0;
@@ -774,12 +804,15 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         return (uint32_t)__builtin_amdgcn_readfirstlane(nxt);
     };
     auto issue_rows = [&](const vuint2 rec_, bool have_) {           // the first kPf rows of a tile (clamped to its own)
-        const uint32_t cb_ = rec_.x * (uint32_t)(kMtMarkers * 8) + (uint32_t)m * 8u;       // (32-bit byte offsets: see load_row)
-        const int rows_ = have_ ? (int)rec_.y : 0;
+        const uint32_t cb_ = rec_.x * kRowBytes + (uint32_t)m * kLaneBytes;       // (32-bit byte offsets: see load_row)
+        const int rows_ = have_ ? (PD ? (int)((rec_.y & 0xffffu) + (rec_.y >> 16)) : (int)rec_.y) : 0;
         const int last_ = rows_ > 0 ? rows_ - 1 : 0;
 #pragma unroll
-        for (int j = 0; j < kPf; ++j)
-            w[j] = *reinterpret_cast<g_cuint2*>(reinterpret_cast<g_cchar*>(g_codes) + (cb_ + (uint32_t)(j < last_ ? j : last_) * (uint32_t)(kMtMarkers * 8)));
+        for (int j = 0; j < kPf; ++j) {
+            g_cchar* a_ = reinterpret_cast<g_cchar*>(g_codes) + (cb_ + (uint32_t)(j < last_ ? j : last_) * kRowBytes);
+            if constexpr (PD) w[j] = *reinterpret_cast<g_cuint*>(a_);
+            else w[j] = *reinterpret_cast<g_cuint2*>(a_);
+        }
     };
     // ---- one uint2 of run words (2 runs, or 4 of the 16-bit lists) into the accumulators ----
     // (first_tag: the tile's first row under PEEL -- its first run starts the sums from `init`, the marker's "other base"
@@ -822,13 +855,27 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
             for (int i = 0; i < 3 * BTL; ++i) {
                 const vdouble2 t = row[i];
-                if (VB2_PD_EMU) {
-                    acc[2 * i] = t.x * ((kFirst && j == 0) ? init : acc[2 * i]);
-                    acc[2 * i + 1] = t.y * ((kFirst && j == 0) ? init : acc[2 * i + 1]);
-                    continue;
-                }
                 acc[2 * i] = fma(n, t.x, (kFirst && j == 0) ? init : acc[2 * i]);
                 acc[2 * i + 1] = fma(n, t.y, (kFirst && j == 0) ? init : acc[2 * i + 1]);
+            }
+        }
+    };
+    // ---- PD: one word of the list = two steps.  A step multiplies the six products of every point by ONE table row; class alt
+    // (the rows behind the tile's ref rows: alt_tag) by the same row read the other way round, pair p <-> 5 - p.  No count, no
+    // conversion: one SDWA add per step and the multiplies ----
+    auto walk_pd = [&](const uint32_t w_cur, double* acc, const uint32_t my_tab, auto alt_tag, auto first_tag, const double init) {
+        constexpr bool kAlt = decltype(alt_tag)::value, kFirst = decltype(first_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t row_addr = my_tab + (j ? (w_cur >> 16) : (w_cur & 0xffffu));
+            lds_cdouble2* row = reinterpret_cast<lds_cdouble2*>(row_addr);
+#pragma unroll
+            for (int i = 0; i < 3 * BTL; ++i) {
+                const vdouble2 t = row[i];
+                const int pt = i / 3, q2 = 2 * (i - 3 * pt);
+                const int a0 = pt * 6 + (kAlt ? 5 - q2 : q2), a1 = pt * 6 + (kAlt ? 4 - q2 : q2 + 1);
+                acc[a0] = ((kFirst && j == 0) ? init : acc[a0]) * t.x;
+                acc[a1] = ((kFirst && j == 0) ? init : acc[a1]) * t.y;
             }
         }
     };
@@ -889,8 +936,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 // level, like the marker summation order does).  The three g1==g2 exponentials do
                 // not depend on (alpha, PC) and were taken at context creation.
                 double x01, x02, x10, x12, x20, x21;
-                const double a_min = vmin2_f64(vmin2_f64(vmin2_f64(a[0], a[1]), vmin2_f64(a[2], a[3])), vmin2_f64(a[4], a[5]));
-                if (VB2_PD_EMU) {
+                const double a_min = PD ? 0.0 : vmin2_f64(vmin2_f64(vmin2_f64(a[0], a[1]), vmin2_f64(a[2], a[3])), vmin2_f64(a[4], a[5]));
+                if constexpr (PD) {
+                    // the products ARE the six likelihoods: no exponential (probability domain)
                     x01 = a[0]; x02 = a[1]; x10 = a[2]; x12 = a[3]; x20 = a[4]; x21 = a[5];
                 } else
                 if (__builtin_expect(a_min < -708.0, 0)) {      // (wave-divergent, and never taken on whole-genome depths: exp_nonpos)
@@ -912,7 +960,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 // of LLK apart (markers with ~1000 reads).  There the sum is redone term by term in the
                 // reference's own order (g1 outer, g2 inner, h:307-309), as round 1 did everywhere;
                 // wave-divergent, and never taken on whole-genome depths.
-                if (!VB2_PD_EMU && __builtin_expect(lk < 0x1p-960, 0)) {
+                if (__builtin_expect(lk < 0x1p-960, 0)) {
                     double r = 0;
                     r += e0 * gf[0] * gf2[0];
                     r += x01 * gf[0] * gf2[1];
@@ -1008,7 +1056,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         }
         const uint32_t it = TPW * unit + (uint32_t)half;     // index in this workgroup's tile list
         const bool have_tile = TPW == 1 || it < ntile_blk;   // TPW > 1: the list's end may leave lanes idle
-        const uint32_t mt = have_tile ? blk + it * nblk : blk;
+        const uint32_t mt = owned_tile(OSH, blk, nblk, have_tile ? it : 0u);
         const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)row_bytes + (uint32_t)g * (6 * BTL * 8));
         const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
         // (one slot, one group: the table's address is the constant behind the exp table -- this file has no static LDS --
@@ -1091,9 +1139,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             __builtin_amdgcn_s_setprio(1);
         // the run words by 32-bit byte offsets from the array's (scalar) base: the list of one sample stays below 4 GiB
         // (Context::create refuses more rows), and a row's address costs no 64-bit vector arithmetic
-        const uint32_t cbase = LCACHE ? 0u : rec.x * (uint32_t)(kMtMarkers * 8) + (uint32_t)m * 8u;
-        const uint32_t crow = rec.x + (uint32_t)m * 8u;      // (LCACHE: this lane's word of the tile's first row, LDS)
-        const int rows = have_tile ? (VB2_PD_EXTRA ? (int)(rec.y + (rec.y + 3u) / 7u) : (int)rec.y) : 0;         // a scalar when TPW == 1
+        const uint32_t cbase = LCACHE ? 0u : rec.x * kRowBytes + (uint32_t)m * kLaneBytes;
+        const uint32_t crow = rec.x + (uint32_t)m * kLaneBytes;      // (LCACHE: this lane's word of the tile's first row, LDS)
+        // a scalar when TPW == 1.  PD: {ref rows | alt rows << 16}: the rows of the two phases (walk_pd)
+        const int rows_ref = PD ? (have_tile ? (int)(rec.y & 0xffffu) : 0) : 0;
+        const int rows = have_tile ? (PD ? rows_ref + (int)(rec.y >> 16) : (int)rec.y) : 0;
         // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
         // tile's last row -- up to kPf useless row loads per item of 6..16 rows -- and every block of kPf rows begins
         // by waiting for all of them.  Measured on one box, depth 8 / 4 / 2: 48-point launch 74.9 / 74.4 / 76.6 us;
@@ -1103,10 +1153,14 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // they came from HBM twice, 573 MB instead of 356 MB per one-point step of 32 C3 samples (FETCH_SIZE, round 3).
         // The row index is clamped to the tile's last row instead: the same cache line again, no new bytes.)
         const int last_row = rows > 0 ? rows - 1 : 0;
-        auto load_row = [&](int j) -> vuint2 {               // row j of this lane's run words
-            if constexpr (LCACHE) return *reinterpret_cast<lds_cuint2v*>(crow + (uint32_t)j * (kMtMarkers * 8u));
-            else return *reinterpret_cast<g_cuint2*>(reinterpret_cast<g_cchar*>(g_codes) +
-                                                      (cbase + (uint32_t)(STREAM ? (j < last_row ? j : last_row) : j) * (uint32_t)(kMtMarkers * 8)));
+        auto load_row = [&](int j) -> RowWord {              // row j of this lane's run words
+            if constexpr (LCACHE && PD) return *reinterpret_cast<lds_cuint*>(crow + (uint32_t)j * kRowBytes);
+            else if constexpr (LCACHE) return *reinterpret_cast<lds_cuint2v*>(crow + (uint32_t)j * kRowBytes);
+            else {
+                g_cchar* a_ = reinterpret_cast<g_cchar*>(g_codes) + (cbase + (uint32_t)(STREAM ? (j < last_row ? j : last_row) : j) * kRowBytes);
+                if constexpr (PD) return *reinterpret_cast<g_cuint*>(a_);
+                else return *reinterpret_cast<g_cuint2*>(a_);
+            }
         };
         if (!PIPE) {
 #pragma unroll
@@ -1117,15 +1171,46 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
             for (int u = 0; u < kPf; ++u) {
                 if (s0 + u >= rows) break;
-                const vuint2 w_cur = w[u];
+                const RowWord w_cur = w[u];
                 if (refill) w[u] = load_row(s0 + u + kPf);
-                if (kFirstBlock && u == 0) walk_word(w_cur, acc, my_tab, my_tab_w16, std::true_type(), cst);
-                else walk_word(w_cur, acc, my_tab, my_tab_w16, std::false_type(), cst);
+                if constexpr (!PD) {
+                    if (kFirstBlock && u == 0) walk_word(w_cur, acc, my_tab, my_tab_w16, std::true_type(), cst);
+                    else walk_word(w_cur, acc, my_tab, my_tab_w16, std::false_type(), cst);
+                }
             }
         };
         VB2_IP_USE(w[0].x);
         VB2_IP_T(ip_t2);
-        if constexpr (PIPE) {
+        if constexpr (PD) {
+            // The tile's ref rows, then its alt rows: TWO loops of one body each (as one loop with a test per row the
+            // compiler kept the twelve products in different registers on the two paths and moved them all where the paths
+            // meet).  The rows in flight are a window of kPf words that moves up one row per iteration.  In the paired shapes
+            // the bounds are per half of the wave: the two tiles are neighbours of the sorted order and nearly always agree.
+            int r = 0;
+            auto next_word = [&]() -> uint32_t {
+                const uint32_t cur = w[0];
+#pragma unroll
+                for (int d = 0; d + 1 < kPf; ++d) w[d] = w[d + 1];
+                w[kPf - 1] = load_row(r + kPf);
+                return cur;
+            };
+            if constexpr (PEEL) {
+                if (rows_ref > 0) {          // (the first row starts the products from the marker's constant)
+                    walk_pd(next_word(), acc, my_tab, std::false_type(), std::true_type(), cst);
+                    r = 1;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
+                }
+            }
+            for (; r < rows_ref; ++r) walk_pd(next_word(), acc, my_tab, std::false_type(), std::false_type(), cst);
+            for (; r < rows; ++r) walk_pd(next_word(), acc, my_tab, std::true_type(), std::false_type(), cst);
+            if constexpr (PIPE) {
+                issue_rows(rec_n2, have_next);
+                cst_nx = other_const(mt_next, have_next);
+                rec_nx = rec_n2;
+            }
+        } else if constexpr (PIPE) {
             // the first kPf rows outside any loop (loads in flight are counted, not drained); an item with more
             // rows -- wide quality alphabets -- refills the ring as before
             const bool more = __any(rows > kPf);
@@ -1442,15 +1527,15 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     }
 }
 
-template <int MODE, int QUEUE, int KSEL = 0>
+template <int MODE, int QUEUE, int KSEL = 0, bool PD = false>
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __restrict__ points,
                 int num_valid, double* __restrict__ partials, double* __restrict__ llk_out,
                 unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
                 unsigned long long done_seq, int ngrp, unsigned long long tag, const Schedule sch)
 {
-    eval_body<MODE, false, NoHook, false, QUEUE, KSEL>(L, ip.v, ip.count, points, num_valid, partials, llk_out, ticket, done_flag, done_seq,
-                                                       blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
+    eval_body<MODE, false, NoHook, false, QUEUE, KSEL, false, 8, PD>(L, ip.v, ip.count, points, num_valid, partials, llk_out, ticket,
+                                                                     done_flag, done_seq, blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
 }
 
 // A call of more points than the LDS holds tables for -- wide quality alphabets: 118 codes x 8 points are 48.5 KB per point
@@ -1462,7 +1547,7 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
 // bits.  The results of the earlier passes are stored through the caches like the last one's (eval_body does that when it
 // is given a flag to raise: theirs is a scratch word on the device), and acknowledged before the storing workgroup draws
 // its next ticket, so the flag the host waits for is behind every pass's results.
-template <int KSEL>
+template <int KSEL, bool PD = false>
 __global__ void __launch_bounds__(Geom<2>::kMaxWaves * 64, Geom<2>::kWavesPerSimd)
 llk_eval_passes_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid, int points_per_pass,
                        double* __restrict__ partials, double* __restrict__ llk_out, unsigned int* __restrict__ tickets,
@@ -1476,7 +1561,7 @@ llk_eval_passes_kernel(const DeviceLayout L, const double* __restrict__ points, 
         const int nv = left < points_per_pass ? left : points_per_pass;
         const bool last = left <= points_per_pass;
         if (pass > 0) __syncthreads();                      // the pass before is done with the workgroup's LDS
-        eval_body<2, false, NoHook, false, 1, KSEL, false, 6>(
+        eval_body<2, false, NoHook, false, 1, KSEL, false, (PD ? 8 : 6), PD>(
             L, nullptr, 0, points + (size_t)first * stride, nv, partials + (size_t)first * gridDim.x, llk_out + first,
             tickets + pass, (last || !done_flag) ? done_flag : scratch_flag, done_seq, blockIdx.x, gridDim.x, nullptr, 0u,
             (nv + 7) / 8, 0ull, Schedule{nullptr, nullptr});
@@ -1497,10 +1582,16 @@ llk_eval_passes_kernel(const DeviceLayout L, const double* __restrict__ points, 
 extern template __global__ void llk_eval_passes_kernel<4>(VB2_PASSES_KERNEL_ARGS);
 extern template __global__ void llk_eval_passes_kernel<2>(VB2_PASSES_KERNEL_ARGS);
 extern template __global__ void llk_eval_passes_kernel<0>(VB2_PASSES_KERNEL_ARGS);
+extern template __global__ void llk_eval_passes_kernel<4, true>(VB2_PASSES_KERNEL_ARGS);
+extern template __global__ void llk_eval_passes_kernel<2, true>(VB2_PASSES_KERNEL_ARGS);
+extern template __global__ void llk_eval_passes_kernel<0, true>(VB2_PASSES_KERNEL_ARGS);
 #elif defined(VB2_TU_PASSES)
 template __global__ void llk_eval_passes_kernel<4>(VB2_PASSES_KERNEL_ARGS);
 template __global__ void llk_eval_passes_kernel<2>(VB2_PASSES_KERNEL_ARGS);
 template __global__ void llk_eval_passes_kernel<0>(VB2_PASSES_KERNEL_ARGS);
+template __global__ void llk_eval_passes_kernel<4, true>(VB2_PASSES_KERNEL_ARGS);
+template __global__ void llk_eval_passes_kernel<2, true>(VB2_PASSES_KERNEL_ARGS);
+template __global__ void llk_eval_passes_kernel<0, true>(VB2_PASSES_KERNEL_ARGS);
 #endif
 
 // Multi-sample launch (BASELINE configs[4]: a cohort in lock-step): workgroup w serves sample
@@ -1508,7 +1599,7 @@ template __global__ void llk_eval_passes_kernel<0>(VB2_PASSES_KERNEL_ARGS);
 // partials, ticket and output slot; samples with num_valid == 0 sit this step out.
 // STATIC: every sample of the launch is known (on the host) to run the static deal: the item loop is compiled for it
 // alone, and pipelined across items (eval_body: PIPE).
-template <int MODE, bool W16, int KSEL = 0, int STATIC = 0>     // KSEL 2 / 4: every sample has that --NumPC and no known-AF column
+template <int MODE, bool W16, int KSEL = 0, int STATIC = 0, bool PD = false>     // KSEL 2 / 4: every sample has that --NumPC and no known-AF column
 __global__ void __launch_bounds__(Geom<MODE>::kMaxWaves * 64, Geom<MODE>::kWavesPerSimd)
 llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* __restrict__ scheds,
                       const double* __restrict__ points,
@@ -1527,7 +1618,7 @@ llk_eval_multi_kernel(const DeviceLayout* __restrict__ layouts, const Schedule* 
     if (nv <= 0) return;                                   // uniform for the workgroup
     const DeviceLayout L = layouts[s];
     const int stride = 2 * L.num_pc + 1;
-    eval_body<MODE, W16, NoHook, true, (STATIC ? 0 : -1), KSEL>(L, mi.v + (size_t)s * NP * stride, mi.count, points + (size_t)s * NP * stride, nv,
+    eval_body<MODE, W16, NoHook, true, (STATIC ? 0 : -1), KSEL, false, 8, PD>(L, mi.v + (size_t)s * NP * stride, mi.count, points + (size_t)s * NP * stride, nv,
                           partials + (size_t)s * (NP + 1) * bps, llk_out + (size_t)s * NP, tickets + s,
                           done_flag, done_seq, (uint32_t)(blockIdx.x % bps), (uint32_t)bps,
                           batch_done, batch_active, 1, use_ticket ? 0ull : done_seq,
@@ -1590,12 +1681,13 @@ LaunchGeom launch_geom(const DeviceLayout& L, int btl, int ngrp)
     bw = bw < 4 ? 4 : (bw > max_waves ? max_waves : bw);
     int grid = (L.num_mt + bw - 1) / bw;
     grid = grid < 1 ? 1 : (grid > grid_target ? grid_target : grid);
+    if (L.pd && grid > (L.num_mt >> 1)) grid = L.num_mt >> 1 > 0 ? L.num_mt >> 1 : 1;      // (a workgroup owns pairs of tiles)
     // Several point groups: a workgroup's work items are (tile, group) pairs, so a small sample -- a marker shard
     // of an 8-GPU run: 12 500 markers = 3-4 tiles per workgroup -- still has work for 16 waves, and 1 024 threads
     // to build its six tables with (4-wave workgroups took 47 us for a 48-point launch on 12 500 markers, against
     // 74 us on 100 000).  The grid, hence the tiles a workgroup owns, stays what it was.
     if (ngrp > 1) {
-        const int items = ((L.num_mt + grid - 1) / grid) * ngrp;
+        const int items = (int)owned_most(L.pd ? 1 : 0, (uint32_t)L.num_mt, (uint32_t)grid) * ngrp;
         if (items > bw) bw = items > max_waves ? max_waves : items;
     }
     return LaunchGeom{grid, bw};
@@ -1632,6 +1724,20 @@ static hipError_t raise_lds_limit(const void* fn)
 }
 
 #ifndef VB2_TU_PASSES      // ---- main unit only, down to the cohort kernels' launcher ----
+// the single-sample kernel of a wave shape: one per way of dealing (queue / static); --NumPC 2 and 4 without a known-AF column
+// have kernels of their own (the static deal of the search shapes only in the general form: a search takes the queue)
+template <int MODE, bool PD>
+static const void* eval_kernel_fn(int ksel, bool dyn)
+{
+    constexpr int kStaticQ = MODE == 2 ? 0 : 1;     // (never selected for MODE != 2: ksel is 0 there)
+    return ksel == 4 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 1, 4, PD>)
+                            : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, kStaticQ, 4, PD>))
+           : ksel == 2 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 1, 2, PD>)
+                              : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, kStaticQ, 2, PD>))
+           : dyn  ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 1, 0, PD>)
+                  : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 0, 0, PD>);
+}
+
 template <int MODE>
 static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, const double* h_points,
                              int num_valid, int ngrp,
@@ -1650,13 +1756,7 @@ static hipError_t launch_btl(const DeviceLayout& L, const double* d_points, cons
     // (the static deal of the search shapes only in the general form: a search takes the queue)
     const bool dyn = eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, ngrp);
     const int ksel = (L.known_af == nullptr && (MODE == 2 || dyn)) ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
-    constexpr int kStaticQ = MODE == 2 ? 0 : 1;     // (never selected for MODE != 2: ksel is 0 there)
-    const void* fn = ksel == 4 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 1, 4>)
-                                      : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, kStaticQ, 4>))
-                     : ksel == 2 ? (dyn ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 1, 2>)
-                                        : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, kStaticQ, 2>))
-                     : dyn  ? reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 1>)
-                            : reinterpret_cast<const void*>(&llk_eval_kernel<MODE, 0>);
+    const void* fn = L.pd ? eval_kernel_fn<MODE, true>(ksel, dyn) : eval_kernel_fn<MODE, false>(ksel, dyn);
     {
         hipError_t e = raise_lds_limit(fn);
         if (e != hipSuccess) return e;
@@ -1707,7 +1807,10 @@ static hipError_t launch_passes(const DeviceLayout& L, const double* d_points, i
     if (!eval_is_dynamic(L, (uint32_t)gm.grid, gm.block_waves, gpp)) return hipSuccess;
     const size_t shmem = eval_shmem_np(L, 8, gm.grid, gm.block_waves, gpp, kCompactExpTabDoubles);
     if (shmem > (size_t)kLdsLimitBytes) return hipSuccess;
-    const void* fn = L.num_pc == 4 ? reinterpret_cast<const void*>(&llk_eval_passes_kernel<4>)
+    const void* fn = L.pd ? (L.num_pc == 4 ? reinterpret_cast<const void*>(&llk_eval_passes_kernel<4, true>)
+                             : L.num_pc == 2 ? reinterpret_cast<const void*>(&llk_eval_passes_kernel<2, true>)
+                                             : reinterpret_cast<const void*>(&llk_eval_passes_kernel<0, true>))
+                     : L.num_pc == 4 ? reinterpret_cast<const void*>(&llk_eval_passes_kernel<4>)
                      : L.num_pc == 2 ? reinterpret_cast<const void*>(&llk_eval_passes_kernel<2>)
                                      : reinterpret_cast<const void*>(&llk_eval_passes_kernel<0>);
     hipError_t e = raise_lds_limit(fn);
@@ -1786,15 +1889,34 @@ size_t eval_shmem_np(const DeviceLayout& L, int np, int nblk, int block_waves, i
 {
     if (exp_tab_doubles <= 0) exp_tab_doubles = kExpTabDoubles;
     const size_t NP = (size_t)np, G = (size_t)ngrp;
-    const size_t items = (size_t)((L.num_mt + nblk - 1) / nblk) * G;      // (one slot per micro-tile and group)
+    const size_t items = (size_t)owned_most(L.pd ? 1 : 0, (uint32_t)L.num_mt, (uint32_t)nblk) * G;      // (one slot per micro-tile and group)
+    const size_t fixed_tabs = L.pd ? 0 : (size_t)exp_tab_doubles + (size_t)kLogTabDoubles;      // (no exp / log table in the probability domain)
     const size_t slots = items <= (size_t)L.dyn_limit * block_waves ? items : (size_t)block_waves * G;
     const size_t bytes = sizeof(double) * (G * (L.num_code + 1) * (size_t)(L.row_bytes / 8) + G * NP + 2 +
                                            G * NP * (2 * L.num_pc + 1) + 1 + G * NP * 2 * L.num_pc +
                                            1 + 2 * (size_t)L.num_prim +
-                                           (size_t)exp_tab_doubles + (size_t)kLogTabDoubles + 2 * slots * NP);
+                                           fixed_tabs + 2 * slots * NP);
     // workgroup 0 stages every workgroup's partial sums ([points][workgroups]) over the dead table
     const size_t stage = sizeof(double) * G * NP * (size_t)nblk;
     return bytes > stage ? bytes : stage;
+}
+
+int pd_row_budget(int num_marker, int num_pc, int num_cu)
+{
+    DeviceLayout T;
+    std::memset(&T, 0, sizeof(T));
+    T.pd = 1;
+    T.row_bytes = kRowBytesWide;
+    T.num_pc = num_pc;
+    T.num_mt = ((num_marker + kMtMarkers - 1) / kMtMarkers + 1) & ~1;
+    T.num_cu = num_cu;
+    T.dyn_limit = tunables().dyn_tiles;
+    for (int rows = kMaxWideCodes; rows > 1; --rows) {
+        T.num_code = T.num_prim = rows;
+        const LaunchGeom gm = launch_geom(T, 2, kMaxGroups);
+        if (eval_shmem_np(T, 8, gm.grid, gm.block_waves, kMaxGroups) <= (size_t)kLdsLimitBytes) return rows;
+    }
+    return 1;
 }
 
 size_t eval_shmem_bytes(const DeviceLayout& L, int btl, int nblk, int block_waves, int ngrp)
@@ -1834,6 +1956,16 @@ static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream)
         return hipGetLastError();
     };
     // (every shape also compiled for --NumPC 2 / 4 without a known-AF column: one-point steps of 32 samples 99 -> 94 us)
+    if (ml.pd) {                      // (every sample a probability-domain context: one list format, no 16-bit copy)
+        if (ml.all_static) {
+            if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, false, 4, 1, true>);
+            if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, false, 2, 1, true>);
+            return go(&llk_eval_multi_kernel<MODE, false, 0, 1, true>);
+        }
+        if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, false, 4, 0, true>);
+        if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, false, 2, 0, true>);
+        return go(&llk_eval_multi_kernel<MODE, false, 0, 0, true>);
+    }
     if (ml.w16) {
         if (ml.all_static) {          // (the pipelined item loop: compiled for the static deal only)
             if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, 4, 1>);
@@ -1866,12 +1998,12 @@ hipError_t launch_llk_eval_multi(const MultiLaunch& ml, hipStream_t stream)
 // flatten_kernels.hip)
 
 bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int tpu, int ngrp,
-                    std::vector<uint32_t>* off, std::vector<uint16_t>* item)
+                    std::vector<uint32_t>* off, std::vector<uint16_t>* item, int own_shift)
 {
     off->clear();
     item->clear();
     if (num_mt <= 0 || nblk <= 0 || nwave <= 0) return false;
-    const uint32_t max_tiles = ((uint32_t)num_mt + nblk - 1) / nblk;
+    const uint32_t max_tiles = owned_most(own_shift, (uint32_t)num_mt, (uint32_t)nblk);
     if ((size_t)((max_tiles + tpu - 1) / tpu) * ngrp > 65535) return false;
     off->reserve((size_t)nblk * nwave + 1);
     std::vector<uint64_t> load(nwave);
@@ -1880,7 +2012,7 @@ bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int t
     // per-marker epilogue and the item's fixed work; only the ratio matters
     constexpr uint64_t kRowCost = 28, kFixCost = 370;
     for (int b = 0; b < nblk; ++b) {
-        const uint32_t ntile = ((uint32_t)num_mt + nblk - 1 - b) / nblk;
+        const uint32_t ntile = owned_count(own_shift, (uint32_t)num_mt, (uint32_t)b, (uint32_t)nblk);
         const uint32_t nunit = (ntile + tpu - 1) / tpu;
         std::fill(load.begin(), load.end(), 0);
         for (auto& v : mine) v.clear();
@@ -1890,7 +2022,7 @@ bool build_schedule(const uint32_t* rows, int num_mt, int nblk, int nwave, int t
             uint32_t r = 0;
             for (int h = 0; h < tpu; ++h) {
                 const uint32_t it = (uint32_t)tpu * u + h;
-                if (it < ntile) r = std::max(r, rows[(size_t)b + (size_t)it * nblk]);
+                if (it < ntile) r = std::max(r, rows[owned_tile(own_shift, (uint32_t)b, (uint32_t)nblk, it)]);
             }
             const uint64_t cost = kRowCost * r + kFixCost;
             for (int g = 0; g < ngrp; ++g) {
@@ -1938,13 +2070,16 @@ size_t resident_state_doubles(int nmax, int num_pc)
            (size_t)resident_stage_doubles(nmax, num_pc);
 }
 
-uint32_t resident_cache_rows(const uint32_t* rows, int num_mt, int nblk)
+uint32_t resident_cache_rows(const uint32_t* rows, int num_mt, int nblk, int own_shift)
 {
     uint32_t most = 0;
-    for (int b = 0; b < nblk && b < num_mt; ++b) {
-        uint32_t off = 0, prev = 0, it = 0;
-        for (int t = b; t < num_mt; t += nblk, ++it) {
-            const uint32_t start = cache_start(off, prev, it);
+    for (int b = 0; b < nblk; ++b) {
+        const uint32_t ntile = owned_count(own_shift, (uint32_t)num_mt, (uint32_t)b, (uint32_t)nblk);
+        uint32_t off = 0, prev = 0;
+        for (uint32_t it = 0; it < ntile; ++it) {
+            const uint32_t t = owned_tile(own_shift, (uint32_t)b, (uint32_t)nblk, it);
+            if (t >= (uint32_t)num_mt) break;
+            const uint32_t start = cache_start(own_shift != 0, off, prev, it);
             off = start + rows[t];
             prev = start;
         }
@@ -1984,7 +2119,7 @@ hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, doubl
     if (ra.cache_rows > 0 && dyn && ra.cache_tiles <= 8 * gm.block_waves) {
         ra.cache_tiles = (ra.cache_tiles + 1) & ~1;
         const size_t at = (shmem + 15) / 16 * 16;
-        const size_t need = (size_t)ra.cache_tiles * 8 + (size_t)ra.cache_rows * kMtMarkers * 8;
+        const size_t need = (size_t)ra.cache_tiles * 8 + (size_t)ra.cache_rows * kMtMarkers * (L.pd ? 4 : 8);
         if (at + need <= (size_t)kLdsLimitBytes) {
             ra.cache_off = (int32_t)(at / sizeof(double));
             shmem = at + need;
@@ -1992,13 +2127,17 @@ hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, doubl
         }
     }
     if (!lcache) ra.cache_rows = 0;
-    const void* fn = lcache ? (ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 4, true>)
-                               : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 2, true>)
-                                           : reinterpret_cast<const void*>(&llk_resident_kernel<1, 0, true>))
-                     : ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 4>)
-                     : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 2>)
-                     : dyn       ? reinterpret_cast<const void*>(&llk_resident_kernel<1>)
-                                 : reinterpret_cast<const void*>(&llk_resident_kernel<0>);
+    auto pick = [&](auto pd_tag) -> const void* {
+        constexpr bool kPd = decltype(pd_tag)::value;
+        return lcache ? (ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 4, true, kPd>)
+                         : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 2, true, kPd>)
+                                     : reinterpret_cast<const void*>(&llk_resident_kernel<1, 0, true, kPd>))
+               : ksel == 4 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 4, false, kPd>)
+               : ksel == 2 ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 2, false, kPd>)
+               : dyn       ? reinterpret_cast<const void*>(&llk_resident_kernel<1, 0, false, kPd>)
+                           : reinterpret_cast<const void*>(&llk_resident_kernel<0, 0, false, kPd>);
+    };
+    const void* fn = L.pd ? pick(std::true_type()) : pick(std::false_type());
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     // Every workgroup must be on a CU at the same time (they all wait for the control wave and for each other's sums).

@@ -34,6 +34,8 @@ namespace vb2 {
     X(host_pack, 0)        /* 1: (with host_flatten) also the kernel-order arrays on the host */                         \
     X(run_sched, -1)       /* order of a tile's runs: -1 scheduled above kSchedMinCodes codes, 0 plain, 1 scheduled */   \
     X(force_narrow, 0)     /* 1: narrow table rows although the dictionary would fit wide ones */                        \
+    X(pd, 1)               /* 0: never the probability-domain layout (llk_kernels.h: kMaxPow) */                         \
+    X(pd_rows, 0)          /* its table rows: 0 = what the LDS holds for a 48-point launch */                            \
     X(digest_multiset, 0)  /* 1: vb2_debug_flatten_digest takes a tile's run words as a multiset per lane */             \
     X(slab_cache, 1)       /* 0: freed device / pinned slabs go back to the driver */                                    \
     X(cpus, 0)             /* CPUs the process may use, 0 = cgroup quota / affinity */                                   \
