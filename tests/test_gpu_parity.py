@@ -1258,8 +1258,9 @@ def test_lockstep_search_regroups_the_unfinished_samples(S, tunable):
             c.close()
 
 
-def test_cohort_steps_on_16bit_run_lists_are_bit_identical():
-    """The steps of a cohort (every wave shape: 1, 2, 4 and 8 points per sample) stream a 16-bit copy of every sample's run lists
+def test_cohort_steps_on_16bit_run_lists_are_bit_identical(tunable):
+    """(Run-word layout: tunable pd = 0 keeps every sample out of the probability-domain layout, which has one list format.)
+    The steps of a cohort (every wave shape: 1, 2, 4 and 8 points per sample) stream a 16-bit copy of every sample's run lists
     (DeviceLayout::codes16: dictionary index | count << 8, re-coded on the device from the 32-bit run words;
     half the HBM bytes per step).  Same runs, same order, same FMAs: a batch on the 16-bit lists returns,
     BIT FOR BIT, what the same batch returns on the 32-bit lists -- for ragged depths (runs split at 31
@@ -1267,6 +1268,7 @@ def test_cohort_steps_on_16bit_run_lists_are_bit_identical():
     with 300 reads per marker, and for both ways the copy comes about (VB2_OPT_COHORT_LAYOUT at creation /
     built by vb2_batch_create) -- and each sample's own single-context evaluation to rounding."""
     import ctypes
+    tunable("pd", 0)
     k = 3
     rng = np.random.default_rng(77)
     datas = [vb.synth.make_pileup(3000, 25, k, alpha_true=0.02, seed=71),

@@ -793,9 +793,13 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         num_code = pd_rows;
         for (int r = 0; r < kNumQual; ++r) {
             if (code_hist[2 * r] + code_hist[2 * r + 1] == 0) continue;
+            // (one record per quality: {pErr, first row | K << 16} -- the table build makes the K rows from one value)
+            const unsigned long long bits = (unsigned long long)((uint32_t)dict_perr.size() | ((uint32_t)kpow[r] << 16));
+            double y;
+            std::memcpy(&y, &bits, sizeof(y));
+            prim.push_back(make_double2(phred[qof[r]], y));
             for (int n = 1; n <= kpow[r]; ++n) {
-                row_off_pd[r][n] = (uint16_t)(prim.size() * kRowBytesWide);
-                prim.push_back(make_double2(phred[qof[r]], (double)n));
+                row_off_pd[r][n] = (uint16_t)(dict_perr.size() * kRowBytesWide);
                 dict_perr.push_back(phred[qof[r]]);
             }
         }

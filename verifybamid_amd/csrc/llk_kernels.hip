@@ -352,11 +352,11 @@ __device__ __forceinline__ double table_entry(double alpha, double perr_signed, 
     return log_tab(val, ltab_addr);
 }
 
-// The same entry BEFORE its logarithm, class ref, to the power n (probability-domain contexts: llk_kernels.h, kMaxPow):
-// the value the reference takes the logarithm of (h:223-225, the same expression order), multiplied up n - 1 times.  A
+// The same entry BEFORE its logarithm, class ref (probability-domain contexts: llk_kernels.h, kMaxPow): the value the
+// reference takes the logarithm of (h:223-225, the same expression order); the table build multiplies it up to P^2 .. P^K.  A
 // negative "probability" (alpha outside [0, 1]) or a NaN becomes NaN, like the reference's log() of it: the marker's
 // likelihood is then NaN, fails `markerLK > 0` and the marker is left out.
-__device__ __forceinline__ double prob_entry(double alpha, double p_err, int n, int g1, int g2)
+__device__ __forceinline__ double prob_entry(double alpha, double p_err, int g1, int g2)
 {
     const double p_ok = 1.0 - p_err;
     const double e1 = (double)g1 * (1.0 / 6.0), e2 = (double)g2 * (1.0 / 6.0);
@@ -364,10 +364,7 @@ __device__ __forceinline__ double prob_entry(double alpha, double p_err, int n, 
     const double one_minus_alpha = 1.0 - alpha;
     double val = (alpha * e1 + one_minus_alpha * e2) * p_err +
                  (alpha * n1 + one_minus_alpha * n2) * p_ok;
-    val = val >= 0.0 ? val : __builtin_nan("");
-    double r = val;
-    for (int i = 1; i < n; ++i) r *= val;
-    return r;
+    return val >= 0.0 ? val : __builtin_nan("");
 }
 
 __device__ __forceinline__ void initial_gf(double af, double* gf)   // h:186-192
@@ -501,8 +498,14 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // a marker's list is one 16-bit row offset per step, ref steps first and alt steps behind them; the six sums are PRODUCTS,
 // class alt multiplies them with the row read the other way round (g -> 2 - g, h:164-177: T[alt][q][g1][g2] is T[ref][q][2-g1][2-g2]),
 // and the epilogue needs no exponential.  Only for contexts whose markers cannot underflow that way (Context::create).
+// SPLIT (a probability-domain launch of more points than a workgroup's LDS holds tables for -- a dictionary of ~100 rows and 48
+// points): the workgroups come in PAIRS that share their tiles and split the point groups -- workgroup 2v takes the first
+// half of the groups, 2v + 1 the second, both over the tiles of the VIRTUAL blocks v and v + grid / 2, i.e. over exactly the
+// tiles two workgroups of a plain launch own.  A tile's product still has its own slot, a virtual block's slots are
+// multiplied in the same order and its sum goes to the same word of the partial sums as in a plain launch of this grid:
+// the same bits, and no second pass over the tiles (llk_eval_passes_kernel: +4 us per pass at C3).
 template <int MODE, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1, int KSEL = 0,
-          bool LCACHE = false, int ESH = 8, bool PD = false>
+          bool LCACHE = false, int ESH = 8, bool PD = false, bool SPLIT = false>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -516,6 +519,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     extern __shared__ __attribute__((aligned(16))) double lds[];
     static_assert(MODE >= 2 && MODE <= 5, "wave shapes 2..5");
     static_assert(!PD || (!W16 && ESH == 8), "probability-domain contexts have one list format and no exp table");
+    static_assert(!SPLIT || (PD && MODE == 2 && QUEUE == 1 && !STREAM && !LCACHE), "split launches: the 8-point shape on the queue");
     constexpr int OSH = PD ? 1 : 0;             // a workgroup owns pairs of neighbouring micro-tiles (owned_tile)
     // the launch is known to carry ONE group of points (every shape but the 8-point one always does; cohort steps too):
     // the group loops and the item -> (group, unit) division go at compile time
@@ -535,7 +539,12 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // A launch carries ngrp groups of NP points; each group has its own table and the
     // (tile, group) pairs are the work items, so a bigger batch re-reads the pileup from
     // L2 per group but pays launch, prologue and reduction once.
-    const int ngrp = ONEGRP ? 1 : ngrp_in;
+    // (SPLIT: this workgroup's half of the launch's groups, the points before them, and its two virtual blocks)
+    const int g_lo = SPLIT ? ((blk & 1u) ? (ngrp_in + 1) / 2 : 0) : 0;
+    const int ngrp = ONEGRP ? 1 : SPLIT ? ((blk & 1u) ? ngrp_in / 2 : (ngrp_in + 1) / 2) : ngrp_in;
+    const int p_off = g_lo * NP;
+    const uint32_t vhalf = SPLIT ? nblk >> 1 : 0u, vb0 = SPLIT ? blk >> 1 : blk;
+    constexpr int NVS = SPLIT ? 2 : 1;          // virtual blocks per workgroup
     const double* const known_af_p = KAF == 0 ? nullptr : L.known_af;
     const int NPT = NP * ngrp;                  // points of this launch
     constexpr int kEtabCopies = (1 << ESH) / 8, kEtabDoubles = PD ? 0 : 64 * kEtabCopies;
@@ -543,9 +552,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     double* etab = lds;                         // [64][32] exp_nonpos's 2^(j/64), bank-replicated; at LDS address 0
     double* ltab = lds + kEtabDoubles;          // [128] {1 / c, log c} of log_tab
     double* tab = ltab + kLtabDoubles;          // [ngrp][nrow][RS]  (PD: neither table above: this one is at address 0)
-    double* red = tab + ngrp * nrow * RS;       // [NPT] block sums; then the work-queue counter
-    unsigned int* queue = reinterpret_cast<unsigned int*>(red + NPT);
-    double* pts = red + NPT + 2;                // [NPT][2k+1] this launch's parameter rows
+    double* red = tab + ngrp * nrow * RS;       // [virtual blocks][NPT] block sums; then the work-queue counter
+    unsigned int* queue = reinterpret_cast<unsigned int*>(red + NVS * NPT);
+    double* pts = red + NVS * NPT + 2;          // [NPT][2k+1] this launch's parameter rows
     // the PCs again, as the epilogue reads them: [group][slot][2k][BTL] -- a lane's BTL points side by
     // side, so one ds_read_b128 (4 LDS cycles) brings a coefficient of both points where two
     // strided 8-byte reads (ds_read2_b64: 8 cycles) did
@@ -578,7 +587,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // parameter rows -> LDS with one coalesced load (they may live in mapped host memory)
     for (int e = tid; e < NPT * stride; e += nthread) {
         const int b = e / stride;
-        const int src = b < num_valid ? b : num_valid - 1;
+        const int src = p_off + b < num_valid ? p_off + b : num_valid - 1;
         const int idx = src * stride + (e - b * stride);
         // resident mode: the rows were just written by another workgroup -> L1-bypassing loads
         const double v = (kAblate & kAblNoMap) ? 0.01 * (double)(1 + idx % 7)
@@ -647,8 +656,17 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                                                : pts[(grp_e * NP + bb) * stride + 2 * k];
             double* gtab = tab + (size_t)grp_e * nrow * RS;
             if constexpr (PD) {
-                // record pi IS row pi: {pErr of its quality, the power n}; class alt reads the same row mirrored
-                gtab[pi * RS + bp] = prob_entry(alpha_e, rec.x, (int)rec.y, g1, g2);
+                // record pi = a QUALITY: {pErr, first row | K << 16}: its rows P^1 .. P^K follow each other, one multiply
+                // apiece (class alt reads the same rows mirrored)
+                const double v = prob_entry(alpha_e, rec.x, g1, g2);
+                double r = v;
+                double* cell = gtab + dc * RS + bp;
+                *cell = r;
+                for (int n = 1; n < twin; ++n) {
+                    r *= v;
+                    cell += RS;
+                    *cell = r;
+                }
             } else {
                 const double v = table_entry(alpha_e, rec.x, g1, g2, ltab_addr);
                 const double tv = W16 ? 0.5 * v : v;
@@ -672,10 +690,12 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // an A/B knob -- pulled longest-first through an LDS counter, each item's product going to its
     // own LDS slot.  Either way the multiplication order is fixed, so the schedule does not
     // change a single bit of the result.
-    const uint32_t ntile_blk = owned_count(OSH, (uint32_t)L.num_mt, blk, nblk);
+    const uint32_t nt_v0 = owned_count(OSH, (uint32_t)L.num_mt, vb0, nblk);
+    const uint32_t nt_v1 = SPLIT ? owned_count(OSH, (uint32_t)L.num_mt, vb0 + vhalf, nblk) : 0u;
+    const uint32_t ntile_blk = SPLIT ? (nt_v0 > nt_v1 ? nt_v0 : nt_v1) : nt_v0;      // (SPLIT: per virtual block, the larger)
     const size_t mp = L.m_pad;
     // work items: (tile, group), or (TPW consecutive owned tiles, group)
-    const uint32_t nunit = (ntile_blk + TPW - 1) / TPW;
+    const uint32_t nunit = SPLIT ? 2u * ntile_blk : (ntile_blk + TPW - 1) / TPW;
     const uint32_t nitem = (kAblate & kAblNoItems) ? 0u : nunit * (uint32_t)ngrp;
     const float inv_nunit = 1.0f / (float)(nunit ? nunit : 1u);
     const uint32_t ngrp_magic = ngrp > 1 ? 0xFFFFFFFFu / (uint32_t)ngrp + 1u : 0u;      // ceil(2^32 / ngrp) for ngrp >= 2
@@ -874,14 +894,15 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 const vdouble2 t = row[i];
                 const int pt = i / 3, q2 = 2 * (i - 3 * pt);
                 const int a0 = pt * 6 + (kAlt ? 5 - q2 : q2), a1 = pt * 6 + (kAlt ? 4 - q2 : q2 + 1);
-                acc[a0] = ((kFirst && j == 0) ? init : acc[a0]) * t.x;
-                acc[a1] = ((kFirst && j == 0) ? init : acc[a1]) * t.y;
+                // (a tile's first step: the products START as the row -- the marker's constant is multiplied in once, at the end)
+                acc[a0] = (kFirst && j == 0) ? t.x : acc[a0] * t.x;
+                acc[a1] = (kFirst && j == 0) ? t.y : acc[a1] * t.y;
             }
         }
     };
     // ---- per-marker epilogue: a marker's likelihood as (mantissa, exponent) per point, from its six sums per point ----
     auto marker_lk = [&](const bool live, const uint32_t pos, const double* acc, const double e0, const double e1, const double e2,
-                         const double* udr, const double mur, const uint32_t my_ptq, double* lk_m, int* lk_e) {
+                         const double* udr, const double mur, const uint32_t my_ptq, double* lk_m, int* lk_e, const double cst_pd) {
 #pragma unroll
         for (int t = 0; t < BTL; ++t) { lk_m[t] = 1.0; lk_e[t] = 0; }
         if constexpr ((kAblate & kAblNoEpi) != 0) {          // (ablation build: the sums and the constants are consumed, nothing is computed from them)
@@ -950,10 +971,25 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                     x10 = exp_nonpos<ESH>(a[2], etab_lane); x12 = exp_nonpos<ESH>(a[3], etab_lane);
                     x20 = exp_nonpos<ESH>(a[4], etab_lane); x21 = exp_nonpos<ESH>(a[5], etab_lane);
                 }
+                double lk;
+                if constexpr (PD) {
+                    // the six products lack the marker's constant exp(c_other) (`cst`): it multiplies their part of the sum
+                    // once; the three g1 == g2 terms hold it since context creation
+                    const double o0 = fma(x02, gf2[2], x01 * gf2[1]);
+                    const double o1 = fma(x12, gf2[2], x10 * gf2[0]);
+                    const double o2 = fma(x21, gf2[1], x20 * gf2[0]);
+                    const double off = fma(o2, gf[2], fma(o1, gf[1], o0 * gf[0]));
+                    const double dg = fma(e2 * gf2[2], gf[2], fma(e1 * gf2[1], gf[1], (e0 * gf2[0]) * gf[0]));
+                    lk = fma(cst_pd, off, dg);
+                    if (__builtin_expect(lk < 0x1p-960, 0)) {
+                        x01 *= cst_pd; x02 *= cst_pd; x10 *= cst_pd; x12 *= cst_pd; x20 *= cst_pd; x21 *= cst_pd;
+                    }
+                } else {
                 const double s0 = fma(x02, gf2[2], fma(x01, gf2[1], e0 * gf2[0]));
                 const double s1 = fma(x12, gf2[2], fma(e1, gf2[1], x10 * gf2[0]));
                 const double s2 = fma(e2, gf2[2], fma(x21, gf2[1], x20 * gf2[0]));
-                double lk = fma(s2, gf[2], fma(s1, gf[1], s0 * gf[0]));
+                lk = fma(s2, gf[2], fma(s1, gf[1], s0 * gf[0]));
+                }
                 // Near the bottom of the double range the factoring is no longer harmless: products with
                 // the priors underflow at different places, and the reference's rule below (h:310-311,
                 // "add log(lk) only if lk > 0") turns that into a marker counted or dropped, 745 units
@@ -1054,9 +1090,12 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             }
             unit = idx - grp * nunit;
         }
-        const uint32_t it = TPW * unit + (uint32_t)half;     // index in this workgroup's tile list
-        const bool have_tile = TPW == 1 || it < ntile_blk;   // TPW > 1: the list's end may leave lanes idle
-        const uint32_t mt = owned_tile(OSH, blk, nblk, have_tile ? it : 0u);
+        // index in this workgroup's tile list (SPLIT: the units alternate between the two virtual blocks -- both lists are
+        // in descending order of rows, so the queue still walks longest first)
+        const uint32_t vs = SPLIT ? (unit & 1u) : 0u;
+        const uint32_t it = SPLIT ? unit >> 1 : TPW * unit + (uint32_t)half;
+        const bool have_tile = SPLIT ? it < (vs ? nt_v1 : nt_v0) : (TPW == 1 || it < ntile_blk);   // TPW > 1: the list's end may leave lanes idle
+        const uint32_t mt = owned_tile(OSH, vb0 + vs * vhalf, nblk, have_tile ? it : 0u);
         const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)row_bytes + (uint32_t)g * (6 * BTL * 8));
         const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
         // (one slot, one group: the table's address is the constant behind the exp table -- this file has no static LDS --
@@ -1112,7 +1151,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // first row is walked outside the row loop
         constexpr bool PEEL = TPW == 1 && !W16 && !PIPE && !LCACHE && QUEUE == 1 && (kAblate & kAblNoReads) == 0;
         double acc[BTL * 6];
-        if constexpr (!PEEL) {
+        if constexpr (!PEEL && !PD) {
 #pragma unroll
             for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
         }
@@ -1194,14 +1233,16 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 w[kPf - 1] = load_row(r + kPf);
                 return cur;
             };
-            if constexpr (PEEL) {
-                if (rows_ref > 0) {          // (the first row starts the products from the marker's constant)
-                    walk_pd(next_word(), acc, my_tab, std::false_type(), std::true_type(), cst);
-                    r = 1;
-                } else {
+            // (the first row's first step IS the products: no initial values, no multiplies)
+            if (rows_ref > 0) {
+                walk_pd(next_word(), acc, my_tab, std::false_type(), std::true_type(), cst);
+                r = 1;
+            } else if (rows > 0) {
+                walk_pd(next_word(), acc, my_tab, std::true_type(), std::true_type(), cst);
+                r = 1;
+            } else {
 #pragma unroll
-                    for (int i = 0; i < BTL * 6; ++i) acc[i] = cst;
-                }
+                for (int i = 0; i < BTL * 6; ++i) acc[i] = 1.0;
             }
             for (; r < rows_ref; ++r) walk_pd(next_word(), acc, my_tab, std::false_type(), std::false_type(), cst);
             for (; r < rows; ++r) walk_pd(next_word(), acc, my_tab, std::true_type(), std::false_type(), cst);
@@ -1246,7 +1287,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // ---- per-marker epilogue: this marker's likelihood as (mantissa, exponent) per point ----
         double lk_m[BTL];
         int lk_e[BTL];
-        marker_lk(live, pos, acc, e0, e1, e2, udr, mur, my_ptq, lk_m, lk_e);
+        marker_lk(live, pos, acc, e0, e1, e2, udr, mur, my_ptq, lk_m, lk_e, cst);
         VB2_IP_USE(lk_m[0]); VB2_IP_USE(lk_m[BTL - 1]);
         VB2_IP_T(ip_t5);
         if (!dyn) {
@@ -1284,7 +1325,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         if (m == 0 && have_tile) {
 #pragma unroll
             for (int t = 0; t < BTL; ++t) {
-                const size_t o = (((size_t)grp * ntile_blk + it) * NP + g * BTL + t) * 2;
+                const size_t o = ((((size_t)grp * NVS + vs) * ntile_blk + it) * NP + g * BTL + t) * 2;
                 tile_llk[o] = lk_m[t];
                 tile_llk[o + 1] = (double)lk_e[t];
             }
@@ -1322,11 +1363,13 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     __syncthreads();
     {
         const uint32_t j16 = (uint32_t)lane & 15u;
-        for (int b = tid >> 4; b < NPT; b += nthread >> 4) {          // (uniform over a row of 16 lanes)
-            const int grp = b / NP, bb = b - grp * NP;
+        for (int b = tid >> 4; b < NVS * NPT; b += nthread >> 4) {          // (uniform over a row of 16 lanes)
+            const int vsb = SPLIT ? b / NPT : 0, bl = b - vsb * NPT;
+            const int grp = bl / NP, bb = bl - grp * NP;
             ScaledProd p{1.0, 0.0};
-            for (uint32_t i = j16; i < nres; i += 16) {
-                const size_t o = (((size_t)grp * nres + i) * NP + bb) * 2;
+            const uint32_t nres_b = SPLIT ? (vsb ? nt_v1 : nt_v0) : nres;
+            for (uint32_t i = j16; i < nres_b; i += 16) {
+                const size_t o = ((((size_t)grp * NVS + vsb) * nres + i) * NP + bb) * 2;
                 p.m *= tile_llk[o];
                 p.e += tile_llk[o + 1];
                 sp_renorm(p);                              // a slot can be as small as 2^-64
@@ -1372,9 +1415,12 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // ---- single-launch mode A (large batches): the last workgroup to arrive sums all partials ----
         // Hand-off through 8-byte agent-scope atomics on both sides (write-through stores,
         // L1-bypassing loads), drained before the ticket is drawn: placement independent.
-        if (tid < NPT)
-            __hip_atomic_store(&partials[(size_t)tid * nblk + blk], red[tid],
+        if (tid < NVS * NPT) {
+            // (SPLIT: the sums of this workgroup's points over virtual block vb0 / vb0 + vhalf, where a plain launch has them)
+            const int vsb = SPLIT ? tid / NPT : 0, bl = tid - vsb * NPT;
+            __hip_atomic_store(&partials[(size_t)(p_off + bl) * nblk + (vb0 + (uint32_t)vsb * vhalf)], red[tid],
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned int* last_flag = queue;                                    // the queue is drained
@@ -1536,6 +1582,18 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
 {
     eval_body<MODE, false, NoHook, false, QUEUE, KSEL, false, 8, PD>(L, ip.v, ip.count, points, num_valid, partials, llk_out, ticket,
                                                                      done_flag, done_seq, blockIdx.x, gridDim.x, nullptr, 0u, ngrp, tag, sch);
+}
+
+// see eval_body, SPLIT
+template <int KSEL>
+__global__ void __launch_bounds__(Geom<2>::kMaxWaves * 64, Geom<2>::kWavesPerSimd)
+llk_eval_split_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid, double* __restrict__ partials,
+                      double* __restrict__ llk_out, unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
+                      unsigned long long done_seq, int ngrp)
+{
+    eval_body<2, false, NoHook, false, 1, KSEL, false, 8, true, true>(L, nullptr, 0, points, num_valid, partials, llk_out, ticket, done_flag,
+                                                                     done_seq, blockIdx.x, gridDim.x, nullptr, 0u, ngrp, 0ull,
+                                                                     Schedule{nullptr, nullptr});
 }
 
 // A call of more points than the LDS holds tables for -- wide quality alphabets: 118 codes x 8 points are 48.5 KB per point
@@ -1825,6 +1883,44 @@ static hipError_t launch_passes(const DeviceLayout& L, const double* d_points, i
     return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
 }
 
+// LDS of a split launch's workgroup (eval_body, SPLIT): the tables of half the groups, the result slots of two virtual blocks
+static size_t split_shmem(const DeviceLayout& L, int grid, int block_waves, int ngrp_total)
+{
+    const int half = (ngrp_total + 1) / 2;
+    return eval_shmem_np(L, 8, grid >= 2 ? grid / 2 : 1, block_waves, half) + sizeof(double) * 8 * (size_t)half;     // (+ the second virtual block's sums)
+}
+
+// see eval_body, SPLIT.  *taken = false: the geometry does not allow it (the caller falls back to passes / several launches)
+static hipError_t launch_split(const DeviceLayout& L, const double* d_points, int num_valid, double* d_partials, double* d_out,
+                               unsigned int* d_ticket, unsigned long long* done_flag, unsigned long long done_seq,
+                               hipStream_t stream, bool* taken)
+{
+    *taken = false;
+    if (!L.pd) return hipSuccess;
+    const int ngrp = (num_valid + 7) / 8;
+    if (ngrp < 2) return hipSuccess;
+    const LaunchGeom gm = launch_geom(L, 2, ngrp);      // (a pair of workgroups has the items of one workgroup of a plain launch, twice)
+    if (gm.grid < 2 || (gm.grid & 1)) return hipSuccess;
+    // every item through the queue, a slot apiece
+    const uint32_t tiles2 = owned_most(1, (uint32_t)L.num_mt, (uint32_t)gm.grid / 2u);
+    if (tiles2 * (uint32_t)((ngrp + 1) / 2) > (uint32_t)(L.dyn_limit * gm.block_waves)) return hipSuccess;
+    const size_t shmem = split_shmem(L, gm.grid, gm.block_waves, ngrp);
+    if (shmem > (size_t)kLdsLimitBytes) return hipSuccess;
+    const int ksel = L.known_af == nullptr ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
+    const void* fn = ksel == 4 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<4>)
+                     : ksel == 2 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<2>)
+                                 : reinterpret_cast<const void*>(&llk_eval_split_kernel<0>);
+    hipError_t e = raise_lds_limit(fn);
+    if (e != hipSuccess) return e;
+    DeviceLayout Lc = L;
+    const double* a_points = d_points;
+    int a_nv = num_valid, a_ngrp = ngrp;
+    unsigned long long a_seq = done_seq;
+    void* args[] = {&Lc, &a_points, &a_nv, &d_partials, &d_out, &d_ticket, &done_flag, &a_seq, &a_ngrp};
+    *taken = true;
+    return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
+}
+
 hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d_points,
                            const double* h_points, double* d_partials, double* d_out,
                            unsigned int* d_ticket,
@@ -1846,6 +1942,18 @@ hipError_t launch_llk_eval(const DeviceLayout& L, int num_point, const double* d
         // (8-point groups need the wide table rows; a context whose dictionary is too big for
         // 16-bit offsets into wide rows has narrow ones and evaluates 4 points per launch)
         const int cap = L.row_bytes == kRowBytesWide ? 8 * max_groups(L, 2, gm2.grid, gm2.block_waves) : 4;
+        // probability-domain contexts: pairs of workgroups split the point groups (Tunables::split 0: passes)
+        if (tn.split && L.pd && tk && reduce_mode != 2 && cap >= 8 && left > cap) {
+            const int take = left < kMaxPointsPerLaunch ? left : kMaxPointsPerLaunch;
+            bool taken = false;
+            unsigned long long* dfp = (done + take >= num_point) ? done_flag : nullptr;
+            hipError_t es = launch_split(L, p, take, d_partials, d_out + done, tk, dfp, done_seq, stream, &taken);
+            if (es != hipSuccess) return es;
+            if (taken) {
+                done += take;
+                continue;
+            }
+        }
         // more points than one launch's tables hold: the passes of ONE launch (Tunables::passes 0: a launch per `cap` points)
         if (tn.passes && tk && reduce_mode != 2 && L.row_bytes == kRowBytesWide && cap >= 8 && left > cap) {
             const int take = left < kMaxPointsPerLaunch ? left : kMaxPointsPerLaunch;
@@ -1911,10 +2019,14 @@ int pd_row_budget(int num_marker, int num_pc, int num_cu)
     T.num_mt = ((num_marker + kMtMarkers - 1) / kMtMarkers + 1) & ~1;
     T.num_cu = num_cu;
     T.dyn_limit = tunables().dyn_tiles;
+    // (the tables of a 48-point launch: all six groups' in one workgroup, or -- Tunables::split -- three in each of a pair)
+    const bool split = tunables().split != 0;
     for (int rows = kMaxWideCodes; rows > 1; --rows) {
         T.num_code = T.num_prim = rows;
         const LaunchGeom gm = launch_geom(T, 2, kMaxGroups);
-        if (eval_shmem_np(T, 8, gm.grid, gm.block_waves, kMaxGroups) <= (size_t)kLdsLimitBytes) return rows;
+        const size_t need = (split && gm.grid >= 2 && !(gm.grid & 1)) ? split_shmem(T, gm.grid, gm.block_waves, kMaxGroups)
+                                  : eval_shmem_np(T, 8, gm.grid, gm.block_waves, kMaxGroups);
+        if (need <= (size_t)kLdsLimitBytes) return rows;
     }
     return 1;
 }

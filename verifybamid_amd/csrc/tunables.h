@@ -22,6 +22,7 @@ namespace vb2 {
     X(reduce, 0)           /* cross-workgroup hand-off: 0 by size, 1 arrival ticket, 2 tagged sets */                   \
     X(tagged_max, 16)      /* launches of up to this many points hand off through tagged sets */                        \
     X(passes, 1)           /* 0: a launch per table-load of points instead of llk_eval_passes_kernel */                 \
+    X(split, 1)            /* 0: probability-domain launches of many points in passes instead of split between workgroup pairs */ \
     X(coop, 1)             /* the resident search kernel goes up with hipLaunchCooperativeKernel (0: plain launch;      \
                               the library also launches plainly by itself when a profiler's tool library is loaded) */  \
     X(dyn_tiles, 10)       /* work items per wave up to which a workgroup's waves pull them through the LDS queue */    \
