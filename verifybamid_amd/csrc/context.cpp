@@ -849,13 +849,13 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             const uint32_t e = eff_pd[active[a]];
             sref[a] = e & 0xffffu;
             salt[a] = e >> 16;
-            ra_max = std::max(ra_max, (salt[a] + 1) / 2);
+            ra_max = std::max(ra_max, salt[a]);
             sr_max = std::max(sr_max, sref[a]);
         }
         std::vector<int64_t> p1(m_active);
         {
             const uint64_t width = (uint64_t)sr_max + 1, nkey = ((uint64_t)ra_max + 1) * width;
-            auto key = [&](int64_t a) { return (uint64_t)((salt[a] + 1) / 2) * width + sref[a]; };
+            auto key = [&](int64_t a) { return (uint64_t)salt[a] * width + sref[a]; };
             if (nkey <= (1u << 22)) {
                 std::vector<int64_t> start((size_t)nkey + 1, 0);
                 for (int64_t a = 0; a < m_active; ++a) ++start[(size_t)(nkey - 1 - key(a)) + 1];
@@ -867,16 +867,17 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             }
         }
         const int full = (int)(m_active / kMtMarkers), tiles = num_mt;
+        // (rr: a tile's ref steps, ra: its alt steps -- the longest marker's of either; rows = two steps each)
         std::vector<uint32_t> rr(tiles, 0), ra(tiles, 0);
         for (int t = 0; t < tiles; ++t)
             for (int64_t m = (int64_t)t * kMtMarkers; m < std::min<int64_t>(m_active, (int64_t)(t + 1) * kMtMarkers); ++m) {
-                rr[t] = std::max(rr[t], (sref[p1[m]] + 1) / 2);
-                ra[t] = std::max(ra[t], (salt[p1[m]] + 1) / 2);
+                rr[t] = std::max(rr[t], sref[p1[m]]);
+                ra[t] = std::max(ra[t], salt[p1[m]]);
             }
         std::vector<int> torder(tiles);
         std::iota(torder.begin(), torder.end(), 0);
         std::stable_sort(torder.begin(), torder.begin() + full, [&](int x, int y) {
-            const uint32_t rx = rr[x] + ra[x], ry = rr[y] + ra[y];
+            const uint32_t rx = (rr[x] + ra[x] + 1) / 2, ry = (rr[y] + ra[y] + 1) / 2;
             return rx != ry ? rx > ry : ra[x] > ra[y];
         });
         if (num_mt & 1) ++num_mt;                               // (a workgroup owns PAIRS of tiles: llk_kernels.h, owned_tile)
@@ -887,12 +888,12 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             mt_row_off[t] = (uint32_t)total_rows;
             if (t >= tiles) continue;
             const int src_t = torder[t];
-            if (rr[src_t] > 0xffffu || ra[src_t] > 0xffffu) {     // (ruled out by pass A's bound: steps beyond 16 bits)
-                set_error("vb2_ctx_create: a marker needs more than 131070 steps");
+            if (rr[src_t] + ra[src_t] > 0xffffu) {     // (ruled out by pass A's bound: steps beyond 16 bits)
+                set_error("vb2_ctx_create: a marker needs more than 65535 steps");
                 return VB2_ERR_INVALID;
             }
-            mt_rows[t] = rr[src_t] + ra[src_t];
-            mt_rec_y[t] = rr[src_t] | (ra[src_t] << 16);
+            mt_rows[t] = (rr[src_t] + ra[src_t] + 1) / 2;
+            mt_rec_y[t] = rr[src_t] | ((rr[src_t] + ra[src_t]) << 16);      // {ref steps, all steps}
             total_rows += mt_rows[t];
             for (int64_t l = 0; l < kMtMarkers; ++l) {
                 const int64_t from = (int64_t)src_t * kMtMarkers + l;
@@ -1092,7 +1093,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             // the marker's steps (pack_pd_kernel, statement for statement): ref runs, then alt runs, a run of count c as
             // ceil(c / K) row offsets; either phase padded to the tile's rows with the row of ones
             uint32_t* out = codes + (size_t)mt_row_off[t] * kMtMarkers + lane;
-            const uint32_t rows_ref = mt_rec_y[t] & 0xffffu, rows_alt = mt_rec_y[t] >> 16;
+            const uint32_t s1 = mt_rec_y[t] & 0xffffu, s2 = mt_rec_y[t] >> 16;
             uint32_t step = 0, cur = 0;
             auto put = [&](uint32_t off) {
                 if (step & 1u) out[(size_t)(step >> 1) * kMtMarkers] = cur | (off << 16);
@@ -1111,7 +1112,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                         left -= c1;
                     }
                 }
-                const uint32_t end = 2u * (cls == 0 ? rows_ref : rows_ref + rows_alt);
+                const uint32_t end = cls == 0 ? s1 : 2u * ((s2 + 1u) >> 1);
                 while (step < end) put(pad_off);
             }
         } else {
@@ -1146,9 +1147,13 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             std::vector<uint16_t> lst[kMtMarkers];
             for (int64_t t = t0; t < t1; ++t) {
                 uint32_t first_step = 0;
+                const uint32_t s1 = mt_rec_y[t] & 0xffffu, s2 = mt_rec_y[t] >> 16;
+                uint16_t* const out16 = reinterpret_cast<uint16_t*>(codes + (size_t)mt_row_off[t] * kMtMarkers);
+                auto half = [&](int l, uint32_t g, uint32_t off) {          // step g of lane l (pack_pd_sched_kernel: put_step)
+                    out16[((size_t)(g >> 1) * kMtMarkers + l) * 2 + (g & 1u)] = (uint16_t)off;
+                };
                 for (uint32_t cls = 0; cls < 2; ++cls) {
-                    const int steps = (int)(2u * (cls == 0 ? (mt_rec_y[t] & 0xffffu) : (mt_rec_y[t] >> 16)));
-                    uint32_t* out = codes + ((size_t)mt_row_off[t] + (first_step >> 1)) * kMtMarkers;
+                    const int steps = (int)(cls == 0 ? s1 : s2 - s1);
                     uint32_t eff16[kMtMarkers];
                     for (int l = 0; l < kMtMarkers; ++l) {
                         lst[l].clear();
@@ -1170,16 +1175,14 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                         }
                         eff16[l] = (uint32_t)lst[l].size();
                     }
-                    auto half = [&](int l, int c, uint32_t off) {
-                        uint32_t& w = out[(size_t)(c >> 1) * kMtMarkers + l];
-                        w = (c & 1) ? ((w & 0xffffu) | (off << 16)) : ((w & 0xffff0000u) | off);
-                    };
                     schedule_tile(S, eff16, steps, num_code, ident,
                                   [&](int l, int j) -> uint32_t { return lst[l][j]; },
-                                  [&](int l, int c, uint32_t rw) { half(l, c, rw * (uint32_t)row_bytes); },
-                                  [&](int l, int c) { half(l, c, pad_off); });
+                                  [&](int l, int c, uint32_t rw) { half(l, first_step + (uint32_t)c, rw * (uint32_t)row_bytes); },
+                                  [&](int l, int c) { half(l, first_step + (uint32_t)c, pad_off); });
                     first_step += (uint32_t)steps;
                 }
+                if (s2 & 1u)
+                    for (int l = 0; l < kMtMarkers; ++l) half(l, s2, pad_off);
             }
         });
     if (!device_pack && run_sched)

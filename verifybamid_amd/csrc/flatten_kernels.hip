@@ -336,7 +336,7 @@ pack_pd_kernel(const PackPdArgs a)
     if (m < a.m_pad) {
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
         const uint2 rec = a.mt_rec[t];
-        const uint32_t rows_ref = rec.y & 0xffffu, rows_alt = rec.y >> 16;
+        const uint32_t s1 = rec.y & 0xffffu, s2 = rec.y >> 16;       // ref steps at [0, s1), alt steps at [s1, s2), two to a row
         const bool have = m < a.m_active;
         const uint32_t nrun = have ? a.nrun[m] : 0u;
         const uint16_t* src = a.runs + (have ? a.src_off[m] : 0u);
@@ -360,7 +360,7 @@ pack_pd_kernel(const PackPdArgs a)
                     left -= c1;
                 }
             }
-            const uint32_t end = 2u * (cls == 0 ? rows_ref : rows_ref + rows_alt);
+            const uint32_t end = cls == 0 ? s1 : 2u * ((s2 + 1u) >> 1);
             while (step < end) put(a.pad_off);
         }
         const int64_t i = have ? (int64_t)a.pidx[m] : 0;
@@ -414,10 +414,13 @@ pack_pd_sched_kernel(const PackPdArgs a)
     }
     const SchedIdentity ident;
     uint32_t first_step = 0;
+    // (a step is a 16-bit half of a word: step g of the tile sits in word g / 2 of the lane's column, half g % 2)
+    uint16_t* const out16 = reinterpret_cast<uint16_t*>(a.codes + (size_t)rec.x * kMtMarkers + lane);
+    auto put_step = [&](uint32_t g, uint32_t off) { out16[(size_t)(g >> 1) * (kMtMarkers * 2) + (g & 1u)] = (uint16_t)off; };
+    const uint32_t s1 = rec.y & 0xffffu, s2 = rec.y >> 16;
 #pragma unroll 1
     for (uint32_t cls = 0; cls < 2; ++cls) {
-        const int steps = (int)(2u * (cls == 0 ? (rec.y & 0xffffu) : (rec.y >> 16)));
-        uint32_t* const out = a.codes + ((size_t)rec.x + (first_step >> 1)) * kMtMarkers + lane;
+        const int steps = (int)(cls == 0 ? s1 : s2 - s1);
         // the lane's steps of this phase, as row indices
         uint32_t n = 0;
         for (uint32_t j = 0; j < nrun; ++j) {
@@ -437,12 +440,8 @@ pack_pd_sched_kernel(const PackPdArgs a)
         const bool plain = sched_is_plain(s_eff[row], steps, a.num_code);      // (the same for the 16 lanes of a row)
         if (plain) {
             if (live) {              // the steps in plain order (pack_pd_kernel's loop)
-                uint32_t step = 0, cur = 0;
-                auto put_plain = [&](uint32_t off) {
-                    if (step & 1u) out[(size_t)(step >> 1) * kMtMarkers] = cur | (off << 16);
-                    else cur = off;
-                    ++step;
-                };
+                uint32_t step = 0;
+                auto put_plain = [&](uint32_t off) { put_step(first_step + step, off); ++step; };
                 for (uint32_t j = 0; j < nrun; ++j) {
                     const uint32_t rw = src[j], idx = rw & 0xffu;
                     if ((idx & 1u) != cls) continue;
@@ -485,12 +484,12 @@ pack_pd_sched_kernel(const PackPdArgs a)
         __syncthreads();
         if (!plain && live) {
             auto off_of = [&](uint32_t v) { return v ? (v - 1u) * (uint32_t)a.row_bytes : a.pad_off; };
-            for (int c = 0; c < steps; c += 2)
-                out[(size_t)(c >> 1) * kMtMarkers] = off_of(s_at[row][c][lane]) | (off_of(s_at[row][c + 1][lane]) << 16);
+            for (int c = 0; c < steps; ++c) put_step(first_step + (uint32_t)c, off_of(s_at[row][c][lane]));
         }
         __syncthreads();
         first_step += (uint32_t)steps;
     }
+    if (live && (s2 & 1u)) put_step(s2, a.pad_off);          // (an odd number of steps: the last word's second half)
 }
 
 hipError_t launch_pack_pd(const PackPdArgs& a, hipStream_t stream)

@@ -825,7 +825,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     };
     auto issue_rows = [&](const vuint2 rec_, bool have_) {           // the first kPf rows of a tile (clamped to its own)
         const uint32_t cb_ = rec_.x * kRowBytes + (uint32_t)m * kLaneBytes;       // (32-bit byte offsets: see load_row)
-        const int rows_ = have_ ? (PD ? (int)((rec_.y & 0xffffu) + (rec_.y >> 16)) : (int)rec_.y) : 0;
+        const int rows_ = have_ ? (PD ? (int)(((rec_.y >> 16) + 1u) >> 1) : (int)rec_.y) : 0;
         const int last_ = rows_ > 0 ? rows_ - 1 : 0;
 #pragma unroll
         for (int j = 0; j < kPf; ++j) {
@@ -883,10 +883,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // ---- PD: one word of the list = two steps.  A step multiplies the six products of every point by ONE table row; class alt
     // (the rows behind the tile's ref rows: alt_tag) by the same row read the other way round, pair p <-> 5 - p.  No count, no
     // conversion: one SDWA add per step and the multiplies ----
-    auto walk_pd = [&](const uint32_t w_cur, double* acc, const uint32_t my_tab, auto alt_tag, auto first_tag, const double init) {
-        constexpr bool kAlt = decltype(alt_tag)::value, kFirst = decltype(first_tag)::value;
+    auto walk_pd = [&](const uint32_t w_cur, double* acc, const uint32_t my_tab, auto alt0_tag, auto alt1_tag, auto first_tag) {
+        constexpr bool kAlt0 = decltype(alt0_tag)::value, kAlt1 = decltype(alt1_tag)::value, kFirst = decltype(first_tag)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            const bool kAlt = j ? kAlt1 : kAlt0;        // (a compile-time value after unrolling)
             const uint32_t row_addr = my_tab + (j ? (w_cur >> 16) : (w_cur & 0xffffu));
             lds_cdouble2* row = reinterpret_cast<lds_cdouble2*>(row_addr);
 #pragma unroll
@@ -1180,9 +1181,10 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // (Context::create refuses more rows), and a row's address costs no 64-bit vector arithmetic
         const uint32_t cbase = LCACHE ? 0u : rec.x * kRowBytes + (uint32_t)m * kLaneBytes;
         const uint32_t crow = rec.x + (uint32_t)m * kLaneBytes;      // (LCACHE: this lane's word of the tile's first row, LDS)
-        // a scalar when TPW == 1.  PD: {ref rows | alt rows << 16}: the rows of the two phases (walk_pd)
-        const int rows_ref = PD ? (have_tile ? (int)(rec.y & 0xffffu) : 0) : 0;
-        const int rows = have_tile ? (PD ? rows_ref + (int)(rec.y >> 16) : (int)rec.y) : 0;
+        // a scalar when TPW == 1.  PD: {ref steps | all steps << 16}: the tile's markers have their ref steps at [0, s1) and
+        // their alt steps at [s1, s2), two steps to a row (walk_pd)
+        const int steps_ref = PD ? (have_tile ? (int)(rec.y & 0xffffu) : 0) : 0;
+        const int rows = have_tile ? (PD ? (int)(((rec.y >> 16) + 1u) >> 1) : (int)rec.y) : 0;
         // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
         // tile's last row -- up to kPf useless row loads per item of 6..16 rows -- and every block of kPf rows begins
         // by waiting for all of them.  Measured on one box, depth 8 / 4 / 2: 48-point launch 74.9 / 74.4 / 76.6 us;
@@ -1233,19 +1235,27 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 w[kPf - 1] = load_row(r + kPf);
                 return cur;
             };
-            // (the first row's first step IS the products: no initial values, no multiplies)
-            if (rows_ref > 0) {
-                walk_pd(next_word(), acc, my_tab, std::false_type(), std::true_type(), cst);
-                r = 1;
-            } else if (rows > 0) {
-                walk_pd(next_word(), acc, my_tab, std::true_type(), std::true_type(), cst);
+            // (the first row's first step IS the products: no initial values, no multiplies).  Rows [0, s1 / 2) hold two ref
+            // steps, the rows behind two alt steps; if s1 is odd, row s1 / 2 holds the last ref and the first alt step.
+            const int rows_ra = steps_ref >> 1;
+            const std::false_type kRef;
+            const std::true_type kAltT, kFirstT;
+            const std::false_type kNotFirst;
+            if (rows > 0) {
+                if (steps_ref >= 2) walk_pd(next_word(), acc, my_tab, kRef, kRef, kFirstT);
+                else if (steps_ref == 1) walk_pd(next_word(), acc, my_tab, kRef, kAltT, kFirstT);
+                else walk_pd(next_word(), acc, my_tab, kAltT, kAltT, kFirstT);
                 r = 1;
             } else {
 #pragma unroll
                 for (int i = 0; i < BTL * 6; ++i) acc[i] = 1.0;
             }
-            for (; r < rows_ref; ++r) walk_pd(next_word(), acc, my_tab, std::false_type(), std::false_type(), cst);
-            for (; r < rows; ++r) walk_pd(next_word(), acc, my_tab, std::true_type(), std::false_type(), cst);
+            for (; r < rows_ra; ++r) walk_pd(next_word(), acc, my_tab, kRef, kRef, kNotFirst);
+            if ((steps_ref & 1) && r == rows_ra && r < rows) {
+                walk_pd(next_word(), acc, my_tab, kRef, kAltT, kNotFirst);
+                ++r;
+            }
+            for (; r < rows; ++r) walk_pd(next_word(), acc, my_tab, kAltT, kAltT, kNotFirst);
             if constexpr (PIPE) {
                 issue_rows(rec_n2, have_next);
                 cst_nx = other_const(mt_next, have_next);
