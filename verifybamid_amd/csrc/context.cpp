@@ -1036,7 +1036,12 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         const int t = (int)(m / kMtMarkers), lane = (int)(m % kMtMarkers);
         if (pd) {
             uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers;
-            for (size_t r = 0; r < (size_t)mt_rows[t]; ++r) row0[r * kMtMarkers + lane] = pad_off | (pad_off << 16);
+            {   // (a lane without a marker: the padding row in either phase)
+                const uint32_t s1 = mt_rec_y[t] & 0xffffu;
+                uint16_t* h16 = reinterpret_cast<uint16_t*>(row0);
+                for (uint32_t g = 0; g < 2u * mt_rows[t]; ++g)
+                    h16[((size_t)(g >> 1) * kMtMarkers + lane) * 2 + (g & 1u)] = (uint16_t)(pad_off + (g >= s1 ? (uint32_t)kPdAltOffset : 0u));
+            }
             continue;
         }
         uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
@@ -1108,12 +1113,12 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                     uint32_t left = rw >> 8;
                     while (left > 0u) {
                         const uint32_t c1 = left > kq ? kq : left;
-                        put(row_off_pd[rank][c1]);
+                        put(row_off_pd[rank][c1] + cls * (uint32_t)kPdAltOffset);
                         left -= c1;
                     }
                 }
                 const uint32_t end = cls == 0 ? s1 : 2u * ((s2 + 1u) >> 1);
-                while (step < end) put(pad_off);
+                while (step < end) put(pad_off + cls * (uint32_t)kPdAltOffset);
             }
         } else {
         uint32_t* row0 = codes + (size_t)mt_row_off[t] * kMtMarkers * 2;
@@ -1177,12 +1182,12 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                     }
                     schedule_tile(S, eff16, steps, num_code, ident,
                                   [&](int l, int j) -> uint32_t { return lst[l][j]; },
-                                  [&](int l, int c, uint32_t rw) { half(l, first_step + (uint32_t)c, rw * (uint32_t)row_bytes); },
-                                  [&](int l, int c) { half(l, first_step + (uint32_t)c, pad_off); });
+                                  [&](int l, int c, uint32_t rw) { half(l, first_step + (uint32_t)c, rw * (uint32_t)row_bytes + cls * (uint32_t)kPdAltOffset); },
+                                  [&](int l, int c) { half(l, first_step + (uint32_t)c, pad_off + cls * (uint32_t)kPdAltOffset); });
                     first_step += (uint32_t)steps;
                 }
                 if (s2 & 1u)
-                    for (int l = 0; l < kMtMarkers; ++l) half(l, s2, pad_off);
+                    for (int l = 0; l < kMtMarkers; ++l) half(l, s2, pad_off + (uint32_t)kPdAltOffset);
             }
         });
     if (!device_pack && run_sched)

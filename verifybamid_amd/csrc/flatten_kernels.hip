@@ -356,12 +356,12 @@ pack_pd_kernel(const PackPdArgs a)
                 uint32_t left = rw >> 8;
                 while (left > 0u) {
                     const uint32_t c1 = left > kq ? kq : left;
-                    put(a.row_off[rank][c1]);
+                    put(a.row_off[rank][c1] + cls * (uint32_t)kPdAltOffset);
                     left -= c1;
                 }
             }
             const uint32_t end = cls == 0 ? s1 : 2u * ((s2 + 1u) >> 1);
-            while (step < end) put(a.pad_off);
+            while (step < end) put(a.pad_off + cls * (uint32_t)kPdAltOffset);
         }
         const int64_t i = have ? (int64_t)a.pidx[m] : 0;
         if (a.kaf_s) a.kaf_s[m] = have ? a.kaf[i] : 0.0;
@@ -449,11 +449,11 @@ pack_pd_sched_kernel(const PackPdArgs a)
                     uint32_t left = rw >> 8;
                     while (left > 0u) {
                         const uint32_t c1 = left > kq ? kq : left;
-                        put_plain(a.row_off[rank][c1]);
+                        put_plain(a.row_off[rank][c1] + cls * (uint32_t)kPdAltOffset);
                         left -= c1;
                     }
                 }
-                while (step < (uint32_t)steps) put_plain(a.pad_off);
+                while (step < (uint32_t)steps) put_plain(a.pad_off + cls * (uint32_t)kPdAltOffset);
             }
         } else {
             TileSched& S = s_state[row];
@@ -483,13 +483,13 @@ pack_pd_sched_kernel(const PackPdArgs a)
         if (!plain) sched_pad(s_state[row], lane, steps, pad);
         __syncthreads();
         if (!plain && live) {
-            auto off_of = [&](uint32_t v) { return v ? (v - 1u) * (uint32_t)a.row_bytes : a.pad_off; };
+            auto off_of = [&](uint32_t v) { return (v ? (v - 1u) * (uint32_t)a.row_bytes : a.pad_off) + cls * (uint32_t)kPdAltOffset; };
             for (int c = 0; c < steps; ++c) put_step(first_step + (uint32_t)c, off_of(s_at[row][c][lane]));
         }
         __syncthreads();
         first_step += (uint32_t)steps;
     }
-    if (live && (s2 & 1u)) put_step(s2, a.pad_off);          // (an odd number of steps: the last word's second half)
+    if (live && (s2 & 1u)) put_step(s2, a.pad_off + (uint32_t)kPdAltOffset);          // (an odd number of steps: the last word's second half)
 }
 
 hipError_t launch_pack_pd(const PackPdArgs& a, hipStream_t stream)

@@ -26,6 +26,10 @@ constexpr int kMaxRunCount = 31;           // the 16-bit prefix of a double hold
 // mirrored), n = 1 .. its quality's K <= kMaxPow; a marker's list is one 16-bit row offset per STEP (a run of count c takes
 // ceil(c / K) steps), ref steps first, then alt steps
 constexpr int kMaxPow = 8;
+// An ALT step's offset points kPdAltOffset bytes into its row: launch shapes of at most four points per table row keep the
+// mirror image of the row's values there, so that their read loops need not know a step's class (the 8-point shape, which has
+// no room for it, takes the offset off again and names its products the other way round)
+constexpr int kPdAltOffset = 192;
 constexpr int kPdSampleMarkers = 2048;     // markers whose run counts choose the K's (before the reads are walked)
 constexpr double kPdMaxBound = 1000.0;     // a marker may lose this many binary orders of magnitude at most (all reads at their
                                            // least likely genotype pair) for its products to stay normal numbers
