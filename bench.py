@@ -300,35 +300,45 @@ def main():
     }
 
     if rank == 0 and args.mode == "sample":
-        # roofline of the dominant kernel: algorithmic bytes per launch / device time
+        # ---- roofline of the dominant kernel: frac = t_ideal / t_measured, t_ideal = the LONGEST of the three
+        # times the launch would take if one resource alone ran at its peak --
+        #   lds : bytes the read loops gather from the LDS tables (48 B per step and point: vb2_info.num_step, computed by the
+        #         library for THIS context; + the projection's coefficient reads) / 157.3 TB/s (256 B/clk/CU x 256 CUs x 2.4 GHz)
+        #   fp64: FP64 vector flops of the launch (instruction classes counted by the committed PMC pass) / 78.6 TFLOP/s
+        #   hbm : HBM-side bytes of the launch (FETCH_SIZE x 2 + WRITE_SIZE of the committed PMC pass) / 8 TB/s
+        # `bound` names the longest.  The fraction rises when the launch gets shorter for the same work and when work is
+        # taken out of the BINDING term only if another term then binds -- it cannot fall because an idle unit got idler.
+        # PMC-derived inputs carry the hash of the kernel sources they were measured on (tools/update_profiles.py): a figure
+        # of another hash is dropped (its term is null, `stale_profile` says so) instead of pricing the old kernel.
+        from verifybamid_amd import _abi as abi_
+        khash = abi_.kernel_source_hash()
+        stale = []
+
+        def fresh(name):
+            pj, psrc = latest_profile(name)
+            if not pj or pj.get("markers") != args.markers or pj.get("num_pc") != k or pj.get("batch", B) != B:
+                return None, None
+            if pj.get("kernel_src_hash") != khash:
+                stale.append(psrc)
+                return None, psrc
+            return pj, psrc
+
         bytes_per_launch = info["algorithmic_bytes_per_eval"] * B
         step_us = 1e3 * dev_ms / args.steps
-        achieved = bytes_per_launch / (step_us * 1e-6) / 1e9
-        # HBM-side bytes and VALU counters cannot be read live (PMC needs rocprofv3): take the values
-        # measured by the committed PMC passes of this same command when the shape matches
-        traffic, traffic_src = None, None
-        tj, tsrc = latest_profile("traffic_b%d.json" % B)
-        if tj and tj.get("markers") == args.markers and tj.get("num_pc") == k:
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], tsrc
-        vj, vsrc = latest_profile("valu_b%d.json" % B)
+        t_meas = step_us * 1e-6
+        achieved = bytes_per_launch / t_meas / 1e9
+        tj, traffic_src = fresh("traffic_b%d.json" % B)
+        traffic = tj["traffic_bytes_per_launch"] if tj else None
+        vj, vsrc = fresh("valu_b%d.json" % B)
         valu = None
-        if vj and vj.get("markers") == args.markers and vj.get("num_pc") == k:
+        if vj:
             valu = {"busy_frac": vj["valu_busy_frac"],
                     "lane_instr_per_marker_point": vj["lane_instr_per_marker_point"],
-                    "lds_busy_frac": vj.get("lds_busy_frac"), "source": vsrc, "note": FP64_VALU_NOTE}
-        # the binding ceiling, next to the nominal one: FP64 VALU issue time / kernel time.  Issue time =
-        # lane-instructions per marker x point (SQ_INSTS_VALU of the committed PMC pass of this command) x
-        # markers x points / (256 CUs x 4 SIMDs x 16 FP64 lanes per clock x 2.4 GHz)
-        # What this box's vector units sustain, measured now on this device (calib_kernels.hip through
-        # vb2_debug_issue_ceiling): FP64 FMAs alone from 16 waves per CU -- the VALU issue ceiling; under sustained FP64
-        # load the clock settles near 1.9 GHz, not the nominal 2.4 -- and the read loop's own mix (12 v_fma_f64 fed by 6
-        # ds_read_b128 per run), which the LDS pipe binds at less than half that.  The read loop is ~40 % of the kernel's
-        # VALU instructions and the kernel as a whole issues 1 ds_read_b128 per ~6 VALU instructions, so the VALU ceiling
-        # is the one that binds: VERDICT r4: `frac` is quoted against THIS, and the nominal SURVEY 8d figure
-        # (algorithmic bytes / time / 8 TB/s) moves to `nominal`.
+                    "lds_busy_frac": vj.get("lds_busy_frac"),
+                    "lds_bank_conflict_frac": (vj["SQ_LDS_BANK_CONFLICT"] / vj["SQ_LDS_IDX_ACTIVE"]) if vj.get("SQ_LDS_IDX_ACTIVE") else None,
+                    "source": vsrc, "note": FP64_VALU_NOTE}
         import ctypes
         ceil3 = (ctypes.c_double * 3)()
-        from verifybamid_amd import _abi as abi_
         lib_ = abi_.lib()
         lib_.vb2_debug_issue_ceiling.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib_.vb2_debug_issue_ceiling.restype = ctypes.c_int
@@ -340,50 +350,52 @@ def main():
                        "source": "measured on this device after the timed region: vb2_debug_issue_ceiling "
                                  "(verifybamid_amd/csrc/calib_kernels.hip; stand-alone: tools/ubench/lds_fma_mix.hip)"}
         ROOFLINE["ceiling"] = ceiling
-        ROOFLINE["lane_instr_headline"] = valu["lane_instr_per_marker_point"] if valu else None
-        valu_frac = valu_achieved = None
-        if valu:
-            valu_achieved = valu["lane_instr_per_marker_point"] * info["num_active_marker"] * B / (step_us * 1e-6)
-            issue_us = (valu["lane_instr_per_marker_point"] * info["num_active_marker"] * B /
-                        (1024 * 16 * 2.4e9)) * 1e6
-            valu["issue_us_per_launch_at_2.4GHz"] = issue_us
-            valu["frac_of_nominal_2.4GHz_issue"] = issue_us / step_us
-            if ceiling:
-                valu_frac = valu_achieved / ceiling["fp64_fma_alone"]
-        # the classical flop roofline next to it: FP64 vector flops of the launch (instruction classes counted by the committed
-        # PMC pass of this command: adds + multiplies + 2 x FMAs, x 64 lanes) / time against the FP64 vector peak,
-        # 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz = 78.6 TFLOP/s.  Unlike lane-instructions/s it does not move when
-        # integer or move instructions leave the kernel.
-        fj, fsrc = latest_profile("flops_b%d.json" % B)
-        fp64 = None
-        if fj and fj.get("markers") == args.markers and fj.get("num_pc") == k:
+        valu_issue_frac = None
+        if valu and ceiling:
+            valu_issue_frac = (valu["lane_instr_per_marker_point"] * info["num_active_marker"] * B / t_meas) / ceiling["fp64_fma_alone"]
+        fj, fsrc = fresh("flops_b%d.json" % B)
+        LDS_PEAK = 256.0 * 256 * 2.4e9          # B/s: ds_read_b128 moves 256 B per clock and CU (MI355X_MICROARCH.md, LDS)
+        FP64_PEAK = 78.6e12
+        lds_bytes = (48.0 * info["num_step"] + 16.0 * k * info["num_active_marker"]) * B
+        terms = {"lds": {"bytes_per_launch": lds_bytes, "peak_TBps": LDS_PEAK / 1e12, "t_us": 1e6 * lds_bytes / LDS_PEAK,
+                         "source": "vb2_info.num_step x 48 B (one table row per step and point) + 16 B x --NumPC per marker and "
+                                   "point (the projection's coefficients), x points; peak = 256 B/clk/CU x 256 CUs x 2.4 GHz"},
+                 "fp64": None, "hbm": None}
+        if fj:
             fl_ = float(fj["fp64_flops_per_launch"])
-            fp64 = {"achieved": fl_ / (step_us * 1e-6) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                    "frac": fl_ / (step_us * 1e-6) / 1e12 / 78.6,
-                    "fp64_flops_per_marker_point": fj["fp64_flops_per_marker_point"],
-                    "fp64_instr_per_marker_point": fj["fp64_instr_per_marker_point"], "source": fsrc,
-                    "note": "FP64 vector peak at the nominal 2.4 GHz; under FP64 load the clock settles near 1.9-2.0 GHz "
-                            "(roofline.ceiling): against the flops the device sustains at that clock the fraction is frac x 2.4 / clock"}
-        ROOFLINE["valu_frac_headline"] = valu_frac
+            terms["fp64"] = {"flops_per_launch": fl_, "peak_TFLOPs": FP64_PEAK / 1e12, "t_us": 1e6 * fl_ / FP64_PEAK,
+                             "fp64_flops_per_marker_point": fj["fp64_flops_per_marker_point"],
+                             "fp64_instr_per_marker_point": fj["fp64_instr_per_marker_point"], "source": fsrc,
+                             "achieved_TFLOPs": fl_ / t_meas / 1e12, "frac_of_peak": fl_ / t_meas / FP64_PEAK}
+        if traffic:
+            terms["hbm"] = {"bytes_per_launch": traffic, "peak_TBps": HBM_PEAK_GBPS / 1e3,
+                            "t_us": 1e6 * traffic / (HBM_PEAK_GBPS * 1e9), "source": traffic_src}
+        have = {n: t["t_us"] for n, t in terms.items() if t}
+        bound = max(have, key=have.get)
+        t_ideal_us = have[bound]
+        frac = t_ideal_us / step_us
+        ROOFLINE["frac_headline"] = frac
         ROOFLINE["us_per_point_headline"] = step_us / B
+        result["config"]["layout"] = ("probability domain (%d table rows)" % info["num_table_row"]) if info.get("layout") else "run words"
         result["roofline"] = {
-            # what binds: FP64 VALU issue under the read loop's LDS traffic.  achieved = VALU lane-instructions per
-            # second of the timed launches (instruction count: SQ_INSTS_VALU of the committed PMC pass of this very
-            # command, `valu.source`); peak = the same quantity of the calibration loop on this device
-            "bound": "valu_fp64", "achieved": (valu_achieved / 1e12) if valu_achieved else None,
-            "peak": (ceiling["fp64_fma_alone"] / 1e12) if ceiling else None, "unit": "T lane-instr/s",
-            "frac": valu_frac, "ceiling": ceiling,
+            "bound": bound, "frac": frac, "t_ideal_us": t_ideal_us, "t_measured_us": step_us, "terms": terms,
+            "achieved": {"lds": lds_bytes / t_meas / 1e12, "unit": "TB/s gathered from LDS"}["lds"] if bound == "lds" else
+                        (terms["fp64"]["achieved_TFLOPs"] if bound == "fp64" else traffic / t_meas / 1e12),
+            "peak": LDS_PEAK / 1e12 if bound == "lds" else (FP64_PEAK / 1e12 if bound == "fp64" else HBM_PEAK_GBPS / 1e3),
+            "unit": "TB/s" if bound != "fp64" else "TFLOP/s",
+            "stale_profile": stale or None, "kernel_src_hash": khash,
+            "valu_issue_frac": valu_issue_frac, "ceiling": ceiling,
             "nominal": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS,
                         "note": "SURVEY 8d: algorithmic bytes per evaluation x points / time / 8 TB/s.  Passes 1 by construction: "
                                 "the 48 points of a launch are served by one L2/LDS-resident copy of the pileup -- the HBM "
                                 "side moves `traffic` bytes per launch (`hbm_actual_GBps`)"},
             "traffic": traffic, "traffic_source": traffic_src,
-            "hbm_actual_GBps": (traffic / (step_us * 1e-6) / 1e9) if traffic else None,
-            "valu": valu, "fp64": fp64, "mfma_util": 0.0,
+            "hbm_actual_GBps": (traffic / t_meas / 1e9) if traffic else None,
+            "valu": valu, "fp64": terms["fp64"], "mfma_util": 0.0,
             "mfma_note": "no MFMA instruction on the path: FP64 MFMA and FP64 VALU share the unit on gfx950 "
                          "(profiles/r01/ubench_mfma_overlap.txt), and the UD x PC projection is 2k FMAs per marker",
-            "kernel": "llk_eval_kernel<%d,true>" % (2 if B > 4 else 3),
+            "kernel": ("llk_eval_split_kernel" if (info.get("layout") and B > 24) else "llk_eval_kernel<%d,...>" % (2 if B > 4 else 3)),
             "launches_per_step": (B + 47) // 48,
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "device_us_per_launch": step_us,
@@ -476,7 +488,7 @@ def main():
                 us = timed_launches(ctx, pts, out, nb, stream, 1500, torch)
                 # frac: against the ceiling that binds -- the time these points take at the headline launch's rate per point,
                 # scaled by the headline's own fraction of the measured issue ceiling; nominal_frac: SURVEY 8d bytes / 8 TB/s
-                vf = ROOFLINE.get("valu_frac_headline")
+                vf = ROOFLINE.get("frac_headline")
                 sp["points_%d" % nb] = {"device_us_per_launch": us, "evals_per_s": nb / us * 1e6,
                                         "frac": (vf * ROOFLINE["us_per_point_headline"] * nb / us) if vf else None,
                                         "us_at_headline_rate": ROOFLINE["us_per_point_headline"] * nb,
@@ -520,18 +532,22 @@ def main():
                     wopt = {"wall_ms_to_converged_alpha": 1e3 * min(t_w), "alpha": west["alpha"], "num_eval": west["num_eval"]}
                 wctx.close()
                 wj, wsrc = latest_profile(pmc_name) if pmc_name else (None, None)
+                from verifybamid_amd import _abi as abi_w
+                if wj and wj.get("kernel_src_hash") != abi_w.kernel_source_hash():
+                    wj = None                                  # (measured on other kernel sources: dropped)
                 li = wj.get("lane_instr_per_marker_point") if wj else None
-                ceil_ = (ROOFLINE.get("ceiling") or {}).get("fp64_fma_alone")
                 nominal = winfo["algorithmic_bytes_per_eval"] * B / (w_us * 1e-6) / 1e9
+                lds_us = 1e6 * (48.0 * winfo["num_step"] + 16.0 * k * winfo["num_active_marker"]) * B / (256.0 * 256 * 2.4e9)
                 obj = {
                     "what": "the headline launch on the same sample shape with base qualities uniform in %d..%d "
                             "(%d dictionary codes instead of %d)" % (q_lo, q_hi, winfo["num_code"], info["num_code"]),
                     "distinct_codes": int(winfo["num_code"]), "reads": int(winfo["num_read"]),
                     "device_us_per_launch": w_us, "evals_per_s": B / w_us * 1e6,
-                    # frac: VALU lane-instructions per second (count: the committed PMC pass of this shape) against the
-                    # issue ceiling measured on this device; nominal: SURVEY 8d bytes against 8 TB/s
-                    "bound": "valu_fp64",
-                    "frac": (li * winfo["num_active_marker"] * B / (w_us * 1e-6) / ceil_) if (li and ceil_) else None,
+                    # frac: the time the launch's LDS gathers alone would take at the LDS peak (the headline's binding term:
+                    # roofline.terms.lds) over the measured time; nominal: SURVEY 8d bytes against 8 TB/s
+                    "bound": "lds", "frac": lds_us / w_us, "t_ideal_us": lds_us,
+                    "layout": "probability domain" if winfo.get("layout") else "run words",
+                    "table_rows": int(winfo["num_table_row"]), "steps_per_marker": winfo["num_step"] / max(1, winfo["num_active_marker"]),
                     "nominal": {"bound": "hbm", "achieved": nominal, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": nominal / HBM_PEAK_GBPS},
                     "ratio_to_headline": (B / w_us * 1e6) / (B / (1e3 * dev_ms / args.steps) * 1e6),
@@ -540,11 +556,10 @@ def main():
                     "lds_busy_frac": wj.get("lds_busy_frac") if wj else None,
                     "lds_bank_conflict_frac": wj.get("lds_bank_conflict_frac") if wj else None, "pmc_source": wsrc,
                     "optimize": wopt, "create_ms": create_times(wide),
-                    "launch": ("one launch of two passes of 24 points (llk_eval_passes_kernel: three point groups' tables fit in "
-                               "LDS beside a compact exp table) when the dictionary is this wide; VB2_PASSES=0: three launches of 16"
-                               if winfo["num_code"] > 80 else
-                               "two launches of llk_eval_kernel<2,true>, 32 + 16 points (four point groups' tables fit in LDS); "
-                               "device_us_per_launch is the 48-point CALL, lane_instr_per_marker_point per launch's own points"),
+                    "launch": ("ONE launch, the six point groups split between workgroup pairs (llk_eval_split_kernel)"
+                               if winfo.get("layout") else
+                               ("one launch of two passes of 24 points (llk_eval_passes_kernel)" if winfo["num_code"] > 80 else
+                                "two launches of llk_eval_kernel<2,...>, 32 + 16 points")),
                 }
                 return obj, wide, w_llk
             result["roofline_wide_alphabet"], wide, wide_llk = alphabet_leg(2, 60, "valu_b%d_wide.json" % B)
@@ -570,8 +585,8 @@ def main():
                 "algorithmic_GBps": info["algorithmic_bytes_per_eval"] * est["num_eval"] / w_opt / 1e9,
                 # frac: the launched points at the headline launch's rate per point (x its fraction of the measured issue
                 # ceiling) over the wall-clock; nominal_*: SURVEY 8d bytes of the useful / launched evaluations over 8 TB/s
-                "frac": (ROOFLINE["valu_frac_headline"] * ROOFLINE["us_per_point_headline"] * est["num_launch_point"] / (1e6 * w_opt))
-                        if ROOFLINE.get("valu_frac_headline") else None,
+                "frac": (ROOFLINE["frac_headline"] * ROOFLINE["us_per_point_headline"] * est["num_launch_point"] / (1e6 * w_opt))
+                        if ROOFLINE.get("frac_headline") else None,
                 "nominal_frac": info["algorithmic_bytes_per_eval"] * est["num_eval"] / w_opt / 1e9 / HBM_PEAK_GBPS,
                 "nominal_frac_launched_points": info["algorithmic_bytes_per_eval"] * est["num_launch_point"] / w_opt / 1e9
                                                 / HBM_PEAK_GBPS,

@@ -115,6 +115,9 @@ typedef struct vb2_info {
      * values agree to rounding either way.  num_table_row: rows of the per-alpha table. */
     int32_t layout;
     int32_t num_table_row;
+    /* read-loop steps per evaluation point, summed over the markers, the tiles' padding included: each reads one 48-byte
+     * table row from LDS (the LDS side of bench.py's roofline) */
+    int64_t num_step;
 } vb2_info;
 
 /* Builds the device-resident SoA form of the input (classification, quality

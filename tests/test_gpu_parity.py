@@ -1387,14 +1387,16 @@ def test_wide_quality_alphabet_at_100k_markers():
 
 
 @pytest.mark.parametrize("shape", [(100000, 4, 2, 60), (20000, 2, 2, 93), (3000, 3, 2, 60)])
-def test_passes_of_one_launch_equal_the_separate_launches_bit_for_bit(shape):
-    """A call of more points than the LDS holds tables for (wide quality alphabets) runs as the passes of ONE launch
+def test_passes_of_one_launch_equal_the_separate_launches_bit_for_bit(shape, tunable):
+    """(Run-word layout: tunable pd = 0; the probability-domain counterpart is
+    test_split_launch_equals_passes_and_plain_launches_bit_for_bit.)  A call of more points than the LDS holds tables for (wide quality alphabets) runs as the passes of ONE launch
     (llk_eval_passes_kernel: own points, partial sums and arrival ticket per pass, a compact exp table so that a third point
     group fits) -- every value bit for bit what separate launches give (vb2_debug_set_eval_passes(0)), whatever the number of
     points (9 .. 48 and beyond one call's 48), and the oracle's to LLK_RTOL; repeated calls give the same bits (the tickets
     go back to zero)."""
     import ctypes
     M, k, q_lo, q_hi = shape
+    tunable("pd", 0)
     lib = _abi.lib()
     lib.vb2_debug_set_eval_passes.argtypes = [ctypes.c_int]
     lib.vb2_debug_set_eval_passes.restype = None
@@ -1436,6 +1438,127 @@ def test_value_of_a_point_does_not_depend_on_the_wave_shape(c2, c3):
             for i in range(0, B - 3, 3):
                 assert np.array_equal(ctx.llk(pc1[i:i + 4], pc2[i:i + 4], al[i:i + 4]), full[i:i + 4]), i
             assert np.array_equal(ctx.llk(pc1[:8], pc2[:8], al[:8]), full[:8])
+
+
+# ------------------------------------------------------------------ probability-domain layout (round 6)
+
+@pytest.mark.parametrize("q", [(20, 40), (10, 45)])
+def test_headline_launch_of_48_points_against_the_oracle(q, tunable):
+    """VERDICT r5, parity thin spots: the headline shape itself -- 48 points in ONE call on a 100 000-marker, depth-30 sample
+    (42 codes: qualities 20..40; 72 codes: 10..45) -- all 48 points against the oracle (ContaminationEstimator.h:194-314) at
+    LLK_RTOL, in BOTH layouts: probability domain (the default here: one split launch, six point groups over workgroup pairs)
+    and run words (tunable pd = 0: six groups through the arrival ticket at 42 codes, 32 + 16 points at 72)."""
+    k = 4
+    d = vb.synth.make_pileup(100000, 30, k, alpha_true=0.05, seed=2, q_lo=q[0], q_hi=q[1])
+    od = oracle_data(d)
+    rng = np.random.default_rng(48)
+    pc1, pc2, al = _random_points(rng, 48, k)
+    want = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=os.cpu_count() or 1) for i in range(48)])
+    seen = []
+    for pd in (1, 0):
+        tunable("pd", pd)
+        with vb.LikelihoodContext(d) as ctx:
+            assert ctx.info()["layout"] == pd
+            got = ctx.llk(pc1, pc2, al)
+            assert rel_err(got, want) <= LLK_RTOL, (pd, rel_err(got, want))
+            assert np.array_equal(got, ctx.llk(pc1, pc2, al))
+            seen.append(got)
+    assert rel_err(seen[0], seen[1]) <= LLK_RTOL
+
+
+def test_probability_domain_layout_is_taken_only_where_no_marker_can_underflow(tunable):
+    """vb2_info.layout: 1 (products of table rows, no exp per genotype pair) when every counted marker's worst case -- all its
+    reads at their least likely genotype pair, times the "other" reads' constant -- stays a normal double; 0 (run words, sums of
+    logarithms: any depth) for deep markers and for quality 0, whose table entries can be 0 or arbitrarily small.  Either way
+    the oracle's values, and where both layouts apply they agree to rounding in every launch shape."""
+    rng = np.random.default_rng(61)
+    cases = [(vb.synth.make_pileup(3000, 30, 2, seed=61), 1),
+             (vb.synth.make_pileup(3000, 30, 4, seed=62, q_lo=2, q_hi=60), 1),
+             (vb.synth.make_pileup(3000, 200, 2, seed=63), 0),                       # 200 reads x -log2(pErr / 3) > 1000
+             (vb.synth.make_pileup(3000, 30, 2, seed=64, q_lo=0, q_hi=40), 0),       # quality 0: entries alpha * const
+             (vb.synth.make_pileup(17, 5, 3, seed=65), 1), (vb.synth.make_pileup(1, 30, 2, seed=66), 1)]
+    for d, want_layout in cases:
+        k = d.num_pc
+        od = oracle_data(d)
+        B = 21
+        pc1, pc2, al = _random_points(rng, B, k)
+        al[0], al[1] = 0.0, 1.0
+        want = np.array([od.llk(pc1[i], pc2[i], al[i]) for i in range(B)])
+        vals = {}
+        for pd in (1, 0):
+            tunable("pd", pd)
+            with vb.LikelihoodContext(d) as ctx:
+                info = ctx.info()
+                assert info["layout"] == (want_layout if pd else 0), (d.num_marker, pd, info["layout"])
+                got = ctx.llk(pc1, pc2, al)
+                assert rel_err(got, want) <= LLK_RTOL
+                one = np.array([ctx.llk(pc1[i:i + 1], pc2[i:i + 1], al[i:i + 1])[0] for i in range(B)])
+                four = np.concatenate([ctx.llk(pc1[i:i + 4], pc2[i:i + 4], al[i:i + 4]) for i in range(0, B - 1, 4)])
+                assert np.array_equal(one, got) and np.array_equal(four, got[:20])          # one value per point, whatever the shape
+                vals[pd] = got
+        assert rel_err(vals[1], vals[0]) <= LLK_RTOL
+
+
+@pytest.mark.parametrize("shape", [(100000, 4, 20, 40), (100000, 4, 2, 60), (12500, 4, 20, 40), (3000, 2, 2, 93)])
+def test_split_launch_equals_passes_and_plain_launches_bit_for_bit(shape, tunable):
+    """Probability domain, more points than a workgroup's LDS holds tables for (~110 table rows, more than 24 points): ONE launch
+    whose workgroups come in pairs that share their tiles and split the point groups (eval_body, SPLIT) -- every value bit for
+    bit what the passes of one launch (tunable split = 0) and what separate launches of <= 24 points give, for 25 .. 48 points
+    and beyond one call's 48; the oracle's to LLK_RTOL."""
+    M, k, q_lo, q_hi = shape
+    d = vb.synth.make_pileup(M, 30, k, alpha_true=0.04, seed=231, q_lo=q_lo, q_hi=q_hi)
+    od = oracle_data(d)
+    rng = np.random.default_rng(218)
+    with vb.LikelihoodContext(d) as ctx:
+        assert ctx.info()["layout"] == 1
+        for B in (24, 25, 33, 40, 41, 48, 50, 97):
+            pc1, pc2, al = rng.normal(0, 0.03, (B, k)), rng.normal(0, 0.03, (B, k)), rng.uniform(0, 0.4, B)
+            tunable("split", 1)
+            got = ctx.llk(pc1, pc2, al)
+            assert np.array_equal(got, ctx.llk(pc1, pc2, al)), B
+            tunable("split", 0)
+            assert np.array_equal(ctx.llk(pc1, pc2, al), got), B
+            tunable("split", 1)
+            plain = np.concatenate([ctx.llk(pc1[i:i + 8], pc2[i:i + 8], al[i:i + 8]) for i in range(0, B, 8)])
+            assert np.array_equal(plain, got), B
+            if B in (25, 48):
+                idx = [0, 8, 16, 23, 24, B - 1]
+                ref = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=os.cpu_count() or 1) for i in idx])
+                assert rel_err(got[idx], ref) <= LLK_RTOL
+
+
+def test_cohort_of_both_layouts_in_one_batch(tunable):
+    """A lock-step cohort whose samples took different layouts (a deep sample and a quality-0 sample beside shallow ones): a
+    launch runs one kind of kernel, so a step evaluates the probability-domain samples and the others in separate launches
+    (Batch::eval_begin) -- every sample's values are those of its own single-context evaluation, bit for bit in the four-point
+    shape, and the oracle's."""
+    k = 3
+    datas = [vb.synth.make_pileup(4000, 30, k, seed=81), vb.synth.make_pileup(2000, 150, k, seed=82),
+             vb.synth.make_pileup(3000, 25, k, seed=83, q_lo=0, q_hi=40), vb.synth.make_pileup(5000, 35, k, seed=84, q_lo=10, q_hi=45)]
+    ctxs = [vb.LikelihoodContext(d) for d in datas]
+    try:
+        assert [c.info()["layout"] for c in ctxs] == [1, 0, 0, 1]
+        rng = np.random.default_rng(85)
+        S = len(ctxs)
+        pc1, pc2, al = rng.normal(0, 0.03, (S, 8, k)), rng.normal(0, 0.03, (S, 8, k)), rng.uniform(0, 0.5, (S, 8))
+        with vb.CohortBatch(ctxs) as batch:
+            for npts in ([4] * S, [1, 2, 4, 3], [2, 0, 1, 2], [8] * S):
+                got = batch.eval(np.array(npts, dtype=np.int32), pc1, pc2, al)
+                for s in range(S):
+                    n = npts[s]
+                    if n == 0:
+                        continue
+                    want = np.array([oracle_data(datas[s]).llk(pc1[s, j], pc2[s, j], al[s, j]) for j in range(n)])
+                    assert rel_err(got[s, :n], want) <= LLK_RTOL, (npts, s)
+        est = None
+        with vb.CohortBatch(ctxs) as batch:
+            est = batch.optimize()
+        for s in range(S):
+            ref = oracle_data(datas[s]).optimize()
+            assert abs(est[s]["alpha"] - ref["alpha"]) <= NORTH_STAR_ALPHA_ATOL
+    finally:
+        for c in ctxs:
+            c.close()
 
 
 def test_cohort_at_the_queue_vs_static_deal_boundary():

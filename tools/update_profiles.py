@@ -5,8 +5,23 @@ search), PMC summary, batch sweep, and the two derived files bench.py reads back
 instructions per marker x point).
 Usage: python tools/update_profiles.py r02"""
 import csv, json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from verifybamid_amd._abi import kernel_source_hash
+# every derived file carries the hash of the kernel sources it was measured on (bench.py: a figure of another hash is dropped)
+KHASH = kernel_source_hash()
+_dump = json.dump
+
+
+def _dump_with_hash(obj, fp, **kw):
+    if isinstance(obj, dict):
+        obj = dict(obj, kernel_src_hash=KHASH)
+    return _dump(obj, fp, **kw)
+
+
+json.dump = _dump_with_hash
+EVAL_KERNELS = ("llk_eval_kernel", "llk_eval_split_kernel")
 src, dst = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles", R)
 os.makedirs(dst, exist_ok=True)
 with open(os.path.join(src, "bench.json")) as f:
@@ -26,7 +41,7 @@ out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.p
 keep, on = [], False
 for l in out.splitlines():
     if l.startswith("##"):
-        on = "llk_eval_kernel" in l
+        on = any(kn in l for kn in EVAL_KERNELS)
     if on:
         keep.append(l)
 open(os.path.join(dst, "bench_b%d_pmc_summary.txt" % B), "w").write(
@@ -39,7 +54,7 @@ def avg(d, name):
     vals = []
     p = [os.path.join(src, d, f) for f in os.listdir(os.path.join(src, d)) if f.endswith("counter_collection.csv")][0]
     for row in csv.DictReader(open(p)):
-        if "llk_eval_kernel" in row["Kernel_Name"] and row["Counter_Name"] == name:
+        if any(kn in row["Kernel_Name"] for kn in EVAL_KERNELS) and row["Counter_Name"] == name:
             vals.append(float(row["Counter_Value"]))
     return sum(vals) / len(vals)
 
@@ -172,6 +187,8 @@ for aname, qlo, qhi in (("wide", 2, 60), ("mid", 10, 45)):
         sq1, gr = first_csv("pmc_%s_sq1" % aname, "counter_collection.csv"), first_csv("pmc_%s_grbm" % aname, "counter_collection.csv")
         if sq1 and gr:
             sub = "llk_eval_passes_kernel"          # (one launch of two passes of 24 points since round 4; VB2_PASSES=0: llk_eval_kernel x 3)
+            if avg_of(gr, sub, "GRBM_GUI_ACTIVE") is None:
+                sub = "llk_eval_split_kernel"       # (round 6, probability domain: one launch, the groups split between workgroup pairs)
             if avg_of(gr, sub, "GRBM_GUI_ACTIVE") is None:
                 sub = "llk_eval_kernel"
             cyc = avg_of(gr, sub, "GRBM_GUI_ACTIVE") / 8.0

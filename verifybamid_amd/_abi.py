@@ -40,7 +40,7 @@ class Info(C.Structure):
         ("num_read_other", C.c_int64), ("num_code", C.c_int32), ("num_tile", C.c_int32),
         ("device_bytes", C.c_int64), ("algorithmic_bytes_per_eval", C.c_int64),
         ("device_name", C.c_char * 64), ("arch", C.c_char * 32), ("cohort_step_bytes", C.c_int64),
-        ("layout", C.c_int32), ("num_table_row", C.c_int32),
+        ("layout", C.c_int32), ("num_table_row", C.c_int32), ("num_step", C.c_int64),
     ]
 
 
@@ -224,3 +224,15 @@ class Vb2Error(RuntimeError):
 def check(code, where):
     if code != VB2_OK:
         raise Vb2Error(code, where)
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the sources of the evaluation kernels: what ties a PMC-derived figure kept under profiles/
+    (instruction counts, HBM-side bytes) to the code it was measured on -- bench.py drops figures whose hash is another."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for name in ("llk_kernels.hip", "resident_kernel.inc", "llk_kernels.h", "kernel_debug.h", "log_table.inc", "Makefile"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]

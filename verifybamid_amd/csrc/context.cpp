@@ -415,33 +415,40 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
             if (depth <= 0 || depth > 4096) continue;                  // (deep markers: the context will not take this layout anyway)
             const uint8_t alt_up = lut->up[(unsigned char)in->alt_base[i]];
+            int touched[2 * kNumQual], ntouched = 0;
             for (int64_t j = 0; j < depth; ++j) {
                 const unsigned char b = (unsigned char)in->bases[beg + j];
                 const unsigned cls = lut->dot[b] ? 0u : (lut->up[b] == alt_up ? 1u : 2u);
                 if (cls == 2u) continue;
-                ++cnt2[lut->qidx[(unsigned char)in->quals[beg + j]] + cls];
+                const int idx = (int)lut->qidx[(unsigned char)in->quals[beg + j]] + (int)cls;
+                if (cnt2[idx]++ == 0) touched[ntouched++] = idx;
             }
-            for (int idx = 0; idx < 2 * kNumQual; ++idx)
-                if (cnt2[idx]) {
-                    ++H[(size_t)(idx >> 1) * 64 + std::min<uint32_t>(cnt2[idx], 63u)];
-                    seen[idx >> 1] = true;
-                    cnt2[idx] = 0;
-                }
+            for (int j = 0; j < ntouched; ++j) {
+                const int idx = touched[j];
+                ++H[(size_t)(idx >> 1) * 64 + std::min<uint32_t>(cnt2[idx], 63u)];
+                seen[idx >> 1] = true;
+                cnt2[idx] = 0;
+            }
         }
         int rows = 2;                                                   // (room for qualities the sample did not meet)
         for (int r = 0; r < kNumQual; ++r) rows += seen[r] ? 1 : 0;
         const int budget = tn.pd_rows > 0 ? tn.pd_rows : pd_row_budget(M, k, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
-        auto steps_at = [&](int r, int kq) {
-            int64_t st = 0;
-            for (int c = 1; c < 64; ++c) st += H[(size_t)r * 64 + c] * ((c + kq - 1) / kq);
-            return st;
-        };
+        // steps of the sampled runs of a quality under K = 1 .. kMaxPow (once), then the greedy walk over the gains
+        std::vector<int64_t> st_at((size_t)kNumQual * (kMaxPow + 1), 0);
+        for (int r = 0; r < kNumQual; ++r) {
+            if (!seen[r]) continue;
+            for (int kq = 1; kq <= kMaxPow; ++kq) {
+                int64_t st = 0;
+                for (int c = 1; c < 64; ++c) st += H[(size_t)r * 64 + c] * ((c + kq - 1) / kq);
+                st_at[(size_t)r * (kMaxPow + 1) + kq] = st;
+            }
+        }
         while (rows < budget) {
             int best = -1;
             int64_t best_gain = 0;
             for (int r = 0; r < kNumQual; ++r) {
                 if (!seen[r] || kpow[r] >= kMaxPow) continue;
-                const int64_t gain = steps_at(r, kpow[r]) - steps_at(r, kpow[r] + 1);
+                const int64_t gain = st_at[(size_t)r * (kMaxPow + 1) + kpow[r]] - st_at[(size_t)r * (kMaxPow + 1) + kpow[r] + 1];
                 if (gain > best_gain) { best_gain = gain; best = r; }
             }
             if (best < 0) break;
@@ -1656,7 +1663,7 @@ void Context::resident_end()
 // acknowledged stores are visible to the HOST before the flag is, so the host does not rely on it: the
 // result words are set to NaN before every step, and a NaN found behind the flag is first taken for a store still on its
 // way (re-read for a few microseconds) and only then for the kernels' own "a workgroup never reported" marker.
-static bool settle_results(const double* out, int n)
+bool settle_results(const double* out, int n)
 {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -1999,6 +2006,9 @@ void Context::fill_info(vb2_info* info) const
     info->cohort_step_bytes = cohort_bytes;
     info->layout = L.pd;
     info->num_table_row = L.num_code;
+    int64_t rows = 0;
+    for (uint32_t r : h_mt_rows) rows += r;
+    info->num_step = rows * 2 * kMtMarkers;
     std::snprintf(info->device_name, sizeof(info->device_name), "%s", device_name);
     std::snprintf(info->arch, sizeof(info->arch), "%s", arch);
 }

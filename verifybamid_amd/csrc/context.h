@@ -182,6 +182,13 @@ public:
 
 }  // namespace vb2
 
+namespace vb2 {
+// Results come back through mapped host memory as relaxed stores behind a relaxed flag (context.cpp): callers set the result
+// words to NaN before a step and, once the flag is seen, wait here a few microseconds for NaNs still on their way.
+// false: a NaN stayed (the kernels' own "a workgroup never reported", or the input's).
+bool settle_results(const double* out, int n);
+}  // namespace vb2
+
 struct vb2_ctx {
     vb2::Context* impl;
 };

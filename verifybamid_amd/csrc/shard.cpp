@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <set>
 #include <string>
@@ -179,7 +180,9 @@ int ShardGroup::create(const vb2_input* in, const int32_t* devices, int num_devi
     // are summed on the host instead -- unless the test stand-in for librccl is bound (VB2_RCCL_LIB), whose
     // ranks may share a device: then the launch -> grouped all-reduce -> publish path runs with N > 1 there too
     const bool host_forced = tunables().shard_reduce_host != 0;
-    const bool shared_ok = (int)distinct.size() < num_device && rccl().ok && rccl().stub;
+    // (the stand-in is only ever bound through VB2_RCCL_LIB -- without it the real librccl is not loaded just to
+    // learn that it is not the stand-in)
+    const bool shared_ok = (int)distinct.size() < num_device && std::getenv("VB2_RCCL_LIB") != nullptr && rccl().ok && rccl().stub;
     g->use_rccl = ((int)distinct.size() == num_device || shared_ok) && !host_forced;
     for (int d = 0; d < num_device; ++d) {
         int lo, hi;
@@ -288,6 +291,9 @@ int ShardGroup::eval_launch(int num_point, const double* pc1, const double* pc2,
                     std::memcpy(row + k, pc2 + (size_t)(done + b) * k, sizeof(double) * k);
                     row[2 * k] = alpha[done + b];
                 }
+                // (the result words are NaN until this step's stores land -- a stale word of the previous step would
+                // be a finite number and be summed silently)
+                for (int b = 0; b < n; ++b) c->h_out[b] = std::numeric_limits<double>::quiet_NaN();
                 int rc;
                 if (use_rccl) {
                     rc = c->eval_device(n, c->d_points, d_part_[s], c->stream, nullptr, 0, c->h_points, attempt);
@@ -338,6 +344,7 @@ int ShardGroup::eval_launch(int num_point, const double* pc1, const double* pc2,
                         VB2_HIP(hipStreamSynchronize(c->stream));
                     }
                 }
+                (void)settle_results(ctx[0]->h_out, n);        // (a store still on its way behind the flag)
                 for (int b = 0; b < n; ++b) {
                     out[done + b] = ctx[0]->h_out[b];
                     any_nan |= std::isnan(out[done + b]);
@@ -358,9 +365,11 @@ int ShardGroup::eval_launch(int num_point, const double* pc1, const double* pc2,
                         }
                     }
                     if (!seen) VB2_HIP(hipStreamSynchronize(c->stream));
+                    if (c->L.num_mt > 0) (void)settle_results(c->h_out, n);
                     for (int b = 0; b < n; ++b) {
-                        any_nan |= std::isnan(c->h_out[b]);
-                        out[done + b] += c->h_out[b];
+                        const double v = c->L.num_mt > 0 ? c->h_out[b] : 0.0;
+                        any_nan |= std::isnan(v);
+                        out[done + b] += v;
                     }
                 }
             }

@@ -2,6 +2,7 @@
 #include "tunables.h"
 
 #include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -40,6 +41,14 @@ void apply_environment(Tunables& t)
         for (const char* p = e.name; *p; ++p) var += (char)std::toupper((unsigned char)*p);
         if (const char* v = std::getenv(var.c_str())) t.*(e.field) = parse_value(v);
     }
+    //  switches of earlier rounds that no code reads any more: said so, once -- set, they would A/B a configuration
+    // against itself (tools/_run_c.sh did)
+    static const char* const kRetired[] = {"VB2_SHARD_REDUCE", "VB2_DIGEST_CODES", "VB2_DICT_ORDER", "VB2_PAIRED", "VB2_GEOM",
+                                           "VB2_GEOM_WAVES", "VB2_GEOM_GRID", "VB2_RELAY_REPS", "VB2_OWN_ROWS",
+                                           "VB2_COHORT_SLOT_WG"};
+    for (const char* name : kRetired)
+        if (std::getenv(name))
+            std::fprintf(stderr, "libvb2: environment variable %s is no longer read (csrc/tunables.h lists the switches)\n", name);
 }
 
 }  // namespace
