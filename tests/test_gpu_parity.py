@@ -1467,15 +1467,17 @@ def test_headline_launch_of_48_points_against_the_oracle(q, tunable):
 
 
 def test_probability_domain_layout_is_taken_only_where_no_marker_can_underflow(tunable):
-    """vb2_info.layout: 1 (products of table rows, no exp per genotype pair) when every counted marker's worst case -- all its
-    reads at their least likely genotype pair, times the "other" reads' constant -- stays a normal double; 0 (run words, sums of
-    logarithms: any depth) for deep markers and for quality 0, whose table entries can be 0 or arbitrarily small.  Either way
-    the oracle's values, and where both layouts apply they agree to rounding in every launch shape."""
+    """vb2_info.layout: 1 (products of table rows, no exp per genotype pair) when every counted marker's likelihood is bound to
+    stay far above the smallest doubles -- its (het, het) term, which no alpha or PC changes, is at least 2^-900 --; 0 (run
+    words, sums of logarithms: any depth) for deep markers.  The products of unlikely genotype pairs may underflow in layout 1
+    (200 reads, quality 0 with alpha = 0 / 1): where the reference's exp() underflows too, and nothing beside the likelihood.
+    Either way the oracle's values, and where both layouts apply they agree to rounding in every launch shape."""
     rng = np.random.default_rng(61)
     cases = [(vb.synth.make_pileup(3000, 30, 2, seed=61), 1),
              (vb.synth.make_pileup(3000, 30, 4, seed=62, q_lo=2, q_hi=60), 1),
-             (vb.synth.make_pileup(3000, 200, 2, seed=63), 0),                       # 200 reads x -log2(pErr / 3) > 1000
-             (vb.synth.make_pileup(3000, 30, 2, seed=64, q_lo=0, q_hi=40), 0),       # quality 0: entries alpha * const
+             (vb.synth.make_pileup(3000, 200, 2, seed=63), 1),                       # (pErr / 3)^200 underflows: an unlikely pair's
+             (vb.synth.make_pileup(1500, 1200, 2, seed=67), 0),                      # 0.5^1200: the likelihood itself is down there
+             (vb.synth.make_pileup(3000, 30, 2, seed=64, q_lo=0, q_hi=40), 1),       # quality 0: entries 0 or alpha * const
              (vb.synth.make_pileup(17, 5, 3, seed=65), 1), (vb.synth.make_pileup(1, 30, 2, seed=66), 1)]
     for d, want_layout in cases:
         k = d.num_pc
@@ -1528,13 +1530,13 @@ def test_split_launch_equals_passes_and_plain_launches_bit_for_bit(shape, tunabl
 
 
 def test_cohort_of_both_layouts_in_one_batch(tunable):
-    """A lock-step cohort whose samples took different layouts (a deep sample and a quality-0 sample beside shallow ones): a
-    launch runs one kind of kernel, so a step evaluates the probability-domain samples and the others in separate launches
+    """A lock-step cohort whose samples took different layouts (two deep samples beside shallow ones): a
+    launch runs one kind of kernel, so a step evaluates the probability-domain samples and the others (here: two deep ones) in separate launches
     (Batch::eval_begin) -- every sample's values are those of its own single-context evaluation, bit for bit in the four-point
     shape, and the oracle's."""
     k = 3
-    datas = [vb.synth.make_pileup(4000, 30, k, seed=81), vb.synth.make_pileup(2000, 150, k, seed=82),
-             vb.synth.make_pileup(3000, 25, k, seed=83, q_lo=0, q_hi=40), vb.synth.make_pileup(5000, 35, k, seed=84, q_lo=10, q_hi=45)]
+    datas = [vb.synth.make_pileup(4000, 30, k, seed=81), vb.synth.make_pileup(1000, 1100, k, seed=82),
+             vb.synth.make_pileup(1500, 1000, k, seed=83, q_lo=0, q_hi=40), vb.synth.make_pileup(5000, 35, k, seed=84, q_lo=10, q_hi=45)]
     ctxs = [vb.LikelihoodContext(d) for d in datas]
     try:
         assert [c.info()["layout"] for c in ctxs] == [1, 0, 0, 1]

@@ -399,13 +399,17 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     unsigned char kpow[kNumQual];
     double lmin[kNumQual];
     std::fill(kpow, kpow + kNumQual, (unsigned char)1);
+    // What a read can cost the marker's likelihood in binary orders of magnitude: the pair (het, het) explains any ref or alt read
+    // with probability c[1] = 0.5 (1 - pErr) + pErr / 6 >= 1 / 6, whatever alpha -- so the likelihood, which holds that pair's term
+    // exp(c_other + D[1]) * GF[1] * GF2[1], is at least 2^-(sum of these + the "other" reads' + 27).  Pass A sums them per marker
+    // (max_bound below): see where `pd` is decided.
     for (int r = 0; r < kNumQual; ++r) {
         const double pe = phred[qof[r]];
-        const double least = std::min(pe / 3.0, 1.0 - pe);            // the least P(read | genotype) of the quality, either class
-        lmin[r] = least > 0.0 ? -std::log2(least) : std::numeric_limits<double>::infinity();
+        lmin[r] = -std::log2(0.5 * (1.0 - pe) + pe / 6.0);
     }
     if (pd_wanted) {
-        std::vector<int64_t> H((size_t)kNumQual * 64, 0);             // [rank][count, 63 = more] runs in the sample
+        static thread_local std::vector<int64_t> H;                   // [rank][count, 63 = more] runs in the sample
+        H.assign((size_t)kNumQual * 64, 0);
         uint32_t cnt2[2 * kNumQual];
         std::fill(cnt2, cnt2 + 2 * kNumQual, 0u);
         const int stride_m = std::max(1, M / kPdSampleMarkers);
@@ -759,9 +763,12 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             order.push_back((idx & 1) * kNumQual + qof[idx >> 1]);
         }
     const int num_code_seen = (int)order.size();              // distinct (class, quality) codes of the data
-    // The probability-domain layout is taken when no counted marker can underflow in it (max_bound: every read at its least
-    // likely genotype pair, times the "other" reads' constant, stays a normal double) -- which also rules out quality 0,
-    // whose entries can be exactly 0 or arbitrarily small (bound = inf) -- and the table's rows fit 16-bit offsets.
+    // The probability-domain layout is taken when every counted marker's likelihood is bound to stay a normal double far from
+    // the bottom of the range (max_bound <= kPdMaxBound: lk >= 2^-(900 + 27)).  The products of UNLIKELY genotype pairs may
+    // well underflow in it -- gradually, to subnormals and 0, where the reference's exp() of their sums of logarithms
+    // underflows too: either is nothing beside a likelihood of 2^-927 or more (below 2^-95 of it), so the `markerLK > 0` rule
+    // (h:310) never decides and the sum's bits are the likely pairs'.  Deep data -- about 850 reads per marker at the usual
+    // qualities -- takes the run words and sums of logarithms.  And the table's rows must fit 16-bit offsets.
     int pd_rows = 0;
     for (int r = 0; r < kNumQual; ++r)
         if (code_hist[2 * r] + code_hist[2 * r + 1] > 0) pd_rows += kpow[r];
@@ -850,7 +857,10 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         // 16 neighbours; the FULL tiles are then put in descending order of their rows (ties: more alt rows first), so that
         // workgroups and waves take them longest first and the two tiles a paired wave shape walks side by side have the
         // same phases; the last, partial tile stays last (positions past the last marker are at the end of every array).
-        std::vector<uint32_t> sref(m_active), salt(m_active);
+        // (scratch a thread keeps from one create to the next: fresh pages cost more than the passes that fill them)
+        static thread_local std::vector<uint32_t> sref, salt;
+        sref.resize(m_active);
+        salt.resize(m_active);
         uint32_t ra_max = 0, sr_max = 0;
         for (int64_t a = 0; a < m_active; ++a) {
             const uint32_t e = eff_pd[active[a]];
@@ -859,7 +869,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             ra_max = std::max(ra_max, salt[a]);
             sr_max = std::max(sr_max, sref[a]);
         }
-        std::vector<int64_t> p1(m_active);
+        static thread_local std::vector<int64_t> p1;
+        p1.resize(m_active);
         {
             const uint64_t width = (uint64_t)sr_max + 1, nkey = ((uint64_t)ra_max + 1) * width;
             auto key = [&](int64_t a) { return (uint64_t)salt[a] * width + sref[a]; };
@@ -883,10 +894,23 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             }
         std::vector<int> torder(tiles);
         std::iota(torder.begin(), torder.end(), 0);
-        std::stable_sort(torder.begin(), torder.begin() + full, [&](int x, int y) {
-            const uint32_t rx = (rr[x] + ra[x] + 1) / 2, ry = (rr[y] + ra[y] + 1) / 2;
-            return rx != ry ? rx > ry : ra[x] > ra[y];
-        });
+        {   // stable, descending by (rows, alt steps): a counting sort when the keys are few (they are), else std::stable_sort
+            uint32_t rows_max = 0, ra_mx = 0;
+            for (int t = 0; t < full; ++t) {
+                rows_max = std::max(rows_max, (rr[t] + ra[t] + 1) / 2);
+                ra_mx = std::max(ra_mx, ra[t]);
+            }
+            const uint64_t wd = (uint64_t)ra_mx + 1, nk = ((uint64_t)rows_max + 1) * wd;
+            auto tkey = [&](int t) { return (uint64_t)((rr[t] + ra[t] + 1) / 2) * wd + ra[t]; };
+            if (nk <= (1u << 20)) {
+                std::vector<int> start((size_t)nk + 1, 0);
+                for (int t = 0; t < full; ++t) ++start[(size_t)(nk - 1 - tkey(t)) + 1];
+                for (size_t d = 1; d < start.size(); ++d) start[d] += start[d - 1];
+                for (int t = 0; t < full; ++t) torder[start[(size_t)(nk - 1 - tkey(t))]++] = t;
+            } else {
+                std::stable_sort(torder.begin(), torder.begin() + full, [&](int x, int y) { return tkey(x) > tkey(y); });
+            }
+        }
         if (num_mt & 1) ++num_mt;                               // (a workgroup owns PAIRS of tiles: llk_kernels.h, owned_tile)
         mt_row_off.resize(num_mt);
         mt_rows.assign(num_mt, 0u);

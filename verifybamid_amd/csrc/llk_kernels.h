@@ -30,9 +30,9 @@ constexpr int kMaxPow = 8;
 // mirror image of the row's values there, so that their read loops need not know a step's class (the 8-point shape, which has
 // no room for it, takes the offset off again and names its products the other way round)
 constexpr int kPdAltOffset = 192;
-constexpr int kPdSampleMarkers = 2048;     // markers whose run counts choose the K's (before the reads are walked)
-constexpr double kPdMaxBound = 1000.0;     // a marker may lose this many binary orders of magnitude at most (all reads at their
-                                           // least likely genotype pair) for its products to stay normal numbers
+constexpr int kPdSampleMarkers = 768;      // markers whose run counts choose the K's (before the reads are walked)
+constexpr double kPdMaxBound = 900.0;      // binary orders of magnitude a marker's likelihood may lie below 1 at most (context.cpp:
+                                           // its (het, het) term's, a lower bound of the likelihood that no alpha or PC changes)
 // d_ticket of launch_llk_eval: kTicketWords zero-initialised unsigned ints -- [0, kTicketScratchWord) the arrival tickets of a
 // launch's passes (llk_eval_passes_kernel; a plain launch uses [0]), two words from kTicketScratchWord on a scratch flag
 constexpr int kTicketScratchWord = 8, kTicketWords = 16;
@@ -209,7 +209,7 @@ struct ClassifyArgs {
     // from the sample; exp(c_other); and, in hist[kMaxCode + 2], the largest kPdMaxBound-style bound of a counted marker
     // (bits of a non-negative double)
     const unsigned char* kpow;     // [kNumQual] quality rank -> K
-    const double* lmin;            // [kNumQual] quality rank -> -log2 of the least entry a read of it can meet (inf: none)
+    const double* lmin;            // [kNumQual] quality rank -> -log2 c[1] of the quality: what a read costs the (het, het) term
     uint32_t* eff_pd;              // out [M]
     double* pother;                // out [M]
 };

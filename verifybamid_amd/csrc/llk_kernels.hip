@@ -30,6 +30,14 @@
 //     order (or, two-kernel mode, by llk_finalize_kernel);
 //   * llk_resident_kernel keeps the same body on the CUs for a whole Nelder-Mead search and
 //     takes its batches from a mailbox in mapped host memory.
+//
+// Two layouts of a sample (DeviceLayout::pd; Context::create decides):
+//   * run words / sums of logarithms, as above: any depth;
+//   * probability domain (round 6; template parameter PD): the table holds P(read | genotype pair, alpha)^n per quality,
+//     n = 1 .. K, class ref only -- class alt is class ref with the genotypes mirrored (h:164-177) --, a marker's list is one
+//     16-bit row offset per STEP (a run of count c = ceil(c / K) steps; ref steps, then alt steps), the six sums are six
+//     PRODUCTS of table rows, and the epilogue needs no exponential: (6 exp + 6 log-table rows) per marker and point less,
+//     at rounding-level differences.  Taken when every marker's likelihood is bound to stay far from the smallest doubles.
 #include "llk_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -1944,8 +1952,11 @@ static hipError_t launch_passes(const DeviceLayout& L, const double* d_points, i
 // LDS of a split launch's workgroup (eval_body, SPLIT): the tables of half the groups, the result slots of two virtual blocks
 static size_t split_shmem(const DeviceLayout& L, int grid, int block_waves, int ngrp_total)
 {
-    const int half = (ngrp_total + 1) / 2;
-    return eval_shmem_np(L, 8, grid >= 2 ? grid / 2 : 1, block_waves, half) + sizeof(double) * 8 * (size_t)half;     // (+ the second virtual block's sums)
+    // (a workgroup of a plain launch of this grid with half the groups, plus the second virtual block's result slots -- as many
+    // as the first's: either block may be the one with a pair of tiles more -- and its sums)
+    const size_t half = (size_t)((ngrp_total + 1) / 2);
+    const size_t slots2 = (size_t)owned_most(1, (uint32_t)L.num_mt, (uint32_t)(grid >= 1 ? grid : 1)) * half;
+    return eval_shmem_np(L, 8, grid >= 1 ? grid : 1, block_waves, (int)half) + sizeof(double) * (2 * slots2 * 8 + 8 * half);
 }
 
 // see eval_body, SPLIT.  *taken = false: the geometry does not allow it (the caller falls back to passes / several launches)
@@ -1960,7 +1971,7 @@ static hipError_t launch_split(const DeviceLayout& L, const double* d_points, in
     const LaunchGeom gm = launch_geom(L, 2, ngrp);      // (a pair of workgroups has the items of one workgroup of a plain launch, twice)
     if (gm.grid < 2 || (gm.grid & 1)) return hipSuccess;
     // every item through the queue, a slot apiece
-    const uint32_t tiles2 = owned_most(1, (uint32_t)L.num_mt, (uint32_t)gm.grid / 2u);
+    const uint32_t tiles2 = 2u * owned_most(1, (uint32_t)L.num_mt, (uint32_t)gm.grid);
     if (tiles2 * (uint32_t)((ngrp + 1) / 2) > (uint32_t)(L.dyn_limit * gm.block_waves)) return hipSuccess;
     const size_t shmem = split_shmem(L, gm.grid, gm.block_waves, ngrp);
     if (shmem > (size_t)kLdsLimitBytes) return hipSuccess;
