@@ -4,7 +4,7 @@
 #   WRITE_SIZE, SQ counters, GRBM_GUI_ACTIVE; each in its own run, with --kernel-trace only),
 #   kernel stats of the other wave shapes (4-point / 1-point launches, cohort steps) and of a search.
 # Usage: bash tools/collect_profiles.sh r02
-R=${1:-r05}
+R=${1:-r06}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err

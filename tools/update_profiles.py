@@ -115,9 +115,9 @@ if os.path.isdir(cm):
     pth = [os.path.join(cm, f) for f in os.listdir(cm) if f.endswith("counter_collection.csv")][0]
     acc = {}
     for row in csv.DictReader(open(pth)):
-        mm = re.search(r"llk_eval_multi_kernel<(\d), (true|false)(?:, (true|false))?(?:, \d+)*>", row["Kernel_Name"])
+        mm = re.search(r"llk_eval_multi_kernel<(\d), (true|false)[^>]*>", row["Kernel_Name"])
         if mm and row["Counter_Name"] == "FETCH_SIZE":
-            acc.setdefault((int(mm.group(1)), mm.group(3) == "true"), []).append(float(row["Counter_Value"]))
+            acc.setdefault((int(mm.group(1)), mm.group(2) == "true"), []).append(float(row["Counter_Value"]))
     np_of = {4: 1, 5: 2, 3: 4, 2: 8}
     ct = {"_what": "HBM-side bytes of one lock-step cohort step of 32 C3-shaped samples, by points per sample: rocprofv3 --pmc "
                    "FETCH_SIZE over tools/prof_modes.py, x2 (gfx950: FETCH_SIZE tallies 64 B per 128-B request), per launch of "
