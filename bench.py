@@ -105,6 +105,21 @@ def self_spawn(n):
     sys.exit(max(abs(p.returncode) for p in procs))
 
 
+def cpus_allowed():
+    """CPUs this process may use: affinity, capped by the cgroup's CFS quota (what the library sizes its reader threads by)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, round(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def latest_profile(name):
     pdir = os.path.join(ROOT, "profiles")
     if not os.path.isdir(pdir):
@@ -473,6 +488,15 @@ def main():
                 "optimize_wall_ms": 1e3 * float(vals[1]), "alpha": est_sh["alpha"], "num_eval": est_sh["num_eval"],
                 "uses_rccl": gi["uses_rccl"], "allreduces": gi["num_allreduce"],
                 "shard_reads_rank0": gi["num_read"],
+                #  what to hold a measured multi-GPU line against -- a PREDICTION, not a measurement: a rank's
+                # launch over markers / N (13 us fixed + 0.38 us per 1 000 markers: the 10 000- and 100 000-marker launches of
+                # profiles/r06) + the step's fixed part measured here at one rank (launch, all-reduce, publish, host wait:
+                # ms_per_step - the plain launch) + ~1.5 us per doubling for the ring.  Strong scaling of a ~50 us step is
+                # latency-bound: near-linear scaling is the sample-parallel mode's (config.parallelism), not this one's.
+                "predicted_us_per_step_by_ranks": {
+                    str(nr): round(13.0 + 0.38 * (args.markers / 1000.0) / nr +
+                                   max(0.0, 1e3 * float(vals[0]) / n2 - (13.0 + 0.38 * args.markers / 1000.0)) * (1 if world == 1 else 0) +
+                                   1.5 * (nr.bit_length() - 1), 1) for nr in (1, 2, 4, 8)} if world == 1 else None,
             }
             g2.close()
         except Exception as exc:                     # noqa: BLE001 -- recorded, not fatal
@@ -688,9 +712,9 @@ def main():
                         # (an untimed call on 64 of the files first: the reader threads' buffers, the pinned and device slabs
                         # and the page cache of the eight files are one-time costs of the process, not of a sample)
                         vb.run_cohort_files(pre, paths[:64], outs[:64], num_pc=k)
-                        t1 = time.perf_counter()
+                        t1, c1 = time.perf_counter(), time.process_time()
                         res = vb.run_cohort_files(pre, paths, outs, num_pc=k)
-                        dtf = time.perf_counter() - t1
+                        dtf, cpuf = time.perf_counter() - t1, time.process_time() - c1
                     finally:
                         os.dup2(saved, 2)
                         os.close(saved)
@@ -701,6 +725,15 @@ def main():
                             "one the reader threads have ready (VB2_COHORT_STREAM=0: groups of 32 one after the other)" % nf,
                     "host_cpus_by_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                     "samples": nf, "samples_ok": ok, "seconds": dtf, "samples_per_s": nf / dtf,
+                    # host or device bound: CPU seconds the process consumed during the call (readers: parse,
+                    # resolve, create; one spinning pipeline thread per device; the releaser) against what its CPU allowance
+                    # (cgroup quota / affinity) offers in that wall-clock; the device side of a sample is the search-only rate
+                    "host_cpu_seconds": cpuf, "host_cpu_ms_per_sample": 1e3 * cpuf / nf,
+                    "cpus_allowed": cpus_allowed(), "host_utilisation": cpuf / (dtf * cpus_allowed()),
+                    "device_ms_per_sample_search_only": result["cohort"].get("optimize_ms_per_sample"),
+                    "bound": "host" if cpuf / (dtf * cpus_allowed()) > 0.8 else
+                             ("device" if result["cohort"].get("optimize_ms_per_sample") and
+                              1e-3 * result["cohort"]["optimize_ms_per_sample"] * nf / dtf > 0.8 else "pipeline (neither side above 80 %)"),
                     "alpha_first": res[0]["alpha"], "alpha_true_first": 0.01,
                     "alpha_by_distinct_sample": [res[i]["alpha"] for i in range(min(nf, 8))],
                     "alpha_true_by_distinct_sample": [0.01 * (1 + i) for i in range(min(nf, 8))],

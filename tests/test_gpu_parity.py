@@ -1158,6 +1158,14 @@ def test_bench_two_ranks_sharing_the_gpu_plumbing():
     assert r["n_gpus"] == 2 and r["steps"] == 50 and r["scaling"] == "weak" and r["value"] > 0
     assert r["config"]["shared_gpu_plumbing_check"] is True and r["config"]["launched_by"] == "self-spawned ranks"
     assert r["parity_probe_max_rel_err"] <= LLK_RTOL
+    # the roofline of the line: t_ideal / t_measured over three terms, the PMC-derived ones tied to the kernel
+    # sources (a figure measured on other sources is dropped and named in stale_profile)
+    rf = r["roofline"]
+    assert rf["bound"] in ("lds", "fp64", "hbm") and 0 < rf["frac"] <= 1.0 and rf["terms"]["lds"]["t_us"] > 0
+    assert abs(rf["frac"] - rf["t_ideal_us"] / rf["t_measured_us"]) < 1e-9
+    assert rf["kernel_src_hash"] == _abi.kernel_source_hash()
+    for term in ("fp64", "hbm"):
+        assert rf["terms"][term] is None or rf["terms"][term]["t_us"] > 0       # (20 000 markers: no committed PMC pass of this shape)
 
 
 def test_shard_group_two_devices_rccl_all_reduce(c2):

@@ -129,28 +129,6 @@ double AmoebaMinimizer::Minimize(double ftol)
         double ytry = ycand[0];
         func->Commit(R, n, ytry);
         const bool accepted = Accept(ihi, R, ytry);      // cpp:390 (Amoeba(ihi,-1.0))
-#ifdef VB2_AMOEBA_STATS
-        {
-            static thread_local int prev = 0, prev2 = 0;
-            static thread_local long trans[4][4] = {{0}}, trans2[16][4] = {{0}}, total = 0;
-            const int cls = ytry <= y_[ilo] ? 1 : ytry >= y_[inhi] ? (accepted ? 2 : 3) : 0;
-            ++trans[prev][cls];
-            ++trans2[prev2 * 4 + prev][cls];
-            prev2 = prev;
-            prev = cls;
-            if (++total % 200 == 0) {
-                std::fprintf(stderr, "amoeba stats after %ld iterations (rows: previous outcome none/E/C_A/C_R; columns: this one)\n", total);
-                for (int a = 0; a < 4; ++a)
-                    std::fprintf(stderr, "  %ld %ld %ld %ld\n", trans[a][0], trans[a][1], trans[a][2], trans[a][3]);
-                long hit1 = 0, hit2 = 0;
-                for (int a = 0; a < 4; ++a) { long best = 0; for (int c = 1; c < 4; ++c) best = std::max(best, trans[a][c]); hit1 += best; }
-                for (int a = 0; a < 16; ++a) { long best = 0; for (int c = 1; c < 4; ++c) best = std::max(best, trans2[a][c]); hit2 += best; }
-                long cr = 0, none = 0;
-                for (int a = 0; a < 4; ++a) { cr += trans[a][3]; none += trans[a][0]; }
-                std::fprintf(stderr, "  second point right: always C_R %ld, by the previous outcome %ld, by the previous two %ld, none needed %ld of %ld\n", cr, hit1, hit2, none, total);
-            }
-        }
-#endif
 
         if (ytry <= y_[ilo]) {                           // cpp:392-394
             double yexp;

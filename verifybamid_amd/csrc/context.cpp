@@ -1282,6 +1282,36 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         if (timing)
             std::fprintf(stderr, "flatten (dry): %.1f ms (classify %.1f, dictionary+sort %.1f, pack %.1f; %d threads)\n",
                          tms(t_start, t_flat), tms(t_start, t_pass1), tms(t_pass1, t_sort), tms(t_sort, t_flat), nthr);
+        if (timing && pd) {
+            // what the read loops will see (a diagnostic of the layout): steps per marker, padding included, and LDS passes
+            // per step -- the 16 markers of a tile read one table row each; different rows whose indices agree mod 16 start
+            // in the same bank group and are served one after the other
+            const uint16_t* h16 = reinterpret_cast<const uint16_t*>(codes);
+            uint64_t steps = 0, passes = 0, pads = 0;
+            for (int t = 0; t < num_mt; ++t) {
+                const uint32_t s1 = mt_rec_y[t] & 0xffffu;
+                for (uint32_t g = 0; g < 2u * mt_rows[t]; ++g) {
+                    int nrow_in[16][4], nin[16];
+                    std::fill(nin, nin + 16, 0);
+                    int worst = 1;
+                    for (int l = 0; l < kMtMarkers; ++l) {
+                        uint32_t off = h16[(((size_t)mt_row_off[t] + (g >> 1)) * kMtMarkers + l) * 2 + (g & 1u)];
+                        if (g >= s1) off -= (uint32_t)kPdAltOffset;
+                        const int row = (int)(off / (uint32_t)row_bytes), r = row & 15;
+                        if (row == num_code) ++pads;
+                        bool seen = false;
+                        for (int q = 0; q < nin[r]; ++q) seen = seen || nrow_in[r][q] == row;
+                        if (!seen && nin[r] < 4) nrow_in[r][nin[r]++] = row;
+                        worst = std::max(worst, nin[r]);
+                    }
+                    passes += (uint64_t)worst;
+                    ++steps;
+                }
+            }
+            std::fprintf(stderr, "  probability domain: %d table rows, %.2f steps per marker (%.2f of them padding), %.3f LDS passes per step\n",
+                         num_code, 16.0 * (double)steps / (double)std::max<int64_t>(1, m_active),
+                         (double)pads / (double)std::max<int64_t>(1, m_active), steps ? (double)passes / (double)steps : 0.0);
+        }
         return VB2_OK;
     }
     c->d_slab = slab_cache().take(slab_cache().dev, dev_total, dev, &c->d_slab_bytes);
