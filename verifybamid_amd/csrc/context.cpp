@@ -407,6 +407,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         const double pe = phred[qof[r]];
         lmin[r] = -std::log2(0.5 * (1.0 - pe) + pe / 6.0);
     }
+    const auto t_k0 = tnow();
     if (pd_wanted) {
         static thread_local std::vector<int64_t> H;                   // [rank][count, 63 = more] runs in the sample
         H.assign((size_t)kNumQual * 64, 0);
@@ -461,6 +462,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         }
     }
 
+    const auto t_k1 = tnow();
     // a marker's runs, in dictionary order, at the position of its reads (runs <= reads): low byte idx, high byte count
     // (scratch that a thread creating one context after the other keeps: fresh pages cost more
     // than the passes that fill them)
@@ -753,6 +755,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             eff_depth.push_back(eff_all[i]);
         }
     const int64_t m_active = (int64_t)active.size();
+    const auto t_act = tnow();
 
     // ---- dictionary: the observed codes, in idx order (see above) ----
     std::vector<int> order;                                   // dictionary index -> class * kNumQual + quality
@@ -939,6 +942,9 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     }
 
     const auto t_sort = tnow();
+    if (timing)
+        std::fprintf(stderr, "  create: K choice %.3f ms, active list %.3f ms, dictionary + sort + tiles %.3f ms\n",
+                     tms(t_k0, t_k1), tms(t_pass1, t_act), tms(t_act, t_sort));
     const int num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     // A run is one dword: low half = byte offset of the code's row in the LDS table (pre-multiplied:
