@@ -495,7 +495,7 @@ def main():
                 # latency-bound: near-linear scaling is the sample-parallel mode's (config.parallelism), not this one's.
                 "predicted_us_per_step_by_ranks": {
                     str(nr): round(13.0 + 0.38 * (args.markers / 1000.0) / nr +
-                                   max(0.0, 1e3 * float(vals[0]) / n2 - (13.0 + 0.38 * args.markers / 1000.0)) * (1 if world == 1 else 0) +
+                                   max(0.0, 1e6 * float(vals[0]) / n2 - (13.0 + 0.38 * args.markers / 1000.0)) * (1 if world == 1 else 0) +
                                    1.5 * (nr.bit_length() - 1), 1) for nr in (1, 2, 4, 8)} if world == 1 else None,
             }
             g2.close()
