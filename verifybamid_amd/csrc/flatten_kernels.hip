@@ -394,8 +394,8 @@ pack_pd_sched_kernel(const PackPdArgs a)
 {
     constexpr int kTiles = 4;
     __shared__ TileSched s_state[kTiles];
-    __shared__ uint16_t s_runs[kTiles][kMtMarkers][kSchedMaxSteps];
-    __shared__ uint16_t s_at[kTiles][kSchedMaxSteps][kMtMarkers];
+    __shared__ uint8_t s_runs[kTiles][kMtMarkers][kSchedMaxSteps];      // (row indices: <= 162 rows -- bytes, so that seven workgroups fit a CU's LDS and every tile of a C3 sample is in flight at once)
+    __shared__ uint8_t s_at[kTiles][kSchedMaxSteps][kMtMarkers];        // (row index + 1; 0 = padding)
     __shared__ uint32_t s_eff[kTiles][kMtMarkers];
     __shared__ uint8_t s_home[kTiles][kSchedMaxPos];
     const int row = threadIdx.x / kMtMarkers, lane = threadIdx.x % kMtMarkers;
@@ -430,7 +430,7 @@ pack_pd_sched_kernel(const PackPdArgs a)
             uint32_t left = rw >> 8;
             while (left > 0u) {
                 const uint32_t c1 = left > kq ? kq : left;
-                if (n < (uint32_t)kSchedMaxSteps) s_runs[row][lane][n] = (uint16_t)(a.row_off[rank][c1] / (uint32_t)a.row_bytes);
+                if (n < (uint32_t)kSchedMaxSteps) s_runs[row][lane][n] = (uint8_t)(a.row_off[rank][c1] / (uint32_t)a.row_bytes);
                 ++n;
                 left -= c1;
             }
@@ -466,7 +466,7 @@ pack_pd_sched_kernel(const PackPdArgs a)
         }
         __syncthreads();
         auto get = [&](int l, int j) -> uint32_t { return s_runs[row][l][j]; };
-        auto put = [&](int l, int c, uint32_t rw) { s_at[row][c][l] = (uint16_t)(rw + 1u); };
+        auto put = [&](int l, int c, uint32_t rw) { s_at[row][c][l] = (uint8_t)(rw + 1u); };
         auto pad = [&](int l, int c) { s_at[row][c][l] = 0; };
         auto home = [&](int d) -> int { return s_home[row][d]; };
         const bool side_by_side = sched_home_commutes(steps > 0 ? steps : 1, a.num_code > 0 ? a.num_code : 1);
