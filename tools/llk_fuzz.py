@@ -9,21 +9,24 @@ rng = np.random.default_rng(int(os.environ.get("VB2_FUZZ_SEED", 1)))
 N = int(os.environ.get("VB2_FUZZ_N", 40))
 worst, bad = 0.0, 0
 for it in range(N):
-    depth = float(rng.choice([2, 10, 30, 150, 700, 1000, 1500]))
+    depth = float(rng.choice([2, 10, 30, 60, 150, 400, 700, 820, 880, 1000, 1500]))      # (probability domain up to ~850 reads)
     M = int(rng.integers(30, 3000 if depth > 500 else 20000)); k = int(rng.integers(1, 11))
     qlo = int(rng.integers(0, 40)); qhi = int(min(93, qlo + rng.integers(0, 50)))
     d = vb.synth.make_pileup(M, depth, k, alpha_true=float(rng.uniform(0, 0.5)), seed=int(rng.integers(1, 10**6)), q_lo=qlo, q_hi=qhi,
                              missing_frac=float(rng.choice([0.0, 0.0, 0.3])))
     od = oracle_data(d)
-    B = int(rng.integers(1, 20))
+    B = int(rng.choice([rng.integers(1, 20), rng.integers(20, 60)]))                         # (beyond 24 points: split launches)
     scale = float(rng.choice([0.01, 0.05, 0.5]))
     pc1 = rng.normal(0, scale, size=(B, k)); pc2 = rng.normal(0, scale, size=(B, k)); al = rng.uniform(0, 1, size=B)
+    al[0] = float(rng.choice([al[0], 0.0, 1.0, 1e-300]))
     with vb.LikelihoodContext(d) as ctx:
         got = ctx.llk(pc1, pc2, al)
+        layout = ctx.info()["layout"]
     want = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=8) for i in range(B)])
     err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
     worst = max(worst, float(err.max()))
     if err.max() > 1e-11:
         bad += 1
-        print("MISMATCH it=%d M=%d depth=%g k=%d q=%d..%d B=%d: max abs diff %.3g (rel %.2e)" % (it, M, depth, k, qlo, qhi, B, np.abs(got - want).max(), err.max()))
-print("llk fuzz: %d of %d cases off, worst relative error %.2e" % (bad, N, worst))
+        print("MISMATCH it=%d M=%d depth=%g k=%d q=%d..%d B=%d layout %d: max abs diff %.3g (rel %.2e)" % (it, M, depth, k, qlo, qhi, B, layout, np.abs(got - want).max(), err.max()))
+    nlay = locals().get("nlay", [0, 0]); nlay[layout] += 1
+print("llk fuzz: %d of %d cases off, worst relative error %.2e; layouts: %d run words, %d probability domain" % (bad, N, worst, nlay[0], nlay[1]))

@@ -397,7 +397,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // whose next power saves the most steps.  Any K's are correct; these are the cheapest.
     const bool pd_wanted = tn.pd != 0 && M > 0 && in->bases && in->quals;
     unsigned char kpow[kNumQual];
-    double lmin[kNumQual];
+    double lhet[kNumQual];
     std::fill(kpow, kpow + kNumQual, (unsigned char)1);
     // What a read can cost the marker's likelihood in binary orders of magnitude: the pair (het, het) explains any ref or alt read
     // with probability c[1] = 0.5 (1 - pErr) + pErr / 6 >= 1 / 6, whatever alpha -- so the likelihood, which holds that pair's term
@@ -405,7 +405,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // (max_bound below): see where `pd` is decided.
     for (int r = 0; r < kNumQual; ++r) {
         const double pe = phred[qof[r]];
-        lmin[r] = -std::log2(0.5 * (1.0 - pe) + pe / 6.0);
+        lhet[r] = -std::log2(0.5 * (1.0 - pe) + pe / 6.0);
     }
     const auto t_k0 = tnow();
     if (pd_wanted) {
@@ -500,7 +500,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     const size_t i_olc = icarve(device_flatten ? 256 * sizeof(double) : 0);
     const size_t i_lc3 = icarve(device_flatten ? (size_t)kMaxCode * 3 * sizeof(double) : 0);
     const size_t i_kpow = icarve(device_flatten && pd_wanted ? (size_t)kNumQual : 0);
-    const size_t i_lmin = icarve(device_flatten && pd_wanted ? (size_t)kNumQual * sizeof(double) : 0);
+    const size_t i_lhet = icarve(device_flatten && pd_wanted ? (size_t)kNumQual * sizeof(double) : 0);
     const size_t i_ud = icarve(in->known_af ? 0 : (size_t)M * k * sizeof(double));
     const size_t i_mu = icarve(in->known_af ? 0 : (size_t)M * sizeof(double));
     const size_t i_kaf = icarve(in->known_af ? (size_t)M * sizeof(double) : 0);
@@ -591,7 +591,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         std::memcpy(inp + i_lc3, lc3.data(), (size_t)kMaxCode * 3 * sizeof(double));
         if (pd_wanted) {
             std::memcpy(inp + i_kpow, kpow, kNumQual);
-            std::memcpy(inp + i_lmin, lmin, kNumQual * sizeof(double));
+            std::memcpy(inp + i_lhet, lhet, kNumQual * sizeof(double));
         }
         if (in->known_af) std::memcpy(inp + i_kaf, in->known_af, (size_t)M * sizeof(double));
         else {
@@ -621,7 +621,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         ca.hi = hi;
         if (pd_wanted) {
             ca.kpow = reinterpret_cast<const unsigned char*>(din + i_kpow);
-            ca.lmin = reinterpret_cast<const double*>(din + i_lmin);
+            ca.lhet = reinterpret_cast<const double*>(din + i_lhet);
             ca.eff_pd = reinterpret_cast<uint32_t*>(din + i_effpd);
             ca.pother = reinterpret_cast<double*>(din + i_pother);
         }
@@ -711,7 +711,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                         const double* lc = &lc3[(size_t)idx * 3];
                         dg[0] += n * lc[0]; dg[1] += n * lc[1]; dg[2] += n * lc[2];
                         const uint32_t kq = kpow[idx >> 1];
-                        if (pd_wanted) bound += n * lmin[idx >> 1];
+                        if (pd_wanted) bound += n * lhet[idx >> 1];
                         while (left > 0) {
                             const uint32_t c1 = left > (uint32_t)kMaxRunCount ? (uint32_t)kMaxRunCount : left;
                             out[eff++] = (uint16_t)(idx | (c1 << 8));

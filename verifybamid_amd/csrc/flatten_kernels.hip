@@ -111,7 +111,7 @@ classify_kernel(const ClassifyArgs a)
     __shared__ double s_lc3[kMaxCode * 3];
     __shared__ unsigned s_hist[kCodeSlots + 2];
     __shared__ unsigned char s_kpow[kNumQual];
-    __shared__ double s_lmin[kNumQual];
+    __shared__ double s_lhet[kNumQual];
     __shared__ unsigned long long s_bound;          // + reads counted (two halves would overflow: kept as 64-bit below)
     __shared__ unsigned long long s_reads, s_others;
     __shared__ unsigned char s_qidx[256];
@@ -127,7 +127,7 @@ classify_kernel(const ClassifyArgs a)
     if (tid == 0) { s_reads = 0ull; s_others = 0ull; s_bound = 0ull; }
     const bool pd = a.kpow != nullptr;
     if (pd)
-        for (int e = tid; e < kNumQual; e += kClassifyThreads) { s_kpow[e] = a.kpow[e]; s_lmin[e] = a.lmin[e]; }
+        for (int e = tid; e < kNumQual; e += kClassifyThreads) { s_kpow[e] = a.kpow[e]; s_lhet[e] = a.lhet[e]; }
     __syncthreads();
 
     const int i = blockIdx.x * kClassifyThreads + tid;
@@ -194,7 +194,7 @@ classify_kernel(const ClassifyArgs a)
                     const double* lc = &s_lc3[idx * 3u];
                     dg0 += n * lc[0]; dg1 += n * lc[1]; dg2 += n * lc[2];
                     const unsigned kq = pd ? (unsigned)s_kpow[idx >> 1] : 1u;
-                    if (pd) bound += n * s_lmin[idx >> 1];
+                    if (pd) bound += n * s_lhet[idx >> 1];
                     while (left > 0u) {
                         const unsigned c1 = left > (unsigned)kMaxRunCount ? (unsigned)kMaxRunCount : left;
                         out[eff++] = (uint16_t)(idx | (c1 << 8));

@@ -209,7 +209,7 @@ struct ClassifyArgs {
     // from the sample; exp(c_other); and, in hist[kMaxCode + 2], the largest kPdMaxBound-style bound of a counted marker
     // (bits of a non-negative double)
     const unsigned char* kpow;     // [kNumQual] quality rank -> K
-    const double* lmin;            // [kNumQual] quality rank -> -log2 c[1] of the quality: what a read costs the (het, het) term
+    const double* lhet;            // [kNumQual] quality rank -> -log2 c[1] of the quality: what a read costs the (het, het) term
     uint32_t* eff_pd;              // out [M]
     double* pother;                // out [M]
 };
