@@ -8,6 +8,9 @@
 //                       instead of the last evaluation's
 //   VB2_STAMP_CTRL      stamp slot 3 of workgroup 0 = the control wave is back from its tile-phase work
 //   VB2_ITEM_PROF       with VB2_WITH_STAMPS: where a wave's time per work item goes (tools/item_prof.py)
+//   VB2_FLAG_RELEASE=0  the host hand-off's flag as a RELAXED system-scope store behind acknowledged write-through result stores (rounds
+//                       4-5; the shipping build stores it with RELEASE semantics, and the host still sets the result words to NaN
+//                       before every step and re-reads a NaN)
 //   VB2_ABLATE=mask     ablation builds -- parts of a launch compiled out, to price what is left:
 //                         1 kAblNoMap     nothing is read from mapped host memory (rows are made up, counts assumed full)
 //                         2 kAblNoTable   the per-alpha table is not built
@@ -20,6 +23,9 @@
 
 #ifndef VB2_ABLATE
 #define VB2_ABLATE 0
+#endif
+#ifndef VB2_FLAG_RELEASE
+#define VB2_FLAG_RELEASE 1      // the flag the host spins on is stored with system-scope RELEASE semantics (0: relaxed; A/B: profiles/r06/ab_flag_release.txt -- no measurable cost)
 #endif
 #ifndef VB2_STAMP_ROUND
 #define VB2_STAMP_ROUND 0

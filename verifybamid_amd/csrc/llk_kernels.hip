@@ -1633,8 +1633,10 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 signal = (t == batch_active - 1);
                 if (signal) __hip_atomic_store(batch_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // (a system-scope RELEASE store, in this one workgroup: VERDICT r5 #6 -- no measurable cost against the relaxed store,
+            // profiles/r06/ab_flag_release.txt; the host's NaN prefill of the result words stays as the second line)
             if (signal)
-                __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(done_flag, done_seq, VB2_FLAG_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -1784,7 +1786,7 @@ llk_finalize_kernel(const double* __restrict__ partials, int nb, int num_point,
     if (done_flag) {                    // (stores through the caches, acknowledged, then the flag: see eval_body)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, VB2_FLAG_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -2355,7 +2357,7 @@ publish_kernel(const double* __restrict__ src, double* __restrict__ dst_mapped, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0)
-        __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(done_flag, done_seq, VB2_FLAG_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 hipError_t launch_publish(const double* d_src, double* d_dst_mapped, int n, unsigned long long* done_flag,
