@@ -657,6 +657,33 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // (the groups one after the other in a rolled loop: side by side -- six logarithms' chains interleaved -- the
         // unrolled body held every group's temporaries and constants at once and spilled scalar registers to vector lanes;
         // it cost 430 vector instructions per thread of a 48-point launch where this costs 285: headline +0.8 %, 118 codes +2.2 %)
+        if constexpr (PD && !ONEGRP) {
+            // (probability domain, several groups: an entry is a dozen dependent FP64 operations and K dependent multiplies -- no
+            // logarithm's forty --, so THREE groups' entries side by side cost few registers and hide each other's latencies:
+            // the tables of a split launch's workgroup 1.8 -> 1.6 us (127 KB of LDS stores: ~0.75 us at the LDS's store rate),
+            // the 48-point launch 51.35 -> 50.6 us on one box)
+            constexpr int kSide = 3;
+            for (int g0 = 0; g0 < ngrp; g0 += kSide) {
+                double v3[kSide], r3[kSide];
+                double* cell3[kSide];
+#pragma unroll
+                for (int u = 0; u < kSide; ++u) {
+                    const int ge = g0 + u < ngrp ? g0 + u : ngrp - 1;      // (past the last group: the last one again, the same values)
+                    v3[u] = prob_entry(pts[(ge * NP + bb) * stride + 2 * k], rec.x, g1, g2);
+                    r3[u] = v3[u];
+                    cell3[u] = tab + (size_t)ge * nrow * RS + dc * RS + bp;
+                    *cell3[u] = r3[u];
+                }
+                for (int n = 1; n < twin; ++n) {
+#pragma unroll
+                    for (int u = 0; u < kSide; ++u) {
+                        r3[u] *= v3[u];
+                        cell3[u] += RS;
+                        *cell3[u] = r3[u];
+                    }
+                }
+            }
+        } else
 #pragma clang loop unroll(disable)
         for (int grp_e = 0; grp_e < ngrp; ++grp_e) {
             const double alpha_e = early_table ? lds_rows[(bb < num_valid ? bb : num_valid - 1) * stride + 2 * k]
