@@ -396,7 +396,9 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // LDS has room for beyond that (pd_row_budget: the tables of a 48-point launch) go, one at a time, to the quality
     // whose next power saves the most steps.  Any K's are correct; these are the cheapest.
     const bool pd_wanted = tn.pd != 0 && M > 0 && in->bases && in->quals;
-    unsigned char kpow[kNumQual];
+    PdDict dict;
+    std::memset(&dict, 0, sizeof(dict));
+    unsigned char* const kpow = dict.kpow;
     double lhet[kNumQual];
     std::fill(kpow, kpow + kNumQual, (unsigned char)1);
     // What a read can cost the marker's likelihood in binary orders of magnitude: the pair (het, het) explains any ref or alt read
@@ -411,32 +413,47 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     if (pd_wanted) {
         static thread_local std::vector<int64_t> H;                   // [rank][count, 63 = more] runs in the sample
         H.assign((size_t)kNumQual * 64, 0);
+        // (the runs of the first kPdPairSample sampled markers, class after class in rank order: the candidate dictionaries are
+        // priced on them with the flatten's own rule, pd_run)
+        static thread_local std::vector<uint16_t> sruns;              // rank | count << 8 (count <= 255), 0xffff = end of a class
+        sruns.clear();
         uint32_t cnt2[2 * kNumQual];
         std::fill(cnt2, cnt2 + 2 * kNumQual, 0u);
         const int stride_m = std::max(1, M / kPdSampleMarkers);
         bool seen[kNumQual];
         std::fill(seen, seen + kNumQual, false);
+        int nsampled = 0;
         for (int i = 0; i < M; i += stride_m) {
             const int64_t beg = in->read_off[i], depth = in->read_off[i + 1] - beg;
             if (depth <= 0 || depth > 4096) continue;                  // (deep markers: the context will not take this layout anyway)
             const uint8_t alt_up = lut->up[(unsigned char)in->alt_base[i]];
-            int touched[2 * kNumQual], ntouched = 0;
+            uint64_t bm[3] = {0, 0, 0};
             for (int64_t j = 0; j < depth; ++j) {
                 const unsigned char b = (unsigned char)in->bases[beg + j];
                 const unsigned cls = lut->dot[b] ? 0u : (lut->up[b] == alt_up ? 1u : 2u);
                 if (cls == 2u) continue;
                 const int idx = (int)lut->qidx[(unsigned char)in->quals[beg + j]] + (int)cls;
-                if (cnt2[idx]++ == 0) touched[ntouched++] = idx;
+                ++cnt2[idx];
+                bm[idx >> 6] |= 1ull << (idx & 63);
             }
-            for (int j = 0; j < ntouched; ++j) {
-                const int idx = touched[j];
-                ++H[(size_t)(idx >> 1) * 64 + std::min<uint32_t>(cnt2[idx], 63u)];
-                seen[idx >> 1] = true;
-                cnt2[idx] = 0;
+            const bool keep = nsampled < kPdPairSample;
+            for (uint32_t cls = 0; cls < 2; ++cls) {
+                for (int w = 0; w < 3; ++w)
+                    for (uint64_t bits = bm[w]; bits; bits &= bits - 1) {
+                        const int idx = w * 64 + __builtin_ctzll(bits);
+                        if ((uint32_t)(idx & 1) != cls) continue;
+                        if (keep) sruns.push_back((uint16_t)((idx >> 1) | (std::min<uint32_t>(cnt2[idx], 255u) << 8)));
+                        ++H[(size_t)(idx >> 1) * 64 + std::min<uint32_t>(cnt2[idx], 63u)];
+                        seen[idx >> 1] = true;
+                        cnt2[idx] = 0;
+                    }
+                if (keep) sruns.push_back((uint16_t)0xffffu);
             }
+            ++nsampled;
         }
-        int rows = 2;                                                   // (room for qualities the sample did not meet)
-        for (int r = 0; r < kNumQual; ++r) rows += seen[r] ? 1 : 0;
+        int nseen = 0, qp = 0;
+        for (int r = 0; r < kNumQual; ++r) nseen += seen[r] ? 1 : 0;
+        while (qp < kNumQual && seen[qp]) ++qp;                         // (the ranks are by frequency: the qualities met are a prefix)
         const int budget = tn.pd_rows > 0 ? tn.pd_rows : pd_row_budget(M, k, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
         // steps of the sampled runs of a quality under K = 1 .. kMaxPow (once), then the greedy walk over the gains
         std::vector<int64_t> st_at((size_t)kNumQual * (kMaxPow + 1), 0);
@@ -448,18 +465,64 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 st_at[(size_t)r * (kMaxPow + 1) + kq] = st;
             }
         }
-        while (rows < budget) {
-            int best = -1;
-            int64_t best_gain = 0;
-            for (int r = 0; r < kNumQual; ++r) {
-                if (!seen[r] || kpow[r] >= kMaxPow) continue;
-                const int64_t gain = st_at[(size_t)r * (kMaxPow + 1) + kpow[r]] - st_at[(size_t)r * (kMaxPow + 1) + kpow[r] + 1];
-                if (gain > best_gain) { best_gain = gain; best = r; }
+        // The rows the LDS has room for are shared between WINDOWS over the most frequent qualities (PdDict: w ranks, exponents
+        // up to E: (E + 1)^w - 1 rows each) and powers P^1 .. P^K of the qualities behind them.  A handful of window shapes,
+        // each over as many of the leading ranks as the rows allow; the powers get what is left, greedily; the sampled markers'
+        // steps decide.  Any choice is correct; this one is the cheapest the sample knows.
+        static const uint8_t kShapes[][2] = {{1, 0}, {2, 1}, {2, 2}, {2, 3}, {2, 4}, {3, 1}, {3, 2}, {4, 1}, {3, 3}, {4, 2}};
+        PdDict best = dict;
+        int64_t best_steps = -1;
+        int best_rows = 0;
+        for (const auto& shape : kShapes) {
+            const int w = shape[0], e = shape[1];
+            if (tn.pd_pairs == 0 && e != 0) break;
+            PdDict cand;
+            std::memset(&cand, 0, sizeof(cand));
+            std::fill(cand.kpow, cand.kpow + kNumQual, (unsigned char)1);
+            int per_win = 1;
+            for (int i = 0; i < w; ++i) per_win *= e + 1;
+            per_win -= 1;
+            // windows over the leading ranks: as many as leave every other quality met its one row
+            int nwin = 0, cover = 0;
+            if (e > 0) {
+                nwin = (qp + w - 1) / w;
+                while (nwin > 0 && 2 + nwin * per_win + std::max(0, nseen - std::min(qp, nwin * w)) > budget) --nwin;
+                cover = std::min(qp, nwin * w);
+                if (nwin == 0) continue;
             }
-            if (best < 0) break;
-            ++kpow[best];
-            ++rows;
+            cand.w = (uint8_t)w;
+            cand.e = (uint8_t)e;
+            cand.qp = (uint8_t)cover;
+            int rows = 2 + nwin * per_win;                               // (2: room for qualities the sample did not meet)
+            for (int r = cover; r < kNumQual; ++r) rows += seen[r] ? 1 : 0;
+            while (rows < budget) {
+                int bst = -1;
+                int64_t best_gain = 0;
+                for (int r = cover; r < kNumQual; ++r) {
+                    if (!seen[r] || cand.kpow[r] >= kMaxPow) continue;
+                    const int64_t gain = st_at[(size_t)r * (kMaxPow + 1) + cand.kpow[r]] - st_at[(size_t)r * (kMaxPow + 1) + cand.kpow[r] + 1];
+                    if (gain > best_gain) { best_gain = gain; bst = r; }
+                }
+                if (bst < 0) break;
+                ++cand.kpow[bst];
+                ++rows;
+            }
+            int64_t steps = 0;
+            {
+                PdWin t{0u, 0u, 0ull};
+                auto count = [&](uint32_t) { ++steps; };
+                for (const uint16_t rw : sruns) {
+                    if (rw == 0xffffu) pd_flush(cand, t, count);
+                    else pd_run(cand, t, rw & 0xffu, rw >> 8, count);
+                }
+            }
+            if (best_steps < 0 || steps < best_steps || (steps == best_steps && rows < best_rows)) {
+                best = cand;
+                best_steps = steps;
+                best_rows = rows;
+            }
         }
+        dict = best;
     }
 
     const auto t_k1 = tnow();
@@ -499,7 +562,6 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     const size_t i_qidx = icarve(device_flatten ? 256 : 0);
     const size_t i_olc = icarve(device_flatten ? 256 * sizeof(double) : 0);
     const size_t i_lc3 = icarve(device_flatten ? (size_t)kMaxCode * 3 * sizeof(double) : 0);
-    const size_t i_kpow = icarve(device_flatten && pd_wanted ? (size_t)kNumQual : 0);
     const size_t i_lhet = icarve(device_flatten && pd_wanted ? (size_t)kNumQual * sizeof(double) : 0);
     const size_t i_ud = icarve(in->known_af ? 0 : (size_t)M * k * sizeof(double));
     const size_t i_mu = icarve(in->known_af ? 0 : (size_t)M * sizeof(double));
@@ -590,7 +652,6 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         std::memcpy(inp + i_olc, lut->other_lc, 256 * sizeof(double));
         std::memcpy(inp + i_lc3, lc3.data(), (size_t)kMaxCode * 3 * sizeof(double));
         if (pd_wanted) {
-            std::memcpy(inp + i_kpow, kpow, kNumQual);
             std::memcpy(inp + i_lhet, lhet, kNumQual * sizeof(double));
         }
         if (in->known_af) std::memcpy(inp + i_kaf, in->known_af, (size_t)M * sizeof(double));
@@ -620,7 +681,8 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         ca.lo = lo;
         ca.hi = hi;
         if (pd_wanted) {
-            ca.kpow = reinterpret_cast<const unsigned char*>(din + i_kpow);
+            ca.pd = 1;
+            ca.dict = dict;
             ca.lhet = reinterpret_cast<const double*>(din + i_lhet);
             ca.eff_pd = reinterpret_cast<uint32_t*>(din + i_effpd);
             ca.pother = reinterpret_cast<double*>(din + i_pother);
@@ -701,6 +763,9 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 double dg[3] = {0.0, 0.0, 0.0};
                 uint32_t steps_ref = 0, steps_alt = 0;
                 double bound = 0.0;
+                PdWin tail_ref{0u, 0u, 0ull}, tail_alt{0u, 0u, 0ull};
+                auto count_ref = [&](uint32_t) { ++steps_ref; };
+                auto count_alt = [&](uint32_t) { ++steps_alt; };
                 for (int w = 0; w < 3; ++w)
                     for (uint64_t bits = bm[w]; bits; bits &= bits - 1) {
                         const unsigned idx = (unsigned)w * 64u + (unsigned)__builtin_ctzll(bits);
@@ -710,16 +775,18 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                         const double n = (double)left;
                         const double* lc = &lc3[(size_t)idx * 3];
                         dg[0] += n * lc[0]; dg[1] += n * lc[1]; dg[2] += n * lc[2];
-                        const uint32_t kq = kpow[idx >> 1];
                         if (pd_wanted) bound += n * lhet[idx >> 1];
                         while (left > 0) {
                             const uint32_t c1 = left > (uint32_t)kMaxRunCount ? (uint32_t)kMaxRunCount : left;
                             out[eff++] = (uint16_t)(idx | (c1 << 8));
                             left -= c1;
-                            const uint32_t st = (c1 + kq - 1u) / kq;
-                            if (idx & 1u) steps_alt += st; else steps_ref += st;
+                            if (!pd_wanted) continue;
+                            if (idx & 1u) pd_run(dict, tail_alt, idx >> 1, c1, count_alt);
+                            else pd_run(dict, tail_ref, idx >> 1, c1, count_ref);
                         }
                     }
+                pd_flush(dict, tail_ref, count_ref);
+                pd_flush(dict, tail_alt, count_alt);
                 // the g1 == g2 terms of h:307-311 are constants of the marker
                 double* cd = cd_tmp + (size_t)i * 4;
                 cd[0] = c_other;
@@ -772,15 +839,21 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     // underflows too: either is nothing beside a likelihood of 2^-927 or more (below 2^-95 of it), so the `markerLK > 0` rule
     // (h:310) never decides and the sum's bits are the likely pairs'.  Deep data -- about 850 reads per marker at the usual
     // qualities -- takes the run words and sums of logarithms.  And the table's rows must fit 16-bit offsets.
-    int pd_rows = 0;
+    int pd_rows = 0, pd_prod_rows = 0, pd_prod2 = 0, pd_per_win = 0, pd_nwin = 0;
+    auto pd_has_rows = [&](int r) { return r >= (int)dict.qp && code_hist[2 * r] + code_hist[2 * r + 1] > 0; };
+    if (dict.qp > 0) {
+        pd_per_win = 1;
+        for (int i = 0; i < dict.w; ++i) pd_per_win *= dict.e + 1;
+        pd_per_win -= 1;
+        pd_nwin = ((int)dict.qp + dict.w - 1) / dict.w;
+        pd_rows = pd_nwin * pd_per_win;
+    }
     for (int r = 0; r < kNumQual; ++r)
-        if (code_hist[2 * r] + code_hist[2 * r + 1] > 0) pd_rows += kpow[r];
+        if (pd_has_rows(r)) pd_rows += kpow[r];
     const bool pd = pd_wanted && m_active > 0 && max_bound <= kPdMaxBound && pd_rows <= kMaxWideCodes && tn.force_narrow == 0;
     int num_code = num_code_seen;                             // rows of the per-alpha table (the padding row not counted)
     std::vector<double> dict_perr;
     std::vector<double2> prim;
-    uint16_t row_off_pd[kNumQual][kMaxPow + 1];
-    std::memset(row_off_pd, 0, sizeof(row_off_pd));
     if (!pd) {
         dict_perr.resize(num_code);
         for (int d = 0; d < num_code; ++d) {
@@ -808,19 +881,65 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     } else {
         // rows: quality after quality in rank order, P^1 .. P^K of each -- a marker's steps walk the table upwards
         num_code = pd_rows;
-        for (int r = 0; r < kNumQual; ++r) {
-            if (code_hist[2 * r] + code_hist[2 * r + 1] == 0) continue;
-            // (one record per quality: {pErr, first row | K << 16} -- the table build makes the K rows from one value)
-            const unsigned long long bits = (unsigned long long)((uint32_t)dict_perr.size() | ((uint32_t)kpow[r] << 16));
+        auto bits_of = [](unsigned long long bits) {
             double y;
             std::memcpy(&y, &bits, sizeof(y));
-            prim.push_back(make_double2(phred[qof[r]], y));
-            for (int n = 1; n <= kpow[r]; ++n) {
-                row_off_pd[r][n] = (uint16_t)(dict_perr.size() * kRowBytesWide);
-                dict_perr.push_back(phred[qof[r]]);
+            return y;
+        };
+        // the windows' rows first (window after window), then the other qualities' P^1 .. P^K
+        dict_perr.assign((size_t)pd_rows, 0.0);
+        const int radix = dict.e + 1;
+        std::vector<double2> prod1, prod2;                     // product records: of two power rows; of rows one of which is a product
+        auto prod_rec = [&](uint32_t ra, uint32_t rb, uint32_t dst) {
+            return make_double2(bits_of((unsigned long long)(ra | (rb << 16))), bits_of((unsigned long long)dst));
+        };
+        int next_row = 0;
+        for (int t = 0; t < pd_nwin; ++t) {
+            const uint32_t base = (uint32_t)next_row;
+            dict.win_base[t] = (uint16_t)base;
+            int mul[kPdMaxWin + 1];
+            mul[0] = 1;
+            for (int i = 0; i < kPdMaxWin; ++i) mul[i + 1] = mul[i] * radix;
+            const int wt = std::min<int>(dict.w, (int)dict.qp - t * dict.w);      // (the last window may hold fewer qualities: its other rows are never read)
+            for (int i = 0; i < wt; ++i) {
+                const int r = t * dict.w + i;
+                // {pErr, first row | K << 16 | rows between P^n and P^(n+1) << 24}: the quality's own powers inside the window
+                prim.push_back(make_double2(phred[qof[r]], bits_of((unsigned long long)((base + (uint32_t)mul[i] - 1u) | ((uint32_t)dict.e << 16) |
+                                                                                       ((uint32_t)mul[i] << 24)))));
             }
+            for (int idx = 1; idx <= pd_per_win; ++idx) {
+                int ex[kPdMaxWin], nz = 0, first_nz[kPdMaxWin];
+                for (int i = 0; i < kPdMaxWin; ++i) {
+                    ex[i] = i < dict.w ? (idx / mul[i]) % radix : 0;
+                    if (ex[i]) first_nz[nz++] = i;
+                }
+                bool in_window = true;
+                for (int i = wt; i < kPdMaxWin; ++i) in_window = in_window && ex[i] == 0;
+                if (nz < 2 || !in_window) continue;
+                auto row_of = [&](int i0, int i1) {          // the row holding the exponents of positions [i0, i1) of first_nz only
+                    int v = 0;
+                    for (int q = i0; q < i1; ++q) v += ex[first_nz[q]] * mul[first_nz[q]];
+                    return base + (uint32_t)v - 1u;
+                };
+                const uint32_t dst = base + (uint32_t)idx - 1u;
+                if (nz == 2) prod1.push_back(prod_rec(row_of(0, 1), row_of(1, 2), dst));
+                else if (nz == 3) prod2.push_back(prod_rec(row_of(0, 2), row_of(2, 3), dst));
+                else prod2.push_back(prod_rec(row_of(0, 2), row_of(2, 4), dst));
+            }
+            next_row += pd_per_win;
         }
+        for (int r = 0; r < kNumQual; ++r) {
+            if (!pd_has_rows(r)) continue;
+            prim.push_back(make_double2(phred[qof[r]], bits_of((unsigned long long)((uint32_t)next_row | ((uint32_t)kpow[r] << 16) | (1u << 24)))));
+            dict.single_row[r] = (uint16_t)next_row;
+            for (int n = 1; n <= kpow[r]; ++n) dict_perr[(size_t)next_row++] = phred[qof[r]];
+        }
+        pd_prod_rows = (int)(prod1.size() + prod2.size());
+        pd_prod2 = (int)prod2.size();
+        prim.insert(prim.end(), prod1.begin(), prod1.end());
+        prim.insert(prim.end(), prod2.begin(), prod2.end());
     }
+    const int num_pair = pd ? pd_prod_rows : 0;
 
     // ---- sort markers by effective depth (descending, stable); 16-marker micro-tiles ----
     // counting sort = the stable descending sort by run count (ties keep panel order)
@@ -1143,17 +1262,14 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 ++step;
             };
             for (uint32_t cls = 0; cls < 2; ++cls) {
+                PdWin tail{0u, 0u, 0ull};
+                auto put_row = [&](uint32_t row) { put(row * (uint32_t)row_bytes + cls * (uint32_t)kPdAltOffset); };
                 for (size_t j = 0; j < eff; ++j) {
                     const uint32_t rw = src[j], idx = rw & 0xffu;
                     if ((idx & 1u) != cls) continue;
-                    const uint32_t rank = idx >> 1, kq = kpow[rank];
-                    uint32_t left = rw >> 8;
-                    while (left > 0u) {
-                        const uint32_t c1 = left > kq ? kq : left;
-                        put(row_off_pd[rank][c1] + cls * (uint32_t)kPdAltOffset);
-                        left -= c1;
-                    }
+                    pd_run(dict, tail, idx >> 1, rw >> 8, put_row);
                 }
+                pd_flush(dict, tail, put_row);
                 const uint32_t end = cls == 0 ? s1 : 2u * ((s2 + 1u) >> 1);
                 while (step < end) put(pad_off + cls * (uint32_t)kPdAltOffset);
             }
@@ -1203,17 +1319,14 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                         if (m < m_active) {
                             const int i = active[perm[m]];
                             const uint16_t* src = runs + (in->read_off[i] - read_base);
+                            PdWin tail{0u, 0u, 0ull};
+                            auto push_row = [&](uint32_t row) { lst[l].push_back((uint16_t)row); };
                             for (int32_t j = 0; j < eff_all[i]; ++j) {
                                 const uint32_t rw = src[j], idx = rw & 0xffu;
                                 if ((idx & 1u) != cls) continue;
-                                const uint32_t rank = idx >> 1, kq = kpow[rank];
-                                uint32_t left = rw >> 8;
-                                while (left > 0u) {
-                                    const uint32_t c1 = left > kq ? kq : left;
-                                    lst[l].push_back((uint16_t)(row_off_pd[rank][c1] / (uint32_t)row_bytes));
-                                    left -= c1;
-                                }
+                                pd_run(dict, tail, idx >> 1, rw >> 8, push_row);
                             }
+                            pd_flush(dict, tail, push_row);
                         }
                         eff16[l] = (uint32_t)lst[l].size();
                     }
@@ -1366,8 +1479,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             pp.total_rows = (uint32_t)total_rows;
             pp.slack_rows = (uint32_t)kCodeSlackRows;
             pp.pad_off = pad_off;
-            std::memcpy(pp.row_off, row_off_pd, sizeof(pp.row_off));
-            std::memcpy(pp.kpow, kpow, sizeof(pp.kpow));
+            pp.dict = dict;
             pp.sched = pd_sched ? 1 : 0;
             pp.num_code = num_code;
             pp.row_bytes = row_bytes;
@@ -1443,6 +1555,9 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
     c->sched_enabled = tn.sched != 0;
     c->device_bytes = (int64_t)dev_total;
     L.num_prim = (int32_t)prim.size();
+    L.num_pair = num_pair;
+    L.num_pair2 = pd ? pd_prod2 : 0;
+    L.reserved1 = 0;
     L.pd = pd ? 1 : 0;
     c->num_code_seen = num_code_seen;
     L.num_code = num_code;

@@ -110,7 +110,7 @@ classify_kernel(const ClassifyArgs a)
     __shared__ double s_other[256];
     __shared__ double s_lc3[kMaxCode * 3];
     __shared__ unsigned s_hist[kCodeSlots + 2];
-    __shared__ unsigned char s_kpow[kNumQual];
+    __shared__ PdDict s_dict;                       // (its row numbers are not assigned yet: the kernel counts steps)
     __shared__ double s_lhet[kNumQual];
     __shared__ unsigned long long s_bound;          // + reads counted (two halves would overflow: kept as 64-bit below)
     __shared__ unsigned long long s_reads, s_others;
@@ -125,9 +125,12 @@ classify_kernel(const ClassifyArgs a)
     for (int e = tid; e < kMaxCode * 3; e += kClassifyThreads) s_lc3[e] = a.lc3[e];
     for (int e = tid; e < kCodeSlots + 2; e += kClassifyThreads) s_hist[e] = 0u;
     if (tid == 0) { s_reads = 0ull; s_others = 0ull; s_bound = 0ull; }
-    const bool pd = a.kpow != nullptr;
-    if (pd)
-        for (int e = tid; e < kNumQual; e += kClassifyThreads) { s_kpow[e] = a.kpow[e]; s_lhet[e] = a.lhet[e]; }
+    const bool pd = a.pd != 0;
+    if (pd) {
+        for (int e = tid; e < kNumQual; e += kClassifyThreads) s_lhet[e] = a.lhet[e];
+        for (int e = tid; e < (int)(sizeof(PdDict) / 2); e += kClassifyThreads)
+            reinterpret_cast<uint16_t*>(&s_dict)[e] = reinterpret_cast<const uint16_t*>(&a.dict)[e];
+    }
     __syncthreads();
 
     const int i = blockIdx.x * kClassifyThreads + tid;
@@ -182,6 +185,9 @@ classify_kernel(const ClassifyArgs a)
             uint16_t* out = a.runs + beg;
             eff = 0;
             double dg0 = 0.0, dg1 = 0.0, dg2 = 0.0, bound = 0.0;
+            PdWin tail_ref{0u, 0u, 0ull}, tail_alt{0u, 0u, 0ull};
+            auto count_ref = [&](uint32_t) { ++steps_ref; };
+            auto count_alt = [&](uint32_t) { ++steps_alt; };
 #pragma unroll 1
             for (int w = 0; w < 3; ++w) {
                 unsigned long long bits = w == 0 ? bm0 : w == 1 ? bm1 : bm2;
@@ -193,18 +199,21 @@ classify_kernel(const ClassifyArgs a)
                     const double n = (double)left;
                     const double* lc = &s_lc3[idx * 3u];
                     dg0 += n * lc[0]; dg1 += n * lc[1]; dg2 += n * lc[2];
-                    const unsigned kq = pd ? (unsigned)s_kpow[idx >> 1] : 1u;
                     if (pd) bound += n * s_lhet[idx >> 1];
                     while (left > 0u) {
                         const unsigned c1 = left > (unsigned)kMaxRunCount ? (unsigned)kMaxRunCount : left;
                         out[eff++] = (uint16_t)(idx | (c1 << 8));
                         left -= c1;
                         if (pd) {
-                            const unsigned st = (c1 + kq - 1u) / kq;
-                            if (idx & 1u) steps_alt += st; else steps_ref += st;
+                            if (idx & 1u) pd_run(s_dict, tail_alt, idx >> 1, c1, count_alt);
+                            else pd_run(s_dict, tail_ref, idx >> 1, c1, count_ref);
                         }
                     }
                 }
+            }
+            if (pd) {
+                pd_flush(s_dict, tail_ref, count_ref);
+                pd_flush(s_dict, tail_alt, count_alt);
             }
             double* cd = a.cd + (size_t)i * 4;
             cd[0] = c_other;
@@ -349,17 +358,14 @@ pack_pd_kernel(const PackPdArgs a)
         };
 #pragma unroll 1
         for (uint32_t cls = 0; cls < (a.sched ? 0u : 2u); ++cls) {      // (sched: pack_pd_sched_kernel writes the steps)
+            PdWin tail{0u, 0u, 0ull};
+            auto put_row = [&](uint32_t row) { put(row * (uint32_t)a.row_bytes + cls * (uint32_t)kPdAltOffset); };
             for (uint32_t j = 0; j < nrun; ++j) {
                 const uint32_t rw = src[j], idx = rw & 0xffu;
                 if ((idx & 1u) != cls) continue;
-                const uint32_t rank = idx >> 1, kq = a.kpow[rank];
-                uint32_t left = rw >> 8;
-                while (left > 0u) {
-                    const uint32_t c1 = left > kq ? kq : left;
-                    put(a.row_off[rank][c1] + cls * (uint32_t)kPdAltOffset);
-                    left -= c1;
-                }
+                pd_run(a.dict, tail, idx >> 1, rw >> 8, put_row);
             }
+            pd_flush(a.dict, tail, put_row);
             const uint32_t end = cls == 0 ? s1 : 2u * ((s2 + 1u) >> 1);
             while (step < end) put(a.pad_off + cls * (uint32_t)kPdAltOffset);
         }
@@ -423,17 +429,18 @@ pack_pd_sched_kernel(const PackPdArgs a)
         const int steps = (int)(cls == 0 ? s1 : s2 - s1);
         // the lane's steps of this phase, as row indices
         uint32_t n = 0;
-        for (uint32_t j = 0; j < nrun; ++j) {
-            const uint32_t rw = src[j], idx = rw & 0xffu;
-            if ((idx & 1u) != cls) continue;
-            const uint32_t rank = idx >> 1, kq = a.kpow[rank];
-            uint32_t left = rw >> 8;
-            while (left > 0u) {
-                const uint32_t c1 = left > kq ? kq : left;
-                if (n < (uint32_t)kSchedMaxSteps) s_runs[row][lane][n] = (uint8_t)(a.row_off[rank][c1] / (uint32_t)a.row_bytes);
+        {
+            PdWin tail{0u, 0u, 0ull};
+            auto stage = [&](uint32_t r) {
+                if (n < (uint32_t)kSchedMaxSteps) s_runs[row][lane][n] = (uint8_t)r;
                 ++n;
-                left -= c1;
+            };
+            for (uint32_t j = 0; j < nrun; ++j) {
+                const uint32_t rw = src[j], idx = rw & 0xffu;
+                if ((idx & 1u) != cls) continue;
+                pd_run(a.dict, tail, idx >> 1, rw >> 8, stage);
             }
+            pd_flush(a.dict, tail, stage);
         }
         s_eff[row][lane] = n;
         __syncthreads();
@@ -442,17 +449,14 @@ pack_pd_sched_kernel(const PackPdArgs a)
             if (live) {              // the steps in plain order (pack_pd_kernel's loop)
                 uint32_t step = 0;
                 auto put_plain = [&](uint32_t off) { put_step(first_step + step, off); ++step; };
+                PdWin tail{0u, 0u, 0ull};
+                auto put_row = [&](uint32_t r) { put_plain(r * (uint32_t)a.row_bytes + cls * (uint32_t)kPdAltOffset); };
                 for (uint32_t j = 0; j < nrun; ++j) {
                     const uint32_t rw = src[j], idx = rw & 0xffu;
                     if ((idx & 1u) != cls) continue;
-                    const uint32_t rank = idx >> 1, kq = a.kpow[rank];
-                    uint32_t left = rw >> 8;
-                    while (left > 0u) {
-                        const uint32_t c1 = left > kq ? kq : left;
-                        put_plain(a.row_off[rank][c1] + cls * (uint32_t)kPdAltOffset);
-                        left -= c1;
-                    }
+                    pd_run(a.dict, tail, idx >> 1, rw >> 8, put_row);
                 }
+                pd_flush(a.dict, tail, put_row);
                 while (step < (uint32_t)steps) put_plain(a.pad_off + cls * (uint32_t)kPdAltOffset);
             }
         } else {

@@ -31,6 +31,11 @@ constexpr int kMaxPow = 8;
 // no room for it, takes the offset off again and names its products the other way round)
 constexpr int kPdAltOffset = 192;
 constexpr int kPdSampleMarkers = 768;      // markers whose run counts choose the K's (before the reads are walked)
+// WINDOW rows (PdDict): the most frequent qualities come in aligned windows of w neighbouring ranks; a window has a row for
+// every product P_1^e1 ... P_w^ew, 0 <= e <= E (not all 0), so that a marker's reads of the window's qualities take ONE step
+// as long as it holds at most E of each
+constexpr int kPdMaxWin = 4;
+constexpr int kPdPairSample = 128;         // markers of the sample on which the candidate dictionaries are priced
 constexpr double kPdMaxBound = 900.0;      // binary orders of magnitude a marker's likelihood may lie below 1 at most (context.cpp:
                                            // its (het, het) term's, a lower bound of the likelihood that no alpha or PC changes)
 // d_ticket of launch_llk_eval: kTicketWords zero-initialised unsigned ints -- [0, kTicketScratchWord) the arrival tickets of a
@@ -75,9 +80,13 @@ struct DeviceLayout {
     int32_t pd;                   // 1: probability-domain layout (see kMaxPow): codes = [rows][16] x uint32 {step, step} of 16-bit
                                   // row offsets, mt_rec = {first row, ref rows | alt rows << 16}, prim = [num_code] {pErr, n},
                                   // ediag[0] = exp(c_other); a workgroup owns PAIRS of neighbouring micro-tiles (owned_tile)
+    int32_t num_pair;             // probability domain: the LAST num_pair records of prim make product rows: {bits: row a | row b << 16,
+                                  // bits: the row} = the product of two rows built from the records before them (PdDict: windows)
     unsigned long long* stamps;   // profiling aid: [grid][8] wall-clock stamps, or nullptr
     int64_t num_active;
     int64_t m_pad;                // num_mt * 16
+    int32_t num_pair2;            // ... and of those the last num_pair2 multiply rows that records of this kind made (a second barrier)
+    int32_t reserved1;
 };
 
 // Static work schedule of one launch shape: wave w of workgroup b evaluates the work items
@@ -114,6 +123,64 @@ __host__ __device__ inline uint32_t owned_count(int sh, uint32_t num_mt, uint32_
 __host__ __device__ inline uint32_t owned_most(int sh, uint32_t num_mt, uint32_t nblk)     // (workgroup 0's count)
 {
     return (((num_mt >> sh) + nblk - 1u) / nblk) << sh;
+}
+
+// The dictionary of a probability-domain context as the flatten sees it: which table rows exist and what a marker's runs cost.
+// Ranks below qp: windows of w ranks; window t's rows start at win_base[t], the row of the exponents (e_0 .. e_{w-1}) at
+// + sum e_i (E + 1)^i - 1.  A marker's reads of a window's qualities (per class) take max_i ceil(c_i / E) steps: every step
+// takes min(c_i, E) of each.  The other ranks: rows P^1 .. P^K of their own from single_row[rank] on, ceil(c / K) steps.
+// Both the step counts (pass A) and the steps (pass B) come from pd_run / pd_flush below: one statement of the rule.
+struct PdDict {
+    uint16_t win_base[kNumQual];                 // [window] first row
+    uint16_t single_row[kNumQual];               // [rank >= qp] row of P^1 (P^2 .. P^K follow)
+    uint8_t kpow[kNumQual];                      // [rank >= qp] K
+    uint8_t w, e, qp, spare;                     // window width, highest exponent, ranks in windows (the last window may be partial)
+};
+struct PdWin {                                   // the open window of a marker's class: its index and the reads of its w qualities
+    uint32_t t;
+    uint32_t open;
+    unsigned long long c;                        // 16 bits per quality
+};
+template <class Emit>
+__host__ __device__ __forceinline__ void pd_flush(const PdDict& D, PdWin& s, Emit&& emit)
+{
+    if (!s.open) return;
+    const uint32_t e = D.e, radix = e + 1u;
+    unsigned long long c = s.c;
+    while (c) {
+        uint32_t idx = 0, mul = 1;
+        unsigned long long left = 0;
+#pragma unroll
+        for (int i = 0; i < kPdMaxWin; ++i) {
+            const uint32_t ci = (uint32_t)(c >> (16 * i)) & 0xffffu;
+            const uint32_t take = ci < e ? ci : e;
+            idx += take * mul;
+            mul *= radix;
+            left |= (unsigned long long)(ci - take) << (16 * i);
+        }
+        emit((uint32_t)D.win_base[s.t] + idx - 1u);
+        c = left;
+    }
+    s.c = 0;
+    s.open = 0;
+}
+// one run of a class: quality rank, n reads (runs come in rank order; a class's walk ends with pd_flush)
+template <class Emit>
+__host__ __device__ __forceinline__ void pd_run(const PdDict& D, PdWin& s, uint32_t rank, uint32_t n, Emit&& emit)
+{
+    if (rank < (uint32_t)D.qp) {
+        const uint32_t w = D.w, t = rank / w, i = rank - t * w;
+        if (s.open && s.t != t) pd_flush(D, s, emit);
+        s.open = 1;
+        s.t = t;
+        s.c += (unsigned long long)n << (16u * i);
+        return;
+    }
+    pd_flush(D, s, emit);
+    const uint32_t kq = D.kpow[rank];
+    const uint32_t full = (n - 1u) / kq, rem = n - full * kq;
+    for (uint32_t f = 0; f < full; ++f) emit((uint32_t)D.single_row[rank] + kq - 1u);
+    emit((uint32_t)D.single_row[rank] + rem - 1u);
 }
 
 struct LaunchGeom { int grid, block_waves; };
@@ -205,10 +272,12 @@ struct ClassifyArgs {
     uint32_t max_depth;            // reads of the deepest marker (below 65 536: 16-bit counters)
     int32_t sanity;                // 1: the +-3 sd depth filter is on
     double lo, hi;                 // its bounds
-    // probability-domain bookkeeping (kpow == nullptr: none): per marker its steps, ref | alt << 16, under the K's chosen
-    // from the sample; exp(c_other); and, in hist[kMaxCode + 2], the largest kPdMaxBound-style bound of a counted marker
-    // (bits of a non-negative double)
-    const unsigned char* kpow;     // [kNumQual] quality rank -> K
+    // probability-domain bookkeeping (pd == 0: none): per marker its steps, ref | alt << 16, under the dictionary chosen
+    // from the sample (dict: the K's and the pair bands; its row numbers are not known yet and not needed to count);
+    // exp(c_other); and, in hist[kMaxCode + 2], the largest kPdMaxBound-style bound of a counted marker (bits of a
+    // non-negative double)
+    int32_t pd;
+    PdDict dict;
     const double* lhet;            // [kNumQual] quality rank -> -log2 c[1] of the quality: what a read costs the (het, het) term
     uint32_t* eff_pd;              // out [M]
     double* pother;                // out [M]
@@ -266,8 +335,7 @@ struct PackPdArgs {
     int64_t m_active, m_pad;
     int32_t k, num_mt;
     uint32_t total_rows, slack_rows, pad_off;
-    uint16_t row_off[kNumQual][kMaxPow + 1];     // [rank][n] byte offset of the row P^n (n = 1 .. K)
-    uint8_t kpow[kNumQual];
+    PdDict dict;                   // the table's rows (a step = row index * row_bytes, + kPdAltOffset for class alt)
     int32_t sched;                 // 1: the steps of a tile's phase are placed by schedule_tile (tile_sched.h), as the runs of a
                                    // wide alphabet's tile are: the rows the 16 markers read in a step then start in 16 different
                                    // bank groups (plain order: 1.25 LDS passes per step at 42 codes; placed: 1.01)

@@ -512,7 +512,7 @@ __host__ __device__ __forceinline__ bool eval_is_dynamic(const DeviceLayout& L, 
 // multiplied in the same order and its sum goes to the same word of the partial sums as in a plain launch of this grid:
 // the same bits, and no second pass over the tiles (llk_eval_passes_kernel: +4 us per pass at C3).
 template <int MODE, bool W16 = false, class Hook = NoHook, bool STREAM = false, int QUEUE = -1, int KSEL = 0,
-          bool LCACHE = false, int ESH = 8, bool PD = false, bool SPLIT = false>
+          bool LCACHE = false, int ESH = 8, bool PD = false, int SPLIT = 0>
 __device__ __forceinline__ void
 eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const double* __restrict__ points, int num_valid,
           double* __restrict__ partials, double* __restrict__ llk_out,
@@ -546,12 +546,14 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // A launch carries ngrp groups of NP points; each group has its own table and the
     // (tile, group) pairs are the work items, so a bigger batch re-reads the pileup from
     // L2 per group but pays launch, prologue and reduction once.
-    // (SPLIT: this workgroup's half of the launch's groups, the points before them, and its two virtual blocks)
-    const int g_lo = SPLIT ? ((blk & 1u) ? (ngrp_in + 1) / 2 : 0) : 0;
-    const int ngrp = ONEGRP ? 1 : SPLIT ? ((blk & 1u) ? ngrp_in / 2 : (ngrp_in + 1) / 2) : ngrp_in;
+    // (SPLIT = S workgroups share their tiles: this workgroup's share of the launch's groups, the points before them, and its S
+    // virtual blocks vb0 + j * vstep)
+    constexpr int NVS = SPLIT ? SPLIT : 1;      // virtual blocks per workgroup
+    const int g_per = SPLIT ? (ngrp_in + NVS - 1) / NVS : ngrp_in;
+    const int g_lo = SPLIT ? (int)(blk % (uint32_t)NVS) * g_per : 0;
+    const int ngrp = ONEGRP ? 1 : SPLIT ? (ngrp_in - g_lo < g_per ? ngrp_in - g_lo : g_per) : ngrp_in;      // (the launcher sees to it that none is empty)
     const int p_off = g_lo * NP;
-    const uint32_t vhalf = SPLIT ? nblk >> 1 : 0u, vb0 = SPLIT ? blk >> 1 : blk;
-    constexpr int NVS = SPLIT ? 2 : 1;          // virtual blocks per workgroup
+    const uint32_t vstep = SPLIT ? nblk / (uint32_t)NVS : 0u, vb0 = SPLIT ? blk / (uint32_t)NVS : blk;
     const double* const known_af_p = KAF == 0 ? nullptr : L.known_af;
     const int NPT = NP * ngrp;                  // points of this launch
     constexpr int kEtabCopies = (1 << ESH) / 8, kEtabDoubles = PD ? 0 : 64 * kEtabCopies;
@@ -623,7 +625,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // entry.  With one group each thread builds about one entry and loads its record directly.
     // (the resident kernel keeps them in LDS from its first round on: a round's table then starts without a trip to L2)
     const bool prim_kept = hook.prim_in_lds() && hook.keep_prim();
-    const bool staged = ngrp > 1 || (hook.prim_in_lds() && !prim_kept);
+    const bool staged = ngrp > 1 || (hook.prim_in_lds() && !prim_kept) || (PD && L.num_pair > 0 && !prim_kept);      // (pair rows: their records from LDS)
     if (staged)
         for (int e = tid; e < L.num_prim; e += nthread) prim_lds[e] = L.prim[e];
     // A search round (its rows are in LDS since the round's staging barrier) builds its one table without waiting
@@ -642,7 +644,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // (a thread's entries for the different groups are independent: computed side by side so
     // that their long dependent logarithm chains overlap)
     const uint32_t ltab_addr = lds_byte_addr(ltab);
-    for (int e = tid; e < ((kAblate & kAblNoTable) ? 0 : L.num_prim * 6 * NP); e += nthread) {
+    const int num_single = PD ? L.num_prim - L.num_pair : L.num_prim;
+    for (int e = tid; e < ((kAblate & kAblNoTable) ? 0 : num_single * 6 * NP); e += nthread) {
         const int pi = e / (6 * NP);
         const int bp = e - pi * (6 * NP);
         const int bb = bp / 6, p = bp - bb * 6;
@@ -674,11 +677,12 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                     cell3[u] = tab + (size_t)ge * nrow * RS + dc * RS + bp;
                     *cell3[u] = r3[u];
                 }
-                for (int n = 1; n < twin; ++n) {
+                const int kq = twin & 0xff, pstride = RS * (twin >> 8);      // (record: first row | K << 16 | rows between P^n and P^(n+1) << 24)
+                for (int n = 1; n < kq; ++n) {
 #pragma unroll
                     for (int u = 0; u < kSide; ++u) {
                         r3[u] *= v3[u];
-                        cell3[u] += RS;
+                        cell3[u] += pstride;
                         *cell3[u] = r3[u];
                     }
                 }
@@ -701,9 +705,10 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 const int mir = kMir + bb * 6 + (5 - p) - bp;
                 *cell = r;
                 if constexpr (NP <= 4 && STREAM) cell[mir] = r;
-                for (int n = 1; n < twin; ++n) {
+                const int kq = twin & 0xff, pstride = RS * (twin >> 8);      // (record: first row | K << 16 | rows between P^n and P^(n+1) << 24)
+                for (int n = 1; n < kq; ++n) {
                     r *= v;
-                    cell += RS;
+                    cell += pstride;
                     *cell = r;
                     if constexpr (NP <= 4 && STREAM) cell[mir] = r;
                 }
@@ -719,6 +724,34 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const int grp_e = e / RS;
         tab[((size_t)grp_e * nrow + L.num_code) * RS + (e - grp_e * RS)] = PD ? 1.0 : 0.0;
     }
+    if constexpr (PD) {
+        // ---- pair rows (PdDict): the product of two of the rows above, entry by entry -- one record per row
+        // {bits: row a | row b << 16, bits: the row}, from LDS ----
+        for (int level = 0; level < 2 && L.num_pair > 0 && !(kAblate & kAblNoTable); ++level) {
+            // (level 1: products of two rows the records of this kind made -- windows of three and four qualities)
+            const int nrec = level == 0 ? L.num_pair - L.num_pair2 : L.num_pair2;
+            if (nrec == 0) break;
+            __syncthreads();
+            const double2* const prec = prim_lds + num_single + (level == 0 ? 0 : L.num_pair - L.num_pair2);
+            for (int e = tid; e < nrec * 6 * NP; e += nthread) {
+                const int pi = e / (6 * NP);
+                const int bp = e - pi * (6 * NP);
+                const double2 rec = prec[pi];
+                const uint32_t ab = (uint32_t)__double_as_longlong(rec.x), dst = (uint32_t)__double_as_longlong(rec.y);
+                const int ra = (int)(ab & 0xffffu) * RS + bp, rb = (int)(ab >> 16) * RS + bp, rd = (int)dst * RS + bp;
+                constexpr int kMir = kPdAltOffset / 8;
+                const int bb = bp / 6, p = bp - bb * 6;
+                const int mir = kMir + bb * 6 + (5 - p) - bp;
+#pragma clang loop unroll(disable)
+                for (int grp_e = 0; grp_e < ngrp; ++grp_e) {
+                    double* gtab = tab + (size_t)grp_e * nrow * RS;
+                    const double v = gtab[ra] * gtab[rb];
+                    gtab[rd] = v;
+                    if constexpr (NP <= 4 && STREAM) gtab[rd + mir] = v;
+                }
+            }
+        }
+    }
     __syncthreads();
     if (stamps && tid == 0) stamps[2] = wall_clock64();
 
@@ -731,11 +764,14 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // own LDS slot.  Either way the multiplication order is fixed, so the schedule does not
     // change a single bit of the result.
     const uint32_t nt_v0 = owned_count(OSH, (uint32_t)L.num_mt, vb0, nblk);
-    const uint32_t nt_v1 = SPLIT ? owned_count(OSH, (uint32_t)L.num_mt, vb0 + vhalf, nblk) : 0u;
-    const uint32_t ntile_blk = SPLIT ? (nt_v0 > nt_v1 ? nt_v0 : nt_v1) : nt_v0;      // (SPLIT: per virtual block, the larger)
+    const uint32_t nt_v1 = SPLIT ? owned_count(OSH, (uint32_t)L.num_mt, vb0 + vstep, nblk) : 0u;
+    const uint32_t nt_v2 = SPLIT > 2 ? owned_count(OSH, (uint32_t)L.num_mt, vb0 + 2u * vstep, nblk) : 0u;
+    auto nt_of = [&](uint32_t vs) { return vs == 0u ? nt_v0 : vs == 1u ? nt_v1 : nt_v2; };
+    // (SPLIT: per virtual block, the largest -- virtual block vb0 has it: owned_count does not grow with the block index)
+    const uint32_t ntile_blk = nt_v0;
     const size_t mp = L.m_pad;
     // work items: (tile, group), or (TPW consecutive owned tiles, group)
-    const uint32_t nunit = SPLIT ? 2u * ntile_blk : (ntile_blk + TPW - 1) / TPW;
+    const uint32_t nunit = SPLIT ? (uint32_t)NVS * ntile_blk : (ntile_blk + TPW - 1) / TPW;
     const uint32_t nitem = (kAblate & kAblNoItems) ? 0u : nunit * (uint32_t)ngrp;
     const float inv_nunit = 1.0f / (float)(nunit ? nunit : 1u);
     const uint32_t ngrp_magic = ngrp > 1 ? 0xFFFFFFFFu / (uint32_t)ngrp + 1u : 0u;      // ceil(2^32 / ngrp) for ngrp >= 2
@@ -1151,10 +1187,10 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         }
         // index in this workgroup's tile list (SPLIT: the units alternate between the two virtual blocks -- both lists are
         // in descending order of rows, so the queue still walks longest first)
-        const uint32_t vs = SPLIT ? (unit & 1u) : 0u;
-        const uint32_t it = SPLIT ? unit >> 1 : TPW * unit + (uint32_t)half;
-        const bool have_tile = SPLIT ? it < (vs ? nt_v1 : nt_v0) : (TPW == 1 || it < ntile_blk);   // TPW > 1: the list's end may leave lanes idle
-        const uint32_t mt = owned_tile(OSH, vb0 + vs * vhalf, nblk, have_tile ? it : 0u);
+        const uint32_t vs = SPLIT ? unit % (uint32_t)NVS : 0u;
+        const uint32_t it = SPLIT ? unit / (uint32_t)NVS : TPW * unit + (uint32_t)half;
+        const bool have_tile = SPLIT ? it < nt_of(vs) : (TPW == 1 || it < ntile_blk);   // TPW > 1: the list's end may leave lanes idle
+        const uint32_t mt = owned_tile(OSH, vb0 + vs * vstep, nblk, have_tile ? it : 0u);
         const uint32_t my_tab = tab_addr + (grp * (uint32_t)nrow * (uint32_t)row_bytes + (uint32_t)g * (6 * BTL * 8));
         const uint32_t my_ptq = ptq_addr + (grp * SLOTS + (uint32_t)g) * (uint32_t)(2 * k * BTL * 8);
         // (one slot, one group: the table's address is the constant behind the exp table -- this file has no static LDS --
@@ -1460,7 +1496,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             const int vsb = SPLIT ? b / NPT : 0, bl = b - vsb * NPT;
             const int grp = bl / NP, bb = bl - grp * NP;
             ScaledProd p{1.0, 0.0};
-            const uint32_t nres_b = SPLIT ? (vsb ? nt_v1 : nt_v0) : nres;
+            const uint32_t nres_b = SPLIT ? nt_of((uint32_t)vsb) : nres;
             for (uint32_t i = j16; i < nres_b; i += 16) {
                 const size_t o = ((((size_t)grp * NVS + vsb) * nres + i) * NP + bb) * 2;
                 p.m *= tile_llk[o];
@@ -1509,9 +1545,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // Hand-off through 8-byte agent-scope atomics on both sides (write-through stores,
         // L1-bypassing loads), drained before the ticket is drawn: placement independent.
         if (tid < NVS * NPT) {
-            // (SPLIT: the sums of this workgroup's points over virtual block vb0 / vb0 + vhalf, where a plain launch has them)
+            // (SPLIT: the sums of this workgroup's points over the virtual blocks vb0 + j * vstep, where a plain launch has them)
             const int vsb = SPLIT ? tid / NPT : 0, bl = tid - vsb * NPT;
-            __hip_atomic_store(&partials[(size_t)(p_off + bl) * nblk + (vb0 + (uint32_t)vsb * vhalf)], red[tid],
+            __hip_atomic_store(&partials[(size_t)(p_off + bl) * nblk + (vb0 + (uint32_t)vsb * vstep)], red[tid],
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1680,13 +1716,13 @@ llk_eval_kernel(const DeviceLayout L, const InlinePoints ip, const double* __res
 }
 
 // see eval_body, SPLIT
-template <int KSEL>
+template <int KSEL, int S>
 __global__ void __launch_bounds__(Geom<2>::kMaxWaves * 64, Geom<2>::kWavesPerSimd)
 llk_eval_split_kernel(const DeviceLayout L, const double* __restrict__ points, int num_valid, double* __restrict__ partials,
                       double* __restrict__ llk_out, unsigned int* __restrict__ ticket, unsigned long long* __restrict__ done_flag,
                       unsigned long long done_seq, int ngrp)
 {
-    eval_body<2, false, NoHook, false, 1, KSEL, false, 8, true, true>(L, nullptr, 0, points, num_valid, partials, llk_out, ticket, done_flag,
+    eval_body<2, false, NoHook, false, 1, KSEL, false, 8, true, S>(L, nullptr, 0, points, num_valid, partials, llk_out, ticket, done_flag,
                                                                      done_seq, blockIdx.x, gridDim.x, nullptr, 0u, ngrp, 0ull,
                                                                      Schedule{nullptr, nullptr});
 }
@@ -1825,6 +1861,8 @@ bool eval_takes_the_queue(const DeviceLayout& L, int nblk, int nwave, int ngrp)
     return eval_is_dynamic(L, (uint32_t)nblk, nwave, ngrp);
 }
 
+static size_t split_shmem(const DeviceLayout& L, int grid, int block_waves, int ngrp_total, int ways);
+
 LaunchGeom launch_geom(const DeviceLayout& L, int btl, int ngrp)
 {
     const int max_waves = Geom<2>::kMaxWaves;
@@ -1835,6 +1873,11 @@ LaunchGeom launch_geom(const DeviceLayout& L, int btl, int ngrp)
     int grid = (L.num_mt + bw - 1) / bw;
     grid = grid < 1 ? 1 : (grid > grid_target ? grid_target : grid);
     if (L.pd && grid > (L.num_mt >> 1)) grid = L.num_mt >> 1 > 0 ? L.num_mt >> 1 : 1;      // (a workgroup owns pairs of tiles)
+    // A dictionary whose tables of a full launch (kMaxGroups groups) do not fit PAIRS of workgroups is split three ways
+    // (eval_body, SPLIT): the grid -- the same for every launch kind of the context, so that a point's sum is the same bits in
+    // all of them -- is then a multiple of 6 (256 CUs: 252 workgroups)
+    if (L.pd && grid >= 12 && split_shmem(L, grid & ~1, max_waves, kMaxGroups, 2) > (size_t)kLdsLimitBytes)
+        grid -= grid % 6;
     // Several point groups: a workgroup's work items are (tile, group) pairs, so a small sample -- a marker shard
     // of an 8-GPU run: 12 500 markers = 3-4 tiles per workgroup -- still has work for 16 waves, and 1 024 threads
     // to build its six tables with (4-wave workgroups took 47 us for a 48-point launch on 12 500 markers, against
@@ -1978,14 +2021,25 @@ static hipError_t launch_passes(const DeviceLayout& L, const double* d_points, i
     return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
 }
 
-// LDS of a split launch's workgroup (eval_body, SPLIT): the tables of half the groups, the result slots of two virtual blocks
-static size_t split_shmem(const DeviceLayout& L, int grid, int block_waves, int ngrp_total)
+// LDS of a split launch's workgroup (eval_body, SPLIT = ways): the tables of its share of the groups, the result slots of `ways` virtual blocks
+static size_t split_shmem(const DeviceLayout& L, int grid, int block_waves, int ngrp_total, int ways)
 {
-    // (a workgroup of a plain launch of this grid with half the groups, plus the second virtual block's result slots -- as many
-    // as the first's: either block may be the one with a pair of tiles more -- and its sums)
-    const size_t half = (size_t)((ngrp_total + 1) / 2);
-    const size_t slots2 = (size_t)owned_most(1, (uint32_t)L.num_mt, (uint32_t)(grid >= 1 ? grid : 1)) * half;
-    return eval_shmem_np(L, 8, grid >= 1 ? grid : 1, block_waves, (int)half) + sizeof(double) * (2 * slots2 * 8 + 8 * half);
+    // (a workgroup of a plain launch of this grid with 1 / ways of the groups, plus the other virtual blocks' result slots -- as
+    // many as the first's -- and their sums)
+    const size_t per = (size_t)((ngrp_total + ways - 1) / ways);
+    const size_t slots1 = (size_t)owned_most(1, (uint32_t)L.num_mt, (uint32_t)(grid >= 1 ? grid : 1)) * per;
+    return eval_shmem_np(L, 8, grid >= 1 ? grid : 1, block_waves, (int)per) + sizeof(double) * ((size_t)(ways - 1) * 2 * slots1 * 8 + (size_t)(ways - 1) * 8 * per);
+}
+// ways of a split launch of ngrp groups: the fewest workgroups per set whose tables fit (0: none does)
+static int split_ways(const DeviceLayout& L, const LaunchGeom& gm, int ngrp)
+{
+    for (int ways = 2; ways <= 3; ++ways) {
+        if (gm.grid < ways || gm.grid % ways || (ways == 3 && tunables().split == 2)) continue;
+        const int per = (ngrp + ways - 1) / ways;
+        if (per * (ways - 1) >= ngrp) continue;            // (a workgroup of the set would have no group)
+        if (split_shmem(L, gm.grid, gm.block_waves, ngrp, ways) <= (size_t)kLdsLimitBytes) return ways;
+    }
+    return 0;
 }
 
 // see eval_body, SPLIT.  *taken = false: the geometry does not allow it (the caller falls back to passes / several launches)
@@ -1997,17 +2051,20 @@ static hipError_t launch_split(const DeviceLayout& L, const double* d_points, in
     if (!L.pd) return hipSuccess;
     const int ngrp = (num_valid + 7) / 8;
     if (ngrp < 2) return hipSuccess;
-    const LaunchGeom gm = launch_geom(L, 2, ngrp);      // (a pair of workgroups has the items of one workgroup of a plain launch, twice)
-    if (gm.grid < 2 || (gm.grid & 1)) return hipSuccess;
+    const LaunchGeom gm = launch_geom(L, 2, ngrp);      // (a set of workgroups has the items of one workgroup of a plain launch, `ways` times)
+    const int ways = split_ways(L, gm, ngrp);
+    if (ways == 0) return hipSuccess;
     // every item through the queue, a slot apiece
-    const uint32_t tiles2 = 2u * owned_most(1, (uint32_t)L.num_mt, (uint32_t)gm.grid);
-    if (tiles2 * (uint32_t)((ngrp + 1) / 2) > (uint32_t)(L.dyn_limit * gm.block_waves)) return hipSuccess;
-    const size_t shmem = split_shmem(L, gm.grid, gm.block_waves, ngrp);
-    if (shmem > (size_t)kLdsLimitBytes) return hipSuccess;
+    const uint32_t tiles_set = (uint32_t)ways * owned_most(1, (uint32_t)L.num_mt, (uint32_t)gm.grid);
+    if (tiles_set * (uint32_t)((ngrp + ways - 1) / ways) > (uint32_t)(L.dyn_limit * gm.block_waves)) return hipSuccess;
+    const size_t shmem = split_shmem(L, gm.grid, gm.block_waves, ngrp, ways);
     const int ksel = L.known_af == nullptr ? (L.num_pc == 4 ? 4 : L.num_pc == 2 ? 2 : 0) : 0;
-    const void* fn = ksel == 4 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<4>)
-                     : ksel == 2 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<2>)
-                                 : reinterpret_cast<const void*>(&llk_eval_split_kernel<0>);
+    const void* fn = ways == 2 ? (ksel == 4 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<4, 2>)
+                                  : ksel == 2 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<2, 2>)
+                                              : reinterpret_cast<const void*>(&llk_eval_split_kernel<0, 2>))
+                               : (ksel == 4 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<4, 3>)
+                                  : ksel == 2 ? reinterpret_cast<const void*>(&llk_eval_split_kernel<2, 3>)
+                                              : reinterpret_cast<const void*>(&llk_eval_split_kernel<0, 3>));
     hipError_t e = raise_lds_limit(fn);
     if (e != hipSuccess) return e;
     DeviceLayout Lc = L;
@@ -2117,12 +2174,12 @@ int pd_row_budget(int num_marker, int num_pc, int num_cu)
     T.num_mt = ((num_marker + kMtMarkers - 1) / kMtMarkers + 1) & ~1;
     T.num_cu = num_cu;
     T.dyn_limit = tunables().dyn_tiles;
-    // (the tables of a 48-point launch: all six groups' in one workgroup, or -- Tunables::split -- three in each of a pair)
-    const bool split = tunables().split != 0;
+    // (the tables of a 48-point launch: all six groups' in one workgroup, or -- Tunables::split = ways -- 6 / ways in each of a set)
     for (int rows = kMaxWideCodes; rows > 1; --rows) {
         T.num_code = T.num_prim = rows;
         const LaunchGeom gm = launch_geom(T, 2, kMaxGroups);
-        const size_t need = (split && gm.grid >= 2 && !(gm.grid & 1)) ? split_shmem(T, gm.grid, gm.block_waves, kMaxGroups)
+        const int ways = split_ways(T, gm, kMaxGroups);
+        const size_t need = (tunables().split != 0 && ways >= 2) ? split_shmem(T, gm.grid, gm.block_waves, kMaxGroups, ways)
                                   : eval_shmem_np(T, 8, gm.grid, gm.block_waves, kMaxGroups);
         if (need <= (size_t)kLdsLimitBytes) return rows;
     }

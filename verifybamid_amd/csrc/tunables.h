@@ -22,7 +22,7 @@ namespace vb2 {
     X(reduce, 0)           /* cross-workgroup hand-off: 0 by size, 1 arrival ticket, 2 tagged sets */                   \
     X(tagged_max, 16)      /* launches of up to this many points hand off through tagged sets */                        \
     X(passes, 1)           /* 0: a launch per table-load of points instead of llk_eval_passes_kernel */                 \
-    X(split, 1)            /* 0: probability-domain launches of many points in passes instead of split between workgroup pairs */ \
+    X(split, 1)            /* probability-domain launches of many points: 0 in passes, 1 split between 2 or 3 workgroups, 2 pairs only */ \
     X(coop, 1)             /* the resident search kernel goes up with hipLaunchCooperativeKernel (0: plain launch;      \
                               the library also launches plainly by itself when a profiler's tool library is loaded) */  \
     X(dyn_tiles, 10)       /* work items per wave up to which a workgroup's waves pull them through the LDS queue */    \
@@ -37,6 +37,7 @@ namespace vb2 {
     X(force_narrow, 0)     /* 1: narrow table rows although the dictionary would fit wide ones */                        \
     X(pd, 1)               /* 0: never the probability-domain layout (llk_kernels.h: kMaxPow) */                         \
     X(pd_rows, 0)          /* its table rows: 0 = what the LDS holds for a 48-point launch */                            \
+    X(pd_pairs, 1)         /* 0: no pair rows in it (llk_kernels.h: PdDict) */                                           \
     X(digest_multiset, 0)  /* 1: vb2_debug_flatten_digest takes a tile's run words as a multiset per lane */             \
     X(slab_cache, 1)       /* 0: freed device / pinned slabs go back to the driver */                                    \
     X(cpus, 0)             /* CPUs the process may use, 0 = cgroup quota / affinity */                                   \
