@@ -493,6 +493,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             cand.w = (uint8_t)w;
             cand.e = (uint8_t)e;
             cand.qp = (uint8_t)cover;
+            cand.per_win = (uint8_t)(e > 0 ? per_win : 0);
             int rows = 2 + nwin * per_win;                               // (2: room for qualities the sample did not meet)
             for (int r = cover; r < kNumQual; ++r) rows += seen[r] ? 1 : 0;
             while (rows < budget) {
@@ -904,8 +905,10 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
             for (int i = 0; i < wt; ++i) {
                 const int r = t * dict.w + i;
                 // {pErr, first row | K << 16 | rows between P^n and P^(n+1) << 24}: the quality's own powers inside the window
-                prim.push_back(make_double2(phred[qof[r]], bits_of((unsigned long long)((base + (uint32_t)mul[i] - 1u) | ((uint32_t)dict.e << 16) |
-                                                                                       ((uint32_t)mul[i] << 24)))));
+                // (an odd window's rows count downwards: pd_win_row -- the record's stride is a signed byte)
+                const uint32_t first = pd_win_row(dict, (uint32_t)t, (uint32_t)mul[i]);
+                const uint32_t stride8 = (uint32_t)(uint8_t)(int8_t)((t & 1) ? -mul[i] : mul[i]);
+                prim.push_back(make_double2(phred[qof[r]], bits_of((unsigned long long)(first | ((uint32_t)dict.e << 16) | (stride8 << 24)))));
             }
             for (int idx = 1; idx <= pd_per_win; ++idx) {
                 int ex[kPdMaxWin], nz = 0, first_nz[kPdMaxWin];
@@ -919,9 +922,9 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 auto row_of = [&](int i0, int i1) {          // the row holding the exponents of positions [i0, i1) of first_nz only
                     int v = 0;
                     for (int q = i0; q < i1; ++q) v += ex[first_nz[q]] * mul[first_nz[q]];
-                    return base + (uint32_t)v - 1u;
+                    return pd_win_row(dict, (uint32_t)t, (uint32_t)v);
                 };
-                const uint32_t dst = base + (uint32_t)idx - 1u;
+                const uint32_t dst = pd_win_row(dict, (uint32_t)t, (uint32_t)idx);
                 if (nz == 2) prod1.push_back(prod_rec(row_of(0, 1), row_of(1, 2), dst));
                 else if (nz == 3) prod2.push_back(prod_rec(row_of(0, 2), row_of(2, 3), dst));
                 else prod2.push_back(prod_rec(row_of(0, 2), row_of(2, 4), dst));

@@ -27,6 +27,12 @@
 #ifndef VB2_FLAG_RELEASE
 #define VB2_FLAG_RELEASE 1      // the flag the host spins on is stored with system-scope RELEASE semantics (0: relaxed; A/B: profiles/r06/ab_flag_release.txt -- no measurable cost)
 #endif
+#ifndef VB2_SOFT_PROLOGUE
+#define VB2_SOFT_PROLOGUE 1     // the resident kernel's control wave starts its round's work at once instead of behind the table build (eval_body; 0: A/B)
+#endif
+#ifndef VB2_CTRL_PRIO
+#define VB2_CTRL_PRIO 3         // the control wave's priority during its tile-phase work
+#endif
 #ifndef VB2_STAMP_ROUND
 #define VB2_STAMP_ROUND 0
 #endif

@@ -134,8 +134,15 @@ struct PdDict {
     uint16_t win_base[kNumQual];                 // [window] first row
     uint16_t single_row[kNumQual];               // [rank >= qp] row of P^1 (P^2 .. P^K follow)
     uint8_t kpow[kNumQual];                      // [rank >= qp] K
-    uint8_t w, e, qp, spare;                     // window width, highest exponent, ranks in windows (the last window may be partial)
+    uint8_t w, e, qp, per_win;                   // window width, highest exponent, ranks in windows (the last window may be partial), rows per window
 };
+// Row of window t's exponent index idx = sum e_i (E + 1)^i (1 .. per_win).  The rows most markers read -- small exponents -- have
+// small indices; ODD windows count downwards, so that two neighbouring windows' frequent rows, which often meet in one step
+// of a tile, start in different bank groups (tile_sched.h).
+__host__ __device__ __forceinline__ uint32_t pd_win_row(const PdDict& D, uint32_t t, uint32_t idx)
+{
+    return (uint32_t)D.win_base[t] + ((t & 1u) ? (uint32_t)D.per_win - idx : idx - 1u);
+}
 struct PdWin {                                   // the open window of a marker's class: its index and the reads of its w qualities
     uint32_t t;
     uint32_t open;
@@ -158,7 +165,7 @@ __host__ __device__ __forceinline__ void pd_flush(const PdDict& D, PdWin& s, Emi
             mul *= radix;
             left |= (unsigned long long)(ci - take) << (16 * i);
         }
-        emit((uint32_t)D.win_base[s.t] + idx - 1u);
+        emit(pd_win_row(D, s.t, idx));
         c = left;
     }
     s.c = 0;

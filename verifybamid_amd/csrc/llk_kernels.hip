@@ -478,6 +478,7 @@ struct NoHook {
     __device__ bool keep_prim() const { return false; }     // ... and an earlier call left them there
     __device__ double* sum_stage() const { return nullptr; } // where workgroup 0 stages the partial sums (nullptr: over the dead tables)
     __device__ uint32_t cache_rec() const { return 0u; }    // LCACHE: LDS byte address of this workgroup's tile records
+    __device__ unsigned int* sync_word() const { return nullptr; }   // a zeroed LDS word: the hook wave skips the prologue (see eval_body)
 };
 // The waves of a workgroup pull (tile, group) items through the LDS queue (per-item result slots) when there
 // are at most dyn_limit of them per wave; else the static deal (cohort launches).
@@ -592,9 +593,28 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     if (stamps && tid == 0) { stamps[0] = wall_clock64(); stamps[4] = 0; }
 
     const bool hook_blk = hook.on_block(), hook_mine = hook.mine();
-    if (tid == 0) *queue = (unsigned int)(nwave - (hook_blk ? 1 : 0));      // waves start on tiles 0..nwave-1
+    // A workgroup with a hook wave (the resident kernel's control wave: wave 0 of workgroup 0) in a probability-domain search
+    // round: that wave starts on its own work AT ONCE -- it builds no table entries and does not come to the prologue's barriers,
+    // which the other waves replace by a counter in LDS (hook.sync_word(), zero at the round's start).  Its work is the round's
+    // longest dependent chain (resident_kernel.inc: control_tile_phase, ~6 us): begun behind the table build it ended 1.5 us
+    // after every other workgroup had its sums in.
+    unsigned int* const soft_word = PD ? hook.sync_word() : nullptr;
+    const bool soft = hook_blk && soft_word != nullptr;
+    if (soft && hook_mine) hook.run();
+    const int ptid = !soft ? tid : hook_mine ? 0x3fffffff : tid - 64, pnthread = soft ? nthread - 64 : nthread;
+    unsigned int soft_gen = 0;
+    auto prologue_sync = [&]() {
+        if (!soft) { __syncthreads(); return; }
+        if (hook_mine) return;
+        soft_gen += (unsigned int)(nwave - 1);
+        // (a wave's LDS operations are performed in order: its table entries are in place when its arrival is counted)
+        if (lane == 0) __hip_atomic_fetch_add(soft_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(soft_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < soft_gen) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    if (ptid == 0) *queue = (unsigned int)(nwave - (hook_blk ? 1 : 0));      // waves start on tiles 0..nwave-1
     // parameter rows -> LDS with one coalesced load (they may live in mapped host memory)
-    for (int e = tid; e < NPT * stride; e += nthread) {
+    for (int e = ptid; e < NPT * stride; e += pnthread) {
         const int b = e / stride;
         const int src = p_off + b < num_valid ? p_off + b : num_valid - 1;
         const int idx = src * stride + (e - b * stride);
@@ -627,13 +647,13 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     const bool prim_kept = hook.prim_in_lds() && hook.keep_prim();
     const bool staged = ngrp > 1 || (hook.prim_in_lds() && !prim_kept) || (PD && L.num_pair > 0 && !prim_kept);      // (pair rows: their records from LDS)
     if (staged)
-        for (int e = tid; e < L.num_prim; e += nthread) prim_lds[e] = L.prim[e];
+        for (int e = ptid; e < L.num_prim; e += pnthread) prim_lds[e] = L.prim[e];
     // A search round (its rows are in LDS since the round's staging barrier) builds its one table without waiting
     // for the copies above: the table needs the alphas only, and takes them from the staged rows (-0.6 us per
     // round; the same for launches whose rows come with the kernel arguments: no gain, not kept).
     const bool early_table = lds_rows != nullptr && !staged;
-    if (!early_table) __syncthreads();
-    if (stamps && tid == 0) stamps[1] = wall_clock64();
+    if (!early_table) prologue_sync();
+    if (stamps && (soft ? ptid : tid) == 0) stamps[1] = wall_clock64();
 
     // ---- per-alpha table, off-diagonal pairs only (h:213-229) ----
     // Class alt is class ref with the genotypes mirrored (g -> 2-g, h:164-177): the entry of
@@ -645,7 +665,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // that their long dependent logarithm chains overlap)
     const uint32_t ltab_addr = lds_byte_addr(ltab);
     const int num_single = PD ? L.num_prim - L.num_pair : L.num_prim;
-    for (int e = tid; e < ((kAblate & kAblNoTable) ? 0 : num_single * 6 * NP); e += nthread) {
+    for (int e = ptid; e < ((kAblate & kAblNoTable) ? 0 : num_single * 6 * NP); e += pnthread) {
         const int pi = e / (6 * NP);
         const int bp = e - pi * (6 * NP);
         const int bb = bp / 6, p = bp - bb * 6;
@@ -677,7 +697,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                     cell3[u] = tab + (size_t)ge * nrow * RS + dc * RS + bp;
                     *cell3[u] = r3[u];
                 }
-                const int kq = twin & 0xff, pstride = RS * (twin >> 8);      // (record: first row | K << 16 | rows between P^n and P^(n+1) << 24)
+                const int kq = twin & 0xff, pstride = RS * (int)(int8_t)(twin >> 8);      // (record: first row | K << 16 | rows from P^n to P^(n+1), a signed byte, << 24)
                 for (int n = 1; n < kq; ++n) {
 #pragma unroll
                     for (int u = 0; u < kSide; ++u) {
@@ -705,7 +725,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 const int mir = kMir + bb * 6 + (5 - p) - bp;
                 *cell = r;
                 if constexpr (NP <= 4 && STREAM) cell[mir] = r;
-                const int kq = twin & 0xff, pstride = RS * (twin >> 8);      // (record: first row | K << 16 | rows between P^n and P^(n+1) << 24)
+                const int kq = twin & 0xff, pstride = RS * (int)(int8_t)(twin >> 8);      // (record: first row | K << 16 | rows from P^n to P^(n+1), a signed byte, << 24)
                 for (int n = 1; n < kq; ++n) {
                     r *= v;
                     cell += pstride;
@@ -720,7 +740,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             }
         }
     }
-    for (int e = tid; e < ngrp * RS; e += nthread) {                  // padding code: zero rows (PD: ones)
+    for (int e = ptid; e < ngrp * RS; e += pnthread) {                // padding code: zero rows (PD: ones)
         const int grp_e = e / RS;
         tab[((size_t)grp_e * nrow + L.num_code) * RS + (e - grp_e * RS)] = PD ? 1.0 : 0.0;
     }
@@ -731,9 +751,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             // (level 1: products of two rows the records of this kind made -- windows of three and four qualities)
             const int nrec = level == 0 ? L.num_pair - L.num_pair2 : L.num_pair2;
             if (nrec == 0) break;
-            __syncthreads();
+            prologue_sync();
             const double2* const prec = prim_lds + num_single + (level == 0 ? 0 : L.num_pair - L.num_pair2);
-            for (int e = tid; e < nrec * 6 * NP; e += nthread) {
+            for (int e = ptid; e < nrec * 6 * NP; e += pnthread) {
                 const int pi = e / (6 * NP);
                 const int bp = e - pi * (6 * NP);
                 const double2 rec = prec[pi];
@@ -752,8 +772,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             }
         }
     }
-    __syncthreads();
-    if (stamps && tid == 0) stamps[2] = wall_clock64();
+    prologue_sync();
+    if (stamps && (soft ? ptid : tid) == 0) stamps[2] = wall_clock64();
 
     // Work distribution.  Workgroup b owns micro-tiles b, b+grid, b+2*grid, ... (the tiles are
     // depth-sorted, so every workgroup -- hence every CU, and every XCD's L2 at every launch --
@@ -864,7 +884,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         s_end = sch.off[blk * (uint32_t)nwave + (uint32_t)wave + 1];
     }
     uint32_t round = 0;
-    if (hook_mine) hook.run();                            // (this wave takes no work items; the others cover for it)
+    if (hook_mine && !soft) hook.run();                   // (this wave takes no work items; the others cover for it)
 #ifdef VB2_STAMP_CTRL     // (profiling build: workgroup 0's slot 3 = the control wave is back from its tile-phase work)
     if (stamps && hook_mine && lane == 0) stamps[3] = wall_clock64();
 #endif
