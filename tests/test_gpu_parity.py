@@ -1509,6 +1509,51 @@ def test_probability_domain_layout_is_taken_only_where_no_marker_can_underflow(t
         assert rel_err(vals[1], vals[0]) <= LLK_RTOL
 
 
+def test_window_rows_of_the_probability_domain(tunable):
+    """PdDict (llk_kernels.h): the most frequent qualities come in aligned windows of w ranks with one table row per product of
+    their powers up to E, so a marker's reads of a window's qualities take one step while it holds at most E of each; the other
+    qualities keep rows P^1 .. P^K of their own.  On 21 equally likely qualities (windows over all of them), 59 (windows over
+    the frequent ones, single rows behind), four binned qualities (counts far above E: several steps per window) and one
+    dominant quality: the oracle's values with and without the windows (tunable pd_pairs), one value per point whatever the
+    launch shape, the host's flatten and the device's the same bits, and fewer steps than powers alone give."""
+    rng = np.random.default_rng(77)
+    d21 = vb.synth.make_pileup(20000, 30, 4, seed=71)
+    d59 = vb.synth.make_pileup(20000, 60, 2, seed=72, q_lo=2, q_hi=60)
+    dbin = vb.synth.make_pileup(20000, 40, 2, seed=73)
+    dbin.quals[:] = np.array([2, 12, 23, 37], dtype=np.uint8)[(dbin.quals - 33) % 4] + 33
+    ddom = vb.synth.make_pileup(20000, 30, 3, seed=74, q_lo=10, q_hi=40)
+    ddom.quals[rng.random(ddom.quals.size) < 0.85] = 37 + 33
+    for name, d, gain in (("21", d21, 0.85), ("59", d59, 0.95), ("binned", dbin, 1.0), ("dominant", ddom, 1.0)):
+        k = d.num_pc
+        od = oracle_data(d)
+        B = 48
+        pc1, pc2, al = _random_points(rng, B, k)
+        want = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=8) for i in range(0, B, 5)])
+        steps, vals = {}, {}
+        for pairs in (1, 0):
+            tunable("pd_pairs", pairs)
+            with vb.LikelihoodContext(d) as ctx:
+                info = ctx.info()
+                assert info["layout"] == 1, name
+                steps[pairs] = info["num_step"]
+                got = ctx.llk(pc1, pc2, al)
+                assert rel_err(got[::5], want) <= LLK_RTOL, (name, pairs)
+                one = np.array([ctx.llk(pc1[i:i + 1], pc2[i:i + 1], al[i:i + 1])[0] for i in range(0, B, 5)])
+                four = np.concatenate([ctx.llk(pc1[i:i + 4], pc2[i:i + 4], al[i:i + 4]) for i in range(0, 8, 4)])
+                assert np.array_equal(one, got[::5]) and np.array_equal(four, got[:8]), (name, pairs)
+                vals[pairs] = got
+            if pairs:
+                tunable("host_flatten", 1)
+                tunable("host_pack", 1)
+                with vb.LikelihoodContext(d) as ctx:
+                    assert ctx.info()["num_step"] == steps[1], name
+                    assert np.array_equal(ctx.llk(pc1, pc2, al), got), name          # the same bytes from either flatten
+                tunable("host_flatten", 0)
+                tunable("host_pack", 0)
+        assert rel_err(vals[1], vals[0]) <= LLK_RTOL, name
+        assert steps[1] <= gain * steps[0], (name, steps)
+
+
 @pytest.mark.parametrize("shape", [(100000, 4, 20, 40), (100000, 4, 2, 60), (12500, 4, 20, 40), (3000, 2, 2, 93)])
 def test_split_launch_equals_passes_and_plain_launches_bit_for_bit(shape, tunable):
     """Probability domain, more points than a workgroup's LDS holds tables for (~110 table rows, more than 24 points): ONE launch

@@ -18,6 +18,8 @@
 //                         8 kAblNoReads   the run words are consumed, the table is not read
 //                        16 kAblNoEpi     the sums and constants are consumed, nothing is computed from them
 //                        32 kAblNoSignal  no hand-off to the host
+//                        64 kAblNoMul     probability domain: the table rows are read, the products not multiplied
+//                       128 kAblNoRowLoads  probability domain: the steps are made up in registers, no loads of the lists
 #ifndef VB2_KERNEL_DEBUG_H_
 #define VB2_KERNEL_DEBUG_H_
 
@@ -38,7 +40,7 @@
 #endif
 
 namespace vb2 {
-constexpr int kAblNoMap = 1, kAblNoTable = 2, kAblNoItems = 4, kAblNoReads = 8, kAblNoEpi = 16, kAblNoSignal = 32;
+constexpr int kAblNoMap = 1, kAblNoTable = 2, kAblNoItems = 4, kAblNoReads = 8, kAblNoEpi = 16, kAblNoSignal = 32, kAblNoMul = 64, kAblNoRowLoads = 128;
 constexpr int kAblate = VB2_ABLATE;
 }  // namespace vb2
 

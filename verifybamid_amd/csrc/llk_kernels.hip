@@ -982,6 +982,10 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // conversion: one SDWA add per step and the multiplies ----
     auto walk_pd = [&](const uint32_t w_cur, double* acc, const uint32_t my_tab, auto alt0_tag, auto alt1_tag, auto first_tag) {
         constexpr bool kAlt0 = decltype(alt0_tag)::value, kAlt1 = decltype(alt1_tag)::value, kFirst = decltype(first_tag)::value;
+        if constexpr ((kAblate & kAblNoReads) != 0) {        // (ablation build: the steps are consumed, the table is not read)
+            acc[0] = (kFirst ? 1.0 : acc[0]) * __hiloint2double((int)((w_cur ^ (w_cur >> 16)) & 0x000fu) | 0x3ff00000, 0);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool kAlt = j ? kAlt1 : kAlt0;        // (a compile-time value after unrolling)
@@ -995,6 +999,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 const int pt = i / 3, q2 = 2 * (i - 3 * pt);
                 const int a0 = pt * 6 + (kAlt ? 5 - q2 : q2), a1 = pt * 6 + (kAlt ? 4 - q2 : q2 + 1);
                 // (a tile's first step: the products START as the row -- the marker's constant is multiplied in once, at the end)
+                if constexpr ((kAblate & kAblNoMul) != 0) {      // (ablation build: the rows are read and consumed, not multiplied)
+                    asm volatile("" ::"v"(t.x), "v"(t.y));
+                    if (kFirst && j == 0) { acc[a0] = t.x; acc[a1] = t.y; }
+                    continue;
+                }
                 acc[a0] = (kFirst && j == 0) ? t.x : acc[a0] * t.x;
                 acc[a1] = (kFirst && j == 0) ? t.y : acc[a1] * t.y;
             }
@@ -1297,8 +1306,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         const uint32_t crow = rec.x + (uint32_t)m * kLaneBytes;      // (LCACHE: this lane's word of the tile's first row, LDS)
         // a scalar when TPW == 1.  PD: {ref steps | all steps << 16}: the tile's markers have their ref steps at [0, s1) and
         // their alt steps at [s1, s2), two steps to a row (walk_pd)
-        const int steps_ref = PD ? (have_tile ? (int)(rec.y & 0xffffu) : 0) : 0;
-        const int rows = have_tile ? (PD ? (int)(((rec.y >> 16) + 1u) >> 1) : (int)rec.y) : 0;
+        // (one tile per wave: both are the same in every lane, and the compiler is told so -- the branches on them are scalar)
+        const int steps_ref_v = PD ? (have_tile ? (int)(rec.y & 0xffffu) : 0) : 0;
+        const int rows_v = have_tile ? (PD ? (int)(((rec.y >> 16) + 1u) >> 1) : (int)rec.y) : 0;
+        const int steps_ref = (PD && TPW == 1) ? __builtin_amdgcn_readfirstlane(steps_ref_v) : steps_ref_v;
+        const int rows = (PD && TPW == 1) ? __builtin_amdgcn_readfirstlane(rows_v) : rows_v;
         // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
         // tile's last row -- up to kPf useless row loads per item of 6..16 rows -- and every block of kPf rows begins
         // by waiting for all of them.  Measured on one box, depth 8 / 4 / 2: 48-point launch 74.9 / 74.4 / 76.6 us;
@@ -1309,6 +1321,10 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // The row index is clamped to the tile's last row instead: the same cache line again, no new bytes.)
         const int last_row = rows > 0 ? rows - 1 : 0;
         auto load_row = [&](int j) -> RowWord {              // row j of this lane's run words
+            if constexpr (PD && (kAblate & kAblNoRowLoads) != 0) {      // (ablation build: no trip to memory for the steps -- made-up rows)
+                const uint32_t r0 = ((uint32_t)m * 7u + (uint32_t)j * 2u) % (uint32_t)nrow, r1 = ((uint32_t)m * 7u + (uint32_t)j * 2u + 1u) % (uint32_t)nrow;
+                return (r0 * (uint32_t)row_bytes) | ((r1 * (uint32_t)row_bytes) << 16);
+            }
             if constexpr (LCACHE && PD) return *reinterpret_cast<lds_cuint*>(crow + (uint32_t)j * kRowBytes);
             else if constexpr (LCACHE) return *reinterpret_cast<lds_cuint2v*>(crow + (uint32_t)j * kRowBytes);
             else {
@@ -1367,13 +1383,21 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             // meet).  The rows in flight are a window of kPf words that moves up one row per iteration.  In the paired shapes
             // the bounds are per half of the wave: the two tiles are neighbours of the sorted order and nearly always agree.
             int r = 0;
-            auto next_word = [&]() -> uint32_t {
-                const uint32_t cur = w[0];
-#pragma unroll
-                for (int d = 0; d + 1 < kPf; ++d) w[d] = w[d + 1];
-                w[kPf - 1] = load_row(r + kPf);
-                return cur;
+            // The rows in flight are a RING of kPf words with fixed slots -- row r in slot r % kPf -- and every step names its
+            // slot at compile time.  (Before, the window MOVED up a register per row: the move of the newest word is a use of
+            // it, so every row began by waiting for the load issued one row earlier.  Worth 0.6 % of a 48-point launch: the
+            // lists' loads hide behind the table reads either way -- with made-up steps and no loads at all, VB2_ABLATE = 128,
+            // the launch is no shorter; profiles/r06/ab_ablations.txt.)
+            static_assert(kPf == 2, "the ring below has two slots");
+            auto row_step = [&](auto slot_tag, auto alt0_tag, auto alt1_tag, auto first_tag) {
+                constexpr int kSlot = decltype(slot_tag)::value;
+                const uint32_t cur = w[kSlot];
+                w[kSlot] = load_row(r + kPf);
+                walk_pd(cur, acc, my_tab, alt0_tag, alt1_tag, first_tag);
+                ++r;
             };
+            const std::integral_constant<int, 0> kS0;
+            const std::integral_constant<int, 1> kS1;
             // (the first row's first step IS the products: no initial values, no multiplies).  Rows [0, s1 / 2) hold two ref
             // steps, the rows behind two alt steps; if s1 is odd, row s1 / 2 holds the last ref and the first alt step.
             const int rows_ra = steps_ref >> 1;
@@ -1381,20 +1405,28 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             const std::true_type kAltT, kFirstT;
             const std::false_type kNotFirst;
             if (rows > 0) {
-                if (steps_ref >= 2) walk_pd(next_word(), acc, my_tab, kRef, kRef, kFirstT);
-                else if (steps_ref == 1) walk_pd(next_word(), acc, my_tab, kRef, kAltT, kFirstT);
-                else walk_pd(next_word(), acc, my_tab, kAltT, kAltT, kFirstT);
-                r = 1;
+                if (steps_ref >= 2) row_step(kS0, kRef, kRef, kFirstT);
+                else if (steps_ref == 1) row_step(kS0, kRef, kAltT, kFirstT);
+                else row_step(kS0, kAltT, kAltT, kFirstT);
             } else {
 #pragma unroll
                 for (int i = 0; i < BTL * 6; ++i) acc[i] = 1.0;
             }
-            for (; r < rows_ra; ++r) walk_pd(next_word(), acc, my_tab, kRef, kRef, kNotFirst);
+            // rows [r, end) of one kind: an odd row first, then pairs, then an even one
+            auto rows_of_kind = [&](const int end, auto alt_tag) {
+                if (r < end && (r & 1)) row_step(kS1, alt_tag, alt_tag, kNotFirst);
+                while (r + 1 < end) {
+                    row_step(kS0, alt_tag, alt_tag, kNotFirst);
+                    row_step(kS1, alt_tag, alt_tag, kNotFirst);
+                }
+                if (r < end) row_step(kS0, alt_tag, alt_tag, kNotFirst);
+            };
+            rows_of_kind(rows_ra, kRef);
             if ((steps_ref & 1) && r == rows_ra && r < rows) {
-                walk_pd(next_word(), acc, my_tab, kRef, kAltT, kNotFirst);
-                ++r;
+                if (r & 1) row_step(kS1, kRef, kAltT, kNotFirst);
+                else row_step(kS0, kRef, kAltT, kNotFirst);
             }
-            for (; r < rows; ++r) walk_pd(next_word(), acc, my_tab, kAltT, kAltT, kNotFirst);
+            rows_of_kind(rows, kAltT);
             if constexpr (PIPE) {
                 issue_rows(rec_n2, have_next);
                 cst_nx = other_const(mt_next, have_next);
