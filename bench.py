@@ -410,7 +410,7 @@ def main():
             "valu": valu, "fp64": terms["fp64"], "mfma_util": 0.0,
             "mfma_note": "no MFMA instruction on the path: FP64 MFMA and FP64 VALU share the unit on gfx950 "
                          "(profiles/r01/ubench_mfma_overlap.txt), and the UD x PC projection is 2k FMAs per marker",
-            "kernel": ("llk_eval_split_kernel" if (info.get("layout") and B > 24) else "llk_eval_kernel<%d,...>" % (2 if B > 4 else 3)),
+            "kernel": ("llk_eval_split_kernel" if (info.get("layout") and B > 16) else "llk_eval_kernel<%d,...>" % (2 if B > 4 else 3)),
             "launches_per_step": (B + 47) // 48,
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "device_us_per_launch": step_us,
@@ -580,7 +580,7 @@ def main():
                     "lds_busy_frac": wj.get("lds_busy_frac") if wj else None,
                     "lds_bank_conflict_frac": wj.get("lds_bank_conflict_frac") if wj else None, "pmc_source": wsrc,
                     "optimize": wopt, "create_ms": create_times(wide),
-                    "launch": ("ONE launch, the six point groups split between workgroup pairs (llk_eval_split_kernel)"
+                    "launch": ("ONE launch, the six point groups split between sets of two or three workgroups (llk_eval_split_kernel)"
                                if winfo.get("layout") else
                                ("one launch of two passes of 24 points (llk_eval_passes_kernel)" if winfo["num_code"] > 80 else
                                 "two launches of llk_eval_kernel<2,...>, 32 + 16 points")),

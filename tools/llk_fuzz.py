@@ -14,6 +14,14 @@ for it in range(N):
     qlo = int(rng.integers(0, 40)); qhi = int(min(93, qlo + rng.integers(0, 50)))
     d = vb.synth.make_pileup(M, depth, k, alpha_true=float(rng.uniform(0, 0.5)), seed=int(rng.integers(1, 10**6)), q_lo=qlo, q_hi=qhi,
                              missing_frac=float(rng.choice([0.0, 0.0, 0.3])))
+    # quality profiles: as drawn (uniform), binned to a few values (deep runs: many steps per window of the probability
+    # domain's dictionary), or one dominant quality
+    prof = int(rng.integers(0, 3))
+    if prof == 1:
+        bins = np.sort(rng.choice(np.arange(qlo, qhi + 1), size=min(qhi - qlo + 1, int(rng.integers(1, 6))), replace=False)).astype(np.uint8)
+        d.quals[:] = bins[(d.quals - 33) % len(bins)] + 33
+    elif prof == 2:
+        d.quals[rng.random(d.quals.size) < rng.uniform(0.5, 0.95)] = int(rng.integers(qlo, qhi + 1)) + 33
     od = oracle_data(d)
     B = int(rng.choice([rng.integers(1, 20), rng.integers(20, 60)]))                         # (beyond 24 points: split launches)
     scale = float(rng.choice([0.01, 0.05, 0.5]))
