@@ -373,6 +373,9 @@ def main():
         FP64_PEAK = 78.6e12
         lds_bytes = (48.0 * info["num_step"] + 16.0 * k * info["num_active_marker"]) * B
         terms = {"lds": {"bytes_per_launch": lds_bytes, "peak_TBps": LDS_PEAK / 1e12, "t_us": 1e6 * lds_bytes / LDS_PEAK,
+                         "steps_per_marker": info["num_step"] / max(1, info["num_active_marker"]), "table_rows": int(info["num_table_row"]),
+                         "note": "the floor of THIS context's layout: a dictionary that needs fewer steps lowers t_ideal and the launch "
+                                 "time together (DESIGN.md section 7) -- compare throughput across layouts, frac within one",
                          "source": "vb2_info.num_step x 48 B (one table row per step and point) + 16 B x --NumPC per marker and "
                                    "point (the projection's coefficients), x points; peak = 256 B/clk/CU x 256 CUs x 2.4 GHz"},
                  "fp64": None, "hbm": None}
