@@ -2080,18 +2080,10 @@ int Context::eval_host(int num_point, const double* pc1, const double* pc2, cons
         }
         std::memcpy(llk_out + done, h_out, sizeof(double) * n);
     }
-    // NaN parameters: in the reference every marker's likelihood is then NaN, fails `markerLK > 0` (h:310) and is
-    // left out -- the sum over no markers, 0 (the kernels' clamps -- v_max / v_min quiet a NaN away -- would answer
-    // with the alpha-free part of the likelihood instead).  alpha enters every table entry, the PCs every allele
-    // frequency unless the frequencies are known.
-    for (int b = 0; b < num_point + served; ++b) {
-        const double* p1 = pc1_all + (size_t)b * k;
-        const double* p2 = pc2_all + (size_t)b * k;
-        bool bad = std::isnan(alpha_all[b]);
-        if (!L.known_af)
-            for (int j = 0; j < k; ++j) bad |= std::isnan(p1[j]) || std::isnan(p2[j]);
-        if (bad && L.num_mt > 0) llk_all[b] = 0.0;
-    }
+    // NaN parameters: the reference's rule (context.h: params_hold_nan)
+    for (int b = 0; b < num_point + served; ++b)
+        if (L.num_mt > 0 && params_hold_nan(pc1_all + (size_t)b * k, pc2_all + (size_t)b * k, alpha_all[b], k, L.known_af != nullptr))
+            llk_all[b] = 0.0;
     return VB2_OK;
 }
 

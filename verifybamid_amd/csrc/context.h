@@ -45,6 +45,19 @@ extern std::atomic<int> g_flatten_thread_cap;   // 0 = no cap on the flatten thr
 
 constexpr int kStagePoints = 256;   // points per host<->device staging round
 
+// NaN parameters: in the reference every marker's likelihood is then NaN, fails `markerLK > 0` (h:310) and is left out
+// -- the sum over no markers, 0 (the kernels' clamps -- v_max / v_min quiet a NaN away -- would answer with the alpha-free part
+// of the likelihood instead).  alpha enters every table entry, the PCs every allele frequency unless the frequencies are known.
+// One statement of the rule for the host entries that take a caller's points (Context::eval_host, ShardGroup::eval; a
+// cohort's steps carry the points of its own optimisers, which do not make NaNs).
+inline bool params_hold_nan(const double* pc1, const double* pc2, double alpha, int k, bool known_af)
+{
+    bool bad = alpha != alpha;
+    if (!known_af)
+        for (int j = 0; j < k; ++j) bad |= pc1[j] != pc1[j] || pc2[j] != pc2[j];
+    return bad;
+}
+
 class Context : public ScheduleProvider {
 public:
     ~Context();

@@ -435,8 +435,15 @@ int ShardGroup::eval(int num_point, const double* pc1, const double* pc2, const 
         return VB2_ERR_INVALID;
     }
     if (num_point == 0) return VB2_OK;
-    if (resident_) return eval_resident(num_point, pc1, pc2, alpha, llk_out);
-    return eval_launch(num_point, pc1, pc2, alpha, llk_out);
+    const int rc = resident_ ? eval_resident(num_point, pc1, pc2, alpha, llk_out) : eval_launch(num_point, pc1, pc2, alpha, llk_out);
+    if (rc != VB2_OK) return rc;
+    // NaN parameters: the reference's rule (context.h: params_hold_nan)
+    // (a group without markers answers 0 anyway: no condition on the shards' sizes, which differ between ranks)
+    bool known_af = false;
+    for (const Context* c : ctx) known_af |= c->L.known_af != nullptr;
+    for (int b = 0; b < num_point; ++b)
+        if (params_hold_nan(pc1 + (size_t)b * num_pc, pc2 + (size_t)b * num_pc, alpha[b], num_pc, known_af)) llk_out[b] = 0.0;
+    return VB2_OK;
 }
 
 int ShardGroup::optimize(const vb2_model* model, vb2_estimate* out, vb2_trace* trace)
