@@ -500,6 +500,10 @@ def test_parameters_at_the_edges_of_the_double_range_follow_the_reference():
         want = [od.llk(pcs, pcs, nan), od.llk(pcs, np.array([nan, 0.0]), 0.05), od.llk(pcs, pcs, 0.05)]
         assert want[0] == 0.0 and want[1] == 0.0 and got[0] == 0.0 and got[1] == 0.0
         assert rel_err(got[2:], want[2:]) <= LLK_RTOL
+    # (the same rule where a sample's markers are sharded: ADVICE r5)
+    with vb.ShardGroup(d, devices=[0, 0]) as grp:
+        got = grp.llk(np.tile(pcs, (3, 1)), np.array([pcs, [nan, 0.0], pcs]), np.array([nan, 0.05, 0.05]))
+        assert got[0] == 0.0 and got[1] == 0.0 and rel_err(got[2:], want[2:]) <= LLK_RTOL
     kaf = vb.PileupData(2, d.ud, d.means, d.read_off, d.bases, d.quals, d.alt_base, np.clip(d.means / 2, 0.01, 0.99),
                         d.avg_depth, d.sd_depth, True, {})
     okaf = oracle_data(kaf)
