@@ -66,7 +66,9 @@ public:
         // thread and one for the rest: the thread of a lock-step search spins on its device's flag between steps, and when it
         // has to queue for a CPU -- or the whole cgroup is throttled because fifteen readers woke up at once -- the device
         // idles (16 CPUs, 256 files: 15 readers 562-587 samples/s with runs at 390; 5 to 10 readers 600-633)
-        const int dflt = std::max(2, std::min(hw - 1 - ndev_, 6 * ndev_));
+        // (round 6: the device needs 1.2 ms per sample, the host 9 ms of one CPU -> EIGHT per device: 4 / 6 / 8 / 10 / 12
+        // readers 500 / 705 / 740 / 750 / 750 samples/s on 16 CPUs)
+        const int dflt = std::max(2, std::min(hw - 1 - ndev_, 8 * ndev_));
         T_ = std::max(1, std::min({a->num_host_thread > 0 ? a->num_host_thread : dflt, std::max(hw, 1) * 4, S_}));
         slots_.resize(S_);
         cnt_.assign(ndev_, 0);
