@@ -1773,7 +1773,7 @@ bool Context::resident_begin()
         ra.h_cmd = d_cmd;
         ra.relay = d_relay;
         ra.relay_reps = 8;                                // (1 .. kRelayReps measured: 8 copies, 32 workgroups polling each)
-        ra.reserved1 = 0;
+        ra.extra_ctl = 0;
         ra.spec = d_relay + resident_words(num_pc);
         ra.h_out = d_out;
         ra.h_done = d_done;

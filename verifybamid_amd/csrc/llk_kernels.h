@@ -383,7 +383,7 @@ struct ResidentArgs {
     int32_t state_off;                   // doubles from the start of dynamic LDS to workgroup 0's search state
     int32_t state_nmax;                  // largest simplex dimension the state was sized for (0 = no MINIMIZE)
     int32_t relay_reps;                  // copies of the relay word in use (1..kRelayReps)
-    int32_t reserved1;
+    int32_t extra_ctl;                   // out: the grid has one workgroup more than the tile workgroups, for the control wave (launch_llk_resident)
     // LDS areas behind the search state (offsets in doubles from the start of dynamic LDS; filled in by
     // launch_llk_resident): workgroup 0's staging of the partial sums ([4][grid]; 0 = over the dead tables, round 3),
     // and the workgroup's own run lists (LCACHE, resident_kernel.inc: cache_start).

@@ -479,6 +479,8 @@ struct NoHook {
     __device__ double* sum_stage() const { return nullptr; } // where workgroup 0 stages the partial sums (nullptr: over the dead tables)
     __device__ uint32_t cache_rec() const { return 0u; }    // LCACHE: LDS byte address of this workgroup's tile records
     __device__ unsigned int* sync_word() const { return nullptr; }   // a zeroed LDS word: the hook wave skips the prologue (see eval_body)
+    __device__ bool collect_only() const { return false; }  // this workgroup owns no tiles: it collects the other workgroups' sums (and hosts the hook wave)
+    __device__ bool no_collect() const { return false; }    // the tagged sets are collected by such a workgroup, not by workgroup 0
 };
 // The waves of a workgroup pull (tile, group) items through the LDS queue (per-item result slots) when there
 // are at most dyn_limit of them per wave; else the static deal (cohort launches).
@@ -592,6 +594,11 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #endif
     if (stamps && tid == 0) { stamps[0] = wall_clock64(); stamps[4] = 0; }
 
+    // A workgroup that owns no tiles (the resident kernel's extra workgroup for the control wave: Hook::collect_only): nothing of
+    // the evaluation -- its hook wave does its work, then all of it collects the tile workgroups' sums below.
+    const bool collect_only = hook.collect_only();
+    if (collect_only && hook.mine()) hook.run();
+    if (!collect_only) {
     const bool hook_blk = hook.on_block(), hook_mine = hook.mine();
     // A workgroup with a hook wave (the resident kernel's control wave: wave 0 of workgroup 0) in a probability-domain search
     // round: that wave starts on its own work AT ONCE -- it builds no table entries and does not come to the prologue's barriers,
@@ -1578,8 +1585,9 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     if (VB2_STAMPS_OF(L) && tid == 0) {
         const unsigned long long t5 = wall_clock64();
         if (stamps) stamps[5] = t5;
-        if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[20 * 8 + 7] += t5 - VB2_STAMPS_OF(L)[7];     // (accumulated: since "has the round")
+        if (blk == 0 && nblk > 32 && !hook.no_collect()) VB2_STAMPS_OF(L)[20 * 8 + 7] += t5 - VB2_STAMPS_OF(L)[7];     // (accumulated: since "has the round")
     }
+    }      // (!collect_only)
     // A result that the host waits for (done_flag: llk_out is mapped host memory) is stored THROUGH the caches (a relaxed
     // system-scope store); before the flag goes out the storing lanes wait for their stores' acknowledgements (vmcnt).
     // Round 3 stored plainly and then fenced -- __threadfence_system, an ACQ_REL counter and a RELEASE flag store: three
@@ -1656,7 +1664,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     // the hand-off costs one store propagation plus one read instead of three dependent
     // round trips through the fabric (store drain, ticket atomic, reload).
     unsigned long long* pw = reinterpret_cast<unsigned long long*>(partials);
-    if (wave == 0) {
+    if (wave == 0 && !collect_only) {
         const unsigned long long bits = lane < NPT ? (unsigned long long)__double_as_longlong(red[lane]) : 0ull;
         // (the sums first: they do not wait for the check word; then the check word from lane 0, which has the XOR of the
         // NPT word hashes after log2(NPT) exchange steps -- a search round's four words: two quad permutes -- instead of a
@@ -1671,7 +1679,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
             __hip_atomic_store(&pw[(size_t)NPT * nblk + blk], x ^ resident_mix(tag), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (blk != 0) return;
+    if (collect_only ? false : (blk != 0 || hook.no_collect())) return;
     if (!hook.sum_stage()) __syncthreads();            // the table is dead: its space stages the partials
     const int nb = (int)nblk;
     double* stage = hook.sum_stage() ? hook.sum_stage() : lds;      // [NPT][nb]
@@ -1731,7 +1739,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     if (VB2_STAMPS_OF(L) && tid == 0) {
         const unsigned long long t6 = wall_clock64();
         if (stamps) stamps[6] = t6;
-        if (blk == 0 && nblk > 32) VB2_STAMPS_OF(L)[21 * 8 + 7] += t6 - VB2_STAMPS_OF(L)[7];
+        if ((collect_only || (blk == 0 && !hook.no_collect())) && nblk > 32) VB2_STAMPS_OF(L)[21 * 8 + 7] += t6 - VB2_STAMPS_OF(L)[7];
     }
     if (done_flag && !(kAblate & kAblNoSignal)) {
         // host hand-off without a stream synchronisation: results (in mapped host memory)
@@ -2466,16 +2474,19 @@ hipError_t launch_llk_resident(const DeviceLayout& L, ResidentArgs* ra_io, doubl
     // rocprofv3 crashes in its exit handler after a cooperative launch: the caller checks profiler_attached()), a
     // runtime that refuses the cooperative launch, and Tunables::coop = 0 -- the bounded waits on both sides then turn
     // a partly resident grid into a retry with plain per-step launches, not a hang.
+    // one workgroup more for the control wave where the grid leaves a CU free (resident_kernel.inc: extra_ctl)
+    ra.extra_ctl = (tunables().ctl_block != 0 && ra.state_nmax > 0 && dyn && gm.grid + 1 <= L.num_cu && gm.grid > 4) ? 1 : 0;
+    const unsigned launch_grid = (unsigned)gm.grid + (ra.extra_ctl ? 1u : 0u);
     DeviceLayout Lc = L;
     ResidentArgs rc = ra;
     void* args[] = {&Lc, &rc, &d_partials, &d_ticket};
     if (cooperative && *cooperative) {
-        e = hipLaunchCooperativeKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, (unsigned int)shmem, stream);
+        e = hipLaunchCooperativeKernel(fn, dim3(launch_grid), dim3(gm.block_waves * 64), args, (unsigned int)shmem, stream);
         if (e == hipSuccess) return e;
         (void)hipGetLastError();
         *cooperative = false;
     }
-    return hipLaunchKernel(fn, dim3(gm.grid), dim3(gm.block_waves * 64), args, shmem, stream);
+    return hipLaunchKernel(fn, dim3(launch_grid), dim3(gm.block_waves * 64), args, shmem, stream);
 }
 
 // After a collective on the same stream: the reduced values go to mapped host memory, then the sequence

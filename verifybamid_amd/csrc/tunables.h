@@ -43,6 +43,7 @@ namespace vb2 {
     X(cpus, 0)             /* CPUs the process may use, 0 = cgroup quota / affinity */                                   \
     /* ---- one sample's search (context.cpp, estimator.cpp) ---- */                                                    \
     X(resident, 1)         /* 0: a launch per search step instead of the resident kernel */                              \
+    X(ctl_block, 1)        /* 0: the control wave lives in workgroup 0 even where the grid leaves a CU free for a workgroup of its own */ \
     X(device_simplex, 1)   /* 0: the resident kernel evaluates, the host optimiser decides */                            \
     X(spin_wait, 1)        /* 0: hipStreamSynchronize instead of spinning on the mapped flag */                          \
     X(lds_cache, 1)        /* 0: the resident kernel reads its run lists from L2 every round */                          \
