@@ -764,7 +764,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 double dg[3] = {0.0, 0.0, 0.0};
                 uint32_t steps_ref = 0, steps_alt = 0;
                 double bound = 0.0;
-                PdWin tail_ref{0u, 0u, 0ull}, tail_alt{0u, 0u, 0ull};
+                PdWin win_ref{0u, 0u, 0ull}, win_alt{0u, 0u, 0ull};
                 auto count_ref = [&](uint32_t) { ++steps_ref; };
                 auto count_alt = [&](uint32_t) { ++steps_alt; };
                 for (int w = 0; w < 3; ++w)
@@ -782,12 +782,12 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                             out[eff++] = (uint16_t)(idx | (c1 << 8));
                             left -= c1;
                             if (!pd_wanted) continue;
-                            if (idx & 1u) pd_run(dict, tail_alt, idx >> 1, c1, count_alt);
-                            else pd_run(dict, tail_ref, idx >> 1, c1, count_ref);
+                            if (idx & 1u) pd_run(dict, win_alt, idx >> 1, c1, count_alt);
+                            else pd_run(dict, win_ref, idx >> 1, c1, count_ref);
                         }
                     }
-                pd_flush(dict, tail_ref, count_ref);
-                pd_flush(dict, tail_alt, count_alt);
+                pd_flush(dict, win_ref, count_ref);
+                pd_flush(dict, win_alt, count_alt);
                 // the g1 == g2 terms of h:307-311 are constants of the marker
                 double* cd = cd_tmp + (size_t)i * 4;
                 cd[0] = c_other;
@@ -1265,14 +1265,14 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                 ++step;
             };
             for (uint32_t cls = 0; cls < 2; ++cls) {
-                PdWin tail{0u, 0u, 0ull};
+                PdWin win{0u, 0u, 0ull};
                 auto put_row = [&](uint32_t row) { put(row * (uint32_t)row_bytes + cls * (uint32_t)kPdAltOffset); };
                 for (size_t j = 0; j < eff; ++j) {
                     const uint32_t rw = src[j], idx = rw & 0xffu;
                     if ((idx & 1u) != cls) continue;
-                    pd_run(dict, tail, idx >> 1, rw >> 8, put_row);
+                    pd_run(dict, win, idx >> 1, rw >> 8, put_row);
                 }
-                pd_flush(dict, tail, put_row);
+                pd_flush(dict, win, put_row);
                 const uint32_t end = cls == 0 ? s1 : 2u * ((s2 + 1u) >> 1);
                 while (step < end) put(pad_off + cls * (uint32_t)kPdAltOffset);
             }
@@ -1322,14 +1322,14 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
                         if (m < m_active) {
                             const int i = active[perm[m]];
                             const uint16_t* src = runs + (in->read_off[i] - read_base);
-                            PdWin tail{0u, 0u, 0ull};
+                            PdWin win{0u, 0u, 0ull};
                             auto push_row = [&](uint32_t row) { lst[l].push_back((uint16_t)row); };
                             for (int32_t j = 0; j < eff_all[i]; ++j) {
                                 const uint32_t rw = src[j], idx = rw & 0xffu;
                                 if ((idx & 1u) != cls) continue;
-                                pd_run(dict, tail, idx >> 1, rw >> 8, push_row);
+                                pd_run(dict, win, idx >> 1, rw >> 8, push_row);
                             }
-                            pd_flush(dict, tail, push_row);
+                            pd_flush(dict, win, push_row);
                         }
                         eff16[l] = (uint32_t)lst[l].size();
                     }

@@ -185,7 +185,7 @@ classify_kernel(const ClassifyArgs a)
             uint16_t* out = a.runs + beg;
             eff = 0;
             double dg0 = 0.0, dg1 = 0.0, dg2 = 0.0, bound = 0.0;
-            PdWin tail_ref{0u, 0u, 0ull}, tail_alt{0u, 0u, 0ull};
+            PdWin win_ref{0u, 0u, 0ull}, win_alt{0u, 0u, 0ull};
             auto count_ref = [&](uint32_t) { ++steps_ref; };
             auto count_alt = [&](uint32_t) { ++steps_alt; };
 #pragma unroll 1
@@ -205,15 +205,15 @@ classify_kernel(const ClassifyArgs a)
                         out[eff++] = (uint16_t)(idx | (c1 << 8));
                         left -= c1;
                         if (pd) {
-                            if (idx & 1u) pd_run(s_dict, tail_alt, idx >> 1, c1, count_alt);
-                            else pd_run(s_dict, tail_ref, idx >> 1, c1, count_ref);
+                            if (idx & 1u) pd_run(s_dict, win_alt, idx >> 1, c1, count_alt);
+                            else pd_run(s_dict, win_ref, idx >> 1, c1, count_ref);
                         }
                     }
                 }
             }
             if (pd) {
-                pd_flush(s_dict, tail_ref, count_ref);
-                pd_flush(s_dict, tail_alt, count_alt);
+                pd_flush(s_dict, win_ref, count_ref);
+                pd_flush(s_dict, win_alt, count_alt);
             }
             double* cd = a.cd + (size_t)i * 4;
             cd[0] = c_other;
@@ -358,14 +358,14 @@ pack_pd_kernel(const PackPdArgs a)
         };
 #pragma unroll 1
         for (uint32_t cls = 0; cls < (a.sched ? 0u : 2u); ++cls) {      // (sched: pack_pd_sched_kernel writes the steps)
-            PdWin tail{0u, 0u, 0ull};
+            PdWin win{0u, 0u, 0ull};
             auto put_row = [&](uint32_t row) { put(row * (uint32_t)a.row_bytes + cls * (uint32_t)kPdAltOffset); };
             for (uint32_t j = 0; j < nrun; ++j) {
                 const uint32_t rw = src[j], idx = rw & 0xffu;
                 if ((idx & 1u) != cls) continue;
-                pd_run(a.dict, tail, idx >> 1, rw >> 8, put_row);
+                pd_run(a.dict, win, idx >> 1, rw >> 8, put_row);
             }
-            pd_flush(a.dict, tail, put_row);
+            pd_flush(a.dict, win, put_row);
             const uint32_t end = cls == 0 ? s1 : 2u * ((s2 + 1u) >> 1);
             while (step < end) put(a.pad_off + cls * (uint32_t)kPdAltOffset);
         }
@@ -430,7 +430,7 @@ pack_pd_sched_kernel(const PackPdArgs a)
         // the lane's steps of this phase, as row indices
         uint32_t n = 0;
         {
-            PdWin tail{0u, 0u, 0ull};
+            PdWin win{0u, 0u, 0ull};
             auto stage = [&](uint32_t r) {
                 if (n < (uint32_t)kSchedMaxSteps) s_runs[row][lane][n] = (uint8_t)r;
                 ++n;
@@ -438,9 +438,9 @@ pack_pd_sched_kernel(const PackPdArgs a)
             for (uint32_t j = 0; j < nrun; ++j) {
                 const uint32_t rw = src[j], idx = rw & 0xffu;
                 if ((idx & 1u) != cls) continue;
-                pd_run(a.dict, tail, idx >> 1, rw >> 8, stage);
+                pd_run(a.dict, win, idx >> 1, rw >> 8, stage);
             }
-            pd_flush(a.dict, tail, stage);
+            pd_flush(a.dict, win, stage);
         }
         s_eff[row][lane] = n;
         __syncthreads();
@@ -449,14 +449,14 @@ pack_pd_sched_kernel(const PackPdArgs a)
             if (live) {              // the steps in plain order (pack_pd_kernel's loop)
                 uint32_t step = 0;
                 auto put_plain = [&](uint32_t off) { put_step(first_step + step, off); ++step; };
-                PdWin tail{0u, 0u, 0ull};
+                PdWin win{0u, 0u, 0ull};
                 auto put_row = [&](uint32_t r) { put_plain(r * (uint32_t)a.row_bytes + cls * (uint32_t)kPdAltOffset); };
                 for (uint32_t j = 0; j < nrun; ++j) {
                     const uint32_t rw = src[j], idx = rw & 0xffu;
                     if ((idx & 1u) != cls) continue;
-                    pd_run(a.dict, tail, idx >> 1, rw >> 8, put_row);
+                    pd_run(a.dict, win, idx >> 1, rw >> 8, put_row);
                 }
-                pd_flush(a.dict, tail, put_row);
+                pd_flush(a.dict, win, put_row);
                 while (step < (uint32_t)steps) put_plain(a.pad_off + cls * (uint32_t)kPdAltOffset);
             }
         } else {

@@ -37,7 +37,7 @@ namespace vb2 {
     X(force_narrow, 0)     /* 1: narrow table rows although the dictionary would fit wide ones */                        \
     X(pd, 1)               /* 0: never the probability-domain layout (llk_kernels.h: kMaxPow) */                         \
     X(pd_rows, 0)          /* its table rows: 0 = what the LDS holds for a 48-point launch */                            \
-    X(pd_pairs, 1)         /* 0: no pair rows in it (llk_kernels.h: PdDict) */                                           \
+    X(pd_pairs, 1)         /* 0: no window rows in it (llk_kernels.h: PdDict) */                                         \
     X(digest_multiset, 0)  /* 1: vb2_debug_flatten_digest takes a tile's run words as a multiset per lane */             \
     X(slab_cache, 1)       /* 0: freed device / pinned slabs go back to the driver */                                    \
     X(cpus, 0)             /* CPUs the process may use, 0 = cgroup quota / affinity */                                   \
