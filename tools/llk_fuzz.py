@@ -32,9 +32,12 @@ for it in range(N):
         layout = ctx.info()["layout"]
     want = np.array([od.llk(pc1[i], pc2[i], al[i], num_thread=8) for i in range(B)])
     err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    if float(err.max()) > worst:
+        worst_case = "it=%d M=%d depth=%g k=%d q=%d..%d B=%d profile %d layout %d alpha[argmax] %.3g" % (it, M, depth, k, qlo, qhi, B, prof, layout, al[int(err.argmax())])
     worst = max(worst, float(err.max()))
     if err.max() > 1e-11:
         bad += 1
         print("MISMATCH it=%d M=%d depth=%g k=%d q=%d..%d B=%d layout %d: max abs diff %.3g (rel %.2e)" % (it, M, depth, k, qlo, qhi, B, layout, np.abs(got - want).max(), err.max()))
     nlay = locals().get("nlay", [0, 0]); nlay[layout] += 1
+print("worst case:", locals().get("worst_case"))
 print("llk fuzz: %d of %d cases off, worst relative error %.2e; layouts: %d run words, %d probability domain" % (bad, N, worst, nlay[0], nlay[1]))
