@@ -1270,8 +1270,10 @@ def test_lockstep_search_regroups_the_unfinished_samples(S, tunable):
             c.close()
 
 
-def test_cohort_steps_on_16bit_run_lists_are_bit_identical(tunable):
-    """(Run-word layout: tunable pd = 0 keeps every sample out of the probability-domain layout, which has one list format.)
+@pytest.mark.parametrize("pd", [0, 1])
+def test_cohort_steps_on_16bit_run_lists_are_bit_identical(pd, tunable):
+    """(pd = 1: the samples take the probability-domain layout and the short copy is its 8-BIT step lists -- a row index per
+    step, four steps to a word, the one- and two-point shapes -- against its own 16-bit offsets; pd = 0: the run-word layout.)
     The steps of a cohort (every wave shape: 1, 2, 4 and 8 points per sample) stream a 16-bit copy of every sample's run lists
     (DeviceLayout::codes16: dictionary index | count << 8, re-coded on the device from the 32-bit run words;
     half the HBM bytes per step).  Same runs, same order, same FMAs: a batch on the 16-bit lists returns,
@@ -1280,7 +1282,7 @@ def test_cohort_steps_on_16bit_run_lists_are_bit_identical(tunable):
     with 300 reads per marker, and for both ways the copy comes about (VB2_OPT_COHORT_LAYOUT at creation /
     built by vb2_batch_create) -- and each sample's own single-context evaluation to rounding."""
     import ctypes
-    tunable("pd", 0)
+    tunable("pd", pd)
     k = 3
     rng = np.random.default_rng(77)
     datas = [vb.synth.make_pileup(3000, 25, k, alpha_true=0.02, seed=71),
@@ -1306,7 +1308,8 @@ def test_cohort_steps_on_16bit_run_lists_are_bit_identical(tunable):
                 results[w16] = [batch.eval(np.array(npts, dtype=np.int32), pc1, pc2, al) for npts in shapes]
             now = [c.info()["cohort_step_bytes"] for c in ctxs]
             for i in range(S):
-                if w16 == 0 or i % 2 == 0 or datas[i].num_read == 0:
+                # (a probability-domain context's short lists are always made by vb2_batch_create)
+                if w16 == 0 or (pd == 0 and i % 2 == 0) or datas[i].num_read == 0:
                     assert now[i] == before[i]                # nothing built (or made at creation already)
                 else:
                     assert now[i] < before[i]                 # made by vb2_batch_create: fewer bytes per step now

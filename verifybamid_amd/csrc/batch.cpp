@@ -513,7 +513,9 @@ int Batch::eval_begin(const int32_t* num_point, const double* pc1, const double*
     ml.w16 = w16_;
     for (int s2 = 0; s2 < num_sample; ++s2)
         if (h_nv_[s2] > 0 && ctx_[s2] && ctx_[s2]->L.pd) ml.pd = true;      // (the step's samples are of one layout: see the top)
-    if (ml.pd) ml.w16 = false;
+    // (probability domain: the short copy is the 8-bit step lists -- they pay where a step is bound by what it streams: 32 C3
+    // samples x 1 point 62.4 -> 58.0 us, x 2 points 77.4 -> 76.0, x 4 points 124.6 -> 126.3: the one- and two-point shapes only)
+    if (ml.pd && NP > 2) ml.w16 = false;
     {   // (the pipelined item loop is compiled for the static deal: every sample of the cohort must run it)
         bool st = true;
         for (int s2 = 0; s2 < num_sample && st; ++s2)

@@ -1545,6 +1545,7 @@ int Context::create_impl(const vb2_input* in, const vb2_options* opt, Context** 
         c->sched_[slot].bytes = sched_bytes[slot];
     }
     c->h_mt_rows.assign(mt_rows.begin(), mt_rows.end());
+    if (pd) c->h_mt_rec_y.assign(mt_rec_y.begin(), mt_rec_y.end());
     c->dbg_regions = {{o_codes, n_codes * sizeof(uint32_t)}, {o_rec, (size_t)num_mt * sizeof(uint2)}};
     if (in->known_af) c->dbg_regions.push_back({o_kaf, (size_t)m_pad * sizeof(double)});
     else {
@@ -2092,7 +2093,7 @@ int Context::ensure_codes16()
     //  two threads may build batches over one context: one of them makes the copy, the other waits
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    if (L.codes16 || L.num_mt == 0 || L.pd) return VB2_OK;      // (a probability-domain context has one list format)
+    if (L.codes16 || L.num_mt == 0) return VB2_OK;
     // the pack kernel goes on this context's stream: behind a resident search kernel it would only start when that
     // kernel gives up after its idle second (and end the session without a word) -- end the session first
     if (resident_active) resident_end();
@@ -2100,12 +2101,13 @@ int Context::ensure_codes16()
     std::vector<uint2> rec16(L.num_mt);
     uint64_t total16 = 0;
     for (int t = 0; t < L.num_mt; ++t) {
-        const uint32_t r16 = (h_mt_rows[t] + 1) / 2;
-        rec16[t] = make_uint2((uint32_t)total16, r16);
+        // (probability domain: 8-bit steps, four to a 32-bit word -- the record keeps the tile's {ref steps | all steps << 16})
+        const uint32_t r16 = L.pd ? ((h_mt_rec_y[t] >> 16) + 3u) / 4u : (h_mt_rows[t] + 1) / 2;
+        rec16[t] = make_uint2((uint32_t)total16, L.pd ? h_mt_rec_y[t] : r16);
         total16 += r16;
     }
     const size_t rec_bytes = ((size_t)L.num_mt * sizeof(uint2) + 255) & ~(size_t)255;
-    const size_t bytes = rec_bytes + (size_t)(total16 + kCodeSlackRows) * kMtMarkers * sizeof(uint2);
+    const size_t bytes = rec_bytes + (size_t)(total16 + kCodeSlackRows) * kMtMarkers * (L.pd ? sizeof(uint32_t) : sizeof(uint2));
     VB2_HIP(hipMalloc(&d_codes16_own, bytes));
     char* base = static_cast<char*>(d_codes16_own);
     const uint2* d_rec = reinterpret_cast<const uint2*>(base);
@@ -2113,7 +2115,9 @@ int Context::ensure_codes16()
     {
         // a failure after the allocation must not leave the block behind (the next call would allocate again)
         hipError_t e = hipMemcpyAsync(base, rec16.data(), rec16.size() * sizeof(uint2), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = launch_pack_codes16(L, d16, d_rec, (uint32_t)total16, stream);
+        if (e == hipSuccess)
+            e = L.pd ? launch_pack_pd_codes8(L, reinterpret_cast<uint32_t*>(d16), d_rec, (uint32_t)total16, stream)
+                     : launch_pack_codes16(L, d16, d_rec, (uint32_t)total16, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);   // (rec16 is a pageable source; and the lists must be complete)
         if (e != hipSuccess) {
             (void)hipFree(d_codes16_own);
@@ -2126,7 +2130,8 @@ int Context::ensure_codes16()
     L.codes16 = d16;
     int64_t rows32 = 0;
     for (int t = 0; t < L.num_mt; ++t) rows32 += h_mt_rows[t];
-    cohort_bytes += ((int64_t)total16 - rows32) * kMtMarkers * 8;
+    // (what a cohort step streams of this sample: the shorter lists instead of the context's own)
+    cohort_bytes += L.pd ? ((int64_t)total16 - rows32) * kMtMarkers * 4 : ((int64_t)total16 - rows32) * kMtMarkers * 8;
     device_bytes += (int64_t)bytes;
     return VB2_OK;
 }

@@ -88,6 +88,7 @@ public:
     std::vector<CohortSched> cohort_sched_;
     std::mutex cohort_mu_;
     std::vector<uint32_t> h_mt_rows;         // rows per micro-tile (host copy: the schedules are built from it)
+    std::vector<uint32_t> h_mt_rec_y;        // probability domain: a tile's {ref steps | all steps << 16} (ensure_codes16: the 8-bit lists)
     static int create(const vb2_input* in, const vb2_options* opt, Context** out);
     static int create_impl(const vb2_input* in, const vb2_options* opt, Context** out, bool dry);
     // device pointers, asynchronous on s (nullptr = own stream)

@@ -303,6 +303,48 @@ hipError_t launch_pack_codes16(const DeviceLayout& L, uint2* codes16, const uint
     return hipGetLastError();
 }
 
+// The cohort steps' 8-bit lists of a probability-domain context (DeviceLayout::codes16 there; eval_body: walk_pd8): one thread per
+// (micro-tile, row of four steps, marker) -- the 16-bit offsets of `codes` re-coded as row indices, a byte apiece (an alt step's
+// offset loses its kPdAltOffset: the step's position says it is one).  Steps past a tile's own, and the slack rows at the end:
+// the padding row.
+__global__ void __launch_bounds__(256)
+pack_pd_codes8_kernel(const DeviceLayout L, uint32_t* __restrict__ codes8, const uint2* __restrict__ mt_rec8, uint32_t rows8_total)
+{
+    const uint32_t pad = (uint32_t)L.num_code;
+    const uint32_t pad4 = pad | (pad << 8) | (pad << 16) | (pad << 24);
+    const int mt = blockIdx.x;
+    if (mt >= L.num_mt) {
+        for (uint32_t e = threadIdx.x; e < (uint32_t)kCodeSlackRows * kMtMarkers; e += blockDim.x)
+            codes8[(size_t)rows8_total * kMtMarkers + e] = pad4;
+        return;
+    }
+    const uint2 r16 = L.mt_rec[mt], r8 = mt_rec8[mt];
+    const uint32_t s1 = r16.y & 0xffffu, s2 = r16.y >> 16, rows8 = (s2 + 3u) >> 2;
+    const uint16_t* h16 = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint32_t*>(L.codes) + (size_t)r16.x * kMtMarkers);
+    for (uint32_t e = threadIdx.x; e < rows8 * kMtMarkers; e += blockDim.x) {
+        const uint32_t row = e / kMtMarkers, m = e % kMtMarkers;
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t g = 4u * row + j;
+            uint32_t idx = pad;
+            if (g < s2) {
+                uint32_t off = h16[((size_t)(g >> 1) * kMtMarkers + m) * 2 + (g & 1u)];
+                if (g >= s1) off -= (uint32_t)kPdAltOffset;
+                idx = off / (uint32_t)L.row_bytes;
+            }
+            w |= idx << (8u * j);
+        }
+        codes8[((size_t)r8.x + row) * kMtMarkers + m] = w;
+    }
+}
+
+hipError_t launch_pack_pd_codes8(const DeviceLayout& L, uint32_t* codes8, const uint2* mt_rec8, uint32_t rows8_total, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pack_pd_codes8_kernel, dim3(L.num_mt + 1), dim3(256), 0, stream, L, codes8, mt_rec8, rows8_total);
+    return hipGetLastError();
+}
+
 // One thread per position of the padded, sorted marker list (see PackArgs): 16 consecutive threads = one micro-tile, so a
 // row of run words leaves as one 128-byte store per tile.
 __global__ void __launch_bounds__(256)

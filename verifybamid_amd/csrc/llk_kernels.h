@@ -259,6 +259,9 @@ hipError_t launch_fill_zero(double* d_out, int n, hipStream_t stream);
 // rows16_total + kCodeSlackRows rows are written, the slack as padding words)
 hipError_t launch_pack_codes16(const DeviceLayout& L, uint2* codes16, const uint2* mt_rec16, uint32_t rows16_total,
                                hipStream_t stream);
+// ... of a probability-domain context: its 16-bit step lists as 8-bit row indices, four steps per 32-bit word (rec8: {first row,
+// ref steps | all steps << 16} like mt_rec; the rows of a tile = ceil(all steps / 4))
+hipError_t launch_pack_pd_codes8(const DeviceLayout& L, uint32_t* codes8, const uint2* mt_rec8, uint32_t rows8_total, hipStream_t stream);
 // The flatten on the device (flatten_kernels.hip).  Pass A, classify_kernel: what the pileup viewer holds goes up as it is --
 // bases, qualities, read offsets, alt alleles -- and one thread per marker classifies, counts, run-length codes and sums
 // the alpha-free terms; the host keeps the dictionary order (known from a sample of the qualities before any read is

@@ -528,7 +528,8 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     static_assert(MODE >= 2 && MODE <= 5, "wave shapes 2..5");
-    static_assert(!PD || (!W16 && ESH == 8), "probability-domain contexts have one list format and no exp table");
+    static_assert(!PD || ESH == 8, "probability-domain contexts have no exp table");
+    static_assert(!(PD && W16) || ((MODE == 4 || MODE == 5) && STREAM), "8-bit step lists: cohort steps of one and two points");
     static_assert(!SPLIT || (PD && MODE == 2 && QUEUE == 1 && !STREAM && !LCACHE), "split launches: the 8-point shape on the queue");
     constexpr int OSH = PD ? 1 : 0;             // a workgroup owns pairs of neighbouring micro-tiles (owned_tile)
     // the launch is known to carry ONE group of points (every shape but the 8-point one always does; cohort steps too):
@@ -929,7 +930,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
     };
     auto issue_rows = [&](const vuint2 rec_, bool have_) {           // the first kPf rows of a tile (clamped to its own)
         const uint32_t cb_ = rec_.x * kRowBytes + (uint32_t)m * kLaneBytes;       // (32-bit byte offsets: see load_row)
-        const int rows_ = have_ ? (PD ? (int)(((rec_.y >> 16) + 1u) >> 1) : (int)rec_.y) : 0;
+        const int rows_ = have_ ? (PD ? (int)(((rec_.y >> 16) + (W16 ? 3u : 1u)) >> (W16 ? 2 : 1)) : (int)rec_.y) : 0;
         const int last_ = rows_ > 0 ? rows_ - 1 : 0;
 #pragma unroll
         for (int j = 0; j < kPf; ++j) {
@@ -1022,6 +1023,26 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint32_t row_addr = my_tab + (j ? (w_cur >> 16) : (w_cur & 0xffffu));
+            lds_cdouble2* row = reinterpret_cast<lds_cdouble2*>(row_addr);
+#pragma unroll
+            for (int i = 0; i < 3 * BTL; ++i) {
+                const vdouble2 t = row[i];
+                acc[2 * i] = (kFirst && j == 0) ? t.x : acc[2 * i] * t.x;
+                acc[2 * i + 1] = (kFirst && j == 0) ? t.y : acc[2 * i + 1] * t.y;
+            }
+        }
+    };
+    // ---- PD, the cohort steps' 8-BIT lists (W16; DeviceLayout::codes16 of a probability-domain context): a word = FOUR steps, a
+    // byte = the row's index; whether a step is an alt step -- its row's mirror image, kPdAltOffset into the row -- follows from
+    // its position in the tile (the ref steps come first: step >= s1).  Half the list bytes of a step that is bound by what it
+    // streams; three vector instructions more per step (index x row stride, the comparison, the choice of the base) ----
+    auto walk_pd8 = [&](const uint32_t w_cur, double* acc, const uint32_t my_tab, auto first_tag, const int step0, const int s1) {
+        constexpr bool kFirst = decltype(first_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t idx = (w_cur >> (8 * j)) & 0xffu;
+            const uint32_t base = (step0 + j >= s1) ? my_tab + (uint32_t)kPdAltOffset : my_tab;
+            const uint32_t row_addr = base + __umul24(idx, (uint32_t)row_bytes);
             lds_cdouble2* row = reinterpret_cast<lds_cdouble2*>(row_addr);
 #pragma unroll
             for (int i = 0; i < 3 * BTL; ++i) {
@@ -1315,7 +1336,7 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
         // their alt steps at [s1, s2), two steps to a row (walk_pd)
         // (one tile per wave: both are the same in every lane, and the compiler is told so -- the branches on them are scalar)
         const int steps_ref_v = PD ? (have_tile ? (int)(rec.y & 0xffffu) : 0) : 0;
-        const int rows_v = have_tile ? (PD ? (int)(((rec.y >> 16) + 1u) >> 1) : (int)rec.y) : 0;
+        const int rows_v = have_tile ? (PD ? (int)(((rec.y >> 16) + (W16 ? 3u : 1u)) >> (W16 ? 2 : 1)) : (int)rec.y) : 0;
         const int steps_ref = (PD && TPW == 1) ? __builtin_amdgcn_readfirstlane(steps_ref_v) : steps_ref_v;
         const int rows = (PD && TPW == 1) ? __builtin_amdgcn_readfirstlane(rows_v) : rows_v;
         // (ONE sample's pileup sits in L2, and a deep prefetch costs more than it hides there: the loads run past the
@@ -1352,8 +1373,13 @@ eval_body(const DeviceLayout& L, const double* ip_v, const int ip_count, const d
                 const RowWord w_cur = w[u];
                 if (refill) w[u] = load_row(s0 + u + kPf);
                 if constexpr (PD) {
-                    if (kFirstBlock && u == 0) walk_pd1(w_cur, acc, my_tab, std::true_type());
-                    else walk_pd1(w_cur, acc, my_tab, std::false_type());
+                    if constexpr (W16) {
+                        if (kFirstBlock && u == 0) walk_pd8(w_cur, acc, my_tab, std::true_type(), (s0 + u) * 4, steps_ref);
+                        else walk_pd8(w_cur, acc, my_tab, std::false_type(), (s0 + u) * 4, steps_ref);
+                    } else {
+                        if (kFirstBlock && u == 0) walk_pd1(w_cur, acc, my_tab, std::true_type());
+                        else walk_pd1(w_cur, acc, my_tab, std::false_type());
+                    }
                 } else {
                     if (kFirstBlock && u == 0) walk_word(w_cur, acc, my_tab, my_tab_w16, std::true_type(), cst);
                     else walk_word(w_cur, acc, my_tab, my_tab_w16, std::false_type(), cst);
@@ -2283,7 +2309,19 @@ static hipError_t launch_multi_mode(const MultiLaunch& ml, hipStream_t stream)
         return hipGetLastError();
     };
     // (every shape also compiled for --NumPC 2 / 4 without a known-AF column: one-point steps of 32 samples 99 -> 94 us)
-    if (ml.pd) {                      // (every sample a probability-domain context: one list format, no 16-bit copy)
+    if (ml.pd) {                      // (every sample a probability-domain context)
+        if constexpr (MODE == 4 || MODE == 5) {    // (the one- and two-point shapes stream the 8-bit step lists when every sample has them: eval_body, walk_pd8)
+            if (ml.w16) {
+                if (ml.all_static) {
+                    if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, 4, 1, true>);
+                    if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, 2, 1, true>);
+                    return go(&llk_eval_multi_kernel<MODE, true, 0, 1, true>);
+                }
+                if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, true, 4, 0, true>);
+                if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, true, 2, 0, true>);
+                return go(&llk_eval_multi_kernel<MODE, true, 0, 0, true>);
+            }
+        }
         if (ml.all_static) {
             if (ml.ksel == 4) return go(&llk_eval_multi_kernel<MODE, false, 4, 1, true>);
             if (ml.ksel == 2) return go(&llk_eval_multi_kernel<MODE, false, 2, 1, true>);
